@@ -1,0 +1,153 @@
+"""Synthetic 16 kHz mono streams and seeded network weights.
+
+There is no network access for datasets or the gated pyannote checkpoints
+(``/root/reference/README.md:101-109``), so measurement and parity use:
+
+* ``synth_stream``: band-limited-noise "speakers" with Markov on/off turns
+  (SURVEY.md §8d config 1/2 generator);
+* ``synth_segmentation_state`` / ``synth_embedding_state``: random-init weights
+  of exactly the published architectures, keyed like the pyannote checkpoints
+  (``sincnet.conv1d.0.filterbank.low_hz_`` ...) so a real state dict can be
+  substituted without touching any other code.
+
+The scales below are not PyTorch's defaults: default init collapses the
+segmentation output to a constant ~0.5, which would never exercise the
+clustering thresholds.  Larger recurrent / classifier gains give activations
+that sweep (0, 1) over time and differ between speakers.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict
+
+import numpy as np
+import torch
+
+SAMPLE_RATE = 16000
+
+
+# --------------------------------------------------------------------------- #
+# audio
+# --------------------------------------------------------------------------- #
+def synth_stream(seed: int, seconds: float, num_speakers: int = 3,
+                 sample_rate: int = SAMPLE_RATE) -> np.ndarray:
+    """One mono float32 stream in [-1, 1], shape (samples,)."""
+    rng = np.random.default_rng(seed)
+    n = int(round(seconds * sample_rate))
+    out = np.zeros(n, dtype=np.float64)
+    t = np.arange(n) / sample_rate
+    hop = sample_rate // 10  # state changes every 100 ms
+    for spk in range(num_speakers):
+        # carrier: noise shaped by a speaker-specific comb of formant-like bands
+        noise = rng.standard_normal(n)
+        spec = np.fft.rfft(noise)
+        freqs = np.fft.rfftfreq(n, 1.0 / sample_rate)
+        env = np.zeros_like(freqs)
+        f0 = 90.0 + 60.0 * spk + 20.0 * rng.random()
+        for c in (f0 * 3, 500 + 230 * spk, 1500 + 310 * spk, 2600 + 170 * spk):
+            env += np.exp(-0.5 * ((freqs - c) / (80.0 + 40.0 * spk)) ** 2)
+        voiced = np.fft.irfft(spec * env, n)
+        voiced /= (np.abs(voiced).max() + 1e-9)
+        voiced *= 0.5 * (1.0 + np.sin(2 * math.pi * f0 * t))  # glottal-ish AM
+        # Markov on/off turns, mean turn ~2 s, mean pause ~3 s
+        state, gate = rng.random() < 0.4, np.zeros(n)
+        for h in range(0, n, hop):
+            p_flip = 0.05 if state else 0.033
+            if rng.random() < p_flip:
+                state = not state
+            gate[h:h + hop] = 1.0 if state else 0.0
+        k = np.hanning(801)
+        gate = np.convolve(gate, k / k.sum(), mode="same")
+        out += 0.35 * gate * voiced
+    out += 0.003 * rng.standard_normal(n)
+    return np.clip(out, -1.0, 1.0).astype(np.float32)
+
+
+def synth_streams(num_streams: int, seconds: float, seed0: int = 0) -> np.ndarray:
+    return np.stack([synth_stream(seed0 + i, seconds) for i in range(num_streams)])
+
+
+def sliding_chunks(stream: np.ndarray, duration: float = 5.0, step: float = 0.5,
+                   sample_rate: int = SAMPLE_RATE) -> np.ndarray:
+    """All full windows of one stream, shape (num_chunks, samples) (a strided view)."""
+    S, H = int(round(duration * sample_rate)), int(round(step * sample_rate))
+    n = (stream.shape[-1] - S) // H + 1
+    return np.lib.stride_tricks.sliding_window_view(stream, S)[::H][:n]
+
+
+# --------------------------------------------------------------------------- #
+# weights
+# --------------------------------------------------------------------------- #
+def _u(g, shape, bound):
+    return (torch.rand(shape, generator=g) * 2 - 1) * bound
+
+
+def _sincnet_state(g: torch.Generator, prefix: str = "sincnet.") -> Dict[str, torch.Tensor]:
+    sd: Dict[str, torch.Tensor] = {}
+    to_mel = lambda hz: 2595.0 * np.log10(1.0 + hz / 700.0)
+    to_hz = lambda mel: 700.0 * (10.0 ** (mel / 2595.0) - 1.0)
+    mel = np.linspace(to_mel(30.0), to_mel(8000.0 - 100.0), 41, dtype="float32")
+    hz = to_hz(mel).astype("float32")
+    low = torch.from_numpy(hz[:-1].copy()).view(-1, 1)
+    band = torch.from_numpy(np.diff(hz).astype("float32")).view(-1, 1)
+    # perturb like a trained bank (a few negative values exercise the abs())
+    low = low * (1.0 + 0.05 * torch.randn(low.shape, generator=g))
+    band = band * (1.0 + 0.10 * torch.randn(band.shape, generator=g))
+    low[3] = -low[3]
+    band[7] = -band[7]
+    sd[prefix + "wav_norm1d.weight"] = torch.tensor([1.0 + 0.2 * torch.randn((), generator=g).item()])
+    sd[prefix + "wav_norm1d.bias"] = torch.tensor([0.05 * torch.randn((), generator=g).item()])
+    sd[prefix + "conv1d.0.filterbank.low_hz_"] = low.float()
+    sd[prefix + "conv1d.0.filterbank.band_hz_"] = band.float()
+    sd[prefix + "conv1d.0.filterbank.window_"] = torch.from_numpy(np.hamming(251)[:125]).float()
+    sd[prefix + "conv1d.0.filterbank.n_"] = (2 * math.pi * torch.arange(-125, 0.0).view(1, -1) / 16000.0)
+    for i, (cin, cout) in ((1, (80, 60)), (2, (60, 60))):
+        b = 1.5 / math.sqrt(cin * 5)
+        sd[prefix + f"conv1d.{i}.weight"] = _u(g, (cout, cin, 5), b)
+        sd[prefix + f"conv1d.{i}.bias"] = _u(g, (cout,), b)
+    for i, c in enumerate((80, 60, 60)):
+        sd[prefix + f"norm1d.{i}.weight"] = 1.0 + 0.3 * _u(g, (c,), 1.0)
+        sd[prefix + f"norm1d.{i}.bias"] = 0.2 * _u(g, (c,), 1.0)
+    return sd
+
+
+def synth_segmentation_state(seed: int = 1234, num_speakers: int = 3,
+                             powerset: bool = False) -> Dict[str, torch.Tensor]:
+    g = torch.Generator().manual_seed(seed)
+    sd = _sincnet_state(g)
+    H = 128
+    for layer in range(4):
+        cin = 60 if layer == 0 else 2 * H
+        for suf in ("", "_reverse"):
+            bi = (2.0 if layer == 0 else 6.0) / math.sqrt(cin)
+            bh = 1.6 / math.sqrt(H)
+            sd[f"lstm.weight_ih_l{layer}{suf}"] = _u(g, (4 * H, cin), bi)
+            sd[f"lstm.weight_hh_l{layer}{suf}"] = _u(g, (4 * H, H), bh)
+            sd[f"lstm.bias_ih_l{layer}{suf}"] = _u(g, (4 * H,), 0.3)
+            sd[f"lstm.bias_hh_l{layer}{suf}"] = _u(g, (4 * H,), 0.3)
+    sd["linear.0.weight"] = _u(g, (128, 256), 5.0 / math.sqrt(256))
+    sd["linear.0.bias"] = _u(g, (128,), 0.1)
+    sd["linear.1.weight"] = _u(g, (128, 128), 4.0 / math.sqrt(128))
+    sd["linear.1.bias"] = _u(g, (128,), 0.1)
+    out = 7 if powerset else num_speakers
+    sd["classifier.weight"] = _u(g, (out, 128), 6.0 / math.sqrt(128))
+    sd["classifier.bias"] = _u(g, (out,), 0.5) - (0.0 if powerset else 0.6)
+    return sd
+
+
+def synth_embedding_state(seed: int = 4321, dimension: int = 512) -> Dict[str, torch.Tensor]:
+    g = torch.Generator().manual_seed(seed)
+    sd = _sincnet_state(g)
+    tdnn = [(60, 512, 5), (512, 512, 3), (512, 512, 3), (512, 512, 1), (512, 1500, 1)]
+    for i, (cin, cout, k) in enumerate(tdnn):
+        b = 1.7 / math.sqrt(cin * k)
+        sd[f"tdnns.{3 * i}.weight"] = _u(g, (cout, cin, k), b)
+        sd[f"tdnns.{3 * i}.bias"] = _u(g, (cout,), b)
+        sd[f"tdnns.{3 * i + 2}.weight"] = 1.0 + 0.3 * _u(g, (cout,), 1.0)
+        sd[f"tdnns.{3 * i + 2}.bias"] = 0.1 * _u(g, (cout,), 1.0)
+        sd[f"tdnns.{3 * i + 2}.running_mean"] = 0.1 * _u(g, (cout,), 1.0)
+        sd[f"tdnns.{3 * i + 2}.running_var"] = 0.6 + 0.8 * torch.rand((cout,), generator=g)
+        sd[f"tdnns.{3 * i + 2}.num_batches_tracked"] = torch.tensor(1000)
+    sd["embedding.weight"] = _u(g, (dimension, 3000), 1.0 / math.sqrt(3000))
+    sd["embedding.bias"] = _u(g, (dimension,), 1.0 / math.sqrt(3000))
+    return sd
