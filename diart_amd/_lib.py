@@ -1,0 +1,135 @@
+"""ctypes binding of ``libdiart_amd.so`` (the C ABI declared in ``include/diart_amd.h``).
+
+There is no CPU fallback: if the shared object is missing or a call fails this module
+raises.  ``load()`` does not need a GPU (the CPU test-suite checks that every declared
+symbol is exported); creating a context does.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from pathlib import Path
+from typing import Optional
+
+_LIB_PATH = Path(__file__).resolve().parent / "libdiart_amd.so"
+_lib: Optional[C.CDLL] = None
+
+c_float_p = C.POINTER(C.c_float)
+c_double_p = C.POINTER(C.c_double)
+c_int_p = C.POINTER(C.c_int)
+vp = C.c_void_p
+
+
+class SincNetWeights(C.Structure):
+    _fields_ = [("wav_gamma", C.c_float), ("wav_beta", C.c_float)] + [
+        (n, vp) for n in ("filt", "in0_g", "in0_b", "w1", "b1", "in1_g", "in1_b",
+                          "w2", "b2", "in2_g", "in2_b")]
+
+
+class SegWeights(C.Structure):
+    _fields_ = [("sinc", SincNetWeights), ("wih", vp * 4), ("bih", vp * 4), ("whh", vp * 4),
+                ("lin0_w", vp), ("lin0_b", vp), ("lin1_w", vp), ("lin1_b", vp),
+                ("cls_w", vp), ("cls_b", vp),
+                ("num_classes", C.c_int), ("powerset", C.c_int), ("num_speakers", C.c_int)]
+
+
+class EmbWeights(C.Structure):
+    _fields_ = [("sinc", SincNetWeights), ("tw", vp * 5), ("tb", vp * 5), ("ts", vp * 5),
+                ("th", vp * 5), ("emb_w", vp), ("emb_b", vp), ("dimension", C.c_int)]
+
+
+# name -> (restype, argtypes); must list every function of include/diart_amd.h
+SIGNATURES = {
+    "dz_last_error": (C.c_char_p, []),
+    "dz_version": (C.c_int, []),
+    "dz_ctx_create": (C.c_int, [C.c_int, C.POINTER(vp)]),
+    "dz_ctx_destroy": (C.c_int, [vp]),
+    "dz_seg_frames_for": (C.c_int, [C.c_int]),
+    "dz_emb_frames_for": (C.c_int, [C.c_int]),
+    "dz_seg_create": (C.c_int, [vp, C.POINTER(SegWeights), C.c_int, C.c_int, C.POINTER(vp)]),
+    "dz_seg_forward": (C.c_int, [vp, vp, C.c_longlong, C.c_int, vp, vp]),
+    "dz_seg_destroy": (C.c_int, [vp]),
+    "dz_emb_create": (C.c_int, [vp, C.POINTER(EmbWeights), C.c_int, C.c_int, C.POINTER(vp)]),
+    "dz_emb_forward": (C.c_int, [vp, vp, C.c_longlong, vp, C.c_int, C.c_int, vp, vp]),
+    "dz_emb_forward_multi": (C.c_int, [vp, vp, C.c_longlong, vp, C.c_int, C.c_int, C.c_int,
+                                       C.c_int, vp, vp]),
+    "dz_emb_destroy": (C.c_int, [vp]),
+    "dz_osp": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_int,
+                         C.c_int, vp, vp]),
+    "dz_l2_normalize": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_float, vp]),
+    "dz_cdist_cosine": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]),
+    "dz_clu_create": (C.c_int, [C.c_double, C.c_double, C.c_double, C.c_int, C.POINTER(vp)]),
+    "dz_clu_reset": (C.c_int, [vp]),
+    "dz_clu_step": (C.c_int, [vp, vp, C.c_int, C.c_int, vp, C.c_int, vp, vp]),
+    "dz_clu_step_batch": (C.c_int, [C.POINTER(vp), C.c_int, vp, C.c_int, C.c_int, vp, C.c_int,
+                                    vp, vp, C.c_int]),
+    "dz_clu_get_centers": (C.c_int, [vp, vp, C.c_int]),
+    "dz_clu_get_active": (C.c_int, [vp, vp]),
+    "dz_clu_dim": (C.c_int, [vp]),
+    "dz_clu_set_state": (C.c_int, [vp, vp, vp, C.c_int]),
+    "dz_clu_destroy": (C.c_int, [vp]),
+    "dz_lsap": (C.c_int, [vp, C.c_int, C.c_int, vp]),
+    # kernel-level entry points
+    "dz_k_convgemm": (C.c_int, [vp, vp, vp]),
+    "dz_k_convgemm_ntile": (C.c_int, [C.c_int]),
+    "dz_k_wave_stats": (C.c_int, [vp, vp, C.c_longlong, C.c_int, C.c_int, vp, vp]),
+    "dz_k_sinc_conv0": (C.c_int, [vp, vp, C.c_longlong, C.c_int, C.c_int, vp, C.c_float,
+                                  C.c_float, vp, vp, vp, vp]),
+    "dz_k_finalize_norm": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp]),
+    "dz_k_lstm": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, vp]),
+    "dz_k_stats_pool": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, vp, C.c_int, C.c_int,
+                                  C.c_int, vp, C.c_int, vp]),
+    "dz_k_powerset": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, vp, vp]),
+}
+
+
+class ConvGemmDesc(C.Structure):
+    _fields_ = [(n, vp) for n in ("X", "W", "bias", "e0", "e1", "nscale", "nshift", "Y", "partials")] + [
+        (n, C.c_int) for n in ("B", "Tin", "Tout", "Cin", "taps", "dil", "K", "Kpad", "Npad",
+                               "Nstore", "ldx", "ldy", "nld", "Tstore")] + [
+        ("xbs", C.c_longlong), ("ybs", C.c_longlong), ("norm_on_load", C.c_int), ("epi", C.c_int)]
+
+
+EPI_BIAS, EPI_BIAS_LEAKY, EPI_BIAS_SIGMOID, EPI_TDNN, EPI_POOL3 = range(5)
+
+
+class DiartAmdError(RuntimeError):
+    pass
+
+
+def lib_path() -> Path:
+    return _LIB_PATH
+
+
+def load() -> C.CDLL:
+    """dlopen the library and attach prototypes.  Raises if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not _LIB_PATH.exists():
+            raise DiartAmdError(
+                f"{_LIB_PATH} not found: build it with `python -m diart_amd.build` "
+                "(hipcc, gfx950).  diart_amd has no CPU fallback.")
+        lib = C.CDLL(str(_LIB_PATH))
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)  # AttributeError if a declared symbol is missing
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        msg = load().dz_last_error().decode("utf-8", "replace")
+        raise DiartAmdError(f"{what or 'libdiart_amd'} failed (code {rc}): {msg}")
+
+
+_contexts = {}
+
+
+def context(device_index: int) -> vp:
+    """One dz_ctx per (process, GPU)."""
+    if device_index not in _contexts:
+        h = vp()
+        check(load().dz_ctx_create(int(device_index), C.byref(h)), "dz_ctx_create")
+        _contexts[device_index] = h
+    return _contexts[device_index]

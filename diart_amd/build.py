@@ -1,0 +1,66 @@
+"""Build libdiart_amd.so in-tree with hipcc for gfx950 (no cmake, no JIT cache).
+
+``python -m diart_amd.build`` or ``diart_amd.build.build()``.  The shared object is
+written next to this file so it travels with the repository snapshot to the GPU box.
+"""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+from pathlib import Path
+
+HERE = Path(__file__).resolve().parent
+CSRC = HERE / "csrc"
+LIB = HERE / "libdiart_amd.so"
+SOURCES = ["api.hip", "k_front.hip", "k_convgemm.hip", "k_lstm.hip", "k_pool.hip", "cluster.cpp"]
+ARCH = "gfx950"
+
+
+def _hipcc() -> str:
+    for cand in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and Path(cand).exists():
+            return cand
+    raise RuntimeError("hipcc not found (set HIPCC)")
+
+
+def _stale(out: Path, deps) -> bool:
+    if not out.exists():
+        return True
+    t = out.stat().st_mtime
+    return any(Path(d).stat().st_mtime > t for d in deps)
+
+
+def build(force: bool = False, verbose: bool = False) -> Path:
+    hipcc = _hipcc()
+    objdir = HERE / "build"
+    objdir.mkdir(exist_ok=True)
+    headers = [CSRC / "dz_common.h", HERE.parent / "include" / "diart_amd.h"]
+    flags = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function"]
+
+    def compile_one(src: str) -> Path:
+        s = CSRC / src
+        o = objdir / (s.stem + ".o")
+        if force or _stale(o, [s, *headers]):
+            cmd = [hipcc, *flags, "-x", "hip", "-c", str(s), "-o", str(o)]
+            r = subprocess.run(cmd, capture_output=True, text=True)
+            if r.returncode != 0:
+                raise RuntimeError(f"hipcc failed on {src}:\n{r.stderr}")
+            if verbose and r.stderr.strip():
+                print(r.stderr, file=sys.stderr)
+        return o
+
+    with ThreadPoolExecutor(max_workers=len(SOURCES)) as ex:
+        objs = list(ex.map(compile_one, SOURCES))
+    if force or _stale(LIB, objs):
+        cmd = [hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", *map(str, objs), "-o", str(LIB), "-lpthread"]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"link failed:\n{r.stderr}")
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

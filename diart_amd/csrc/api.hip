@@ -1,0 +1,515 @@
+// C-ABI entry points of libdiart_amd.so (see include/diart_amd.h) and the launch sequences
+// of the two networks.  Everything here is host code driving the kernels in k_*.hip.
+#include "dz_common.h"
+
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+#include <new>
+
+// ---------------------------------------------------------------------------
+// errors
+// ---------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+void dz_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+extern "C" const char* dz_last_error(void) { return g_err; }
+extern "C" int dz_version(void) { return DZ_VERSION; }
+
+// ---------------------------------------------------------------------------
+// context + scratch arena
+// ---------------------------------------------------------------------------
+struct dz_ctx {
+    int device;
+};
+
+struct Arena {
+    char* base = nullptr;
+    size_t size = 0, used = 0;
+    // first pass (base == nullptr) only measures
+    float* take(size_t nfloats) {
+        const size_t bytes = (nfloats * sizeof(float) + 255) & ~size_t(255);
+        float* p = base ? reinterpret_cast<float*>(base + used) : nullptr;
+        used += bytes;
+        return p;
+    }
+};
+
+extern "C" int dz_ctx_create(int hip_device, dz_ctx** out) {
+    DZ_REQUIRE(out != nullptr, "dz_ctx_create: out is NULL");
+    int n = 0;
+    DZ_HIP(hipGetDeviceCount(&n));
+    DZ_REQUIRE(hip_device >= 0 && hip_device < n, "dz_ctx_create: device %d of %d", hip_device, n);
+    hipDeviceProp_t prop;
+    DZ_HIP(hipGetDeviceProperties(&prop, hip_device));
+    DZ_REQUIRE(strncmp(prop.gcnArchName, "gfx950", 6) == 0,
+               "dz_ctx_create: device %d is %s, this library is built for gfx950 only", hip_device,
+               prop.gcnArchName);
+    dz_ctx* c = new (std::nothrow) dz_ctx;
+    DZ_REQUIRE(c != nullptr, "dz_ctx_create: out of memory");
+    c->device = hip_device;
+    *out = c;
+    return 0;
+}
+extern "C" int dz_ctx_destroy(dz_ctx* ctx) {
+    delete ctx;
+    return 0;
+}
+
+// ---------------------------------------------------------------------------
+// geometry of the SincNet front-end for S samples
+// ---------------------------------------------------------------------------
+struct SincGeom {
+    int S, F0, P0, T1, P1, T2, P2;  // conv frames / pooled frames per stage
+    int nt0, nt1, nt2;              // tiles carrying instance-norm partials
+    bool ok;
+};
+static SincGeom sinc_geom(int S) {
+    SincGeom g;
+    memset(&g, 0, sizeof(g));
+    g.S = S;
+    if (S < 251) return g;
+    g.F0 = (S - 251) / 10 + 1;
+    g.P0 = g.F0 / 3;
+    g.T1 = g.P0 - 4;
+    g.P1 = g.T1 > 0 ? g.T1 / 3 : 0;
+    g.T2 = g.P1 - 4;
+    g.P2 = g.T2 > 0 ? g.T2 / 3 : 0;
+    g.nt0 = (g.F0 + 191) / 192;
+    g.nt1 = g.T1 > 0 ? dz_convgemm_ntile(g.T1) : 0;
+    g.nt2 = g.T2 > 0 ? dz_convgemm_ntile(g.T2) : 0;
+    g.ok = g.P2 > 0;
+    return g;
+}
+extern "C" int dz_seg_frames_for(int num_samples) { return sinc_geom(num_samples).P2; }
+extern "C" int dz_emb_frames_for(int num_samples) {
+    const int f = sinc_geom(num_samples).P2 - 4 - 4 - 6;
+    return f > 0 ? f : 0;
+}
+
+struct SincScratch {
+    float *stats, *y0, *part0, *sc0, *sh0, *y1, *part1, *sc1, *sh1, *y2, *part2, *sc2, *sh2;
+    void carve(Arena& a, const SincGeom& g, int Bm) {
+        stats = a.take((size_t)Bm * 2);
+        y0 = a.take((size_t)Bm * g.P0 * 80);
+        part0 = a.take((size_t)Bm * g.nt0 * 80 * 2);
+        sc0 = a.take((size_t)Bm * 80);
+        sh0 = a.take((size_t)Bm * 80);
+        y1 = a.take((size_t)Bm * g.P1 * 64);
+        part1 = a.take((size_t)Bm * g.nt1 * 64 * 2);
+        sc1 = a.take((size_t)Bm * 64);
+        sh1 = a.take((size_t)Bm * 64);
+        y2 = a.take((size_t)Bm * g.P2 * 64);
+        part2 = a.take((size_t)Bm * g.nt2 * 64 * 2);
+        sc2 = a.take((size_t)Bm * 64);
+        sh2 = a.take((size_t)Bm * 64);
+    }
+};
+
+// wave -> y2 [B][P2][64] (pre-norm) + sc2/sh2: the consumer applies InstanceNorm + LeakyReLU
+// on load.  7 launches.
+static int run_sincnet(const dz_sincnet_weights& w, const SincGeom& g, const SincScratch& s,
+                       const float* wave, long long stride, int B, hipStream_t st) {
+    int rc;
+    if ((rc = dz_launch_wave_stats(wave, stride, B, g.S, s.stats, st))) return rc;
+    if ((rc = dz_launch_sinc_conv0(wave, stride, B, g.S, s.stats, w.wav_gamma, w.wav_beta, w.filt,
+                                   s.y0, g.P0, s.part0, g.nt0, st)))
+        return rc;
+    if ((rc = dz_launch_finalize_norm(s.part0, B, g.nt0, 80, g.P0, w.in0_g, w.in0_b, s.sc0, s.sh0,
+                                      st)))
+        return rc;
+    DzConvGemm p;
+    memset(&p, 0, sizeof(p));
+    // conv1: 80 -> 60(64), k5, + pool3
+    p.X = s.y0; p.W = w.w1; p.bias = w.b1; p.nscale = s.sc0; p.nshift = s.sh0; p.nld = 80;
+    p.Y = s.y1; p.partials = s.part1;
+    p.B = B; p.Tin = g.P0; p.Tout = g.T1; p.Cin = 80; p.taps = 5; p.dil = 1; p.K = 400;
+    p.Kpad = 416; p.Npad = 64; p.Nstore = 64; p.ldx = 80; p.ldy = 64; p.Tstore = g.P1;
+    p.xbs = (long long)g.P0 * 80; p.ybs = (long long)g.P1 * 64;
+    p.norm_on_load = 1; p.epi = DZ_EPI_POOL3;
+    if ((rc = dz_launch_convgemm(p, st))) return rc;
+    if ((rc = dz_launch_finalize_norm(s.part1, B, g.nt1, 64, g.P1, w.in1_g, w.in1_b, s.sc1, s.sh1,
+                                      st)))
+        return rc;
+    // conv2: 60(64) -> 60(64), k5, + pool3
+    p.X = s.y1; p.W = w.w2; p.bias = w.b2; p.nscale = s.sc1; p.nshift = s.sh1; p.nld = 64;
+    p.Y = s.y2; p.partials = s.part2;
+    p.Tin = g.P1; p.Tout = g.T2; p.Cin = 64; p.K = 320; p.Kpad = 320; p.ldx = 64;
+    p.Tstore = g.P2; p.xbs = (long long)g.P1 * 64; p.ybs = (long long)g.P2 * 64;
+    if ((rc = dz_launch_convgemm(p, st))) return rc;
+    return dz_launch_finalize_norm(s.part2, B, g.nt2, 64, g.P2, w.in2_g, w.in2_b, s.sc2, s.sh2, st);
+}
+
+static int check_wave(const char* who, const float* d_wave, long long stride, int S) {
+    DZ_REQUIRE(d_wave != nullptr, "%s: d_wave is NULL", who);
+    DZ_REQUIRE(((uintptr_t)d_wave & 15) == 0 && (stride & 3) == 0,
+               "%s: waveform rows must be 16-byte aligned (ptr %p, stride %lld)", who,
+               (const void*)d_wave, stride);
+    DZ_REQUIRE(stride >= 0, "%s: negative stride", who);
+    (void)S;
+    return 0;
+}
+
+// ---------------------------------------------------------------------------
+// segmentation
+// ---------------------------------------------------------------------------
+struct dz_seg {
+    dz_ctx* ctx;
+    dz_seg_weights w;
+    SincGeom g;
+    int Bm;
+    char* arena;
+    SincScratch ss;
+    float *gx, *h0, *h1, *m0, *m1, *logit;
+};
+
+static void seg_carve(dz_seg* s, Arena& a) {
+    const size_t rows = (size_t)s->Bm * s->g.P2;
+    s->ss.carve(a, s->g, s->Bm);
+    s->gx = a.take(rows * 1024);
+    s->h0 = a.take(rows * 256);
+    s->h1 = a.take(rows * 256);
+    s->m0 = a.take(rows * 128);
+    s->m1 = a.take(rows * 128);
+    s->logit = a.take(rows * 8);
+}
+
+extern "C" int dz_seg_create(dz_ctx* ctx, const dz_seg_weights* w, int max_batch, int num_samples,
+                             dz_seg** out) {
+    DZ_REQUIRE(ctx && w && out, "dz_seg_create: NULL argument");
+    DZ_REQUIRE(max_batch >= 1, "dz_seg_create: max_batch %d", max_batch);
+    const SincGeom g = sinc_geom(num_samples);
+    DZ_REQUIRE(g.ok, "dz_seg_create: %d samples is too short for SincNet", num_samples);
+    DZ_REQUIRE(w->num_classes >= 1 && w->num_classes <= 8, "dz_seg_create: num_classes %d",
+               w->num_classes);
+    if (w->powerset)
+        DZ_REQUIRE(w->num_classes == 1 + w->num_speakers + w->num_speakers * (w->num_speakers - 1) / 2,
+                   "dz_seg_create: powerset with %d classes / %d speakers", w->num_classes,
+                   w->num_speakers);
+    DZ_HIP(hipSetDevice(ctx->device));
+    dz_seg* s = new (std::nothrow) dz_seg;
+    DZ_REQUIRE(s != nullptr, "dz_seg_create: out of memory");
+    s->ctx = ctx; s->w = *w; s->g = g; s->Bm = max_batch; s->arena = nullptr;
+    Arena measure;
+    seg_carve(s, measure);
+    hipError_t e = hipMalloc((void**)&s->arena, measure.used);
+    if (e != hipSuccess) {
+        dz_set_error("dz_seg_create: hipMalloc(%zu) failed: %s", measure.used, hipGetErrorString(e));
+        delete s;
+        return 1;
+    }
+    DZ_HIP(hipMemset(s->arena, 0, measure.used));
+    Arena real;
+    real.base = s->arena; real.size = measure.used;
+    seg_carve(s, real);
+    *out = s;
+    return 0;
+}
+
+extern "C" int dz_seg_destroy(dz_seg* seg) {
+    if (seg) {
+        if (seg->arena) hipFree(seg->arena);
+        delete seg;
+    }
+    return 0;
+}
+
+extern "C" int dz_seg_forward(dz_seg* s, const float* d_wave, long long wave_stride, int B,
+                              float* d_out, void* stream) {
+    DZ_REQUIRE(s && d_out, "dz_seg_forward: NULL argument");
+    DZ_REQUIRE(B >= 1 && B <= s->Bm, "dz_seg_forward: batch %d outside [1, %d]", B, s->Bm);
+    int rc;
+    if ((rc = check_wave("dz_seg_forward", d_wave, wave_stride, s->g.S))) return rc;
+    DZ_HIP(hipSetDevice(s->ctx->device));
+    hipStream_t st = (hipStream_t)stream;
+    const int F = s->g.P2;
+    if ((rc = run_sincnet(s->w.sinc, s->g, s->ss, d_wave, wave_stride, B, st))) return rc;
+
+    // 4 x { x-projection of both directions as one GEMM (N = 1024); persistent recurrence }
+    const float* lin = nullptr;
+    for (int layer = 0; layer < 4; ++layer) {
+        DzConvGemm p;
+        memset(&p, 0, sizeof(p));
+        p.W = s->w.wih[layer]; p.bias = s->w.bih[layer]; p.Y = s->gx;
+        p.taps = 1; p.dil = 1; p.Npad = 1024; p.Nstore = 1024; p.ldy = 1024; p.epi = DZ_EPI_BIAS;
+        if (layer == 0) {
+            p.X = s->ss.y2; p.nscale = s->ss.sc2; p.nshift = s->ss.sh2; p.nld = 64;
+            p.norm_on_load = 1;
+            p.B = B; p.Tin = p.Tout = p.Tstore = F; p.Cin = 64; p.K = 64; p.Kpad = 64; p.ldx = 64;
+            p.xbs = (long long)F * 64; p.ybs = (long long)F * 1024;
+        } else {
+            p.X = lin;
+            p.B = 1; p.Tin = p.Tout = p.Tstore = B * F; p.Cin = 256; p.K = 256; p.Kpad = 256;
+            p.ldx = 256;
+        }
+        if ((rc = dz_launch_convgemm(p, st))) return rc;
+        float* hout = (layer & 1) ? s->h1 : s->h0;
+        if ((rc = dz_launch_lstm(s->gx, s->w.whh[layer], hout, B, F, st))) return rc;
+        lin = hout;
+    }
+    // Linear(256,128)+leaky, Linear(128,128)+leaky, classifier
+    DzConvGemm p;
+    memset(&p, 0, sizeof(p));
+    p.B = 1; p.Tin = p.Tout = p.Tstore = B * F; p.taps = 1; p.dil = 1;
+    p.X = lin; p.W = s->w.lin0_w; p.bias = s->w.lin0_b; p.Y = s->m0;
+    p.Cin = 256; p.K = 256; p.Kpad = 256; p.ldx = 256; p.Npad = 128; p.Nstore = 128; p.ldy = 128;
+    p.epi = DZ_EPI_BIAS_LEAKY;
+    if ((rc = dz_launch_convgemm(p, st))) return rc;
+    p.X = s->m0; p.W = s->w.lin1_w; p.bias = s->w.lin1_b; p.Y = s->m1;
+    p.Cin = 128; p.K = 128; p.Kpad = 128; p.ldx = 128;
+    if ((rc = dz_launch_convgemm(p, st))) return rc;
+    p.X = s->m1; p.W = s->w.cls_w; p.bias = s->w.cls_b;
+    p.Npad = 64; p.Nstore = s->w.num_classes; p.ldy = s->w.num_classes;
+    if (s->w.powerset) {
+        // log_softmax is monotone: argmax of the logits == argmax of the log-probabilities
+        p.Y = s->logit; p.epi = DZ_EPI_BIAS;
+        if ((rc = dz_launch_convgemm(p, st))) return rc;
+        return dz_launch_powerset(s->logit, B * F, s->w.num_classes, s->w.num_speakers, d_out, st);
+    }
+    p.Y = d_out; p.epi = DZ_EPI_BIAS_SIGMOID;
+    return dz_launch_convgemm(p, st);
+}
+
+// ---------------------------------------------------------------------------
+// embedding
+// ---------------------------------------------------------------------------
+struct dz_emb {
+    dz_ctx* ctx;
+    dz_emb_weights w;
+    SincGeom g;
+    int Bm, T[5];
+    char* arena;
+    SincScratch ss;
+    float *a, *b, *x5, *pooled;
+};
+static const int kTdnnTaps[5] = {5, 3, 3, 1, 1};
+static const int kTdnnDil[5] = {1, 2, 3, 1, 1};
+static const int kPoolLd = 3008;
+static const int kMaxSpk = 8;
+
+static void emb_carve(dz_emb* e, Arena& a) {
+    e->ss.carve(a, e->g, e->Bm);
+    e->a = a.take((size_t)e->Bm * e->T[0] * 512);
+    e->b = a.take((size_t)e->Bm * e->T[0] * 512);
+    e->x5 = a.take((size_t)e->Bm * e->T[4] * 1536);
+    e->pooled = a.take((size_t)e->Bm * kMaxSpk * kPoolLd);
+}
+
+extern "C" int dz_emb_create(dz_ctx* ctx, const dz_emb_weights* w, int max_batch, int num_samples,
+                             dz_emb** out) {
+    DZ_REQUIRE(ctx && w && out, "dz_emb_create: NULL argument");
+    DZ_REQUIRE(max_batch >= 1, "dz_emb_create: max_batch %d", max_batch);
+    DZ_REQUIRE(w->dimension == 512, "dz_emb_create: dimension %d (only 512 is built)", w->dimension);
+    const SincGeom g = sinc_geom(num_samples);
+    DZ_REQUIRE(g.ok && g.P2 > 14, "dz_emb_create: %d samples is too short", num_samples);
+    DZ_HIP(hipSetDevice(ctx->device));
+    dz_emb* e = new (std::nothrow) dz_emb;
+    DZ_REQUIRE(e != nullptr, "dz_emb_create: out of memory");
+    e->ctx = ctx; e->w = *w; e->g = g; e->Bm = max_batch; e->arena = nullptr;
+    int t = g.P2;
+    for (int i = 0; i < 5; ++i) {
+        t -= (kTdnnTaps[i] - 1) * kTdnnDil[i];
+        e->T[i] = t;
+    }
+    Arena measure;
+    emb_carve(e, measure);
+    hipError_t err = hipMalloc((void**)&e->arena, measure.used);
+    if (err != hipSuccess) {
+        dz_set_error("dz_emb_create: hipMalloc(%zu) failed: %s", measure.used, hipGetErrorString(err));
+        delete e;
+        return 1;
+    }
+    DZ_HIP(hipMemset(e->arena, 0, measure.used));
+    Arena real;
+    real.base = e->arena; real.size = measure.used;
+    emb_carve(e, real);
+    *out = e;
+    return 0;
+}
+
+extern "C" int dz_emb_destroy(dz_emb* emb) {
+    if (emb) {
+        if (emb->arena) hipFree(emb->arena);
+        delete emb;
+    }
+    return 0;
+}
+
+// frame features: wave (B) -> x5 [B][T5][1536]
+static int emb_frames(dz_emb* e, const float* d_wave, long long stride, int B, hipStream_t st) {
+    int rc;
+    if ((rc = run_sincnet(e->w.sinc, e->g, e->ss, d_wave, stride, B, st))) return rc;
+    const int cin[5] = {64, 512, 512, 512, 512};
+    const int npad[5] = {512, 512, 512, 512, 1536};
+    const float* in = e->ss.y2;
+    int tin = e->g.P2;
+    for (int i = 0; i < 5; ++i) {
+        DzConvGemm p;
+        memset(&p, 0, sizeof(p));
+        float* outp = (i == 4) ? e->x5 : ((i & 1) ? e->b : e->a);
+        p.X = in; p.W = e->w.tw[i]; p.bias = e->w.tb[i]; p.e0 = e->w.ts[i]; p.e1 = e->w.th[i];
+        p.Y = outp;
+        p.B = B; p.Tin = tin; p.Tout = p.Tstore = e->T[i]; p.Cin = cin[i]; p.taps = kTdnnTaps[i];
+        p.dil = kTdnnDil[i]; p.K = cin[i] * kTdnnTaps[i]; p.Kpad = (p.K + 31) / 32 * 32;
+        p.Npad = npad[i]; p.Nstore = npad[i]; p.ldx = cin[i]; p.ldy = npad[i];
+        p.xbs = (long long)tin * cin[i]; p.ybs = (long long)e->T[i] * npad[i];
+        p.epi = DZ_EPI_TDNN;
+        if (i == 0) {
+            p.nscale = e->ss.sc2; p.nshift = e->ss.sh2; p.nld = 64; p.norm_on_load = 1;
+        }
+        if ((rc = dz_launch_convgemm(p, st))) return rc;
+        in = outp;
+        tin = e->T[i];
+    }
+    return 0;
+}
+
+static int emb_head(dz_emb* e, const float* d_weights, int Fw, int rows, int rows_per_x,
+                    int normalize, float* d_out, hipStream_t st) {
+    int rc;
+    if ((rc = dz_launch_stats_pool(e->x5, e->T[4], 1500, 1536, d_weights, Fw, rows, rows_per_x,
+                                   e->pooled, kPoolLd, st)))
+        return rc;
+    DzConvGemm p;
+    memset(&p, 0, sizeof(p));
+    p.X = e->pooled; p.W = e->w.emb_w; p.bias = e->w.emb_b; p.Y = d_out;
+    p.B = 1; p.Tin = p.Tout = p.Tstore = rows; p.Cin = kPoolLd; p.taps = 1; p.dil = 1;
+    p.K = kPoolLd; p.Kpad = kPoolLd; p.Npad = 512; p.Nstore = 512; p.ldx = kPoolLd; p.ldy = 512;
+    p.epi = DZ_EPI_BIAS;
+    if ((rc = dz_launch_convgemm(p, st))) return rc;
+    if (normalize) return dz_launch_l2norm(d_out, rows, 512, 1.f, st);
+    return 0;
+}
+
+extern "C" int dz_emb_forward(dz_emb* e, const float* d_wave, long long wave_stride,
+                              const float* d_weights, int n_rows, int weight_frames, float* d_out,
+                              void* stream) {
+    DZ_REQUIRE(e && d_out, "dz_emb_forward: NULL argument");
+    DZ_REQUIRE(n_rows >= 1 && n_rows <= e->Bm, "dz_emb_forward: %d rows outside [1, %d]", n_rows,
+               e->Bm);
+    DZ_REQUIRE(d_weights == nullptr || weight_frames >= 2, "dz_emb_forward: weight_frames %d",
+               weight_frames);
+    int rc;
+    if ((rc = check_wave("dz_emb_forward", d_wave, wave_stride, e->g.S))) return rc;
+    DZ_HIP(hipSetDevice(e->ctx->device));
+    hipStream_t st = (hipStream_t)stream;
+    if ((rc = emb_frames(e, d_wave, wave_stride, n_rows, st))) return rc;
+    return emb_head(e, d_weights, d_weights ? weight_frames : e->T[4], n_rows, 1, 0, d_out, st);
+}
+
+extern "C" int dz_emb_forward_multi(dz_emb* e, const float* d_wave, long long wave_stride,
+                                    const float* d_weights, int batch, int num_speakers,
+                                    int weight_frames, int normalize, float* d_out, void* stream) {
+    DZ_REQUIRE(e && d_out && d_weights, "dz_emb_forward_multi: NULL argument");
+    DZ_REQUIRE(batch >= 1 && batch <= e->Bm, "dz_emb_forward_multi: batch %d outside [1, %d]",
+               batch, e->Bm);
+    DZ_REQUIRE(num_speakers >= 1 && num_speakers <= kMaxSpk,
+               "dz_emb_forward_multi: %d speakers outside [1, %d]", num_speakers, kMaxSpk);
+    DZ_REQUIRE(weight_frames >= 2, "dz_emb_forward_multi: weight_frames %d", weight_frames);
+    int rc;
+    if ((rc = check_wave("dz_emb_forward_multi", d_wave, wave_stride, e->g.S))) return rc;
+    DZ_HIP(hipSetDevice(e->ctx->device));
+    hipStream_t st = (hipStream_t)stream;
+    if ((rc = emb_frames(e, d_wave, wave_stride, batch, st))) return rc;
+    return emb_head(e, d_weights, weight_frames, batch * num_speakers, num_speakers, normalize,
+                    d_out, st);
+}
+
+// ---------------------------------------------------------------------------
+// small ops
+// ---------------------------------------------------------------------------
+extern "C" int dz_osp(dz_ctx* ctx, const float* d_seg, int batch, int frames, int speakers,
+                      float gamma, float beta, int normalize, int speaker_major, float* d_out,
+                      void* stream) {
+    DZ_REQUIRE(ctx && d_seg && d_out, "dz_osp: NULL argument");
+    DZ_REQUIRE(batch >= 1 && frames >= 1, "dz_osp: empty input");
+    DZ_HIP(hipSetDevice(ctx->device));
+    return dz_launch_osp(d_seg, batch, frames, speakers, gamma, beta, normalize, speaker_major,
+                         d_out, (hipStream_t)stream);
+}
+
+extern "C" int dz_l2_normalize(dz_ctx* ctx, float* d_emb, int rows, int dim, float norm,
+                               void* stream) {
+    DZ_REQUIRE(ctx && d_emb, "dz_l2_normalize: NULL argument");
+    DZ_REQUIRE(rows >= 1 && dim >= 1, "dz_l2_normalize: empty input");
+    DZ_HIP(hipSetDevice(ctx->device));
+    return dz_launch_l2norm(d_emb, rows, dim, norm, (hipStream_t)stream);
+}
+
+extern "C" int dz_cdist_cosine(dz_ctx* ctx, const float* d_emb, const double* d_centers,
+                               int n_streams, int k_local, int g_global, int dim, double* d_out,
+                               void* stream) {
+    DZ_REQUIRE(ctx && d_emb && d_centers && d_out, "dz_cdist_cosine: NULL argument");
+    DZ_REQUIRE(n_streams >= 1 && k_local >= 1 && g_global >= 1 && dim >= 1,
+               "dz_cdist_cosine: empty input");
+    DZ_HIP(hipSetDevice(ctx->device));
+    return dz_launch_cdist(d_emb, d_centers, n_streams, k_local, g_global, dim, d_out,
+                           (hipStream_t)stream);
+}
+
+// ---------------------------------------------------------------------------
+// kernel-level entry points (parity tests)
+// ---------------------------------------------------------------------------
+extern "C" int dz_k_convgemm(dz_ctx* ctx, const dz_convgemm_desc* d, void* stream) {
+    DZ_REQUIRE(ctx && d, "dz_k_convgemm: NULL argument");
+    DZ_HIP(hipSetDevice(ctx->device));
+    return dz_launch_convgemm(*d, (hipStream_t)stream);
+}
+extern "C" int dz_k_convgemm_ntile(int t_out) { return dz_convgemm_ntile(t_out); }
+extern "C" int dz_k_wave_stats(dz_ctx* ctx, const float* d_wave, long long stride, int batch,
+                               int samples, float* d_stats, void* stream) {
+    DZ_REQUIRE(ctx && d_stats, "dz_k_wave_stats: NULL argument");
+    int rc;
+    if ((rc = check_wave("dz_k_wave_stats", d_wave, stride, samples))) return rc;
+    DZ_HIP(hipSetDevice(ctx->device));
+    return dz_launch_wave_stats(d_wave, stride, batch, samples, d_stats, (hipStream_t)stream);
+}
+extern "C" int dz_k_sinc_conv0(dz_ctx* ctx, const float* d_wave, long long stride, int batch,
+                               int samples, const float* d_stats, float gamma, float beta,
+                               const float* d_filt, float* d_y0, float* d_partials, void* stream) {
+    DZ_REQUIRE(ctx && d_stats && d_filt && d_y0 && d_partials, "dz_k_sinc_conv0: NULL argument");
+    int rc;
+    if ((rc = check_wave("dz_k_sinc_conv0", d_wave, stride, samples))) return rc;
+    const SincGeom g = sinc_geom(samples);
+    DZ_REQUIRE(g.P0 > 0, "dz_k_sinc_conv0: %d samples is too short", samples);
+    DZ_HIP(hipSetDevice(ctx->device));
+    return dz_launch_sinc_conv0(d_wave, stride, batch, samples, d_stats, gamma, beta, d_filt, d_y0,
+                                g.P0, d_partials, g.nt0, (hipStream_t)stream);
+}
+extern "C" int dz_k_finalize_norm(dz_ctx* ctx, const float* d_partials, int batch, int ntile,
+                                  int channels, int frames, const float* d_gamma,
+                                  const float* d_beta, float* d_scale, float* d_shift,
+                                  void* stream) {
+    DZ_REQUIRE(ctx && d_partials && d_gamma && d_beta && d_scale && d_shift,
+               "dz_k_finalize_norm: NULL argument");
+    DZ_HIP(hipSetDevice(ctx->device));
+    return dz_launch_finalize_norm(d_partials, batch, ntile, channels, frames, d_gamma, d_beta,
+                                   d_scale, d_shift, (hipStream_t)stream);
+}
+extern "C" int dz_k_lstm(dz_ctx* ctx, const float* d_gx, const float* d_whh, float* d_hout,
+                         int batch, int frames, void* stream) {
+    DZ_REQUIRE(ctx && d_gx && d_whh && d_hout, "dz_k_lstm: NULL argument");
+    DZ_REQUIRE(batch >= 1 && frames >= 1, "dz_k_lstm: empty input");
+    DZ_HIP(hipSetDevice(ctx->device));
+    return dz_launch_lstm(d_gx, d_whh, d_hout, batch, frames, (hipStream_t)stream);
+}
+extern "C" int dz_k_stats_pool(dz_ctx* ctx, const float* d_x, int frames, int channels, int ldx,
+                               const float* d_weights, int weight_frames, int rows,
+                               int rows_per_x, float* d_out, int ldo, void* stream) {
+    DZ_REQUIRE(ctx && d_x && d_out, "dz_k_stats_pool: NULL argument");
+    DZ_REQUIRE(rows >= 1 && rows_per_x >= 1 && frames >= 2, "dz_k_stats_pool: empty input");
+    DZ_HIP(hipSetDevice(ctx->device));
+    return dz_launch_stats_pool(d_x, frames, channels, ldx, d_weights,
+                                d_weights ? weight_frames : frames, rows, rows_per_x, d_out, ldo,
+                                (hipStream_t)stream);
+}
+extern "C" int dz_k_powerset(dz_ctx* ctx, const float* d_logits, int rows, int classes,
+                             int speakers, float* d_out, void* stream) {
+    DZ_REQUIRE(ctx && d_logits && d_out, "dz_k_powerset: NULL argument");
+    DZ_HIP(hipSetDevice(ctx->device));
+    return dz_launch_powerset(d_logits, rows, classes, speakers, d_out, (hipStream_t)stream);
+}

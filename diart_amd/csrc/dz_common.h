@@ -1,0 +1,74 @@
+// Shared declarations for libdiart_amd (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+#include "../../include/diart_amd.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// v_mfma_f32_16x16x4_f32: exact-f32 matrix FMA, 32 cycles/SIMD issue (MI355X_MICROARCH.md).
+// Lane l supplies A[i=l&15][k=l>>4] and B[k=l>>4][j=l&15]; D: col j=l&15, rows 4*(l>>4)+r.
+#define DZ_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+
+#define DZ_LEAKY_SLOPE 0.01f
+
+// ---------------------------------------------------------------------------
+// error plumbing (api.hip)
+// ---------------------------------------------------------------------------
+void dz_set_error(const char* fmt, ...);
+#define DZ_HIP(expr)                                                                     \
+    do {                                                                                 \
+        hipError_t _e = (expr);                                                          \
+        if (_e != hipSuccess) {                                                          \
+            dz_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, \
+                         __LINE__);                                                      \
+            return 1;                                                                    \
+        }                                                                                \
+    } while (0)
+#define DZ_REQUIRE(cond, ...)           \
+    do {                                \
+        if (!(cond)) {                  \
+            dz_set_error(__VA_ARGS__);  \
+            return 2;                   \
+        }                               \
+    } while (0)
+
+// ---------------------------------------------------------------------------
+// kernel launch wrappers (one per .hip file)
+// ---------------------------------------------------------------------------
+// k_front.hip ---------------------------------------------------------------
+// per-chunk mean / rstd of the raw waveform -> stats[B][2]
+int dz_launch_wave_stats(const float* wave, long long stride, int B, int S, float* stats,
+                         hipStream_t st);
+// InstanceNorm(1)+sinc conv(80x251, stride 10)+abs+maxpool3 -> y0[B][P0][80], partials
+int dz_launch_sinc_conv0(const float* wave, long long stride, int B, int S, const float* stats,
+                         float gamma, float beta, const float* filt, float* y0, int P0,
+                         float* partials, int ntile, hipStream_t st);
+// partial (sum,sumsq) -> per (b,c) scale/shift of InstanceNorm1d(C, affine)
+int dz_launch_finalize_norm(const float* partials, int B, int ntile, int C, int T,
+                            const float* gamma, const float* beta, float* scale, float* shift,
+                            hipStream_t st);
+
+// k_convgemm.hip ------------------------------------------------------------
+typedef dz_convgemm_desc DzConvGemm;
+int dz_launch_convgemm(const DzConvGemm& p, hipStream_t st);
+int dz_convgemm_ntile(int Tout);
+
+// k_lstm.hip ----------------------------------------------------------------
+// gx [B*T][1024] (dir*512+gate*128+unit, biases included), whh [2][512][128]
+// -> hout [B][T][256] (fwd | bwd)
+int dz_launch_lstm(const float* gx, const float* whh, float* hout, int B, int T, hipStream_t st);
+
+// k_pool.hip ----------------------------------------------------------------
+// weighted statistics pooling; X [nx][T][ldx] (C valid channels), weights [rows][Fw] or null,
+// row r pools X[r / rows_per_x]; out [rows][ldo] = mean | std (std at column C)
+int dz_launch_stats_pool(const float* X, int T, int C, int ldx, const float* weights, int Fw,
+                         int rows, int rows_per_x, float* out, int ldo, hipStream_t st);
+int dz_launch_osp(const float* seg, int B, int F, int K, float gamma, float beta, int normalize,
+                  int speaker_major, float* out, hipStream_t st);
+int dz_launch_l2norm(float* x, int rows, int dim, float norm, hipStream_t st);
+int dz_launch_powerset(const float* logp, int rows, int classes, int speakers, float* out,
+                       hipStream_t st);
+int dz_launch_cdist(const float* emb, const double* centers, int n, int k, int g, int dim,
+                    double* out, hipStream_t st);

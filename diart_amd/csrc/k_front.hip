@@ -1,0 +1,207 @@
+// SincNet front-end kernels (shared by the segmentation and embedding networks):
+//   wave_stats     per-chunk mean / rstd of the raw 5 s window   (InstanceNorm1d(1))
+//   sinc_conv0     normalise-on-load + 80x251 sinc FIR bank (stride 10) on fp32 MFMA
+//                  + abs + MaxPool1d(3) + per-tile (sum, sumsq) partials
+//   finalize_norm  partials -> per (chunk, channel) scale / shift of InstanceNorm1d(C, affine)
+// Restates pyannote.audio SincNet.forward (third party; called from
+// /root/reference/src/diart/models.py:133 and :262; graph in SURVEY.md Appendix A.1).
+#include "dz_common.h"
+
+// ---------------------------------------------------------------------------
+// wave_stats: one workgroup per chunk; two passes (mean, then centred variance) so the
+// variance does not cancel; 16 B coalesced reads of the window, wave shuffles + LDS.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ double dz_block_sum(double v, double* red) {
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+    __syncthreads();
+    if (l == 0) red[w] = v;
+    __syncthreads();
+    double t = 0.0;
+    const int nw = blockDim.x >> 6;
+    for (int i = 0; i < nw; ++i) t += red[i];
+    return t;
+}
+
+__global__ __launch_bounds__(256) void wave_stats_kernel(const float* __restrict__ wave,
+                                                         long long stride, int S,
+                                                         float* __restrict__ stats) {
+    __shared__ double red[4];
+    const float* x = wave + (long long)blockIdx.x * stride;
+    const int n4 = S >> 2;
+    float s = 0.f;
+    for (int i = threadIdx.x; i < n4; i += 256) {
+        const float4 v = reinterpret_cast<const float4*>(x)[i];
+        s += (v.x + v.y) + (v.z + v.w);
+    }
+    for (int i = (n4 << 2) + threadIdx.x; i < S; i += 256) s += x[i];
+    const double mean_d = dz_block_sum((double)s, red) / (double)S;
+    const float mean = (float)mean_d;
+    float ss = 0.f;
+    for (int i = threadIdx.x; i < n4; i += 256) {
+        const float4 v = reinterpret_cast<const float4*>(x)[i];
+        const float a = v.x - mean, b = v.y - mean, c = v.z - mean, d = v.w - mean;
+        ss += (a * a + b * b) + (c * c + d * d);
+    }
+    for (int i = (n4 << 2) + threadIdx.x; i < S; i += 256) {
+        const float a = x[i] - mean;
+        ss += a * a;
+    }
+    const double var = dz_block_sum((double)ss, red) / (double)S;  // biased, like InstanceNorm
+    if (threadIdx.x == 0) {
+        stats[2 * blockIdx.x] = mean;
+        stats[2 * blockIdx.x + 1] = (float)(1.0 / sqrt(var + 1e-5));
+    }
+}
+
+int dz_launch_wave_stats(const float* wave, long long stride, int B, int S, float* stats,
+                         hipStream_t st) {
+    hipLaunchKernelGGL(wave_stats_kernel, dim3(B), dim3(256), 0, st, wave, stride, S, stats);
+    DZ_HIP(hipGetLastError());
+    return 0;
+}
+
+// ---------------------------------------------------------------------------
+// sinc_conv0.  As a GEMM per chunk: out[t][c] = sum_k xn[10 t + k] * filt[k][c],
+// M = 7975 frames, N = 80 filters, K = 251 (+1 zero tap).  One workgroup = 192 conv
+// frames (= 64 pooled) x 80 filters; 4 waves x (3 M-frags x 5 N-frags) of 16x16x4 f32 MFMA.
+// LDS: the whole filter bank k-major (conflict-free B reads: bank = 16*(k&1) + j) and the
+// 2162-sample window slice the tile touches (A reads at stride 10 dwords: 10*i + q hits
+// 32 distinct banks per half-wave).  Every sample is read from HBM once per tile and reused
+// 25x from LDS.
+// ---------------------------------------------------------------------------
+#define C0_FR 192
+#define C0_XS (C0_FR * 10 + 256)
+#define C0_K4 63
+#define C0_OLD 81
+
+__global__ __launch_bounds__(256) void sinc_conv0_kernel(
+    const float* __restrict__ wave, long long stride, int S, const float* __restrict__ stats,
+    float gamma, float beta, const float* __restrict__ filt, float* __restrict__ y0, int P0,
+    float* __restrict__ partials, int ntile) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* filt_s = smem;             // [252][80]
+    float* xs = smem + 252 * 80;      // [C0_XS]
+    float* out_s = smem;              // [192][81], aliases filt_s after the K loop
+    const int b = blockIdx.y, tile = blockIdx.x, tid = threadIdx.x;
+
+    for (int i = tid; i < 252 * 80 / 4; i += 256)
+        reinterpret_cast<float4*>(filt_s)[i] = reinterpret_cast<const float4*>(filt)[i];
+    {
+        const float mean = stats[2 * b], rstd = stats[2 * b + 1];
+        const float* wb = wave + (long long)b * stride;
+        const int s0 = tile * (C0_FR * 10);
+        for (int i = tid; i < C0_XS; i += 256) {
+            const int s = s0 + i;
+            xs[i] = (s < S) ? ((wb[s] - mean) * rstd) * gamma + beta : 0.f;
+        }
+    }
+    __syncthreads();
+
+    const int w = tid >> 6, l = tid & 63, i = l & 15, q = l >> 4;
+    f32x4 acc[3][5];
+#pragma unroll
+    for (int mt = 0; mt < 3; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 5; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const float* xa = xs + 10 * (48 * w + i) + q;
+    const float* fb = filt_s + q * 80 + i;
+#pragma unroll 7
+    for (int ks = 0; ks < C0_K4; ++ks) {
+        float a[3], bb[5];
+#pragma unroll
+        for (int mt = 0; mt < 3; ++mt) a[mt] = xa[4 * ks + 160 * mt];
+#pragma unroll
+        for (int nt = 0; nt < 5; ++nt) bb[nt] = fb[320 * ks + 16 * nt];
+#pragma unroll
+        for (int mt = 0; mt < 3; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 5; ++nt) acc[mt][nt] = DZ_MFMA(a[mt], bb[nt], acc[mt][nt]);
+    }
+    __syncthreads();  // filt_s is dead from here: reuse as the output tile
+
+#pragma unroll
+    for (int mt = 0; mt < 3; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 5; ++nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                out_s[(48 * w + 16 * mt + 4 * q + r) * C0_OLD + 16 * nt + i] =
+                    fabsf(acc[mt][nt][r]);
+    __syncthreads();
+
+    const int p0 = tile * 64;
+    for (int idx = tid; idx < 64 * 80; idx += 256) {
+        const int pr = idx / 80, n = idx - pr * 80;
+        const float* o = out_s + (3 * pr) * C0_OLD + n;
+        const float v = fmaxf(fmaxf(o[0], o[C0_OLD]), o[2 * C0_OLD]);
+        const bool valid = (p0 + pr) < P0;
+        if (valid) y0[((long long)b * P0 + p0 + pr) * 80 + n] = v;
+        out_s[(3 * pr) * C0_OLD + n] = valid ? v : 0.f;
+    }
+    __syncthreads();
+    if (tid < 80) {
+        float s = 0.f, ss = 0.f;
+        for (int pr = 0; pr < 64; ++pr) {
+            const float v = out_s[(3 * pr) * C0_OLD + tid];
+            s += v;
+            ss += v * v;
+        }
+        float* pp = partials + (((long long)b * ntile + tile) * 80 + tid) * 2;
+        pp[0] = s;
+        pp[1] = ss;
+    }
+}
+
+int dz_launch_sinc_conv0(const float* wave, long long stride, int B, int S, const float* stats,
+                         float gamma, float beta, const float* filt, float* y0, int P0,
+                         float* partials, int ntile, hipStream_t st) {
+    const size_t lds = (252 * 80 + C0_XS) * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        DZ_HIP(hipFuncSetAttribute((const void*)sinc_conv0_kernel,
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(sinc_conv0_kernel, dim3(ntile, B), dim3(256), lds, st, wave, stride, S,
+                       stats, gamma, beta, filt, y0, P0, partials, ntile);
+    DZ_HIP(hipGetLastError());
+    return 0;
+}
+
+// ---------------------------------------------------------------------------
+// finalize_norm: fixed-order (deterministic) reduction of the tile partials in fp64.
+// scale = gamma * rstd, shift = beta - mean * scale  (InstanceNorm1d, eps 1e-5, biased var)
+// ---------------------------------------------------------------------------
+__global__ void finalize_norm_kernel(const float* __restrict__ partials, int B, int ntile, int C,
+                                     int T, const float* __restrict__ gamma,
+                                     const float* __restrict__ beta, float* __restrict__ scale,
+                                     float* __restrict__ shift) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= B * C) return;
+    const int b = idx / C, c = idx - b * C;
+    double s = 0.0, ss = 0.0;
+    for (int t = 0; t < ntile; ++t) {
+        const float* pp = partials + (((long long)b * ntile + t) * C + c) * 2;
+        s += (double)pp[0];
+        ss += (double)pp[1];
+    }
+    const double mean = s / T;
+    double var = ss / T - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const double rstd = 1.0 / sqrt(var + 1e-5);
+    const double sc = (double)gamma[c] * rstd;
+    scale[idx] = (float)sc;
+    shift[idx] = (float)((double)beta[c] - mean * sc);
+}
+
+int dz_launch_finalize_norm(const float* partials, int B, int ntile, int C, int T,
+                            const float* gamma, const float* beta, float* scale, float* shift,
+                            hipStream_t st) {
+    const int n = B * C;
+    hipLaunchKernelGGL(finalize_norm_kernel, dim3((n + 255) / 256), dim3(256), 0, st, partials, B,
+                       ntile, C, T, gamma, beta, scale, shift);
+    DZ_HIP(hipGetLastError());
+    return 0;
+}

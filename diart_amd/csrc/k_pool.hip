@@ -1,0 +1,340 @@
+// Small bandwidth-bound kernels around the two networks:
+//   stats_pool   weighted statistics pooling (paper Eq. 1; pyannote StatsPool), all K
+//                speakers of a chunk in one pass over the frame features
+//   osp          OverlappedSpeechPenalty        /root/reference/src/diart/functional.py:6-13
+//                (+ min-max option              /root/reference/src/diart/blocks/embedding.py:102-106)
+//   l2norm       EmbeddingNormalization         /root/reference/src/diart/functional.py:16-27
+//   powerset     Powerset.to_multilabel (hard)  /root/reference/src/diart/models.py:29-39
+//   cdist        cosine distances, fp64         /root/reference/src/diart/mapping.py:171-176
+#include "dz_common.h"
+
+namespace {
+
+// ---------------------------------------------------------------------------
+// stats_pool: one workgroup = (64-channel slab, one chunk).  The [T][64] slab of frame
+// features is read from HBM once (256 B coalesced rows), parked in LDS, and used for both
+// passes (weighted mean, then centred second moment) of all K speakers.  Lanes = channels,
+// the 4 waves split the frames; partial sums meet in LDS.
+// ---------------------------------------------------------------------------
+template <int K>
+__global__ __launch_bounds__(256) void stats_pool_kernel(
+    const float* __restrict__ X, int T, int C, int ldx, const float* __restrict__ weights, int Fw,
+    int ktot, int kofs, float* __restrict__ out, int ldo) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* xs = smem;                 // [T][64]
+    float* wk = xs + T * 64;          // [K][T]
+    float* red = wk + K * T;          // [4][K][64]
+    const int c0 = blockIdx.x * 64, xi = blockIdx.y, tid = threadIdx.x;
+    const int c = tid & 63, ph = tid >> 6;
+
+    const float* Xb = X + (long long)xi * T * ldx;
+    for (int idx = tid; idx < T * 64; idx += 256) {
+        const int t = idx >> 6, cc = idx & 63;
+        xs[idx] = (c0 + cc < C) ? Xb[(long long)t * ldx + c0 + cc] : 0.f;
+    }
+    // temporal weights, resampled to T frames like F.interpolate(mode="linear",
+    // align_corners=False) (ATen area_pixel_compute_source_index)
+    const float scale = (float)Fw / (float)T;
+    for (int idx = tid; idx < K * T; idx += 256) {
+        const int k = idx / T, t = idx - k * T;
+        float wv = 1.f;
+        if (weights) {
+            const float* wr = weights + (long long)(xi * ktot + kofs + k) * Fw;
+            if (Fw == T) {
+                wv = wr[t];
+            } else {
+                float src = scale * ((float)t + 0.5f) - 0.5f;
+                if (src < 0.f) src = 0.f;
+                const int i0 = (int)src;
+                const int i1 = i0 + (i0 < Fw - 1 ? 1 : 0);
+                const float l1 = src - (float)i0;
+                wv = (1.f - l1) * wr[i0] + l1 * wr[i1];
+            }
+        }
+        wk[idx] = wv;
+    }
+    __syncthreads();
+
+    float v1[K], v2[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        float a = 0.f, b2 = 0.f;
+        for (int t = (tid & 63); t < T; t += 64) {
+            const float wv = wk[k * T + t];
+            a += wv;
+            b2 += wv * wv;
+        }
+        for (int o = 32; o > 0; o >>= 1) {
+            a += __shfl_xor(a, o, 64);
+            b2 += __shfl_xor(b2, o, 64);
+        }
+        v1[k] = a;
+        v2[k] = b2;
+    }
+
+    float mean[K], acc[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) acc[k] = 0.f;
+    for (int t = ph; t < T; t += 4) {
+        const float x = xs[t * 64 + c];
+#pragma unroll
+        for (int k = 0; k < K; ++k) acc[k] += x * wk[k * T + t];
+    }
+#pragma unroll
+    for (int k = 0; k < K; ++k) red[(ph * K + k) * 64 + c] = acc[k];
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const float s = (red[(0 * K + k) * 64 + c] + red[(1 * K + k) * 64 + c]) +
+                        (red[(2 * K + k) * 64 + c] + red[(3 * K + k) * 64 + c]);
+        mean[k] = s / v1[k];
+        acc[k] = 0.f;
+    }
+    __syncthreads();
+    for (int t = ph; t < T; t += 4) {
+        const float x = xs[t * 64 + c];
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const float d = x - mean[k];
+            acc[k] += (d * d) * wk[k * T + t];
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < K; ++k) red[(ph * K + k) * 64 + c] = acc[k];
+    __syncthreads();
+    if (ph == 0 && c0 + c < C) {
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const float s = (red[(0 * K + k) * 64 + c] + red[(1 * K + k) * 64 + c]) +
+                            (red[(2 * K + k) * 64 + c] + red[(3 * K + k) * 64 + c]);
+            const float var = s / (v1[k] - v2[k] / v1[k]);
+            float* o = out + (long long)(xi * ktot + kofs + k) * ldo;
+            o[c0 + c] = mean[k];
+            o[C + c0 + c] = sqrtf(var);
+        }
+    }
+}
+
+template <int K>
+int launch_pool(const float* X, int T, int C, int ldx, const float* weights, int Fw, int nx,
+                int ktot, int kofs, float* out, int ldo, hipStream_t st) {
+    const size_t lds = sizeof(float) * ((size_t)T * 64 + (size_t)K * T + 4 * K * 64);
+    DZ_REQUIRE(lds <= 160 * 1024, "stats_pool: %d frames do not fit in LDS", T);
+    DZ_HIP(hipFuncSetAttribute((const void*)stats_pool_kernel<K>,
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((stats_pool_kernel<K>), dim3((C + 63) / 64, nx), dim3(256), lds, st, X, T, C,
+                       ldx, weights, Fw, ktot, kofs, out, ldo);
+    DZ_HIP(hipGetLastError());
+    return 0;
+}
+
+// ---------------------------------------------------------------------------
+// osp: one workgroup per chunk, thread = frame.  K <= 8 speakers.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ float powg(float x, float gamma) {
+    // torch.pow(tensor, scalar) special-cases 2 and 3 as repeated products
+    if (gamma == 3.f) return (x * x) * x;
+    if (gamma == 2.f) return x * x;
+    if (gamma == 1.f) return x;
+    return powf(x, gamma);
+}
+
+__global__ __launch_bounds__(256) void osp_kernel(const float* __restrict__ seg, int F, int K,
+                                                  float gamma, float beta, int normalize,
+                                                  int speaker_major, float* __restrict__ out) {
+    extern __shared__ float wbuf[];  // [F][K] then [2][K] min/max
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const float* sb = seg + (long long)b * F * K;
+    for (int f = tid; f < F; f += 256) {
+        float s[8], e[8];
+        float m = -INFINITY;
+        for (int k = 0; k < K; ++k) {
+            s[k] = sb[f * K + k];
+            m = fmaxf(m, beta * s[k]);
+        }
+        float sum = 0.f;
+        for (int k = 0; k < K; ++k) {
+            e[k] = expf(beta * s[k] - m);
+            sum += e[k];
+        }
+        for (int k = 0; k < K; ++k) {
+            const float pr = e[k] / sum;
+            float wv = powg(s[k], gamma) * powg(pr, gamma);
+            if (wv < 1e-8f) wv = 1e-8f;
+            wbuf[f * K + k] = wv;
+        }
+    }
+    __syncthreads();
+    float* mm = wbuf + F * K;
+    if (normalize) {
+        if (tid < K) {
+            float lo = INFINITY, hi = -INFINITY;
+            bool nan = false;
+            for (int f = 0; f < F; ++f) {
+                const float v = wbuf[f * K + tid];
+                nan |= (v != v);
+                lo = fminf(lo, v);
+                hi = fmaxf(hi, v);
+            }
+            if (nan) lo = hi = NAN;  // torch min/max propagate NaN
+            mm[tid] = lo;
+            mm[K + tid] = hi;
+        }
+        __syncthreads();
+    }
+    float* ob = out + (long long)b * F * K;
+    for (int idx = tid; idx < F * K; idx += 256) {
+        const int f = idx / K, k = idx - f * K;
+        float v = wbuf[idx];
+        if (normalize) {
+            v = (v - mm[k]) / (mm[K + k] - mm[k]);
+            if (v != v) v = 1e-8f;  // nan_to_num_(1e-8)
+            else if (v == INFINITY) v = 3.4028234663852886e38f;
+            else if (v == -INFINITY) v = -3.4028234663852886e38f;
+        }
+        if (speaker_major) ob[k * F + f] = v;
+        else ob[idx] = v;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// l2norm: one wave per row, in place:  x <- (norm * x) / ||x||_2
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void l2norm_kernel(float* __restrict__ x, int rows, int dim,
+                                                     float norm) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), l = threadIdx.x & 63;
+    if (row >= rows) return;
+    float* r = x + (long long)row * dim;
+    float ss = 0.f;
+    for (int i = l; i < dim; i += 64) ss += r[i] * r[i];
+    for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
+    const float n = sqrtf(ss);
+    for (int i = l; i < dim; i += 64) r[i] = (norm * r[i]) / n;
+}
+
+// ---------------------------------------------------------------------------
+// powerset -> multilabel: one_hot(argmax) @ mapping, subsets ordered by size then
+// lexicographically, at most 2 speakers per frame.
+// ---------------------------------------------------------------------------
+__global__ void powerset_kernel(const float* __restrict__ logit, int rows, int classes,
+                                int speakers, float* __restrict__ out) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= rows) return;
+    const float* p = logit + (long long)r * classes;
+    int best = 0;
+    float bv = p[0];
+    for (int c = 1; c < classes; ++c)
+        if (p[c] > bv) {
+            bv = p[c];
+            best = c;
+        }
+    int a = -1, b2 = -1;
+    if (best >= 1 && best <= speakers) {
+        a = best - 1;
+    } else if (best > speakers) {
+        int idx = best - speakers - 1;
+        for (int i = 0; i < speakers && a < 0; ++i) {
+            const int cnt = speakers - 1 - i;
+            if (idx < cnt) {
+                a = i;
+                b2 = i + 1 + idx;
+            } else {
+                idx -= cnt;
+            }
+        }
+    }
+    float* o = out + (long long)r * speakers;
+    for (int s = 0; s < speakers; ++s) o[s] = (s == a || s == b2) ? 1.f : 0.f;
+}
+
+// ---------------------------------------------------------------------------
+// cdist (cosine, fp64) for N streams: one workgroup per (stream, local speaker);
+// wave w takes centroids w, w+4, ...; scipy: 1 - u.v / (|u||v|), clipped to [-1,1].
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ double wave_sum(double v) {
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+__global__ __launch_bounds__(256) void cdist_kernel(const float* __restrict__ emb,
+                                                    const double* __restrict__ centers, int k,
+                                                    int g, int dim, double* __restrict__ out) {
+    const int n = blockIdx.x / k, kk = blockIdx.x - n * k;
+    const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+    const float* e = emb + ((long long)n * k + kk) * dim;
+    double ee = 0.0;
+    for (int i = l; i < dim; i += 64) ee += (double)e[i] * (double)e[i];
+    ee = sqrt(wave_sum(ee));
+    for (int gg = w; gg < g; gg += 4) {
+        const double* c = centers + ((long long)n * g + gg) * dim;
+        double dot = 0.0, cc = 0.0;
+        for (int i = l; i < dim; i += 64) {
+            const double cv = c[i];
+            dot += (double)e[i] * cv;
+            cc += cv * cv;
+        }
+        dot = wave_sum(dot);
+        cc = sqrt(wave_sum(cc));
+        if (l == 0) {
+            double cosv = dot / (ee * cc);
+            if (fabs(cosv) > 1.0) cosv = copysign(1.0, cosv);
+            out[((long long)n * k + kk) * g + gg] = 1.0 - cosv;
+        }
+    }
+}
+
+}  // namespace
+
+int dz_launch_stats_pool(const float* X, int T, int C, int ldx, const float* weights, int Fw,
+                         int rows, int rows_per_x, float* out, int ldo, hipStream_t st) {
+    DZ_REQUIRE(rows % rows_per_x == 0, "stats_pool: rows %% rows_per_x != 0");
+    const int nx = rows / rows_per_x;
+    int kofs = 0;
+    while (kofs < rows_per_x) {
+        const int kk = rows_per_x - kofs >= 4 ? 4 : rows_per_x - kofs;
+        int rc;
+        switch (kk) {
+            case 4: rc = launch_pool<4>(X, T, C, ldx, weights, Fw, nx, rows_per_x, kofs, out, ldo, st); break;
+            case 3: rc = launch_pool<3>(X, T, C, ldx, weights, Fw, nx, rows_per_x, kofs, out, ldo, st); break;
+            case 2: rc = launch_pool<2>(X, T, C, ldx, weights, Fw, nx, rows_per_x, kofs, out, ldo, st); break;
+            default: rc = launch_pool<1>(X, T, C, ldx, weights, Fw, nx, rows_per_x, kofs, out, ldo, st); break;
+        }
+        if (rc) return rc;
+        kofs += kk;
+    }
+    return 0;
+}
+
+int dz_launch_osp(const float* seg, int B, int F, int K, float gamma, float beta, int normalize,
+                  int speaker_major, float* out, hipStream_t st) {
+    DZ_REQUIRE(K >= 1 && K <= 8, "osp: 1 <= speakers <= 8 (got %d)", K);
+    const size_t lds = sizeof(float) * ((size_t)F * K + 2 * K);
+    DZ_REQUIRE(lds <= 64 * 1024, "osp: %d frames x %d speakers do not fit in LDS", F, K);
+    hipLaunchKernelGGL(osp_kernel, dim3(B), dim3(256), lds, st, seg, F, K, gamma, beta, normalize,
+                       speaker_major, out);
+    DZ_HIP(hipGetLastError());
+    return 0;
+}
+
+int dz_launch_l2norm(float* x, int rows, int dim, float norm, hipStream_t st) {
+    hipLaunchKernelGGL(l2norm_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, x, rows, dim, norm);
+    DZ_HIP(hipGetLastError());
+    return 0;
+}
+
+int dz_launch_powerset(const float* logp, int rows, int classes, int speakers, float* out,
+                       hipStream_t st) {
+    DZ_REQUIRE(classes == 1 + speakers + speakers * (speakers - 1) / 2,
+               "powerset: %d classes is not 'at most 2 of %d speakers'", classes, speakers);
+    hipLaunchKernelGGL(powerset_kernel, dim3((rows + 255) / 256), dim3(256), 0, st, logp, rows,
+                       classes, speakers, out);
+    DZ_HIP(hipGetLastError());
+    return 0;
+}
+
+int dz_launch_cdist(const float* emb, const double* centers, int n, int k, int g, int dim,
+                    double* out, hipStream_t st) {
+    hipLaunchKernelGGL(cdist_kernel, dim3(n * k), dim3(256), 0, st, emb, centers, k, g, dim, out);
+    DZ_HIP(hipGetLastError());
+    return 0;
+}

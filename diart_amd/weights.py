@@ -1,0 +1,167 @@
+"""State dict (pyannote checkpoint key names) -> packed fp32 device tensors for the kernels.
+
+PyTorch-ROCm only *holds* the weights (north-star: "PyTorch-ROCm holds only the weight
+tensors"); all arithmetic on them happens in ``libdiart_amd.so``.  Packing happens once,
+on the CPU, at load time:
+
+* sinc FIR bank generated from ``low_hz_ / band_hz_`` (asteroid ``ParamSincFB.filters``,
+  SURVEY.md Appendix A.1) and stored k-major ``[252][80]`` (tap 251 is a zero pad);
+* conv / TDNN weights reordered ``[co][tap][ci]`` so an im2col row of channels-last
+  activations is contiguous, channel counts padded 60 -> 64 and 1500 -> 1536 with zeros;
+* ``BatchNorm1d`` (eval) folded to a per-channel scale / shift applied after LeakyReLU;
+* LSTM: both directions' ``W_ih`` stacked to one ``[1024][K]`` GEMM operand, ``b_ih+b_hh``
+  pre-summed, ``W_hh`` as ``[2][512][128]``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from typing import Dict, List
+
+import torch
+
+from . import _lib
+
+BN_EPS = 1e-5
+
+
+def sinc_filters(low_hz_: torch.Tensor, band_hz_: torch.Tensor, window_: torch.Tensor,
+                 n_: torch.Tensor, sample_rate: float = 16000.0, min_low_hz: float = 50.0,
+                 min_band_hz: float = 50.0) -> torch.Tensor:
+    """[80][251] band-pass filters: 40 cos (even) then 40 sin (odd)."""
+    low = min_low_hz + torch.abs(low_hz_.float())
+    high = torch.clamp(low + min_band_hz + torch.abs(band_hz_.float()), min_low_hz, sample_rate / 2)
+    band = (high - low)[:, 0]
+    n_ = n_.float().view(1, -1)
+    window_ = window_.float()
+    ft_low, ft_high = torch.matmul(low, n_), torch.matmul(high, n_)
+    out = []
+    for kind in ("cos", "sin"):
+        if kind == "cos":
+            left = ((torch.sin(ft_high) - torch.sin(ft_low)) / (n_ / 2)) * window_
+            center = 2 * band.view(-1, 1)
+            right = torch.flip(left, dims=[1])
+        else:
+            left = ((torch.cos(ft_low) - torch.cos(ft_high)) / (n_ / 2)) * window_
+            center = torch.zeros_like(band.view(-1, 1))
+            right = -torch.flip(left, dims=[1])
+        out.append(torch.cat([left, center, right], dim=1) / (2 * band[:, None]))
+    return torch.cat(out, dim=0)
+
+
+def _pad2(w: torch.Tensor, rows: int, cols: int) -> torch.Tensor:
+    out = torch.zeros(rows, cols, dtype=torch.float32)
+    out[: w.shape[0], : w.shape[1]] = w
+    return out
+
+
+def _pad1(v: torch.Tensor, n: int) -> torch.Tensor:
+    out = torch.zeros(n, dtype=torch.float32)
+    out[: v.shape[0]] = v
+    return out
+
+
+def _conv_pack(w: torch.Tensor, cin_pad: int, n_pad: int, k_pad: int) -> torch.Tensor:
+    """Conv1d weight [co][ci][tap] -> [n_pad][k_pad] with k = tap*cin_pad + ci."""
+    co, ci, taps = w.shape
+    t = torch.zeros(co, taps, cin_pad, dtype=torch.float32)
+    t[:, :, :ci] = w.float().permute(0, 2, 1)
+    return _pad2(t.reshape(co, taps * cin_pad), n_pad, k_pad)
+
+
+class _Packed:
+    """Keeps the device tensors alive and exposes their addresses."""
+
+    def __init__(self, device: torch.device):
+        self.device = device
+        self.tensors: List[torch.Tensor] = []
+
+    def put(self, t: torch.Tensor) -> int:
+        d = t.detach().to(dtype=torch.float32).contiguous().to(self.device)
+        self.tensors.append(d)
+        return d.data_ptr()
+
+    def nbytes(self) -> int:
+        return sum(t.numel() * 4 for t in self.tensors)
+
+
+def _pack_sincnet(sd: Dict[str, torch.Tensor], pk: _Packed, prefix: str = "sincnet.") -> _lib.SincNetWeights:
+    g = lambda k: sd[prefix + k].detach().cpu()
+    filt = sinc_filters(g("conv1d.0.filterbank.low_hz_"), g("conv1d.0.filterbank.band_hz_"),
+                        g("conv1d.0.filterbank.window_"), g("conv1d.0.filterbank.n_"))
+    assert filt.shape == (80, 251)
+    w = _lib.SincNetWeights()
+    w.wav_gamma = float(g("wav_norm1d.weight").reshape(-1)[0])
+    w.wav_beta = float(g("wav_norm1d.bias").reshape(-1)[0])
+    w.filt = pk.put(_pad2(filt.t().contiguous(), 252, 80))
+    w.in0_g, w.in0_b = pk.put(g("norm1d.0.weight")), pk.put(g("norm1d.0.bias"))
+    w.w1 = pk.put(_conv_pack(g("conv1d.1.weight"), 80, 64, 416))
+    w.b1 = pk.put(_pad1(g("conv1d.1.bias"), 64))
+    w.in1_g, w.in1_b = pk.put(_pad1(g("norm1d.1.weight"), 64)), pk.put(_pad1(g("norm1d.1.bias"), 64))
+    w.w2 = pk.put(_conv_pack(g("conv1d.2.weight"), 64, 64, 320))
+    w.b2 = pk.put(_pad1(g("conv1d.2.bias"), 64))
+    w.in2_g, w.in2_b = pk.put(_pad1(g("norm1d.2.weight"), 64)), pk.put(_pad1(g("norm1d.2.bias"), 64))
+    return w
+
+
+class PackedSegmentation:
+    """``dz_seg_weights`` + the tensors behind it."""
+
+    def __init__(self, sd: Dict[str, torch.Tensor], device: torch.device, powerset: bool = False,
+                 num_speakers: int | None = None):
+        pk = _Packed(device)
+        g = lambda k: sd[k].detach().cpu().float()
+        w = _lib.SegWeights()
+        w.sinc = _pack_sincnet(sd, pk)
+        for layer in range(4):
+            wih = torch.cat([g(f"lstm.weight_ih_l{layer}"), g(f"lstm.weight_ih_l{layer}_reverse")], 0)
+            kpad = 64 if layer == 0 else 256
+            w.wih[layer] = pk.put(_pad2(wih, 1024, kpad))
+            bias = torch.cat([g(f"lstm.bias_ih_l{layer}") + g(f"lstm.bias_hh_l{layer}"),
+                              g(f"lstm.bias_ih_l{layer}_reverse") + g(f"lstm.bias_hh_l{layer}_reverse")], 0)
+            w.bih[layer] = pk.put(bias)
+            whh = torch.stack([g(f"lstm.weight_hh_l{layer}"), g(f"lstm.weight_hh_l{layer}_reverse")], 0)
+            assert whh.shape == (2, 512, 128)
+            w.whh[layer] = pk.put(whh)
+        w.lin0_w, w.lin0_b = pk.put(g("linear.0.weight")), pk.put(g("linear.0.bias"))
+        w.lin1_w, w.lin1_b = pk.put(g("linear.1.weight")), pk.put(g("linear.1.bias"))
+        cls_w, cls_b = g("classifier.weight"), g("classifier.bias")
+        ncls = cls_w.shape[0]
+        w.cls_w, w.cls_b = pk.put(_pad2(cls_w, 64, 128)), pk.put(_pad1(cls_b, 64))
+        w.num_classes = ncls
+        w.powerset = 1 if powerset else 0
+        if powerset:
+            # classes = 1 + S + S(S-1)/2  ->  S
+            s = num_speakers or int(round((-1 + math.sqrt(1 + 8 * (ncls - 1))) / 2))
+            w.num_speakers = s
+        else:
+            w.num_speakers = ncls
+        self.struct, self.pack = w, pk
+        self.num_speakers = int(w.num_speakers)
+
+
+class PackedEmbedding:
+    """``dz_emb_weights`` + the tensors behind it."""
+
+    TDNN = [(64, 512, 512), (512, 512, 512), (512, 512, 512), (512, 512, 512), (512, 1500, 1536)]
+
+    def __init__(self, sd: Dict[str, torch.Tensor], device: torch.device):
+        pk = _Packed(device)
+        g = lambda k: sd[k].detach().cpu().float()
+        w = _lib.EmbWeights()
+        w.sinc = _pack_sincnet(sd, pk)
+        for i, (cin_pad, cout, npad) in enumerate(self.TDNN):
+            cw = g(f"tdnns.{3 * i}.weight")
+            assert cw.shape[0] == cout
+            k = cw.shape[2] * cin_pad
+            w.tw[i] = pk.put(_conv_pack(cw, cin_pad, npad, (k + 31) // 32 * 32))
+            w.tb[i] = pk.put(_pad1(g(f"tdnns.{3 * i}.bias"), npad))
+            bn = f"tdnns.{3 * i + 2}."
+            scale = g(bn + "weight") / torch.sqrt(g(bn + "running_var") + BN_EPS)
+            shift = g(bn + "bias") - g(bn + "running_mean") * scale
+            w.ts[i], w.th[i] = pk.put(_pad1(scale, npad)), pk.put(_pad1(shift, npad))
+        ew = g("embedding.weight")
+        assert ew.shape == (512, 3000), "only the 512-d x-vector head is built"
+        w.emb_w, w.emb_b = pk.put(_pad2(ew, 512, 3008)), pk.put(g("embedding.bias"))
+        w.dimension = 512
+        self.struct, self.pack = w, pk

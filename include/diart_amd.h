@@ -1,0 +1,204 @@
+/*
+ * diart_amd.h — C ABI of libdiart_amd.so: diart's per-chunk diarization hot path
+ * on MI355X (gfx950), hand-written HIP.
+ *
+ * The reference (juanmc2005/diart v0.9) has no FFI: its plugin boundary is Python
+ * duck typing ("Custom models", /root/reference/README.md:186-209).  Each entry point
+ * below states which reference call it replaces; `diart_amd/_lib.py` holds the ctypes
+ * binding a maintainer would add, and INTEGRATION.md shows how the resulting objects
+ * plug into diart.models.SegmentationModel / EmbeddingModel unchanged.
+ *
+ * Conventions: every function returns 0 on success, non-zero on failure with a
+ * message retrievable through dz_last_error() (thread local).  All `d_*` pointers
+ * are DEVICE pointers owned by the caller (torch-ROCm tensors); the library only
+ * borrows them for the duration of the call and owns nothing but its scratch arena.
+ * `stream` is a hipStream_t passed as void* (NULL = default stream).  Calls on one
+ * handle must be serialised by the caller; distinct handles are independent.
+ */
+#ifndef DIART_AMD_H
+#define DIART_AMD_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DZ_VERSION 100
+
+typedef struct dz_ctx dz_ctx;
+typedef struct dz_seg dz_seg;
+typedef struct dz_emb dz_emb;
+typedef struct dz_clu dz_clu;
+
+const char* dz_last_error(void);
+int dz_version(void);
+
+/* one context per (process, GPU) */
+int dz_ctx_create(int hip_device, dz_ctx** out);
+int dz_ctx_destroy(dz_ctx* ctx);
+
+/* SincNet(stride 10) frame count for a chunk of `num_samples` (293 for 80000):
+ * the F of SegmentationModel's (batch, frames, speakers) output,
+ * /root/reference/src/diart/models.py:188-198. */
+int dz_seg_frames_for(int num_samples);
+/* frames left after the 5 TDNN layers (279 for 80000). */
+int dz_emb_frames_for(int num_samples);
+
+/* ---- packed weights (device pointers, fp32; layouts in DESIGN.md §3) ------- */
+typedef struct {
+    float wav_gamma, wav_beta;   /* InstanceNorm1d(1, affine) on the waveform        */
+    const float* filt;           /* [252][80]  sinc FIR bank, k-major, tap 251 = 0   */
+    const float* in0_g;          /* [80]  InstanceNorm1d(80) gamma                   */
+    const float* in0_b;          /* [80]                     beta                    */
+    const float* w1;             /* [64][416]  conv1 [co][tap*80+ci], zero padded    */
+    const float* b1;             /* [64]                                             */
+    const float* in1_g;          /* [64]                                             */
+    const float* in1_b;          /* [64]                                             */
+    const float* w2;             /* [64][320]  conv2 [co][tap*64+ci]                 */
+    const float* b2;             /* [64]                                             */
+    const float* in2_g;          /* [64]                                             */
+    const float* in2_b;          /* [64]                                             */
+} dz_sincnet_weights;
+
+typedef struct {
+    dz_sincnet_weights sinc;
+    const float* wih[4];         /* [1024][Kpad] rows = dir*512 + gate*128 + unit    */
+    const float* bih[4];         /* [1024]  b_ih + b_hh                              */
+    const float* whh[4];         /* [2][512][128]                                    */
+    const float* lin0_w;         /* [128][256] */
+    const float* lin0_b;         /* [128]      */
+    const float* lin1_w;         /* [128][128] */
+    const float* lin1_b;         /* [128]      */
+    const float* cls_w;          /* [64][128]  classifier rows, zero padded          */
+    const float* cls_b;          /* [64]       */
+    int num_classes;             /* K (multilabel) or 7 (powerset)                   */
+    int powerset;                /* 1: log-softmax -> hard multilabel (models.py:29-39) */
+    int num_speakers;            /* speakers of the multilabel output (3)            */
+} dz_seg_weights;
+
+typedef struct {
+    dz_sincnet_weights sinc;
+    const float* tw[5];          /* TDNN conv weights [Npad][Kpad], [co][tap*Cin+ci] */
+    const float* tb[5];          /* conv bias [Npad]                                 */
+    const float* ts[5];          /* folded BatchNorm1d(eval) scale  [Npad]           */
+    const float* th[5];          /* folded BatchNorm1d(eval) shift  [Npad]           */
+    const float* emb_w;          /* [512][3008]  Linear(3000, D), zero padded        */
+    const float* emb_b;          /* [512] */
+    int dimension;               /* D = 512 */
+} dz_emb_weights;
+
+/* ---- segmentation: replaces the callable behind SegmentationModel.__call__ --
+ * /root/reference/src/diart/models.py:188-198 (-> pyannote PyanNet.forward, :133)
+ * waveform (B,1,S) -> (B,F,K).  d_wave rows are `wave_stride` floats apart so a
+ * rolling window can be addressed in place (operators.py:44-100).             */
+int dz_seg_create(dz_ctx* ctx, const dz_seg_weights* w, int max_batch, int num_samples, dz_seg** out);
+int dz_seg_forward(dz_seg* seg, const float* d_wave, long long wave_stride, int batch,
+                   float* d_out, void* stream);
+int dz_seg_destroy(dz_seg* seg);
+
+/* ---- embedding: replaces the callable behind EmbeddingModel.__call__ --------
+ * /root/reference/src/diart/models.py:248-265 (-> XVectorSincNet.forward, :262)
+ * waveform (N,1,S), weights (N,Fw) or NULL -> (N,D)                             */
+int dz_emb_create(dz_ctx* ctx, const dz_emb_weights* w, int max_batch, int num_samples, dz_emb** out);
+int dz_emb_forward(dz_emb* emb, const float* d_wave, long long wave_stride,
+                   const float* d_weights, int n_rows, int weight_frames,
+                   float* d_out, void* stream);
+/* De-duplicated form of SpeakerEmbedding.__call__ (blocks/embedding.py:51-65): the
+ * reference repeats each waveform K times and runs the full network per copy; only
+ * the statistics pooling depends on the speaker, so frame features are computed once
+ * per chunk and pooled K times.  d_weights is (B,K,Fw) speaker-major ("(batch spk)
+ * frame", embedding.py:58); output (B,K,D).  normalize!=0 additionally applies
+ * EmbeddingNormalization(norm=1) (functional.py:16-27).                          */
+int dz_emb_forward_multi(dz_emb* emb, const float* d_wave, long long wave_stride,
+                         const float* d_weights, int batch, int num_speakers,
+                         int weight_frames, int normalize, float* d_out, void* stream);
+int dz_emb_destroy(dz_emb* emb);
+
+/* ---- OverlappedSpeechPenalty: functional.py:6-13 + blocks/embedding.py:98-107
+ * d_seg (B,F,K) -> weights.  speaker_major=0: (B,F,K) like the reference block;
+ * speaker_major=1: (B,K,F), the layout dz_emb_forward_multi consumes.           */
+int dz_osp(dz_ctx* ctx, const float* d_seg, int batch, int frames, int speakers,
+           float gamma, float beta, int normalize, int speaker_major,
+           float* d_out, void* stream);
+
+/* ---- EmbeddingNormalization(norm): functional.py:16-27; rows (R,D) in place  */
+int dz_l2_normalize(dz_ctx* ctx, float* d_emb, int rows, int dim, float norm, void* stream);
+
+/* ---- cosine distances for N streams at once: mapping.py:171-176 (scipy cdist,
+ * fp64).  d_emb (N,K,D) f32, d_centers (N,G,D) f64 -> d_out (N,K,G) f64.        */
+int dz_cdist_cosine(dz_ctx* ctx, const float* d_emb, const double* d_centers,
+                    int n_streams, int k_local, int g_global, int dim,
+                    double* d_out, void* stream);
+
+/* ---- kernel-level entry points ---------------------------------------------
+ * The building blocks of dz_seg_forward / dz_emb_forward, exported so that each HIP
+ * kernel can be parity-tested on its own against a torch fp32 restatement of the same
+ * op (tests/test_gpu_kernels.py).  Layouts: DESIGN.md §3.                          */
+enum { DZ_EPI_BIAS = 0, DZ_EPI_BIAS_LEAKY = 1, DZ_EPI_BIAS_SIGMOID = 2, DZ_EPI_TDNN = 3,
+       DZ_EPI_POOL3 = 4 };
+typedef struct {
+    const float* X;       /* [B][Tin][ldx] channels-last input                       */
+    const float* W;       /* [Npad][Kpad], k = tap*Cin + c, zero padded              */
+    const float* bias;    /* [Npad]                                                  */
+    const float* e0;      /* TDNN: folded BatchNorm scale [Npad]                     */
+    const float* e1;      /* TDNN: folded BatchNorm shift [Npad]                     */
+    const float* nscale;  /* norm-on-load [B][nld] (InstanceNorm+LeakyReLU of input) */
+    const float* nshift;
+    float* Y;             /* [B][Tstore][ldy]                                        */
+    float* partials;      /* POOL3: [B][ntile][Npad][2] (sum, sumsq) of pooled rows  */
+    int B, Tin, Tout, Cin, taps, dil, K, Kpad, Npad, Nstore, ldx, ldy, nld, Tstore;
+    long long xbs, ybs;   /* batch strides in floats                                 */
+    int norm_on_load;     /* 0/1                                                     */
+    int epi;              /* DZ_EPI_*                                                */
+} dz_convgemm_desc;
+int dz_k_convgemm(dz_ctx* ctx, const dz_convgemm_desc* desc, void* stream);
+int dz_k_convgemm_ntile(int t_out);
+int dz_k_wave_stats(dz_ctx* ctx, const float* d_wave, long long stride, int batch, int samples,
+                    float* d_stats, void* stream);
+/* y0 (B, P0, 80) with P0 = ((S-251)/10+1)/3; partials (B, ntile0, 80, 2), ntile0 = ceil(F0/192) */
+int dz_k_sinc_conv0(dz_ctx* ctx, const float* d_wave, long long stride, int batch, int samples,
+                    const float* d_stats, float gamma, float beta, const float* d_filt,
+                    float* d_y0, float* d_partials, void* stream);
+int dz_k_finalize_norm(dz_ctx* ctx, const float* d_partials, int batch, int ntile, int channels,
+                       int frames, const float* d_gamma, const float* d_beta, float* d_scale,
+                       float* d_shift, void* stream);
+/* gx (B*T, 1024) = x-projection incl. biases, whh (2,512,128) -> hout (B,T,256)      */
+int dz_k_lstm(dz_ctx* ctx, const float* d_gx, const float* d_whh, float* d_hout, int batch,
+              int frames, void* stream);
+int dz_k_stats_pool(dz_ctx* ctx, const float* d_x, int frames, int channels, int ldx,
+                    const float* d_weights, int weight_frames, int rows, int rows_per_x,
+                    float* d_out, int ldo, void* stream);
+int dz_k_powerset(dz_ctx* ctx, const float* d_logits, int rows, int classes, int speakers,
+                  float* d_out, void* stream);
+
+/* ---- OnlineSpeakerClustering (host, fp64): blocks/clustering.py:10-218 with
+ * the SpeakerMap algebra of mapping.py:179-360 and scipy's rectangular LSAP.   */
+int dz_clu_create(double tau_active, double rho_update, double delta_new,
+                  int max_speakers, dz_clu** out);
+int dz_clu_reset(dz_clu* clu);
+/* one chunk: seg (F,K) f32, emb (K,D) f32 (NaN allowed) -> scores (F,G) f64
+ * (zeros for unassigned global speakers, mapping.py:341-360).
+ * assign_out (K) receives the global speaker of each local speaker or -1.       */
+int dz_clu_step(dz_clu* clu, const float* seg, int frames, int k_local,
+                const float* emb, int dim, double* scores_out, int* assign_out);
+/* the same for n independent streams (one clu handle each), run on host threads;
+ * seg (n,F,K), emb (n,K,D), scores (n,F,G), assign (n,K).                        */
+int dz_clu_step_batch(dz_clu** clus, int n, const float* seg, int frames, int k_local,
+                      const float* emb, int dim, double* scores_out, int* assign_out,
+                      int num_threads);
+/* state: centers (G,D) f64 copied to `out` (returns 1 if not initialised yet),
+ * active mask (G) ints.                                                          */
+int dz_clu_get_centers(dz_clu* clu, double* out, int dim);
+int dz_clu_get_active(dz_clu* clu, int* out_mask);
+/* embedding dimension of the centroid matrix, 0 before the first chunk (centers is None) */
+int dz_clu_dim(dz_clu* clu);
+int dz_clu_set_state(dz_clu* clu, const double* centers, const int* active_mask, int dim);
+int dz_clu_destroy(dz_clu* clu);
+
+/* exposed for tests: scipy.optimize.linear_sum_assignment (minimise), rows<=cols
+ * or transposed internally; col4row (nr) gets the column of each row.            */
+int dz_lsap(const double* cost, int nr, int nc, int* col4row);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DIART_AMD_H */

@@ -1,0 +1,329 @@
+"""Per-kernel parity: every HIP kernel vs a plain PyTorch fp32 (CPU) restatement of the same op,
+called through the C ABI (dz_k_* entry points).  Tolerances are fp32 round-off class: the
+kernels compute in exact-f32 MFMA / f32 VALU, only the summation order differs from ATen.
+"""
+import ctypes as C
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from diart_amd import _lib
+
+pytestmark = pytest.mark.gpu
+
+
+def _ctx(dev):
+    return _lib.context(dev.index or 0)
+
+
+def _sync():
+    torch.cuda.synchronize()
+
+
+def _rel(a, b):
+    a, b = a.double(), b.double()
+    return ((a - b).abs().max() / (b.abs().max() + 1e-30)).item()
+
+
+# --------------------------------------------------------------------------- #
+def test_wave_stats(gpu):
+    g = torch.Generator().manual_seed(0)
+    S = 80000
+    x = torch.randn(5, S, generator=g) * 0.1 + torch.tensor([0.0, 0.3, -0.2, 0.01, 1.0])[:, None]
+    big = torch.zeros(5, S + 64)
+    big[:, :S] = x
+    d = big.to(gpu)
+    st = torch.empty(5, 2, device=gpu)
+    lib = _lib.load()
+    _lib.check(lib.dz_k_wave_stats(_ctx(gpu), d.data_ptr(), d.stride(0), 5, S, st.data_ptr(), None))
+    _sync()
+    mean = x.double().mean(1)
+    rstd = 1.0 / torch.sqrt(x.double().var(1, unbiased=False) + 1e-5)
+    assert torch.allclose(st[:, 0].cpu().double(), mean, atol=1e-6)
+    assert torch.allclose(st[:, 1].cpu().double(), rstd, rtol=2e-6)
+
+
+def test_sinc_conv0(gpu):
+    from diart_amd.synth import synth_segmentation_state, synth_stream, sliding_chunks
+    from diart_amd.weights import sinc_filters
+    sd = synth_segmentation_state()
+    p = "sincnet.conv1d.0.filterbank."
+    filt = sinc_filters(sd[p + "low_hz_"], sd[p + "band_hz_"], sd[p + "window_"], sd[p + "n_"])
+    S, B = 80000, 3
+    x = torch.from_numpy(sliding_chunks(synth_stream(5, 8.0))[:B].copy())
+    gamma, beta = 1.3, -0.05
+    xn = F.instance_norm(x[:, None, :]) * gamma + beta
+    ref = F.max_pool1d(F.conv1d(xn, filt[:, None, :], stride=10).abs(), 3, 3)  # (B,80,2658)
+    P0 = ref.shape[2]
+    assert P0 == 2658
+    lib = _lib.load()
+    d = x.to(gpu)
+    st = torch.empty(B, 2, device=gpu)
+    _lib.check(lib.dz_k_wave_stats(_ctx(gpu), d.data_ptr(), d.stride(0), B, S, st.data_ptr(), None))
+    fk = torch.zeros(252, 80)
+    fk[:251] = filt.t()
+    fk = fk.to(gpu)
+    nt = (7975 + 191) // 192
+    y0 = torch.full((B, P0, 80), float("nan"), device=gpu)
+    part = torch.full((B, nt, 80, 2), float("nan"), device=gpu)
+    _lib.check(lib.dz_k_sinc_conv0(_ctx(gpu), d.data_ptr(), d.stride(0), B, S, st.data_ptr(), gamma,
+                                   beta, fk.data_ptr(), y0.data_ptr(), part.data_ptr(), None))
+    _sync()
+    got = y0.cpu().permute(0, 2, 1)
+    assert not torch.isnan(got).any()
+    assert _rel(got, ref) < 2e-5
+    ps = part.cpu().double().sum(1)  # (B,80,2)
+    assert torch.allclose(ps[..., 0], ref.double().sum(2), rtol=1e-5)
+    assert torch.allclose(ps[..., 1], (ref.double() ** 2).sum(2), rtol=1e-5)
+    # finalize -> scale/shift of InstanceNorm1d(80, affine)
+    gam, bet = torch.rand(80) + 0.5, torch.randn(80) * 0.1
+    sc, sh = torch.empty(B, 80, device=gpu), torch.empty(B, 80, device=gpu)
+    dg, db = gam.to(gpu), bet.to(gpu)
+    _lib.check(lib.dz_k_finalize_norm(_ctx(gpu), part.data_ptr(), B, nt, 80, P0, dg.data_ptr(),
+                                      db.data_ptr(), sc.data_ptr(), sh.data_ptr(), None))
+    _sync()
+    normed = got * sc.cpu()[:, :, None] + sh.cpu()[:, :, None]
+    refn = F.instance_norm(ref) * gam[None, :, None] + bet[None, :, None]
+    assert (normed - refn).abs().max().item() < 2e-4
+
+
+# --------------------------------------------------------------------------- #
+def _run_convgemm(gpu, X, W, bias, *, taps, dil, epi, Npad, Nstore, Kpad, e0=None, e1=None,
+                  nscale=None, nshift=None, Tstore=None, ldy=None):
+    """X (B,Tin,Cin) channels-last; W (Npad,Kpad) packed."""
+    lib = _lib.load()
+    B, Tin, Cin = X.shape
+    Tout = Tin - (taps - 1) * dil
+    Tstore = Tout if Tstore is None else Tstore
+    ldy = Nstore if ldy is None else ldy
+    dX, dW, db = X.contiguous().to(gpu), W.contiguous().to(gpu), bias.to(gpu)
+    Y = torch.full((B, Tstore, ldy), float("nan"), device=gpu)
+    d = _lib.ConvGemmDesc()
+    d.X, d.W, d.bias, d.Y = dX.data_ptr(), dW.data_ptr(), db.data_ptr(), Y.data_ptr()
+    keep = [dX, dW, db]
+    if e0 is not None:
+        de0, de1 = e0.to(gpu), e1.to(gpu)
+        d.e0, d.e1 = de0.data_ptr(), de1.data_ptr()
+        keep += [de0, de1]
+    if nscale is not None:
+        dsc, dsh = nscale.contiguous().to(gpu), nshift.contiguous().to(gpu)
+        d.nscale, d.nshift, d.nld, d.norm_on_load = dsc.data_ptr(), dsh.data_ptr(), nscale.shape[1], 1
+        keep += [dsc, dsh]
+    ntile = lib.dz_k_convgemm_ntile(Tout)
+    part = None
+    if epi == _lib.EPI_POOL3:
+        part = torch.full((B, ntile, Npad, 2), float("nan"), device=gpu)
+        d.partials = part.data_ptr()
+    d.B, d.Tin, d.Tout, d.Cin, d.taps, d.dil = B, Tin, Tout, Cin, taps, dil
+    d.K, d.Kpad, d.Npad, d.Nstore, d.ldx, d.ldy, d.Tstore = taps * Cin, Kpad, Npad, Nstore, Cin, ldy, Tstore
+    d.xbs, d.ybs, d.epi = Tin * Cin, Tstore * ldy, epi
+    _lib.check(lib.dz_k_convgemm(_ctx(gpu), C.byref(d), None), "dz_k_convgemm")
+    _sync()
+    return Y.cpu(), (part.cpu() if part is not None else None)
+
+
+def _pack(w, cin_pad, npad, kpad):
+    from diart_amd.weights import _conv_pack
+    return _conv_pack(w, cin_pad, npad, kpad)
+
+
+@pytest.mark.parametrize("M,K,N,epi", [(293 * 2 + 5, 64, 1024, "bias"), (500, 256, 1024, "bias"),
+                                       (97, 256, 128, "leaky"), (200, 128, 3, "sigmoid"),
+                                       (192, 3008, 512, "bias64")])
+def test_convgemm_linear(gpu, M, K, N, epi):
+    g = torch.Generator().manual_seed(M + K)
+    X = torch.randn(1, M, K, generator=g)
+    W = torch.randn(N, K, generator=g) / math.sqrt(K)
+    b = torch.randn(N, generator=g)
+    Npad = 64 if N <= 64 else (N + 127) // 128 * 128
+    if epi == "bias64":
+        Npad = N
+    Wp = torch.zeros(Npad, K)
+    Wp[:N] = W
+    bp = torch.zeros(Npad)
+    bp[:N] = b
+    code = {"bias": _lib.EPI_BIAS, "bias64": _lib.EPI_BIAS, "leaky": _lib.EPI_BIAS_LEAKY,
+            "sigmoid": _lib.EPI_BIAS_SIGMOID}[epi]
+    Y, _ = _run_convgemm(gpu, X, Wp, bp, taps=1, dil=1, epi=code, Npad=Npad, Nstore=N, Kpad=K)
+    ref = X[0].double() @ W.double().t() + b.double()
+    if epi == "leaky":
+        ref = F.leaky_relu(ref, 0.01)
+    if epi == "sigmoid":
+        ref = torch.sigmoid(ref)
+    assert not torch.isnan(Y).any()
+    assert (Y[0].double() - ref).abs().max().item() < 2e-5 * max(1.0, ref.abs().max().item())
+
+
+@pytest.mark.parametrize("Cin,Cout,taps,dil,Tin", [(60, 512, 5, 1, 293), (512, 512, 3, 2, 289),
+                                                   (512, 512, 3, 3, 285), (512, 1500, 1, 1, 279)])
+def test_convgemm_tdnn(gpu, Cin, Cout, taps, dil, Tin):
+    g = torch.Generator().manual_seed(Cin + taps)
+    B = 2
+    cin_pad = 64 if Cin == 60 else Cin
+    x = torch.randn(B, Cin, Tin, generator=g)
+    w = torch.randn(Cout, Cin, taps, generator=g) / math.sqrt(Cin * taps)
+    bias = torch.randn(Cout, generator=g) * 0.1
+    s0, s1 = torch.rand(Cout, generator=g) + 0.5, torch.randn(Cout, generator=g) * 0.1
+    npad = (Cout + 127) // 128 * 128
+    kpad = (taps * cin_pad + 31) // 32 * 32
+    Wp = _pack(w, cin_pad, npad, kpad)
+    pad1 = lambda v: torch.cat([v, torch.zeros(npad - Cout)])
+    X = torch.zeros(B, Tin, cin_pad)
+    X[:, :, :Cin] = x.permute(0, 2, 1)
+    nscale = nshift = None
+    xin = x
+    if Cin == 60:  # first TDNN consumes the instance-normed SincNet output: norm-on-load
+        nscale = torch.zeros(B, 64)
+        nshift = torch.zeros(B, 64)
+        nscale[:, :60] = torch.rand(B, 60, generator=g) + 0.5
+        nshift[:, :60] = torch.randn(B, 60, generator=g) * 0.2
+        xin = F.leaky_relu(x * nscale[:, :60, None] + nshift[:, :60, None], 0.01)
+    Y, _ = _run_convgemm(gpu, X, Wp, pad1(bias), taps=taps, dil=dil, epi=_lib.EPI_TDNN, Npad=npad,
+                         Nstore=npad, Kpad=kpad, e0=pad1(s0), e1=pad1(s1), nscale=nscale, nshift=nshift)
+    ref = F.leaky_relu(F.conv1d(xin.double(), w.double(), bias.double(), dilation=dil), 0.01)
+    ref = ref * s0.double()[None, :, None] + s1.double()[None, :, None]
+    got = Y[:, :, :Cout].permute(0, 2, 1).double()
+    assert not torch.isnan(Y).any()
+    assert (Y[:, :, Cout:] == 0).all()
+    assert (got - ref).abs().max().item() < 3e-5 * max(1.0, ref.abs().max().item())
+
+
+@pytest.mark.parametrize("Cin,Tin", [(80, 2658), (60, 884)])
+def test_convgemm_pool3(gpu, Cin, Tin):
+    g = torch.Generator().manual_seed(Cin)
+    B, Cout, taps = 2, 60, 5
+    cin_pad = 80 if Cin == 80 else 64
+    x = torch.randn(B, Cin, Tin, generator=g).abs()
+    w = torch.randn(Cout, Cin, taps, generator=g) / math.sqrt(Cin * taps)
+    bias = torch.randn(Cout, generator=g) * 0.1
+    kpad = (taps * cin_pad + 31) // 32 * 32
+    Wp = _pack(w, cin_pad, 64, kpad)
+    X = torch.zeros(B, Tin, cin_pad)
+    X[:, :, :Cin] = x.permute(0, 2, 1)
+    nscale, nshift = torch.zeros(B, cin_pad), torch.zeros(B, cin_pad)
+    nscale[:, :Cin] = torch.rand(B, Cin, generator=g) + 0.5
+    nshift[:, :Cin] = torch.randn(B, Cin, generator=g) * 0.2 - 0.3
+    xin = F.leaky_relu(x * nscale[:, :Cin, None] + nshift[:, :Cin, None], 0.01)
+    ref = F.max_pool1d(F.conv1d(xin.double(), w.double(), bias.double()), 3, 3)
+    Tp = ref.shape[2]
+    bp = torch.cat([bias, torch.zeros(4)])
+    Y, part = _run_convgemm(gpu, X, Wp, bp, taps=taps, dil=1, epi=_lib.EPI_POOL3, Npad=64, Nstore=64,
+                            Kpad=kpad, nscale=nscale, nshift=nshift, Tstore=Tp, ldy=64)
+    got = Y[:, :, :Cout].permute(0, 2, 1).double()
+    assert not torch.isnan(Y).any() and not torch.isnan(part).any()
+    assert (Y[:, :, Cout:] == 0).all()
+    assert (got - ref).abs().max().item() < 3e-5 * max(1.0, ref.abs().max().item())
+    ps = part.double().sum(1)[:, :Cout]
+    assert torch.allclose(ps[..., 0], ref.sum(2), rtol=1e-5, atol=1e-4)
+    assert torch.allclose(ps[..., 1], (ref ** 2).sum(2), rtol=1e-5, atol=1e-4)
+
+
+# --------------------------------------------------------------------------- #
+@pytest.mark.parametrize("B,T", [(1, 293), (3, 40), (17, 64)])
+def test_lstm_recurrence(gpu, B, T):
+    g = torch.Generator().manual_seed(B * 100 + T)
+    H, I = 128, 32
+    lstm = torch.nn.LSTM(I, H, 1, bidirectional=True, batch_first=True)
+    with torch.no_grad():
+        for p in lstm.parameters():
+            p.copy_((torch.rand(p.shape, generator=g) * 2 - 1) * 0.25)
+    x = torch.randn(B, T, I, generator=g)
+    with torch.no_grad():
+        ref, _ = lstm(x)
+        gx = torch.cat([x @ lstm.weight_ih_l0.t() + lstm.bias_ih_l0 + lstm.bias_hh_l0,
+                        x @ lstm.weight_ih_l0_reverse.t() + lstm.bias_ih_l0_reverse + lstm.bias_hh_l0_reverse],
+                       dim=-1)  # (B,T,1024)
+        whh = torch.stack([lstm.weight_hh_l0, lstm.weight_hh_l0_reverse]).contiguous()
+    dgx, dw = gx.contiguous().to(gpu), whh.to(gpu)
+    hout = torch.full((B, T, 256), float("nan"), device=gpu)
+    _lib.check(_lib.load().dz_k_lstm(_ctx(gpu), dgx.data_ptr(), dw.data_ptr(), hout.data_ptr(), B, T, None))
+    _sync()
+    got = hout.cpu()
+    assert not torch.isnan(got).any()
+    assert (got - ref).abs().max().item() < 2e-5
+
+
+# --------------------------------------------------------------------------- #
+@pytest.mark.parametrize("K,Fw", [(1, 293), (3, 293), (4, 293), (5, 293), (3, 279), (1, 0)])
+def test_stats_pool(gpu, K, Fw):
+    from oracle.models_ref import stats_pool_ref
+    g = torch.Generator().manual_seed(K * 7 + Fw)
+    nx, T, Cc, ld = 3, 279, 1500, 1536
+    x = torch.randn(nx, T, ld, generator=g) + 0.5
+    rows = nx * K
+    w = None
+    if Fw:
+        w = torch.rand(rows, Fw, generator=g) ** 3 + 1e-8
+    dx = x.to(gpu)
+    dw = w.to(gpu) if w is not None else None
+    out = torch.full((rows, 3008), float("nan"), device=gpu)
+    _lib.check(_lib.load().dz_k_stats_pool(_ctx(gpu), dx.data_ptr(), T, Cc, ld,
+                                           dw.data_ptr() if dw is not None else None, Fw, rows, K,
+                                           out.data_ptr(), 3008, None))
+    _sync()
+    seq = x[:, :, :Cc].permute(0, 2, 1).repeat_interleave(K, dim=0)  # (rows,C,T)
+    ref = stats_pool_ref(seq, w)
+    got = out.cpu()[:, :3000]
+    assert not torch.isnan(got).any()
+    assert (got - ref).abs().max().item() < 2e-5 * max(1.0, ref.abs().max().item())
+
+
+@pytest.mark.parametrize("normalize", [False, True])
+@pytest.mark.parametrize("K", [3, 4])
+def test_osp(gpu, K, normalize):
+    from oracle.functional_ref import overlapped_speech_penalty_ref
+    g = torch.Generator().manual_seed(K)
+    B, Fr = 5, 293
+    seg = torch.rand(B, Fr, K, generator=g)
+    seg[1, :, 0] = 0.0
+    seg[2] = 0.5  # constant -> min == max -> NaN -> 1e-8 when normalising
+    ref = overlapped_speech_penalty_ref(seg, 3.0, 10.0, normalize)
+    d = seg.to(gpu)
+    for major in (0, 1):
+        out = torch.empty(B, Fr, K, device=gpu)
+        _lib.check(_lib.load().dz_osp(_ctx(gpu), d.data_ptr(), B, Fr, K, 3.0, 10.0, int(normalize),
+                                      major, out.data_ptr(), None))
+        _sync()
+        got = out.cpu()
+        if major:
+            got = got.view(B, K, Fr).permute(0, 2, 1)
+        assert torch.allclose(got, ref, rtol=2e-5, atol=1e-9)
+
+
+def test_l2norm_and_cdist(gpu):
+    from scipy.spatial.distance import cdist
+    g = torch.Generator().manual_seed(3)
+    e = torch.randn(7, 3, 512, generator=g)
+    d = e.clone().to(gpu)
+    _lib.check(_lib.load().dz_l2_normalize(_ctx(gpu), d.data_ptr(), 21, 512, 1.0, None))
+    _sync()
+    ref = e / e.norm(dim=-1, keepdim=True)
+    assert torch.allclose(d.cpu(), ref, rtol=1e-5, atol=1e-7)
+    cen = torch.randn(7, 20, 512, generator=g, dtype=torch.float64)
+    cen[:, 5] = 0.0  # unused centroid -> NaN like scipy
+    dc = cen.to(gpu)
+    out = torch.empty(7, 3, 20, dtype=torch.float64, device=gpu)
+    _lib.check(_lib.load().dz_cdist_cosine(_ctx(gpu), d.data_ptr(), dc.data_ptr(), 7, 3, 20, 512,
+                                           out.data_ptr(), None))
+    _sync()
+    got = out.cpu().numpy()
+    for n in range(7):
+        with np.errstate(invalid="ignore", divide="ignore"):
+            r = cdist(d.cpu().numpy()[n].astype(np.float64), cen.numpy()[n], metric="cosine")
+        assert np.isnan(got[n][:, 5]).all()
+        m = ~np.isnan(r)
+        assert np.allclose(got[n][m], r[m], rtol=0, atol=1e-12)
+
+
+def test_powerset(gpu):
+    from oracle.models_ref import powerset_to_multilabel
+    g = torch.Generator().manual_seed(9)
+    lp = torch.log_softmax(torch.randn(1000, 7, generator=g), dim=-1)
+    d = lp.to(gpu)
+    out = torch.empty(1000, 3, device=gpu)
+    _lib.check(_lib.load().dz_k_powerset(_ctx(gpu), d.data_ptr(), 1000, 7, 3, out.data_ptr(), None))
+    _sync()
+    assert torch.equal(out.cpu(), powerset_to_multilabel(lp))
