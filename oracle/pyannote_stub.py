@@ -1,0 +1,115 @@
+"""Minimal stand-in for the two ``pyannote.core`` symbols the reference's hot-path files touch,
+plus a by-path loader for those files.  TEST INFRASTRUCTURE, used only in the build container
+(``/root/reference`` does not exist on the GPU box) by ``tests/golden/make_golden.py`` to produce
+the committed fixtures, i.e. to pin the oracle against the reference's OWN code:
+
+* ``/root/reference/src/diart/functional.py``, ``mapping.py``, ``features.py``
+* ``/root/reference/src/diart/blocks/clustering.py``, ``blocks/embedding.py``, ``blocks/segmentation.py``
+
+``pyannote.core`` itself is not installed here.  Surface provided:
+``SlidingWindow(start, duration, step)``, ``SlidingWindowFeature(data, sliding_window)`` with
+``.data / .sliding_window / .extent / __getitem__``, ``Segment``, and
+``pyannote.core.utils.distance.cdist`` == ``scipy.spatial.distance.cdist`` for "cosine".
+"""
+from __future__ import annotations
+
+import importlib.util
+import sys
+import types
+from pathlib import Path
+
+import numpy as np
+
+
+class Segment:
+    def __init__(self, start: float, end: float):
+        self.start, self.end = start, end
+
+    @property
+    def duration(self):
+        return self.end - self.start
+
+    @property
+    def middle(self):
+        return 0.5 * (self.start + self.end)
+
+
+class SlidingWindow:
+    def __init__(self, duration: float = 0.03, step: float = 0.01, start: float = 0.0, end=None):
+        self.duration, self.step, self.start, self.end = duration, step, start, end
+
+    def __getitem__(self, i: int) -> Segment:
+        s = self.start + i * self.step
+        return Segment(s, s + self.duration)
+
+
+class SlidingWindowFeature:
+    def __init__(self, data: np.ndarray, sliding_window: SlidingWindow):
+        self.data, self.sliding_window = data, sliding_window
+
+    def __getitem__(self, i):
+        return self.data[i]
+
+    def __len__(self):
+        return self.data.shape[0]
+
+    @property
+    def extent(self) -> Segment:
+        sw = self.sliding_window
+        n = self.data.shape[0]
+        return Segment(sw.start, sw.start + (n - 1) * sw.step + sw.duration)
+
+
+def install() -> None:
+    """Register the stand-in as ``pyannote.core`` (only if the real one is absent)."""
+    if "pyannote.core" in sys.modules:
+        return
+    from scipy.spatial.distance import cdist
+    pkg = types.ModuleType("pyannote")
+    pkg.__path__ = []
+    core = types.ModuleType("pyannote.core")
+    core.__path__ = []
+    core.SlidingWindow, core.SlidingWindowFeature, core.Segment = SlidingWindow, SlidingWindowFeature, Segment
+    utils = types.ModuleType("pyannote.core.utils")
+    utils.__path__ = []
+    dist = types.ModuleType("pyannote.core.utils.distance")
+    dist.cdist = cdist
+    sys.modules.update({"pyannote": pkg, "pyannote.core": core, "pyannote.core.utils": utils,
+                        "pyannote.core.utils.distance": dist})
+
+
+def load_reference(root: str = "/root/reference/src/diart"):
+    """Import the reference's hot-path modules by path under the package name ``diart_ref``
+    WITHOUT running its ``__init__`` files (they pull in rx / pyannote.audio / torchaudio).
+    Returns a namespace with .functional .mapping .features .models .clustering .embedding
+    .segmentation."""
+    install()
+    sys.dont_write_bytecode = True  # never write __pycache__ into the read-only reference tree
+    rootp = Path(root)
+    if not rootp.exists():
+        raise FileNotFoundError(f"{root} is not available (only present in the build container)")
+    for name, path in (("diart_ref", rootp), ("diart_ref.blocks", rootp / "blocks")):
+        if name not in sys.modules:
+            m = types.ModuleType(name)
+            m.__path__ = [str(path)]
+            sys.modules[name] = m
+
+    def _load(name: str, rel: str):
+        full = f"diart_ref.{name}"
+        if full in sys.modules:
+            return sys.modules[full]
+        spec = importlib.util.spec_from_file_location(full, rootp / rel)
+        mod = importlib.util.module_from_spec(spec)
+        sys.modules[full] = mod
+        spec.loader.exec_module(mod)
+        return mod
+
+    ns = types.SimpleNamespace()
+    ns.functional = _load("functional", "functional.py")
+    ns.mapping = _load("mapping", "mapping.py")
+    ns.features = _load("features", "features.py")
+    ns.models = _load("models", "models.py")
+    ns.clustering = _load("blocks.clustering", "blocks/clustering.py")
+    ns.embedding = _load("blocks.embedding", "blocks/embedding.py")
+    ns.segmentation = _load("blocks.segmentation", "blocks/segmentation.py")
+    return ns

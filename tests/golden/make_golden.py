@@ -1,0 +1,95 @@
+"""Generate the golden fixtures from the REFERENCE'S OWN CODE (build container only).
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
+
+Runs /root/reference/src/diart/{functional.py, mapping.py, blocks/clustering.py,
+blocks/embedding.py} (loaded by path with the pyannote.core stand-in of oracle/pyannote_stub.py)
+on the seeded inputs of scenarios.py and stores inputs + outputs as small .npz files next to this
+script.  The fixtures pin oracle/functional_ref.py and oracle/clustering_ref.py, and through them
+the HIP / C++ product path.
+"""
+import sys
+from pathlib import Path
+
+import numpy as np
+import torch
+
+HERE = Path(__file__).resolve().parent
+sys.path.insert(0, str(HERE.parent.parent))
+sys.path.insert(0, str(HERE))
+
+from oracle.pyannote_stub import SlidingWindow, SlidingWindowFeature, load_reference  # noqa: E402
+import scenarios  # noqa: E402
+
+
+def main():
+    ref = load_reference()
+    # ---- functional.py -------------------------------------------------------------
+    seg, emb = scenarios.functional_inputs()
+    out = {}
+    for gamma, beta in ((3, 10), (2, 5), (1.5, 10)):
+        w = ref.functional.overlapped_speech_penalty(torch.from_numpy(seg), gamma, beta)
+        out[f"osp_g{gamma}_b{beta}"] = w.numpy()
+    for norm in (False, True):   # blocks/embedding.py:98-107
+        block = ref.embedding.OverlappedSpeechPenalty(3, 10, normalize=norm)
+        out[f"osp_block_norm{int(norm)}"] = block(torch.from_numpy(seg)).numpy()
+    out["normalize"] = ref.functional.normalize_embeddings(torch.from_numpy(emb)).numpy()
+    out["normalize_2d"] = ref.functional.normalize_embeddings(torch.from_numpy(emb[0]), norm=2.5).numpy()
+    np.savez_compressed(HERE / "functional.npz", seg=seg, emb=emb, **out)
+
+    # ---- blocks/embedding.py plumbing with a toy model (ordering / squeeze semantics) --------
+    def toy(wave, weights=None):
+        if weights is None:
+            return torch.stack([wave[:, 0, :100].sum(-1), wave[:, 0, -100:].sum(-1)], -1)
+        return torch.stack([wave[:, 0, :100].sum(-1), weights.sum(-1), weights[:, :10].sum(-1),
+                            (weights * torch.arange(weights.shape[1])).sum(-1)], -1)
+    rng = np.random.default_rng(5)
+    wav = rng.standard_normal((3, 800, 1)).astype(np.float32)
+    sg = rng.random((3, 29, 3)).astype(np.float32)
+    plumb = {"wav": wav, "sg": sg}
+    model = ref.models.EmbeddingModel(lambda: toy)
+    oase = ref.embedding.OverlapAwareSpeakerEmbedding(model, 3, 10, norm=1, device=torch.device("cpu"))
+    plumb["oase_b3"] = oase(torch.from_numpy(wav), torch.from_numpy(sg)).numpy()
+    plumb["oase_b1"] = oase(torch.from_numpy(wav[:1]), torch.from_numpy(sg[:1])).numpy()
+    se = ref.embedding.SpeakerEmbedding(model, torch.device("cpu"))
+    plumb["se_noweights"] = se(torch.from_numpy(wav)).numpy()
+    np.savez_compressed(HERE / "embedding_plumbing.npz", **plumb)
+
+    # ---- blocks/clustering.py ---------------------------------------------------------
+    for name in scenarios.CLUSTERING:
+        inp = scenarios.clustering_inputs(name)
+        clu = ref.clustering.OnlineSpeakerClustering(inp["tau"], inp["rho"], inp["delta"], "cosine", inp["G"])
+        T, F, K = inp["seg"].shape
+        assign = -np.ones((T, K), dtype=np.int64)
+        active = np.zeros((T, inp["G"]), dtype=np.int8)
+        score_sum = np.zeros((T, inp["G"]))
+        raised = np.zeros(T, dtype=np.int8)
+        centers_trace = np.zeros((T, inp["G"]))
+        for t in range(T):
+            swf = SlidingWindowFeature(inp["seg"][t], SlidingWindow(start=0.5 * t, duration=5 / F, step=5 / F))
+            try:
+                res = clu(swf, torch.from_numpy(inp["emb"][t]))
+            except (AssertionError, ValueError) as exc:
+                raised[t] = 1
+                print(f"  [{name}] step {t}: reference raised {type(exc).__name__}: {exc}")
+                continue
+            for g in range(inp["G"]):
+                col = res.data[:, g]
+                if col.any():
+                    src = [k for k in range(K) if np.array_equal(col, inp["seg"][t][:, k].astype(np.float64))]
+                    for k in src:
+                        if assign[t, k] < 0:
+                            assign[t, k] = g
+                            break
+            score_sum[t] = res.data.sum(0)
+            active[t, sorted(clu.active_centers)] = 1
+            centers_trace[t] = clu.centers.sum(1)
+        np.savez_compressed(HERE / f"clustering_{name}.npz", seg=inp["seg"], emb=inp["emb"],
+                            params=np.array([inp["tau"], inp["rho"], inp["delta"], inp["G"]]),
+                            assign=assign, active=active, score_sum=score_sum, raised=raised,
+                            centers_trace=centers_trace, centers=clu.centers)
+        print(name, "steps", T, "final speakers", int(active[-1].sum()), "raised", int(raised.sum()))
+
+
+if __name__ == "__main__":
+    main()
