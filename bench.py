@@ -1,0 +1,229 @@
+#!/usr/bin/env python
+"""bench.py — real-time streams per GPU of diart's per-chunk hot path on MI355X.
+
+A "step" = one pass of the hot path over one batch of synthetic input: the current 5 s window of
+each of the 64 concurrent 16 kHz streams of one GPU (BASELINE.json configs[1]) goes through
+SpeakerSegmentation -> OverlappedSpeechPenalty -> SpeakerEmbedding (x3 speakers) -> normalisation
+-> OnlineSpeakerClustering, exactly the lines 186-203 of the reference's SpeakerDiarization.__call__.
+Windows advance by 500 ms per step and are read in place from the streams, which are resident in
+HBM before the timed region starts.
+
+    value = chunks/s / 2  = number of real-time streams the job sustains at a 500 ms step
+            (each live stream emits 2 chunks per second), whole job, all GPUs.
+
+N > 1 (launched by torch.distributed.run): every rank owns 64 streams of its own (weak scaling,
+streams are independent — no data-path collective); rank 0 synthesises the weights and broadcasts
+them over RCCL; timing is barrier + synchronize on both sides, max over ranks.
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+import torch
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+MMAC = {  # algorithmic MACs per 5 s chunk per launch, launches per forward
+    "sinc_conv0": 160_138_000, "conv1_pool": 63_696_000, "conv2_pool": 15_840_000,
+    "lstm_proj": (293 * 60 * 1024 + 3 * 293 * 256 * 1024) / 4, "lstm_rec": 2 * 293 * 512 * 128,
+    "seg_mlp": (293 * 256 * 128 + 293 * 128 * 128) / 2, "seg_classifier": 293 * 128 * 3,
+    "tdnn1": 289 * 512 * 300, "tdnn2": 285 * 512 * 1536, "tdnn3": 279 * 512 * 1536,
+    "tdnn4": 279 * 512 * 512, "tdnn5": 279 * 1500 * 512, "emb_linear": 3 * 3000 * 512,
+}
+ALG_GFLOP_PER_CHUNK = 3.352   # 1.312 seg + 2.039 emb de-duplicated
+PEAK_F32_MATRIX_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, dense
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--streams", type=int, default=64, help="concurrent streams per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-chunks", type=int, default=8, help="chunks in the bounded CPU sample")
+    ap.add_argument("--kernel-table", type=str, default="", help="write the per-kernel table here")
+    return ap.parse_args()
+
+
+def kernel_table(lib, chunks_per_launch):
+    rows = []
+    name, ms, n = C.c_char_p(), C.c_double(), C.c_longlong()
+    for tag in range(24):
+        lib.dz_prof_get(tag, C.byref(name), C.byref(ms), C.byref(n))
+        if n.value == 0:
+            continue
+        nm = name.value.decode()
+        avg_ms = ms.value / n.value
+        row = {"kernel": nm, "launches": n.value, "total_ms": round(ms.value, 3), "avg_us": round(avg_ms * 1e3, 2)}
+        if nm in MMAC:
+            flop = 2.0 * MMAC[nm] * chunks_per_launch
+            row["alg_gflop_per_launch"] = round(flop / 1e9, 3)
+            row["tflops"] = round(flop / (avg_ms * 1e-3) / 1e12, 2)
+        rows.append(row)
+    return rows
+
+
+def cpu_baseline(seg_state, emb_state, audio_cpu, n_chunks):
+    """The oracle ("port" of the reference CPU path) on the host cores, reference-style:
+    embedding network run on K repeated waveforms per chunk (blocks/embedding.py:57)."""
+    from oracle.models_ref import PyanNetRef, XVectorSincNetRef
+    from oracle.functional_ref import overlapped_speech_penalty_ref, normalize_embeddings_ref
+    from oracle.clustering_ref import OnlineSpeakerClusteringRef
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    seg_m, emb_m = PyanNetRef().eval(), XVectorSincNetRef().eval()
+    seg_m.load_state_dict(seg_state)
+    emb_m.load_state_dict(emb_state)
+    x = audio_cpu[:n_chunks, None, :80000].contiguous()
+    clus = [OnlineSpeakerClusteringRef(0.6, 0.3, 1.0, "cosine", 20) for _ in range(n_chunks)]
+
+    def one():
+        with torch.no_grad():
+            seg = seg_m(x)
+            w = overlapped_speech_penalty_ref(seg)
+            rows = x.repeat(1, 3, 1).reshape(n_chunks * 3, 1, -1)
+            emb = emb_m(rows, w.permute(0, 2, 1).reshape(n_chunks * 3, -1)).view(n_chunks, 3, -1)
+            emb = normalize_embeddings_ref(emb)
+        for i in range(n_chunks):
+            clus[i](seg[i].numpy(), emb[i].numpy())
+
+    def dedup():
+        with torch.no_grad():
+            seg = seg_m(x)
+            emb_m.forward_multi(x, overlapped_speech_penalty_ref(seg))
+
+    one()  # warm-up
+    t0 = time.monotonic()
+    reps = 0
+    while time.monotonic() - t0 < 12.0 or reps < 2:
+        one()
+        reps += 1
+    dt = time.monotonic() - t0
+    cps = reps * n_chunks / dt
+    t1 = time.monotonic()
+    dedup()
+    cps_dedup = n_chunks / (time.monotonic() - t1)
+    return {"value": round(cps / 2, 3), "unit": "xRT streams (chunks/s / 2)", "cores": cores,
+            "kind": "port",
+            "sample": f"{reps} passes over {n_chunks} chunks (5 s each) of the same synthetic streams, "
+                      f"torch-CPU fp32 restatement with the same weights, embedding run on 3 repeated "
+                      f"waveforms per chunk as the reference does, {dt:.1f} s; "
+                      f"de-duplicated CPU variant: {cps_dedup / 2:.3f} xRT"}
+
+
+def main():
+    args = parse()
+    from diart_amd import _lib, distributed as D
+    from diart_amd.models import HipEmbedding, HipSegmentation
+    from diart_amd.pipeline import StreamBatch
+    from diart_amd.synth import synth_embedding_state, synth_segmentation_state, synth_streams
+
+    rank, world, local = D.init_from_env()
+    assert world == args.gpus or world == 1, f"WORLD_SIZE={world} but --gpus {args.gpus}"
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X GPU (the HIP path has no CPU fallback)")
+    device = torch.device("cuda", local)
+    torch.cuda.set_device(device)
+    lib = _lib.load()
+
+    # ---- weights: synthesised on rank 0, broadcast over RCCL ---------------------------
+    seg_state = synth_segmentation_state() if rank == 0 or world == 1 else None
+    emb_state = synth_embedding_state() if rank == 0 or world == 1 else None
+    if world > 1:
+        seg_spec = D.state_spec(synth_segmentation_state()) if rank != 0 else D.state_spec(seg_state)
+        emb_spec = D.state_spec(synth_embedding_state()) if rank != 0 else D.state_spec(emb_state)
+        seg_state = D.broadcast_state(seg_state, seg_spec, device)
+        emb_state = D.broadcast_state(emb_state, emb_spec, device)
+
+    # ---- synthetic streams of this rank, resident in HBM -------------------------------
+    n = args.streams
+    hop, S = 8000, 80000
+    total_steps = args.steps + args.warmup
+    seconds = (S + hop * (total_steps + 1)) / 16000.0
+    audio_cpu = torch.from_numpy(synth_streams(n, seconds, seed0=rank * n))
+    audio = audio_cpu.to(device)
+    assert audio.stride(0) % 4 == 0
+
+    pipe = StreamBatch(HipSegmentation(seg_state, max_batch=n), HipEmbedding(emb_state, max_batch=n),
+                       n, device=device, cluster_threads=min(8, os.cpu_count() or 1))
+
+    def window(t):
+        return audio[:, t * hop: t * hop + S]
+
+    def run(t_first, count):
+        prev = None
+        for t in range(t_first, t_first + count):
+            tk = pipe.launch(window(t))
+            if prev is not None:
+                pipe.finish(prev, want_scores=True)
+            prev = tk
+        pipe.finish(prev, want_scores=True)
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+
+    run(0, args.warmup)
+    torch.cuda.synchronize()
+    lib.dz_prof_enable(1)
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run(args.warmup, args.steps)
+    torch.cuda.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    lib.dz_prof_collect()
+    lib.dz_prof_enable(0) if False else None
+
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    if rank == 0:
+        chunks = world * n * args.steps
+        cps = chunks / elapsed
+        table = kernel_table(lib, n)
+        dom = max((r for r in table if "tflops" in r), key=lambda r: r["total_ms"])
+        roof = {"bound": "mfma", "kernel": dom["kernel"], "achieved": dom["tflops"],
+                "peak": PEAK_F32_MATRIX_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(dom["tflops"] / PEAK_F32_MATRIX_TFLOPS, 4), "traffic": None,
+                "avg_launch_us": dom["avg_us"],
+                "whole_path_tflops": round(cps / world * ALG_GFLOP_PER_CHUNK / 1e3, 2)}
+        out = {
+            "metric": "real-time-factor xRT streams/GPU @500ms step", "value": round(cps / 2, 2),
+            "unit": "xRT 16 kHz streams (chunks/s / 2)", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "configs[1]: single MI355X, 5 s window / 500 ms step, "
+                                   "pyannote/segmentation + pyannote/embedding architectures "
+                                   "(random-init weights), %d concurrent synthetic 16 kHz streams per GPU" % n,
+                       "streams_per_gpu": n, "chunks_per_step": world * n, "parallelism": f"streams x{world}"},
+            "roofline": roof,
+        }
+        if args.kernel_table:
+            Path(args.kernel_table).parent.mkdir(parents=True, exist_ok=True)
+            Path(args.kernel_table).write_text(json.dumps(table, indent=1))
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(seg_state, emb_state, audio_cpu, args.cpu_chunks)
+        elif not args.no_cpu_baseline:
+            out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

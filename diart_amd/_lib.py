@@ -52,7 +52,13 @@ SIGNATURES = {
     "dz_emb_forward": (C.c_int, [vp, vp, C.c_longlong, vp, C.c_int, C.c_int, vp, vp]),
     "dz_emb_forward_multi": (C.c_int, [vp, vp, C.c_longlong, vp, C.c_int, C.c_int, C.c_int,
                                        C.c_int, vp, vp]),
+    "dz_emb_frames": (C.c_int, [vp, vp, C.c_longlong, C.c_int, vp]),
+    "dz_emb_pool": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]),
     "dz_emb_destroy": (C.c_int, [vp]),
+    "dz_prof_enable": (C.c_int, [C.c_int]),
+    "dz_prof_collect": (C.c_int, []),
+    "dz_prof_get": (C.c_int, [C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_double),
+                              C.POINTER(C.c_longlong)]),
     "dz_osp": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_int,
                          C.c_int, vp, vp]),
     "dz_l2_normalize": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_float, vp]),

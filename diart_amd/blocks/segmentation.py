@@ -1,0 +1,38 @@
+"""``SpeakerSegmentation`` block (reference: ``/root/reference/src/diart/blocks/segmentation.py``).
+
+waveform ``(samples, channels)`` or ``(batch, samples, channels)`` as SlidingWindowFeature /
+ndarray / Tensor -> speaker activations ``(batch, frames, speakers)`` of the same kind, on the
+host, exactly like the reference block; the forward pass itself is ``dz_seg_forward``.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+from ..features import TemporalFeatureFormatter, TemporalFeatures
+from ..models import SegmentationModel
+
+
+class SpeakerSegmentation:
+    def __init__(self, model: SegmentationModel, device: Optional[torch.device] = None):
+        self.model = model
+        self.model.eval()
+        self.device = device if device is not None else torch.device(
+            "cuda" if torch.cuda.is_available() else "cpu")
+        self.model.to(self.device)
+        self.formatter = TemporalFeatureFormatter()
+
+    @staticmethod
+    def from_pretrained(model, use_hf_token=True, device: Optional[torch.device] = None):
+        return SpeakerSegmentation(SegmentationModel.from_pretrained(model, use_hf_token), device)
+
+    def __call__(self, waveform: TemporalFeatures) -> TemporalFeatures:
+        wave = self.formatter.cast(waveform)            # (batch, samples, channels) float32
+        if wave.shape[2] != 1:
+            raise ValueError(f"expected mono audio, got {wave.shape[2]} channels")
+        # (b, s, 1) -> (b, 1, s) is a pure view for mono audio: no transpose kernel, no copy
+        rows = wave.transpose(1, 2)
+        with torch.no_grad():
+            out = self.model(rows.to(self.device)).cpu()
+        return self.formatter.restore_type(out)

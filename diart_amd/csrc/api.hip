@@ -61,6 +61,76 @@ extern "C" int dz_ctx_destroy(dz_ctx* ctx) {
 }
 
 // ---------------------------------------------------------------------------
+// per-kernel timing with HIP events on the launch stream (bench.py's roofline leg).
+// Off by default; when on, every launch issued by the forward passes is bracketed by an
+// event pair taken from a fixed pool; dz_prof_collect() synchronises and accumulates.
+// ---------------------------------------------------------------------------
+enum { PROF_POOL = 8192, PROF_TAGS = 24 };
+static const char* kProfNames[PROF_TAGS] = {
+    "wave_stats", "sinc_conv0", "finalize_norm", "conv1_pool", "conv2_pool", "lstm_proj",
+    "lstm_rec", "seg_mlp", "seg_classifier", "tdnn1", "tdnn2", "tdnn3", "tdnn4", "tdnn5",
+    "stats_pool", "emb_linear", "l2norm", "osp", "powerset", "cdist", "", "", "", ""};
+enum { T_WAVE = 0, T_CONV0, T_FIN, T_CONV1, T_CONV2, T_PROJ, T_REC, T_MLP, T_CLS, T_TDNN1, T_TDNN2,
+       T_TDNN3, T_TDNN4, T_TDNN5, T_POOL, T_EMBLIN, T_L2, T_OSP, T_PSET, T_CDIST };
+struct Prof {
+    bool on = false;
+    int used = 0;
+    hipEvent_t ev[PROF_POOL][2];
+    int tag[PROF_POOL];
+    bool made = false;
+    double ms[PROF_TAGS];
+    long long n[PROF_TAGS];
+};
+static Prof g_prof;
+struct ProfScope {
+    int slot = -1;
+    hipStream_t st;
+    ProfScope(int tag, hipStream_t s) : st(s) {
+        if (g_prof.on && g_prof.used < PROF_POOL) {
+            slot = g_prof.used++;
+            g_prof.tag[slot] = tag;
+            (void)hipEventRecord(g_prof.ev[slot][0], st);
+        }
+    }
+    ~ProfScope() {
+        if (slot >= 0) (void)hipEventRecord(g_prof.ev[slot][1], st);
+    }
+};
+extern "C" int dz_prof_enable(int on) {
+    if (on && !g_prof.made) {
+        for (int i = 0; i < PROF_POOL; ++i) {
+            DZ_HIP(hipEventCreate(&g_prof.ev[i][0]));
+            DZ_HIP(hipEventCreate(&g_prof.ev[i][1]));
+        }
+        g_prof.made = true;
+    }
+    g_prof.on = on != 0;
+    g_prof.used = 0;
+    for (int t = 0; t < PROF_TAGS; ++t) { g_prof.ms[t] = 0.0; g_prof.n[t] = 0; }
+    return 0;
+}
+// drains the event pool (device must be idle or will be synchronised); returns #tags
+extern "C" int dz_prof_collect(void) {
+    DZ_HIP(hipDeviceSynchronize());
+    for (int i = 0; i < g_prof.used; ++i) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, g_prof.ev[i][0], g_prof.ev[i][1]) == hipSuccess) {
+            g_prof.ms[g_prof.tag[i]] += ms;
+            g_prof.n[g_prof.tag[i]] += 1;
+        }
+    }
+    g_prof.used = 0;
+    return PROF_TAGS;
+}
+extern "C" int dz_prof_get(int tag, const char** name, double* total_ms, long long* launches) {
+    if (tag < 0 || tag >= PROF_TAGS) return 2;
+    if (name) *name = kProfNames[tag];
+    if (total_ms) *total_ms = g_prof.ms[tag];
+    if (launches) *launches = g_prof.n[tag];
+    return 0;
+}
+
+// ---------------------------------------------------------------------------
 // geometry of the SincNet front-end for S samples
 // ---------------------------------------------------------------------------
 struct SincGeom {
@@ -115,13 +185,15 @@ struct SincScratch {
 static int run_sincnet(const dz_sincnet_weights& w, const SincGeom& g, const SincScratch& s,
                        const float* wave, long long stride, int B, hipStream_t st) {
     int rc;
-    if ((rc = dz_launch_wave_stats(wave, stride, B, g.S, s.stats, st))) return rc;
+    { ProfScope ps(T_WAVE, st); if ((rc = dz_launch_wave_stats(wave, stride, B, g.S, s.stats, st))) return rc; }
+    { ProfScope ps(T_CONV0, st);
     if ((rc = dz_launch_sinc_conv0(wave, stride, B, g.S, s.stats, w.wav_gamma, w.wav_beta, w.filt,
                                    s.y0, g.P0, s.part0, g.nt0, st)))
-        return rc;
+        return rc; }
+    { ProfScope ps(T_FIN, st);
     if ((rc = dz_launch_finalize_norm(s.part0, B, g.nt0, 80, g.P0, w.in0_g, w.in0_b, s.sc0, s.sh0,
                                       st)))
-        return rc;
+        return rc; }
     DzConvGemm p;
     memset(&p, 0, sizeof(p));
     // conv1: 80 -> 60(64), k5, + pool3
@@ -131,16 +203,18 @@ static int run_sincnet(const dz_sincnet_weights& w, const SincGeom& g, const Sin
     p.Kpad = 416; p.Npad = 64; p.Nstore = 64; p.ldx = 80; p.ldy = 64; p.Tstore = g.P1;
     p.xbs = (long long)g.P0 * 80; p.ybs = (long long)g.P1 * 64;
     p.norm_on_load = 1; p.epi = DZ_EPI_POOL3;
-    if ((rc = dz_launch_convgemm(p, st))) return rc;
+    { ProfScope ps(T_CONV1, st); if ((rc = dz_launch_convgemm(p, st))) return rc; }
+    { ProfScope ps(T_FIN, st);
     if ((rc = dz_launch_finalize_norm(s.part1, B, g.nt1, 64, g.P1, w.in1_g, w.in1_b, s.sc1, s.sh1,
                                       st)))
-        return rc;
+        return rc; }
     // conv2: 60(64) -> 60(64), k5, + pool3
     p.X = s.y1; p.W = w.w2; p.bias = w.b2; p.nscale = s.sc1; p.nshift = s.sh1; p.nld = 64;
     p.Y = s.y2; p.partials = s.part2;
     p.Tin = g.P1; p.Tout = g.T2; p.Cin = 64; p.K = 320; p.Kpad = 320; p.ldx = 64;
     p.Tstore = g.P2; p.xbs = (long long)g.P1 * 64; p.ybs = (long long)g.P2 * 64;
-    if ((rc = dz_launch_convgemm(p, st))) return rc;
+    { ProfScope ps(T_CONV2, st); if ((rc = dz_launch_convgemm(p, st))) return rc; }
+    ProfScope ps(T_FIN, st);
     return dz_launch_finalize_norm(s.part2, B, g.nt2, 64, g.P2, w.in2_g, w.in2_b, s.sc2, s.sh2, st);
 }
 
@@ -212,7 +286,7 @@ extern "C" int dz_seg_create(dz_ctx* ctx, const dz_seg_weights* w, int max_batch
 
 extern "C" int dz_seg_destroy(dz_seg* seg) {
     if (seg) {
-        if (seg->arena) hipFree(seg->arena);
+        if (seg->arena) (void)hipFree(seg->arena);
         delete seg;
     }
     return 0;
@@ -246,9 +320,10 @@ extern "C" int dz_seg_forward(dz_seg* s, const float* d_wave, long long wave_str
             p.B = 1; p.Tin = p.Tout = p.Tstore = B * F; p.Cin = 256; p.K = 256; p.Kpad = 256;
             p.ldx = 256;
         }
-        if ((rc = dz_launch_convgemm(p, st))) return rc;
+        { ProfScope ps(T_PROJ, st); if ((rc = dz_launch_convgemm(p, st))) return rc; }
         float* hout = (layer & 1) ? s->h1 : s->h0;
-        if ((rc = dz_launch_lstm(s->gx, s->w.whh[layer], hout, B, F, st))) return rc;
+        { ProfScope ps(T_REC, st);
+          if ((rc = dz_launch_lstm(s->gx, s->w.whh[layer], hout, B, F, st))) return rc; }
         lin = hout;
     }
     // Linear(256,128)+leaky, Linear(128,128)+leaky, classifier
@@ -258,19 +333,21 @@ extern "C" int dz_seg_forward(dz_seg* s, const float* d_wave, long long wave_str
     p.X = lin; p.W = s->w.lin0_w; p.bias = s->w.lin0_b; p.Y = s->m0;
     p.Cin = 256; p.K = 256; p.Kpad = 256; p.ldx = 256; p.Npad = 128; p.Nstore = 128; p.ldy = 128;
     p.epi = DZ_EPI_BIAS_LEAKY;
-    if ((rc = dz_launch_convgemm(p, st))) return rc;
+    { ProfScope ps(T_MLP, st); if ((rc = dz_launch_convgemm(p, st))) return rc; }
     p.X = s->m0; p.W = s->w.lin1_w; p.bias = s->w.lin1_b; p.Y = s->m1;
     p.Cin = 128; p.K = 128; p.Kpad = 128; p.ldx = 128;
-    if ((rc = dz_launch_convgemm(p, st))) return rc;
+    { ProfScope ps(T_MLP, st); if ((rc = dz_launch_convgemm(p, st))) return rc; }
     p.X = s->m1; p.W = s->w.cls_w; p.bias = s->w.cls_b;
     p.Npad = 64; p.Nstore = s->w.num_classes; p.ldy = s->w.num_classes;
     if (s->w.powerset) {
         // log_softmax is monotone: argmax of the logits == argmax of the log-probabilities
         p.Y = s->logit; p.epi = DZ_EPI_BIAS;
-        if ((rc = dz_launch_convgemm(p, st))) return rc;
+        { ProfScope ps(T_CLS, st); if ((rc = dz_launch_convgemm(p, st))) return rc; }
+        ProfScope ps(T_PSET, st);
         return dz_launch_powerset(s->logit, B * F, s->w.num_classes, s->w.num_speakers, d_out, st);
     }
     p.Y = d_out; p.epi = DZ_EPI_BIAS_SIGMOID;
+    ProfScope ps(T_CLS, st);
     return dz_launch_convgemm(p, st);
 }
 
@@ -333,7 +410,7 @@ extern "C" int dz_emb_create(dz_ctx* ctx, const dz_emb_weights* w, int max_batch
 
 extern "C" int dz_emb_destroy(dz_emb* emb) {
     if (emb) {
-        if (emb->arena) hipFree(emb->arena);
+        if (emb->arena) (void)hipFree(emb->arena);
         delete emb;
     }
     return 0;
@@ -361,7 +438,7 @@ static int emb_frames(dz_emb* e, const float* d_wave, long long stride, int B, h
         if (i == 0) {
             p.nscale = e->ss.sc2; p.nshift = e->ss.sh2; p.nld = 64; p.norm_on_load = 1;
         }
-        if ((rc = dz_launch_convgemm(p, st))) return rc;
+        { ProfScope ps(T_TDNN1 + i, st); if ((rc = dz_launch_convgemm(p, st))) return rc; }
         in = outp;
         tin = e->T[i];
     }
@@ -371,17 +448,21 @@ static int emb_frames(dz_emb* e, const float* d_wave, long long stride, int B, h
 static int emb_head(dz_emb* e, const float* d_weights, int Fw, int rows, int rows_per_x,
                     int normalize, float* d_out, hipStream_t st) {
     int rc;
+    { ProfScope ps(T_POOL, st);
     if ((rc = dz_launch_stats_pool(e->x5, e->T[4], 1500, 1536, d_weights, Fw, rows, rows_per_x,
                                    e->pooled, kPoolLd, st)))
-        return rc;
+        return rc; }
     DzConvGemm p;
     memset(&p, 0, sizeof(p));
     p.X = e->pooled; p.W = e->w.emb_w; p.bias = e->w.emb_b; p.Y = d_out;
     p.B = 1; p.Tin = p.Tout = p.Tstore = rows; p.Cin = kPoolLd; p.taps = 1; p.dil = 1;
     p.K = kPoolLd; p.Kpad = kPoolLd; p.Npad = 512; p.Nstore = 512; p.ldx = kPoolLd; p.ldy = 512;
     p.epi = DZ_EPI_BIAS;
-    if ((rc = dz_launch_convgemm(p, st))) return rc;
-    if (normalize) return dz_launch_l2norm(d_out, rows, 512, 1.f, st);
+    { ProfScope ps(T_EMBLIN, st); if ((rc = dz_launch_convgemm(p, st))) return rc; }
+    if (normalize) {
+        ProfScope ps(T_L2, st);
+        return dz_launch_l2norm(d_out, rows, 512, 1.f, st);
+    }
     return 0;
 }
 
@@ -419,6 +500,29 @@ extern "C" int dz_emb_forward_multi(dz_emb* e, const float* d_wave, long long wa
                     d_out, st);
 }
 
+// frame features only (SincNet + 5 TDNN) -> internal buffer; independent of the segmentation,
+// so a caller can run it on a second stream beside dz_seg_forward
+extern "C" int dz_emb_frames(dz_emb* e, const float* d_wave, long long wave_stride, int batch,
+                             void* stream) {
+    DZ_REQUIRE(e, "dz_emb_frames: NULL argument");
+    DZ_REQUIRE(batch >= 1 && batch <= e->Bm, "dz_emb_frames: batch %d outside [1, %d]", batch, e->Bm);
+    int rc;
+    if ((rc = check_wave("dz_emb_frames", d_wave, wave_stride, e->g.S))) return rc;
+    DZ_HIP(hipSetDevice(e->ctx->device));
+    return emb_frames(e, d_wave, wave_stride, batch, (hipStream_t)stream);
+}
+// pooling + Linear (+ normalisation) of the frame features left by the last dz_emb_frames
+extern "C" int dz_emb_pool(dz_emb* e, const float* d_weights, int batch, int num_speakers,
+                           int weight_frames, int normalize, float* d_out, void* stream) {
+    DZ_REQUIRE(e && d_out && d_weights, "dz_emb_pool: NULL argument");
+    DZ_REQUIRE(batch >= 1 && batch <= e->Bm, "dz_emb_pool: batch %d outside [1, %d]", batch, e->Bm);
+    DZ_REQUIRE(num_speakers >= 1 && num_speakers <= kMaxSpk, "dz_emb_pool: %d speakers", num_speakers);
+    DZ_REQUIRE(weight_frames >= 2, "dz_emb_pool: weight_frames %d", weight_frames);
+    DZ_HIP(hipSetDevice(e->ctx->device));
+    return emb_head(e, d_weights, weight_frames, batch * num_speakers, num_speakers, normalize,
+                    d_out, (hipStream_t)stream);
+}
+
 // ---------------------------------------------------------------------------
 // small ops
 // ---------------------------------------------------------------------------
@@ -428,6 +532,7 @@ extern "C" int dz_osp(dz_ctx* ctx, const float* d_seg, int batch, int frames, in
     DZ_REQUIRE(ctx && d_seg && d_out, "dz_osp: NULL argument");
     DZ_REQUIRE(batch >= 1 && frames >= 1, "dz_osp: empty input");
     DZ_HIP(hipSetDevice(ctx->device));
+    ProfScope ps(T_OSP, (hipStream_t)stream);
     return dz_launch_osp(d_seg, batch, frames, speakers, gamma, beta, normalize, speaker_major,
                          d_out, (hipStream_t)stream);
 }

@@ -172,10 +172,26 @@ struct SpeakerMap {
     }
 };
 
-// scipy.spatial.distance.cdist(..., "cosine") for one pair, fp64
+// scipy.spatial.distance.cdist(..., "cosine"), fp64.  The scipy 1.15 x86-64 build sums dot
+// products in two interleaved lanes (SSE2 doubles: even / odd elements, lanes added at the
+// end, then the odd tail).  The order is reproduced exactly: with duplicated embeddings two
+// rows of the cost matrix tie, and which one the Hungarian step favours depends on the last
+// bit of the other entries (tests/golden/clustering_crowded.npz step 29 pins this).
+#pragma clang fp contract(off)
+double dot2(const double* u, const double* v, int n) {
+    double s0 = 0.0, s1 = 0.0;
+    const int m = n & ~1;
+    for (int i = 0; i < m; i += 2) {
+        s0 += u[i] * v[i];
+        s1 += u[i + 1] * v[i + 1];
+    }
+    double s = s0 + s1;
+    for (int i = m; i < n; ++i) s += u[i] * v[i];
+    return s;
+}
+
 double cosine_dist(const double* u, const double* v, int n, double nu, double nv) {
-    double dot = 0.0;
-    for (int i = 0; i < n; ++i) dot += u[i] * v[i];
+    const double dot = dot2(u, v, n);
     double c = dot / (nu * nv);
     if (std::fabs(c) > 1.0) c = std::copysign(1.0, c);
     return 1.0 - c;
@@ -268,16 +284,12 @@ int identify(dz_clu* c, const float* seg, int F, int K, const float* emb32, int 
     SpeakerMap dist(K, G);
     std::vector<double> cn(G);
     for (int g = 0; g < G; ++g) {
-        double s = 0.0;
         const double* v = &c->centers[(size_t)g * D];
-        for (int d = 0; d < D; ++d) s += v[d] * v[d];
-        cn[g] = std::sqrt(s);
+        cn[g] = std::sqrt(dot2(v, v, D));
     }
     for (int k = 0; k < K; ++k) {
         const double* u = &emb[(size_t)k * D];
-        double s = 0.0;
-        for (int d = 0; d < D; ++d) s += u[d] * u[d];
-        const double un = std::sqrt(s);
+        const double un = std::sqrt(dot2(u, u, D));
         for (int g = 0; g < G; ++g)
             dist.at(k, g) = cosine_dist(u, &c->centers[(size_t)g * D], D, un, cn[g]);
     }

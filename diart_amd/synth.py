@@ -32,21 +32,23 @@ SAMPLE_RATE = 16000
 def synth_stream(seed: int, seconds: float, num_speakers: int = 3,
                  sample_rate: int = SAMPLE_RATE) -> np.ndarray:
     """One mono float32 stream in [-1, 1], shape (samples,)."""
+    from scipy import fft as sfft
     rng = np.random.default_rng(seed)
     n = int(round(seconds * sample_rate))
+    nfft = sfft.next_fast_len(n, real=True)
     out = np.zeros(n, dtype=np.float64)
     t = np.arange(n) / sample_rate
     hop = sample_rate // 10  # state changes every 100 ms
+    freqs = sfft.rfftfreq(nfft, 1.0 / sample_rate)
     for spk in range(num_speakers):
         # carrier: noise shaped by a speaker-specific comb of formant-like bands
-        noise = rng.standard_normal(n)
-        spec = np.fft.rfft(noise)
-        freqs = np.fft.rfftfreq(n, 1.0 / sample_rate)
+        noise = rng.standard_normal(nfft, dtype=np.float32)
+        spec = sfft.rfft(noise)
         env = np.zeros_like(freqs)
         f0 = 90.0 + 60.0 * spk + 20.0 * rng.random()
         for c in (f0 * 3, 500 + 230 * spk, 1500 + 310 * spk, 2600 + 170 * spk):
             env += np.exp(-0.5 * ((freqs - c) / (80.0 + 40.0 * spk)) ** 2)
-        voiced = np.fft.irfft(spec * env, n)
+        voiced = sfft.irfft(spec * env.astype(np.float32), nfft)[:n].astype(np.float64)
         voiced /= (np.abs(voiced).max() + 1e-9)
         voiced *= 0.5 * (1.0 + np.sin(2 * math.pi * f0 * t))  # glottal-ish AM
         # Markov on/off turns, mean turn ~2 s, mean pause ~3 s
@@ -57,14 +59,19 @@ def synth_stream(seed: int, seconds: float, num_speakers: int = 3,
                 state = not state
             gate[h:h + hop] = 1.0 if state else 0.0
         k = np.hanning(801)
-        gate = np.convolve(gate, k / k.sum(), mode="same")
+        from scipy.signal import fftconvolve
+        gate = fftconvolve(gate, k / k.sum(), mode="same")
         out += 0.35 * gate * voiced
     out += 0.003 * rng.standard_normal(n)
     return np.clip(out, -1.0, 1.0).astype(np.float32)
 
 
 def synth_streams(num_streams: int, seconds: float, seed0: int = 0) -> np.ndarray:
-    return np.stack([synth_stream(seed0 + i, seconds) for i in range(num_streams)])
+    """(num_streams, samples); stream i uses seed seed0 + i.  Generated on host threads."""
+    import os
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max_workers=min(32, os.cpu_count() or 1)) as ex:
+        return np.stack(list(ex.map(lambda i: synth_stream(seed0 + i, seconds), range(num_streams))))
 
 
 def sliding_chunks(stream: np.ndarray, duration: float = 5.0, step: float = 0.5,

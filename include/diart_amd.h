@@ -111,6 +111,13 @@ int dz_emb_forward(dz_emb* emb, const float* d_wave, long long wave_stride,
 int dz_emb_forward_multi(dz_emb* emb, const float* d_wave, long long wave_stride,
                          const float* d_weights, int batch, int num_speakers,
                          int weight_frames, int normalize, float* d_out, void* stream);
+/* The two halves of dz_emb_forward_multi.  dz_emb_frames (SincNet + TDNN stack, 99.5 % of the
+ * embedding FLOPs) does not depend on the segmentation, so it can run on a second stream while
+ * dz_seg_forward's latency-bound LSTM occupies a handful of CUs; dz_emb_pool then consumes the
+ * OSP weights.  The frame features stay in the handle's scratch between the two calls.        */
+int dz_emb_frames(dz_emb* emb, const float* d_wave, long long wave_stride, int batch, void* stream);
+int dz_emb_pool(dz_emb* emb, const float* d_weights, int batch, int num_speakers,
+                int weight_frames, int normalize, float* d_out, void* stream);
 int dz_emb_destroy(dz_emb* emb);
 
 /* ---- OverlappedSpeechPenalty: functional.py:6-13 + blocks/embedding.py:98-107
@@ -193,6 +200,13 @@ int dz_clu_get_active(dz_clu* clu, int* out_mask);
 int dz_clu_dim(dz_clu* clu);
 int dz_clu_set_state(dz_clu* clu, const double* centers, const int* active_mask, int dim);
 int dz_clu_destroy(dz_clu* clu);
+
+/* ---- per-kernel timing (HIP events on the launch stream) for bench.py's roofline leg ----
+ * dz_prof_enable(1) starts bracketing every kernel the forward passes launch; dz_prof_collect()
+ * synchronises the device and accumulates; dz_prof_get(tag) reads name / total ms / launches. */
+int dz_prof_enable(int on);
+int dz_prof_collect(void);
+int dz_prof_get(int tag, const char** name, double* total_ms, long long* launches);
 
 /* exposed for tests: scipy.optimize.linear_sum_assignment (minimise), rows<=cols
  * or transposed internally; col4row (nr) gets the column of each row.            */

@@ -38,16 +38,21 @@ def main():
     np.savez_compressed(HERE / "functional.npz", seg=seg, emb=emb, **out)
 
     # ---- blocks/embedding.py plumbing with a toy model (ordering / squeeze semantics) --------
-    def toy(wave, weights=None):
-        if weights is None:
-            return torch.stack([wave[:, 0, :100].sum(-1), wave[:, 0, -100:].sum(-1)], -1)
-        return torch.stack([wave[:, 0, :100].sum(-1), weights.sum(-1), weights[:, :10].sum(-1),
-                            (weights * torch.arange(weights.shape[1])).sum(-1)], -1)
+    class Toy:  # custom-model contract of README.md:186-209: __call__ + .to(device)
+        def to(self, device):
+            return self
+
+        def __call__(self, wave, weights=None):
+            if weights is None:
+                return torch.stack([wave[:, 0, :100].sum(-1), wave[:, 0, -100:].sum(-1)], -1)
+            return torch.stack([wave[:, 0, :100].sum(-1), weights.sum(-1), weights[:, :10].sum(-1),
+                                (weights * torch.arange(weights.shape[1])).sum(-1)], -1)
+    toy = Toy()
     rng = np.random.default_rng(5)
     wav = rng.standard_normal((3, 800, 1)).astype(np.float32)
     sg = rng.random((3, 29, 3)).astype(np.float32)
     plumb = {"wav": wav, "sg": sg}
-    model = ref.models.EmbeddingModel(lambda: toy)
+    model = ref.models.EmbeddingModel(lambda: toy)  # noqa: E731
     oase = ref.embedding.OverlapAwareSpeakerEmbedding(model, 3, 10, norm=1, device=torch.device("cpu"))
     plumb["oase_b3"] = oase(torch.from_numpy(wav), torch.from_numpy(sg)).numpy()
     plumb["oase_b1"] = oase(torch.from_numpy(wav[:1]), torch.from_numpy(sg[:1])).numpy()

@@ -1,0 +1,140 @@
+"""Incremental clustering: C++ (libdiart_amd, through the Python block) vs the reference's own
+outputs (tests/golden/clustering_*.npz) and vs the numpy oracle on long random runs.  CPU only.
+Bit-exact bar: identical assignment sequences and active sets; centroids within 1e-9."""
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+
+from diart_amd import _lib
+from diart_amd.blocks.clustering import BatchedSpeakerClustering, OnlineSpeakerClustering
+from diart_amd.features import SlidingWindow, SlidingWindowFeature
+from oracle.clustering_ref import OnlineSpeakerClusteringRef
+
+GOLD = Path(__file__).resolve().parent / "golden"
+sys.path.insert(0, str(GOLD))
+import scenarios  # noqa: E402
+
+
+def _swf(a):
+    return SlidingWindowFeature(a, SlidingWindow(start=0.0, duration=0.1, step=0.1))
+
+
+@pytest.mark.parametrize("name", list(scenarios.CLUSTERING))
+def test_cpp_matches_reference_golden(name):
+    z = np.load(GOLD / f"clustering_{name}.npz")
+    tau, rho, delta, G = z["params"]
+    clu = OnlineSpeakerClustering(tau, rho, delta, "cosine", int(G))
+    assert clu.centers is None and clu.active_centers == set()
+    for t in range(z["seg"].shape[0]):
+        out = clu(_swf(z["seg"][t]), torch.from_numpy(z["emb"][t]))
+        assert out.data.shape == (z["seg"].shape[1], int(G)) and out.data.dtype == np.float64
+        # same columns filled with the same local speakers as the reference
+        assert np.allclose(out.data.sum(0), z["score_sum"][t], rtol=0, atol=1e-9), (name, t)
+        for k in range(z["seg"].shape[2]):
+            g = z["assign"][t, k]
+            if g >= 0:
+                assert np.array_equal(out.data[:, g], z["seg"][t][:, k].astype(np.float64)), (name, t, k)
+        act = np.zeros(int(G), dtype=np.int8)
+        act[sorted(clu.active_centers)] = 1
+        assert np.array_equal(act, z["active"][t]), (name, t)
+        assert np.allclose(clu.centers.sum(1), z["centers_trace"][t], rtol=0, atol=1e-9), (name, t)
+    assert np.allclose(clu.centers, z["centers"], rtol=0, atol=1e-9)
+
+
+@pytest.mark.parametrize("name", list(scenarios.CLUSTERING))
+def test_oracle_matches_reference_golden(name):
+    z = np.load(GOLD / f"clustering_{name}.npz")
+    tau, rho, delta, G = z["params"]
+    ref = OnlineSpeakerClusteringRef(tau, rho, delta, "cosine", int(G))
+    for t in range(z["seg"].shape[0]):
+        scores, assign = ref(z["seg"][t], z["emb"][t])
+        assert np.allclose(scores.sum(0), z["score_sum"][t], rtol=0, atol=1e-12), (name, t)
+        act = np.zeros(int(G), dtype=np.int8)
+        act[sorted(ref.active_centers)] = 1
+        assert np.array_equal(act, z["active"][t])
+    assert np.allclose(ref.centers, z["centers"], rtol=0, atol=1e-12)
+
+
+@pytest.mark.parametrize("seed,K,D,G,delta", [(0, 3, 32, 20, 1.0), (1, 4, 16, 20, 0.8), (2, 3, 8, 3, 0.5),
+                                               (3, 4, 12, 4, 0.9), (4, 3, 512, 20, 1.057)])
+def test_cpp_matches_oracle_long_random(seed, K, D, G, delta):
+    """>= 10k steps in total across the parametrisations, with NaN embeddings, silent chunks,
+    duplicated embeddings (ties) and more speakers than centroids."""
+    rng = np.random.default_rng(seed)
+    T, F = (2500 if D < 100 else 400), 24
+    pool = rng.standard_normal((G + 6, D))
+    cpp = OnlineSpeakerClustering(0.55, 0.25, delta, "cosine", G)
+    ref = OnlineSpeakerClusteringRef(0.55, 0.25, delta, "cosine", G)
+    for t in range(T):
+        seg = (rng.random((F, K)) * (rng.random(K) < 0.8) * rng.choice([0.3, 0.8, 1.0], K)).astype(np.float32)
+        emb = (pool[rng.choice(len(pool), K, replace=False)] + 0.4 * rng.standard_normal((K, D))).astype(np.float32)
+        emb /= np.linalg.norm(emb, axis=1, keepdims=True)
+        r = rng.random()
+        if r < 0.05:
+            emb[rng.integers(K)] = np.nan
+        elif r < 0.1:
+            emb[1] = emb[0]
+        elif r < 0.13:
+            seg[:] = 0
+        want, want_assign = ref(seg, emb)
+        got = cpp(_swf(seg), torch.from_numpy(emb)).data
+        assert np.array_equal(got, want), (seed, t)
+        assert cpp.active_centers == ref.active_centers
+    assert np.allclose(cpp.centers, ref.centers, rtol=0, atol=1e-9)
+
+
+def test_lsap_matches_scipy():
+    from scipy.optimize import linear_sum_assignment
+    rng = np.random.default_rng(0)
+    lib = _lib.load()
+    for it in range(4000):
+        nr, nc = rng.integers(1, 7), rng.integers(1, 9)
+        kind = it % 4
+        if kind == 0:
+            m = rng.random((nr, nc))
+        elif kind == 1:
+            m = rng.integers(0, 3, (nr, nc)).astype(np.float64)          # many ties
+        elif kind == 2:
+            m = np.where(rng.random((nr, nc)) < 0.5, 1e10, rng.random((nr, nc)) * 2)  # sentinels
+        else:
+            m = np.full((nr, nc), 1e10)
+            m[rng.integers(nr), rng.integers(nc)] = 0.0
+        m = np.ascontiguousarray(m)
+        col = np.empty(nr, dtype=np.int32)
+        assert lib.dz_lsap(m.ctypes.data, nr, nc, col.ctypes.data) == 0
+        r, c = linear_sum_assignment(m)
+        want = -np.ones(nr, dtype=np.int32)
+        want[r] = c
+        assert np.array_equal(col, want), (it, m)
+    bad = np.array([[np.nan, 1.0]])
+    assert lib.dz_lsap(bad.ctypes.data, 1, 2, np.empty(1, np.int32).ctypes.data) != 0
+
+
+def test_batched_equals_sequential_and_reset():
+    rng = np.random.default_rng(7)
+    N, T, F, K, D = 6, 40, 16, 3, 24
+    batch = BatchedSpeakerClustering(N, 0.5, 0.2, 0.9, 20, num_threads=3)
+    single = [OnlineSpeakerClustering(0.5, 0.2, 0.9, "cosine", 20) for _ in range(N)]
+    for t in range(T):
+        seg = rng.random((N, F, K)).astype(np.float32)
+        emb = rng.standard_normal((N, K, D)).astype(np.float32)
+        scores, assign = batch(seg, emb)
+        for i in range(N):
+            want = single[i](_swf(seg[i]), torch.from_numpy(emb[i])).data
+            assert np.array_equal(scores[i], want)
+    batch.reset()
+    assert all(s.centers is None for s in batch.streams)
+
+
+def test_argument_errors():
+    clu = OnlineSpeakerClustering(0.5, 0.3, 1.0)
+    with pytest.raises(ValueError):
+        clu(_swf(np.zeros((10, 3), np.float32)), torch.zeros(2, 8))   # K mismatch
+    with pytest.raises(ValueError):
+        OnlineSpeakerClustering(0.5, 0.3, 1.0, metric="euclidean")
+    clu(_swf(np.ones((10, 3), np.float32)), torch.randn(3, 8))
+    with pytest.raises(_lib.DiartAmdError):
+        clu(_swf(np.ones((10, 3), np.float32)), torch.randn(3, 9))    # dimension changed
