@@ -42,6 +42,13 @@ ALG_GFLOP_PER_CHUNK = 3.352   # 1.312 seg + 2.039 emb de-duplicated (SURVEY.md Â
 PEAK_F32_MATRIX_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, dense
 
 
+_T0 = time.monotonic()
+
+
+def log(msg):
+    print(f"[bench +{time.monotonic() - _T0:7.1f}s] {msg}", file=sys.stderr, flush=True)
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -78,7 +85,9 @@ def cpu_baseline(seg_state, emb_state, audio_cpu, n_chunks):
     from oracle.models_ref import PyanNetRef, XVectorSincNetRef
     from oracle.functional_ref import overlapped_speech_penalty_ref, normalize_embeddings_ref
     from oracle.clustering_ref import OnlineSpeakerClusteringRef
-    cores = os.cpu_count() or 1
+    # intra-op threads: every core up to 32 (beyond that torch's per-timestep OpenMP barriers in
+    # the LSTM make the CPU path slower, not faster); "cores" reports what was actually used
+    cores = min(os.cpu_count() or 1, int(os.environ.get("DZ_CPU_THREADS", "32")))
     torch.set_num_threads(cores)
     seg_m, emb_m = PyanNetRef().eval(), XVectorSincNetRef().eval()
     seg_m.load_state_dict(seg_state)
@@ -101,12 +110,18 @@ def cpu_baseline(seg_state, emb_state, audio_cpu, n_chunks):
             seg = seg_m(x)
             emb_m.forward_multi(x, overlapped_speech_penalty_ref(seg))
 
-    one()  # warm-up
+    t0 = time.monotonic()
+    one()  # warm-up (also bounds the leg: a slow host measures this single pass only)
+    warm = time.monotonic() - t0
+    log(f"cpu baseline: warm-up pass over {n_chunks} chunks took {warm:.1f}s on {cores} threads")
     t0 = time.monotonic()
     reps = 0
-    while time.monotonic() - t0 < 12.0 or reps < 2:
+    budget = 12.0
+    while reps < 1 or (time.monotonic() - t0 < budget and reps < 50):
         one()
         reps += 1
+        if warm > 10.0:
+            break
     dt = time.monotonic() - t0
     cps = reps * n_chunks / dt
     t1 = time.monotonic()
@@ -127,6 +142,7 @@ def main():
     from diart_amd.pipeline import StreamBatch
     from diart_amd.synth import synth_embedding_state, synth_segmentation_state, synth_streams
 
+    log("start")
     rank, world, local = D.init_from_env()
     assert world == args.gpus or world == 1, f"WORLD_SIZE={world} but --gpus {args.gpus}"
     if not torch.cuda.is_available():
@@ -149,8 +165,10 @@ def main():
     hop, S = 8000, 80000
     total_steps = args.steps + args.warmup
     seconds = (S + hop * (total_steps + 1)) / 16000.0
+    log(f"synthesising {n} streams of {seconds:.1f}s")
     audio_cpu = torch.from_numpy(synth_streams(n, seconds, seed0=rank * n))
     audio = audio_cpu.to(device)
+    log("streams resident in HBM")
     assert audio.stride(0) % 4 == 0
 
     pipe = StreamBatch(HipSegmentation(seg_state, max_batch=n), HipEmbedding(emb_state, max_batch=n),
@@ -174,6 +192,7 @@ def main():
 
     run(0, args.warmup)
     torch.cuda.synchronize()
+    log("warm-up done")
     lib.dz_prof_enable(1)
     barrier()
     torch.cuda.synchronize()
@@ -182,8 +201,8 @@ def main():
     torch.cuda.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0
+    log(f"timed region done: {elapsed:.3f}s for {args.steps} steps")
     lib.dz_prof_collect()
-    lib.dz_prof_enable(0) if False else None
 
     if world > 1:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
@@ -216,6 +235,7 @@ def main():
             Path(args.kernel_table).parent.mkdir(parents=True, exist_ok=True)
             Path(args.kernel_table).write_text(json.dumps(table, indent=1))
         if not args.no_cpu_baseline and world == 1:
+            print(json.dumps(dict(out, cpu_baseline="pending")), file=sys.stderr, flush=True)
             out["cpu_baseline"] = cpu_baseline(seg_state, emb_state, audio_cpu, args.cpu_chunks)
         elif not args.no_cpu_baseline:
             out["cpu_baseline"] = None

@@ -1,0 +1,122 @@
+"""Host-side logic that needs no GPU: feature formatter, weight packing, LazyModel contract,
+stream sharding, and the world_size-2 weight broadcast over gloo."""
+import os
+import pickle
+import socket
+import subprocess
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+
+from diart_amd import models as M
+from diart_amd.features import SlidingWindow, SlidingWindowFeature, TemporalFeatureFormatter
+from diart_amd.synth import synth_embedding_state, synth_segmentation_state
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def test_formatter_roundtrip_kinds():
+    f = TemporalFeatureFormatter()
+    swf = SlidingWindowFeature(np.zeros((80000, 1), dtype=np.float64), SlidingWindow(start=2.5, duration=1 / 16000, step=1 / 16000))
+    t = f.cast(swf)
+    assert t.shape == (1, 80000, 1) and t.dtype == torch.float32
+    out = f.restore_type(torch.zeros(1, 293, 3))
+    assert isinstance(out, SlidingWindowFeature) and out.data.shape == (293, 3)
+    assert abs(out.sliding_window.start - 2.5) < 1e-12 and abs(out.sliding_window.duration - 5 / 293) < 1e-12
+    assert isinstance(f.restore_type(f.cast(np.zeros((4, 10, 2), np.float32))), np.ndarray)
+    assert isinstance(f.restore_type(f.cast(torch.zeros(10, 2))), torch.Tensor)
+    with pytest.raises(ValueError):
+        f.cast([1, 2, 3])
+    with pytest.raises(AssertionError):
+        f.cast(torch.zeros(3))
+
+
+def test_packing_layouts():
+    from diart_amd.weights import PackedEmbedding, PackedSegmentation, _conv_pack
+    w = torch.arange(2 * 3 * 5, dtype=torch.float32).reshape(2, 3, 5)   # [co][ci][tap]
+    p = _conv_pack(w, 4, 64, 32)
+    assert p.shape == (64, 32)
+    assert p[1, 2 * 4 + 1] == w[1, 1, 2] and p[0, 3] == 0 and p[2:].abs().sum() == 0
+    sd = synth_embedding_state()
+    pe = PackedEmbedding(sd, torch.device("cpu"))
+    assert pe.pack.nbytes() > 17_000_000
+    ps = PackedSegmentation(synth_segmentation_state(), torch.device("cpu"))
+    assert ps.num_speakers == 3 and ps.struct.num_classes == 3
+    pp = PackedSegmentation(synth_segmentation_state(powerset=True), torch.device("cpu"), powerset=True)
+    assert pp.num_speakers == 3 and pp.struct.num_classes == 7
+
+
+def test_lazy_model_contract_and_pickle():
+    calls = []
+
+    class Custom:                         # README "Custom models": __call__ + .to
+        def to(self, device):
+            calls.append(device)
+            return self
+
+        def __call__(self, wav, weights=None):
+            return np.ones((wav.shape[0], 4), dtype=np.float32)
+
+    m = M.EmbeddingModel(lambda: Custom())
+    assert not m.is_in_memory()
+    m.eval()
+    m.to(torch.device("cpu"))
+    out = m(torch.zeros(2, 1, 10), None)
+    assert isinstance(out, torch.Tensor) and out.shape == (2, 4) and calls == [torch.device("cpu")]
+    lazy = M.SegmentationModel.from_state(synth_segmentation_state(), max_batch=3)
+    again = pickle.loads(pickle.dumps(lazy))
+    assert not again.is_in_memory() and again.get_model.max_batch == 3
+    with pytest.raises(NotImplementedError):
+        M.SegmentationModel.from_pretrained("model.onnx")
+    with pytest.raises(FileNotFoundError):
+        M.EmbeddingModel.from_pretrained("pyannote/embedding")
+
+
+def test_stream_and_file_sharding():
+    from diart_amd.distributed import shard_files_lpt, shard_streams
+    owned = [shard_streams(512, r, 8) for r in range(8)]
+    assert sorted(sum(owned, [])) == list(range(512)) and all(len(o) == 64 for o in owned)
+    parts = shard_files_lpt([10, 9, 8, 7, 1, 1, 1, 1], 4)
+    assert sorted(sum(parts, [])) == list(range(8))
+    assert max(sum([10, 9, 8, 7, 1, 1, 1, 1][i] for i in p) for p in parts) == 10
+
+
+WORKER = r'''
+import os, sys, torch
+sys.path.insert(0, sys.argv[1])
+from diart_amd import distributed as D
+from diart_amd.synth import synth_segmentation_state
+rank, world, local = D.init_from_env("gloo")
+ref = synth_segmentation_state()
+state = ref if rank == 0 else None
+got = D.broadcast_state(state, D.state_spec(ref), torch.device("cpu"))
+assert set(got) == set(ref)
+for k in ref:
+    assert got[k].dtype == ref[k].dtype and torch.equal(got[k].float(), ref[k].float()), k
+mine = D.shard_streams(10, rank, world)
+allv = D.gather_counts([float(len(mine)), float(rank)], torch.device("cpu"))
+assert [v[0] for v in allv] == [5.0, 5.0] and [v[1] for v in allv] == [0.0, 1.0]
+torch.distributed.barrier()
+print("rank", rank, "ok")
+'''
+
+
+def test_weight_broadcast_world_size_2_gloo(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", LOCAL_RANK=str(rank),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), PYTHONDONTWRITEBYTECODE="1")
+        procs.append(subprocess.Popen([sys.executable, str(script), str(ROOT)], env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=180)[0] for p in procs]
+    for rank, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, o
+        assert f"rank {rank} ok" in o
