@@ -57,6 +57,8 @@ def parse():
     ap.add_argument("--streams", type=int, default=64, help="concurrent streams per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-chunks", type=int, default=8, help="chunks in the bounded CPU sample")
+    ap.add_argument("--cpu-worker", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--cpu-threads", type=int, default=8, help=argparse.SUPPRESS)
     ap.add_argument("--kernel-table", type=str, default="", help="write the per-kernel table here")
     return ap.parse_args()
 
@@ -79,20 +81,33 @@ def kernel_table(lib, chunks_per_launch):
     return rows
 
 
-def cpu_baseline(seg_state, emb_state, audio_cpu, n_chunks):
-    """The oracle ("port" of the reference CPU path) on the host cores, reference-style:
-    embedding network run on K repeated waveforms per chunk (blocks/embedding.py:57)."""
+def _usable_cores():
+    """Cores this process may really use: affinity mask capped by the cgroup CPU quota (a box can
+    show 256 logical CPUs while the container is limited to a handful; OpenMP teams larger than the
+    quota spin against each other in torch's per-timestep LSTM barriers)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = Path("/sys/fs/cgroup/cpu.max").read_text().split()
+        if quota != "max":
+            n = min(n, max(1, int(float(quota) / float(period))))
+    except Exception:
+        pass
+    return max(1, n)
+
+
+def cpu_baseline_worker(n_chunks, threads, budget_s):
+    """Runs in a CHILD process that never touches the GPU (``bench.py --cpu-worker``): the oracle
+    ("port" of the reference CPU path) on the host cores, reference-style — the embedding network
+    run on K repeated waveforms per chunk (blocks/embedding.py:57), clustering per chunk."""
+    torch.set_num_threads(threads)
     from oracle.models_ref import PyanNetRef, XVectorSincNetRef
     from oracle.functional_ref import overlapped_speech_penalty_ref, normalize_embeddings_ref
     from oracle.clustering_ref import OnlineSpeakerClusteringRef
-    # intra-op threads: every core up to 32 (beyond that torch's per-timestep OpenMP barriers in
-    # the LSTM make the CPU path slower, not faster); "cores" reports what was actually used
-    cores = min(os.cpu_count() or 1, int(os.environ.get("DZ_CPU_THREADS", "32")))
-    torch.set_num_threads(cores)
+    from diart_amd.synth import synth_embedding_state, synth_segmentation_state, synth_streams
     seg_m, emb_m = PyanNetRef().eval(), XVectorSincNetRef().eval()
-    seg_m.load_state_dict(seg_state)
-    emb_m.load_state_dict(emb_state)
-    x = audio_cpu[:n_chunks, None, :80000].contiguous()
+    seg_m.load_state_dict(synth_segmentation_state())
+    emb_m.load_state_dict(synth_embedding_state())
+    x = torch.from_numpy(synth_streams(n_chunks, 5.0, seed0=0))[:, None, :80000].contiguous()
     clus = [OnlineSpeakerClusteringRef(0.6, 0.3, 1.0, "cosine", 20) for _ in range(n_chunks)]
 
     def one():
@@ -111,32 +126,58 @@ def cpu_baseline(seg_state, emb_state, audio_cpu, n_chunks):
             emb_m.forward_multi(x, overlapped_speech_penalty_ref(seg))
 
     t0 = time.monotonic()
-    one()  # warm-up (also bounds the leg: a slow host measures this single pass only)
+    one()  # warm-up
     warm = time.monotonic() - t0
-    log(f"cpu baseline: warm-up pass over {n_chunks} chunks took {warm:.1f}s on {cores} threads")
     t0 = time.monotonic()
     reps = 0
-    budget = 12.0
-    while reps < 1 or (time.monotonic() - t0 < budget and reps < 50):
+    while reps < 1 or (time.monotonic() - t0 < budget_s and reps < 200):
         one()
         reps += 1
-        if warm > 10.0:
+        if warm > budget_s:
             break
     dt = time.monotonic() - t0
     cps = reps * n_chunks / dt
     t1 = time.monotonic()
     dedup()
     cps_dedup = n_chunks / (time.monotonic() - t1)
-    return {"value": round(cps / 2, 3), "unit": "xRT streams (chunks/s / 2)", "cores": cores,
-            "kind": "port",
-            "sample": f"{reps} passes over {n_chunks} chunks (5 s each) of the same synthetic streams, "
-                      f"torch-CPU fp32 restatement with the same weights, embedding run on 3 repeated "
-                      f"waveforms per chunk as the reference does, {dt:.1f} s; "
-                      f"de-duplicated CPU variant: {cps_dedup / 2:.3f} xRT"}
+    print(json.dumps({
+        "value": round(cps / 2, 3), "unit": "xRT 16 kHz streams (chunks/s / 2)", "cores": threads,
+        "kind": "port",
+        "sample": f"{reps} passes over {n_chunks} chunks (5 s each) of the same synthetic stream "
+                  f"generator, torch-CPU fp32 restatement (oracle/) with the same seeded weights, "
+                  f"embedding run on 3 repeated waveforms per chunk as the reference does "
+                  f"(blocks/embedding.py:57) + clustering, {dt:.1f} s of CPU work after a {warm:.1f} s "
+                  f"warm-up pass; de-duplicated CPU variant: {cps_dedup / 2:.3f} xRT"}), flush=True)
+
+
+def cpu_baseline(n_chunks):
+    """Bounded CPU leg: child process, hard timeout, so the bench line always appears."""
+    import subprocess
+    usable = _usable_cores()
+    threads = max(1, min(usable, int(os.environ.get("DZ_CPU_THREADS", "16"))))
+    cmd = [sys.executable, str(ROOT / "bench.py"), "--cpu-worker", "--cpu-chunks", str(n_chunks),
+           "--cpu-threads", str(threads)]
+    env = dict(os.environ, OMP_NUM_THREADS=str(threads), MKL_NUM_THREADS=str(threads),
+               HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="")
+    log(f"cpu baseline: {threads} threads of {usable} usable cores ({os.cpu_count()} logical)")
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=150, env=env)
+    except subprocess.TimeoutExpired:
+        log("cpu baseline: child exceeded 150 s, killed")
+        return {"value": None, "unit": "xRT 16 kHz streams (chunks/s / 2)", "cores": threads,
+                "kind": "port", "sample": "timed out after 150 s"}
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    if r.returncode != 0 or not lines:
+        log("cpu baseline failed: " + r.stderr[-400:])
+        return {"value": None, "unit": "xRT 16 kHz streams (chunks/s / 2)", "cores": threads,
+                "kind": "port", "sample": "child failed: " + r.stderr[-200:]}
+    return json.loads(lines[-1])
 
 
 def main():
     args = parse()
+    if args.cpu_worker:
+        return cpu_baseline_worker(args.cpu_chunks, args.cpu_threads, 12.0)
     from diart_amd import _lib, distributed as D
     from diart_amd.models import HipEmbedding, HipSegmentation
     from diart_amd.pipeline import StreamBatch
@@ -236,7 +277,7 @@ def main():
             Path(args.kernel_table).write_text(json.dumps(table, indent=1))
         if not args.no_cpu_baseline and world == 1:
             print(json.dumps(dict(out, cpu_baseline="pending")), file=sys.stderr, flush=True)
-            out["cpu_baseline"] = cpu_baseline(seg_state, emb_state, audio_cpu, args.cpu_chunks)
+            out["cpu_baseline"] = cpu_baseline(args.cpu_chunks)
         elif not args.no_cpu_baseline:
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)

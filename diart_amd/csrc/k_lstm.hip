@@ -2,112 +2,106 @@
 // (pyannote PyanNet's nn.LSTM(60,128,4,bidirectional), called from
 // /root/reference/src/diart/models.py:133; SURVEY.md Appendix A.1 step 2, kernel K5).
 //
-// One workgroup = 16 chunks ("sequences") x one direction, resident for all T steps.
-//   gates^T[512][16] = W_hh[512][128] . h^T[128][16]  (+ x-projection computed beforehand)
-// W_hh never leaves the register file: 8 waves, wave w owns hidden units [16w,16w+16) for
-// all four gates -> 4 gates x 32 k-steps = 128 A-fragments of v_mfma_f32_16x16x4_f32 per
-// lane.  h_t is exchanged through a double-buffered LDS image laid out [k/32][seq][36] so
-// that a lane's 32 consecutive k come from 8 conflict-free ds_read_b128.  k is permuted
-// (lane quarter q covers k in [32q, 32q+32)) identically for both operands.
-// The cell state and the four gate pre-activations of (unit, seq) live in the MFMA
-// accumulator layout, so the gate non-linearities need no data movement.
+// The recurrence is a chain of T dependent 512x128 mat-vec products per (chunk, direction):
+// latency bound, so the layout is chosen to (1) spread the chains over as many CUs as there
+// are chains and (2) keep W_hh out of memory altogether.
+//
+//   one workgroup (512 threads) = ONE chunk x ONE direction, resident for all T steps
+//   W_hh (512 x 128 f32 = 256 KiB) lives in the CU's vector registers: 128 per lane
+//   lane (u, p): hidden unit u = 16*wave + lane/4, k-quarter p = lane%4
+//                holds W[gate][u][16*jj + 4*p + e] for the 4 gates, jj < 8, e < 4
+//   step:  h_{t-1} is read from LDS as 8 x ds_read_b128 (the 4 lanes of a quad read one
+//          64-byte line: conflict-free), 128 v_fma_f32 per lane, 3 DPP adds fold the four
+//          k-quarters so that lane p ends with the complete pre-activation of gate p, one
+//          exp+rcp per lane, a quad broadcast (4 DPP moves) gives every lane i,f,g,o.
+//
+// f32 MFMA runs at the f32 VALU rate on gfx950 (MI355X_MICROARCH.md: 64 FLOP/clk/SIMD both),
+// so the matrix pipe buys nothing here, while its 16-column minimum would force 16 chunks
+// through one CU (the first version of this kernel: 8 workgroups for 64 chunks, 5.9 us/step).
+// With one chain per CU, 64 chunks x 2 directions occupy 128 of the 256 CUs and the x-vector
+// TDNN stack of the same step runs beside it on the rest.
 #include "dz_common.h"
 
 namespace {
 
-constexpr int HS_LD = 36;  // 32 used + 4 pad: row pitch of 9 sixteen-byte slots (odd)
+// quad_perm DPP controls
+constexpr int DPP_XOR1 = 0xB1;  // [1,0,3,2]
+constexpr int DPP_XOR2 = 0x4E;  // [2,3,0,1]
+template <int CTRL>
+__device__ __forceinline__ float dpp(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
 
-__device__ __forceinline__ float sigmoidf(float x) { return 1.f / (1.f + expf(-x)); }
+// sigmoid through the hardware exp2 / rcp (1 ulp each)
+__device__ __forceinline__ float fast_sigmoid(float x) {
+    return __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.44269504088896341f * x));
+}
 
 __global__ __launch_bounds__(512) void lstm_rec_kernel(const float* __restrict__ gx,
                                                        const float* __restrict__ whh,
                                                        float* __restrict__ hout, int B, int T) {
-    __shared__ __attribute__((aligned(16))) float hs[2][4][16][HS_LD];
-    const int dir = blockIdx.y;
-    const int b0 = blockIdx.x * 16;
-    const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, li = l & 15, q = l >> 4;
+    __shared__ __attribute__((aligned(16))) float hs[2][128];
+    const int b = blockIdx.x, dir = blockIdx.y;
+    const int tid = threadIdx.x, p = tid & 3, u = tid >> 2;
 
-    // A fragments: wreg[g][ks] = W[g*128 + 16w + li][32q + ks]
+    // slot j of lane p holds gate (j ^ p): the three DPP adds below then need no selects
     float wreg[4][32];
     {
         const float* Wd = whh + (long long)dir * 512 * 128;
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const float* row = Wd + (long long)(g * 128 + 16 * w + li) * 128 + 32 * q;
+        for (int j = 0; j < 4; ++j) {
+            const float* row = Wd + (long long)((j ^ p) * 128 + u) * 128 + 4 * p;
 #pragma unroll
-            for (int k4 = 0; k4 < 8; ++k4) {
-                const float4 v = reinterpret_cast<const float4*>(row)[k4];
-                wreg[g][4 * k4 + 0] = v.x;
-                wreg[g][4 * k4 + 1] = v.y;
-                wreg[g][4 * k4 + 2] = v.z;
-                wreg[g][4 * k4 + 3] = v.w;
+            for (int jj = 0; jj < 8; ++jj) {
+                const float4 v = *reinterpret_cast<const float4*>(row + 16 * jj);
+                wreg[j][4 * jj + 0] = v.x;
+                wreg[j][4 * jj + 1] = v.y;
+                wreg[j][4 * jj + 2] = v.z;
+                wreg[j][4 * jj + 3] = v.w;
             }
         }
     }
-    for (int i = tid; i < 2 * 4 * 16 * HS_LD; i += 512) (&hs[0][0][0][0])[i] = 0.f;
+    if (tid < 256) (&hs[0][0])[tid] = 0.f;
 
-    // this lane's sequence (column li) and hidden units u0..u0+3 (rows 4q..4q+3 of wave w)
-    int bseq = b0 + li;
-    const bool seq_valid = bseq < B;
-    if (!seq_valid) bseq = B - 1;
-    const int u0 = 16 * w + 4 * q;
-    const float* gbase = gx + (long long)bseq * T * 1024 + dir * 512 + u0;
-    float* hbase = hout + (long long)bseq * T * 256 + dir * 128 + u0;
+    // lane p owns gate p (PyTorch order i, f, g, o); g = tanh(x) = 2*sigmoid(2x) - 1
+    const float act_scale = (p == 2) ? 2.f : 1.f;
+    const float act_shift = (p == 2) ? -1.f : 0.f;
+    const float* gbase = gx + (long long)b * T * 1024 + dir * 512 + p * 128 + u;
+    float* hbase = hout + (long long)b * T * 256 + dir * 128 + u;
 
-    float cst[4] = {0.f, 0.f, 0.f, 0.f};
-    f32x4 gnext[4];
-    {
-        const int tt = dir ? T - 1 : 0;
-#pragma unroll
-        for (int g = 0; g < 4; ++g)
-            gnext[g] = *reinterpret_cast<const f32x4*>(gbase + (long long)tt * 1024 + g * 128);
-    }
+    float c = 0.f;
+    float gnext = gbase[(long long)(dir ? T - 1 : 0) * 1024];
     __syncthreads();
 
     for (int s = 0; s < T; ++s) {
         const int cur = s & 1;
         const int tt = dir ? T - 1 - s : s;
-        f32x4 acc[4];
-#pragma unroll
-        for (int g = 0; g < 4; ++g) acc[g] = gnext[g];
-        if (s + 1 < T) {  // prefetch next step's x-projection while the MFMAs run
-            const int tn = dir ? tt - 1 : tt + 1;
-#pragma unroll
-            for (int g = 0; g < 4; ++g)
-                gnext[g] = *reinterpret_cast<const f32x4*>(gbase + (long long)tn * 1024 + g * 128);
-        }
-        // B fragments: hreg[ks] = h[seq li][32q + ks]
-        float hreg[32];
-        {
-            const float* hp = &hs[cur][q][li][0];
-#pragma unroll
-            for (int k4 = 0; k4 < 8; ++k4) {
-                const f32x4 v = reinterpret_cast<const f32x4*>(hp)[k4];
-                hreg[4 * k4 + 0] = v[0];
-                hreg[4 * k4 + 1] = v[1];
-                hreg[4 * k4 + 2] = v[2];
-                hreg[4 * k4 + 3] = v[3];
-            }
-        }
-#pragma unroll
-        for (int ks = 0; ks < 32; ++ks)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) acc[g] = DZ_MFMA(wreg[g][ks], hreg[ks], acc[g]);
+        const float gcur = gnext;
+        if (s + 1 < T) gnext = gbase[(long long)(dir ? tt - 1 : tt + 1) * 1024];
 
-        // PyTorch gate order i, f, g, o
-        f32x4 hv;
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        const float* hp = &hs[cur][4 * p];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const float ig = sigmoidf(acc[0][r]);
-            const float fg = sigmoidf(acc[1][r]);
-            const float gg = tanhf(acc[2][r]);
-            const float og = sigmoidf(acc[3][r]);
-            cst[r] = fg * cst[r] + ig * gg;
-            hv[r] = og * tanhf(cst[r]);
+        for (int jj = 0; jj < 8; ++jj) {
+            const f32x4 hv = *reinterpret_cast<const f32x4*>(hp + 16 * jj);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[j] = fmaf(wreg[j][4 * jj + e], hv[e], acc[j]);
         }
-        // unit u0 -> k = u0: plane u0/32 = w>>1, offset u0%32 = (w&1)*16 + 4q
-        *reinterpret_cast<f32x4*>(&hs[cur ^ 1][w >> 1][li][(w & 1) * 16 + 4 * q]) = hv;
-        if (seq_valid) *reinterpret_cast<f32x4*>(hbase + (long long)tt * 256) = hv;
+        // fold the k-quarters: lane p ends with gate p (slot j of lane q is gate j ^ q)
+        const float a0 = acc[0] + dpp<DPP_XOR1>(acc[1]);
+        const float a1 = acc[2] + dpp<DPP_XOR1>(acc[3]);
+        const float pre = a0 + dpp<DPP_XOR2>(a1) + gcur;
+
+        const float act = act_scale * fast_sigmoid(act_scale * pre) + act_shift;
+        const float ig = dpp<0x00>(act), fg = dpp<0x55>(act), gg = dpp<0xAA>(act), og = dpp<0xFF>(act);
+        c = fg * c + ig * gg;
+        const float h = og * (2.f * fast_sigmoid(2.f * c) - 1.f);
+        if (p == 0) {
+            hs[cur ^ 1][u] = h;
+            hbase[(long long)tt * 256] = h;
+        }
         __syncthreads();
     }
 }
@@ -115,7 +109,7 @@ __global__ __launch_bounds__(512) void lstm_rec_kernel(const float* __restrict__
 }  // namespace
 
 int dz_launch_lstm(const float* gx, const float* whh, float* hout, int B, int T, hipStream_t st) {
-    dim3 grid((B + 15) / 16, 2);
+    dim3 grid(B, 2);
     hipLaunchKernelGGL(lstm_rec_kernel, grid, dim3(512), 0, st, gx, whh, hout, B, T);
     DZ_HIP(hipGetLastError());
     return 0;
