@@ -92,7 +92,8 @@ class ConvGemmDesc(C.Structure):
     _fields_ = [(n, vp) for n in ("X", "W", "bias", "e0", "e1", "nscale", "nshift", "Y", "partials")] + [
         (n, C.c_int) for n in ("B", "Tin", "Tout", "Cin", "taps", "dil", "K", "Kpad", "Npad",
                                "Nstore", "ldx", "ldy", "nld", "Tstore")] + [
-        ("xbs", C.c_longlong), ("ybs", C.c_longlong), ("norm_on_load", C.c_int), ("epi", C.c_int)]
+        ("xbs", C.c_longlong), ("ybs", C.c_longlong), ("norm_on_load", C.c_int), ("epi", C.c_int),
+        ("ksplit", C.c_int), ("ysplit", C.c_longlong)]
 
 
 EPI_BIAS, EPI_BIAS_LEAKY, EPI_BIAS_SIGMOID, EPI_TDNN, EPI_POOL3 = range(5)

@@ -361,12 +361,13 @@ struct dz_emb {
     int Bm, T[5];
     char* arena;
     SincScratch ss;
-    float *a, *b, *x5, *pooled;
+    float *a, *b, *x5, *pooled, *parts;
 };
 static const int kTdnnTaps[5] = {5, 3, 3, 1, 1};
 static const int kTdnnDil[5] = {1, 2, 3, 1, 1};
 static const int kPoolLd = 3008;
 static const int kMaxSpk = 8;
+static const int kEmbSplit = 16;  // split-K of Linear(3000, 512): 8 tiles -> 128 workgroups
 
 static void emb_carve(dz_emb* e, Arena& a) {
     e->ss.carve(a, e->g, e->Bm);
@@ -374,6 +375,7 @@ static void emb_carve(dz_emb* e, Arena& a) {
     e->b = a.take((size_t)e->Bm * e->T[0] * 512);
     e->x5 = a.take((size_t)e->Bm * e->T[4] * 1536);
     e->pooled = a.take((size_t)e->Bm * kMaxSpk * kPoolLd);
+    e->parts = a.take((size_t)kEmbSplit * e->Bm * kMaxSpk * 512);
 }
 
 extern "C" int dz_emb_create(dz_ctx* ctx, const dz_emb_weights* w, int max_batch, int num_samples,
@@ -454,16 +456,15 @@ static int emb_head(dz_emb* e, const float* d_weights, int Fw, int rows, int row
         return rc; }
     DzConvGemm p;
     memset(&p, 0, sizeof(p));
-    p.X = e->pooled; p.W = e->w.emb_w; p.bias = e->w.emb_b; p.Y = d_out;
+    // M = rows is tiny (3 per chunk): split K 16 ways so 128 workgroups share the 3008-deep
+    // contraction, then reduce the partials in fixed order (+ L2 normalisation) in one pass
+    p.X = e->pooled; p.W = e->w.emb_w; p.bias = e->w.emb_b; p.Y = e->parts;
     p.B = 1; p.Tin = p.Tout = p.Tstore = rows; p.Cin = kPoolLd; p.taps = 1; p.dil = 1;
     p.K = kPoolLd; p.Kpad = kPoolLd; p.Npad = 512; p.Nstore = 512; p.ldx = kPoolLd; p.ldy = 512;
-    p.epi = DZ_EPI_BIAS;
+    p.epi = DZ_EPI_BIAS; p.ksplit = kEmbSplit; p.ysplit = (long long)rows * 512;
     { ProfScope ps(T_EMBLIN, st); if ((rc = dz_launch_convgemm(p, st))) return rc; }
-    if (normalize) {
-        ProfScope ps(T_L2, st);
-        return dz_launch_l2norm(d_out, rows, 512, 1.f, st);
-    }
-    return 0;
+    ProfScope ps(T_L2, st);
+    return dz_launch_splitk_finish(e->parts, kEmbSplit, p.ysplit, rows, 512, normalize, d_out, st);
 }
 
 extern "C" int dz_emb_forward(dz_emb* e, const float* d_wave, long long wave_stride,

@@ -68,6 +68,8 @@ int dz_launch_stats_pool(const float* X, int T, int C, int ldx, const float* wei
 int dz_launch_osp(const float* seg, int B, int F, int K, float gamma, float beta, int normalize,
                   int speaker_major, float* out, hipStream_t st);
 int dz_launch_l2norm(float* x, int rows, int dim, float norm, hipStream_t st);
+int dz_launch_splitk_finish(const float* parts, int nsplit, long long stride, int rows, int dim,
+                            int normalize, float* out, hipStream_t st);
 int dz_launch_powerset(const float* logp, int rows, int classes, int speakers, float* out,
                        hipStream_t st);
 int dz_launch_cdist(const float* emb, const double* centers, int n, int k, int g, int dim,

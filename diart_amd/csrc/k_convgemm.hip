@@ -41,7 +41,8 @@ __global__ __launch_bounds__(256) void convgemm_kernel(DzConvGemm p) {
     using C = Cfg<BN>;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x;
-    const int b = blockIdx.z;
+    const int nsplit = p.ksplit > 1 ? p.ksplit : 1;
+    const int b = blockIdx.z / nsplit, ks = blockIdx.z - b * nsplit;
     const int t0 = blockIdx.x * BM;
     const int n0 = blockIdx.y * BN;
 
@@ -112,11 +113,13 @@ __global__ __launch_bounds__(256) void convgemm_kernel(DzConvGemm p) {
 #pragma unroll
         for (int nt = 0; nt < C::NT; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    const int nk = p.Kpad / KT;
-    load_tile(0);
-    store_tile(0);
+    const int nk_all = p.Kpad / KT;
+    const int kt0 = (int)((long long)nk_all * ks / nsplit);
+    const int nk = (int)((long long)nk_all * (ks + 1) / nsplit);
+    load_tile(kt0);
+    store_tile(kt0 & 1);
     __syncthreads();
-    for (int kt = 0; kt < nk; ++kt) {
+    for (int kt = kt0; kt < nk; ++kt) {
         const int buf = kt & 1;
         if (kt + 1 < nk) load_tile(kt + 1);
         const float* As = smem + buf * C::TILE;
@@ -186,11 +189,11 @@ __global__ __launch_bounds__(256) void convgemm_kernel(DzConvGemm p) {
         return;
     }
 
-    float* Yb = p.Y + (long long)b * p.ybs;
+    float* Yb = p.Y + (long long)b * p.ybs + (long long)ks * p.ysplit;
 #pragma unroll
     for (int nt = 0; nt < C::NT; ++nt) {
         const int n = n0 + wn * (BN / 2) + nt * 16 + li;
-        const float bv = p.bias[n];
+        const float bv = ks == 0 ? p.bias[n] : 0.f;
         float e0 = 1.f, e1 = 0.f;
         if (EPI == DZ_EPI_TDNN) {
             e0 = p.e0[n];
@@ -223,7 +226,7 @@ int launch(const DzConvGemm& p, hipStream_t st) {
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS));
         attr_set = true;
     }
-    dim3 grid((p.Tout + BM - 1) / BM, p.Npad / BN, p.B);
+    dim3 grid((p.Tout + BM - 1) / BM, p.Npad / BN, p.B * (p.ksplit > 1 ? p.ksplit : 1));
     hipLaunchKernelGGL((convgemm_kernel<BN, PRO, EPI>), grid, dim3(256), C::LDS, st, p);
     DZ_HIP(hipGetLastError());
     return 0;
@@ -237,6 +240,8 @@ int dz_launch_convgemm(const DzConvGemm& p, hipStream_t st) {
     DZ_REQUIRE(p.Kpad % KT == 0 && p.Cin % 4 == 0 && p.ldx % 4 == 0, "convgemm: bad K/Cin/ldx");
     DZ_REQUIRE(p.K <= p.Kpad && p.K == p.taps * p.Cin, "convgemm: K mismatch");
     DZ_REQUIRE(p.Tout == p.Tin - (p.taps - 1) * p.dil && p.Tout > 0, "convgemm: Tout mismatch");
+    DZ_REQUIRE(p.ksplit <= 1 || (p.epi == DZ_EPI_BIAS && p.ksplit <= p.Kpad / KT),
+               "convgemm: split-K needs the plain bias epilogue and ksplit <= k-tiles");
     const bool wide = (p.Npad % 128 == 0);
     DZ_REQUIRE(p.Npad % 64 == 0, "convgemm: Npad must be a multiple of 64");
     const bool pro = p.norm_on_load != 0;

@@ -37,10 +37,21 @@ __device__ __forceinline__ float fast_sigmoid(float x) {
     return __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.44269504088896341f * x));
 }
 
+// LDS-only workgroup barrier: __syncthreads() also drains vmcnt (its fence covers global
+// memory), which would put the ~1 us completion latency of the h_t global store on the
+// critical path of every step.  Only the LDS image of h_t has to be visible to the other waves.
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+constexpr int RING = 16;   // h_t history kept in LDS (slot (t+1) & 15); flushed every 8 steps
+constexpr int BLK = 8;     // steps per flush
+constexpr int PF = 4;      // x-projection prefetch distance in steps
+
 __global__ __launch_bounds__(512) void lstm_rec_kernel(const float* __restrict__ gx,
                                                        const float* __restrict__ whh,
                                                        float* __restrict__ hout, int B, int T) {
-    __shared__ __attribute__((aligned(16))) float hs[2][128];
+    __shared__ __attribute__((aligned(16))) float hs[RING][128];
     const int b = blockIdx.x, dir = blockIdx.y;
     const int tid = threadIdx.x, p = tid & 3, u = tid >> 2;
 
@@ -61,26 +72,23 @@ __global__ __launch_bounds__(512) void lstm_rec_kernel(const float* __restrict__
             }
         }
     }
-    if (tid < 256) (&hs[0][0])[tid] = 0.f;
+    if (tid < 128) hs[0][tid] = 0.f;
 
     // lane p owns gate p (PyTorch order i, f, g, o); g = tanh(x) = 2*sigmoid(2x) - 1
     const float act_scale = (p == 2) ? 2.f : 1.f;
     const float act_shift = (p == 2) ? -1.f : 0.f;
-    const float* gbase = gx + (long long)b * T * 1024 + dir * 512 + p * 128 + u;
-    float* hbase = hout + (long long)b * T * 256 + dir * 128 + u;
+    // step s works on frame tt(s) = s (forward) or T-1-s (backward)
+    const long long tstep = dir ? -1024 : 1024;
+    const float* gptr = gx + ((long long)b * T + (dir ? T - 1 : 0)) * 1024 + dir * 512 + p * 128 + u;
+    float* hrow = hout + (long long)b * T * 256 + dir * 128;
+    // flush role of this thread: step i = tid / 64 of the block, units 2*(tid % 64), +1
+    const int fl_i = tid >> 6, fl_u = (tid & 63) * 2;
 
     float c = 0.f;
-    float gnext = gbase[(long long)(dir ? T - 1 : 0) * 1024];
-    __syncthreads();
-
-    for (int s = 0; s < T; ++s) {
-        const int cur = s & 1;
-        const int tt = dir ? T - 1 - s : s;
-        const float gcur = gnext;
-        if (s + 1 < T) gnext = gbase[(long long)(dir ? tt - 1 : tt + 1) * 1024];
-
+    auto gload = [&](int s) { return gptr[(long long)(s < T ? s : T - 1) * tstep]; };
+    auto step = [&](int s, float gcur) {
         float acc[4] = {0.f, 0.f, 0.f, 0.f};
-        const float* hp = &hs[cur][4 * p];
+        const float* hp = &hs[s & (RING - 1)][4 * p];
 #pragma unroll
         for (int jj = 0; jj < 8; ++jj) {
             const f32x4 hv = *reinterpret_cast<const f32x4*>(hp + 16 * jj);
@@ -93,17 +101,47 @@ __global__ __launch_bounds__(512) void lstm_rec_kernel(const float* __restrict__
         const float a0 = acc[0] + dpp<DPP_XOR1>(acc[1]);
         const float a1 = acc[2] + dpp<DPP_XOR1>(acc[3]);
         const float pre = a0 + dpp<DPP_XOR2>(a1) + gcur;
-
         const float act = act_scale * fast_sigmoid(act_scale * pre) + act_shift;
-        const float ig = dpp<0x00>(act), fg = dpp<0x55>(act), gg = dpp<0xAA>(act), og = dpp<0xFF>(act);
+        const float ig = dpp<0x00>(act), fg = dpp<0x55>(act), gg = dpp<0xAA>(act),
+                    og = dpp<0xFF>(act);
         c = fg * c + ig * gg;
-        const float h = og * (2.f * fast_sigmoid(2.f * c) - 1.f);
-        if (p == 0) {
-            hs[cur ^ 1][u] = h;
-            hbase[(long long)tt * 256] = h;
+        if (p == 0) hs[(s + 1) & (RING - 1)][u] = og * (2.f * fast_sigmoid(2.f * c) - 1.f);
+        lds_barrier();
+    };
+    // h of steps s0 .. s0+n-1 -> global (coalesced 256 B per step-row).  Nothing waits on these
+    // stores: a ring slot is only rewritten 8 barriers after it was flushed.
+    auto flush = [&](int s0, int n) {
+        const int s = s0 + fl_i;
+        if (fl_i < n) {
+            const int tt = dir ? T - 1 - s : s;
+            const float2 v = *reinterpret_cast<const float2*>(&hs[(s + 1) & (RING - 1)][fl_u]);
+            *reinterpret_cast<float2*>(hrow + (long long)tt * 256 + fl_u) = v;
         }
-        __syncthreads();
+    };
+
+    float gq[PF];
+#pragma unroll
+    for (int i = 0; i < PF; ++i) gq[i] = gload(i);
+    __syncthreads();
+
+    int s0 = 0;
+    for (; s0 + BLK <= T; s0 += BLK) {
+#pragma unroll
+        for (int i = 0; i < BLK; ++i) {
+            const float gcur = gq[i % PF];
+            gq[i % PF] = gload(s0 + i + PF);
+            step(s0 + i, gcur);
+        }
+        flush(s0, BLK);
     }
+    for (int s = s0; s < T; ++s) {
+        const float gcur = gq[0];
+#pragma unroll
+        for (int i = 0; i + 1 < PF; ++i) gq[i] = gq[i + 1];
+        gq[PF - 1] = gload(s + PF);
+        step(s, gcur);
+    }
+    flush(s0, T - s0);
 }
 
 }  // namespace

@@ -213,6 +213,36 @@ __global__ __launch_bounds__(256) void l2norm_kernel(float* __restrict__ x, int 
 }
 
 // ---------------------------------------------------------------------------
+// splitk_finish: out[r][:] = sum_z parts[z][r][:] in fixed order (deterministic, unlike
+// atomics), optionally followed by x <- x / ||x||_2.  One wave per row, dim <= 512.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void splitk_finish_kernel(const float* __restrict__ parts,
+                                                            int nsplit, long long stride, int rows,
+                                                            int dim, int normalize,
+                                                            float* __restrict__ out) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), l = threadIdx.x & 63;
+    if (row >= rows) return;
+    float v[8];
+    float ss = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int i = l + 64 * j;
+        float a = 0.f;
+        if (i < dim)
+            for (int z = 0; z < nsplit; ++z) a += parts[(long long)z * stride + (long long)row * dim + i];
+        v[j] = a;
+        ss += a * a;
+    }
+    for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
+    const float n = sqrtf(ss);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int i = l + 64 * j;
+        if (i < dim) out[(long long)row * dim + i] = normalize ? v[j] / n : v[j];
+    }
+}
+
+// ---------------------------------------------------------------------------
 // powerset -> multilabel: one_hot(argmax) @ mapping, subsets ordered by size then
 // lexicographically, at most 2 speakers per frame.
 // ---------------------------------------------------------------------------
@@ -318,6 +348,15 @@ int dz_launch_osp(const float* seg, int B, int F, int K, float gamma, float beta
 
 int dz_launch_l2norm(float* x, int rows, int dim, float norm, hipStream_t st) {
     hipLaunchKernelGGL(l2norm_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, x, rows, dim, norm);
+    DZ_HIP(hipGetLastError());
+    return 0;
+}
+
+int dz_launch_splitk_finish(const float* parts, int nsplit, long long stride, int rows, int dim,
+                            int normalize, float* out, hipStream_t st) {
+    DZ_REQUIRE(dim <= 512, "splitk_finish: dim %d > 512", dim);
+    hipLaunchKernelGGL(splitk_finish_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, parts, nsplit,
+                       stride, rows, dim, normalize, out);
     DZ_HIP(hipGetLastError());
     return 0;
 }

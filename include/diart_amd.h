@@ -156,6 +156,9 @@ typedef struct {
     long long xbs, ybs;   /* batch strides in floats                                 */
     int norm_on_load;     /* 0/1                                                     */
     int epi;              /* DZ_EPI_*                                                */
+    int ksplit;           /* 0/1: off.  >1 (DZ_EPI_BIAS only): split z of the K loop writes its
+                             partial sums to Y + z*ysplit (bias in split 0); the caller reduces */
+    long long ysplit;     /* floats between the partial outputs of consecutive splits */
 } dz_convgemm_desc;
 int dz_k_convgemm(dz_ctx* ctx, const dz_convgemm_desc* desc, void* stream);
 int dz_k_convgemm_ntile(int t_out);

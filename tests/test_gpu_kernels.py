@@ -92,7 +92,7 @@ def test_sinc_conv0(gpu):
 
 # --------------------------------------------------------------------------- #
 def _run_convgemm(gpu, X, W, bias, *, taps, dil, epi, Npad, Nstore, Kpad, e0=None, e1=None,
-                  nscale=None, nshift=None, Tstore=None, ldy=None):
+                  nscale=None, nshift=None, Tstore=None, ldy=None, ksplit=0):
     """X (B,Tin,Cin) channels-last; W (Npad,Kpad) packed."""
     lib = _lib.load()
     B, Tin, Cin = X.shape
@@ -100,8 +100,9 @@ def _run_convgemm(gpu, X, W, bias, *, taps, dil, epi, Npad, Nstore, Kpad, e0=Non
     Tstore = Tout if Tstore is None else Tstore
     ldy = Nstore if ldy is None else ldy
     dX, dW, db = X.contiguous().to(gpu), W.contiguous().to(gpu), bias.to(gpu)
-    Y = torch.full((B, Tstore, ldy), float("nan"), device=gpu)
+    Y = torch.full((max(ksplit, 1) * B, Tstore, ldy), float("nan"), device=gpu)
     d = _lib.ConvGemmDesc()
+    d.ksplit, d.ysplit = ksplit, B * Tstore * ldy
     d.X, d.W, d.bias, d.Y = dX.data_ptr(), dW.data_ptr(), db.data_ptr(), Y.data_ptr()
     keep = [dX, dW, db]
     if e0 is not None:
@@ -132,22 +133,28 @@ def _pack(w, cin_pad, npad, kpad):
 
 @pytest.mark.parametrize("M,K,N,epi", [(293 * 2 + 5, 64, 1024, "bias"), (500, 256, 1024, "bias"),
                                        (97, 256, 128, "leaky"), (200, 128, 3, "sigmoid"),
-                                       (192, 3008, 512, "bias64")])
+                                       (192, 3008, 512, "bias64"), (192, 3008, 512, "split16"),
+                                       (7, 96, 128, "split3")])
 def test_convgemm_linear(gpu, M, K, N, epi):
     g = torch.Generator().manual_seed(M + K)
     X = torch.randn(1, M, K, generator=g)
     W = torch.randn(N, K, generator=g) / math.sqrt(K)
     b = torch.randn(N, generator=g)
     Npad = 64 if N <= 64 else (N + 127) // 128 * 128
-    if epi == "bias64":
+    ksplit = int(epi[5:]) if epi.startswith("split") else 0
+    if epi == "bias64" or ksplit:
         Npad = N
     Wp = torch.zeros(Npad, K)
     Wp[:N] = W
     bp = torch.zeros(Npad)
     bp[:N] = b
     code = {"bias": _lib.EPI_BIAS, "bias64": _lib.EPI_BIAS, "leaky": _lib.EPI_BIAS_LEAKY,
-            "sigmoid": _lib.EPI_BIAS_SIGMOID}[epi]
-    Y, _ = _run_convgemm(gpu, X, Wp, bp, taps=1, dil=1, epi=code, Npad=Npad, Nstore=N, Kpad=K)
+            "sigmoid": _lib.EPI_BIAS_SIGMOID}.get(epi, _lib.EPI_BIAS)
+    Y, _ = _run_convgemm(gpu, X, Wp, bp, taps=1, dil=1, epi=code, Npad=Npad, Nstore=N, Kpad=K,
+                         ksplit=ksplit)
+    if ksplit:   # partial sums of the K slices, bias in slice 0
+        assert not torch.isnan(Y).any()
+        Y = Y.double().sum(0, keepdim=True).float()
     ref = X[0].double() @ W.double().t() + b.double()
     if epi == "leaky":
         ref = F.leaky_relu(ref, 0.01)

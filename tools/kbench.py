@@ -1,0 +1,124 @@
+#!/usr/bin/env python
+"""Isolated timing of the HIP kernels at the config-2 shapes (64 chunks), one kernel at a time
+on an otherwise idle GPU (torch events on the stream the kernel is launched on).
+usage: python tools/kbench.py [--batch 64] [--only lstm,tdnn2,...]"""
+import argparse
+import ctypes as C
+import json
+import sys
+from pathlib import Path
+
+import torch
+
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+from diart_amd import _lib  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--batch", type=int, default=64)
+ap.add_argument("--only", type=str, default="")
+ap.add_argument("--reps", type=int, default=20)
+args = ap.parse_args()
+only = set(filter(None, args.only.split(",")))
+dev = torch.device("cuda", 0)
+lib = _lib.load()
+ctx = _lib.context(0)
+B = args.batch
+st = torch.cuda.current_stream(dev).cuda_stream
+results = {}
+
+
+def timeit(name, fn, flop=None, bytes_=None):
+    if only and name not in only:
+        return
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(args.reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) * 1e3 / args.reps
+    row = {"us": round(us, 1)}
+    if flop:
+        row["tflops"] = round(flop / us / 1e6, 2)
+    if bytes_:
+        row["gbps"] = round(bytes_ / us / 1e3, 1)
+    results[name] = row
+    print(f"{name:14s} {us:9.1f} us  {row.get('tflops', '')} TF  {row.get('gbps', '')} GB/s", flush=True)
+
+
+def convgemm(name, Bn, Tin, Cin, N, taps, dil, epi, Npad=None, pro=False, pool=False, ksplit=0):
+    Npad = Npad or N
+    Tout = Tin - (taps - 1) * dil
+    K = taps * Cin
+    Kpad = (K + 31) // 32 * 32
+    X = torch.randn(Bn, Tin, Cin, device=dev)
+    W = torch.randn(Npad, Kpad, device=dev) * 0.05
+    bias = torch.zeros(Npad, device=dev)
+    e0 = torch.ones(Npad, device=dev)
+    Tstore = Tout // 3 if pool else Tout
+    Y = torch.empty(max(ksplit, 1) * Bn, Tstore, Npad, device=dev)
+    d = _lib.ConvGemmDesc()
+    d.X, d.W, d.bias, d.Y, d.e0, d.e1 = (X.data_ptr(), W.data_ptr(), bias.data_ptr(), Y.data_ptr(),
+                                         e0.data_ptr(), bias.data_ptr())
+    keep = [X, W, bias, e0, Y]
+    if pro:
+        sc = torch.ones(Bn, Cin, device=dev)
+        d.nscale, d.nshift, d.nld, d.norm_on_load = sc.data_ptr(), sc.data_ptr(), Cin, 1
+        keep.append(sc)
+    if pool:
+        part = torch.empty(Bn, lib.dz_k_convgemm_ntile(Tout), Npad, 2, device=dev)
+        d.partials = part.data_ptr()
+        keep.append(part)
+    d.B, d.Tin, d.Tout, d.Cin, d.taps, d.dil = Bn, Tin, Tout, Cin, taps, dil
+    d.K, d.Kpad, d.Npad, d.Nstore, d.ldx, d.ldy, d.Tstore = K, Kpad, Npad, Npad, Cin, Npad, Tstore
+    d.xbs, d.ybs, d.epi = Tin * Cin, Tstore * Npad, epi
+    d.ksplit, d.ysplit = ksplit, Bn * Tstore * Npad
+    flop = 2.0 * Bn * Tout * K * N
+    timeit(name, lambda: _lib.check(lib.dz_k_convgemm(ctx, C.byref(d), st), name), flop=flop)
+    return keep
+
+
+F = 293
+# ---- LSTM recurrence --------------------------------------------------------------------
+gx = torch.randn(B, F, 1024, device=dev) * 0.5
+whh = torch.randn(2, 512, 128, device=dev) * 0.1
+hout = torch.empty(B, F, 256, device=dev)
+timeit("lstm", lambda: _lib.check(lib.dz_k_lstm(ctx, gx.data_ptr(), whh.data_ptr(), hout.data_ptr(), B, F, st)),
+       flop=2.0 * B * F * 2 * 512 * 128)
+# ---- sinc conv0 -----------------------------------------------------------------------------
+wave = torch.randn(B, 80000, device=dev) * 0.1
+stats = torch.zeros(B, 2, device=dev)
+stats[:, 1] = 1.0
+filt = torch.randn(252, 80, device=dev) * 0.05
+y0 = torch.empty(B, 2658, 80, device=dev)
+part0 = torch.empty(B, 42, 80, 2, device=dev)
+timeit("wave_stats", lambda: _lib.check(lib.dz_k_wave_stats(ctx, wave.data_ptr(), 80000, B, 80000, stats.data_ptr(), st)),
+       bytes_=B * 80000 * 4.0)
+timeit("sinc_conv0", lambda: _lib.check(lib.dz_k_sinc_conv0(ctx, wave.data_ptr(), 80000, B, 80000, stats.data_ptr(), 1.0, 0.0,
+                                                           filt.data_ptr(), y0.data_ptr(), part0.data_ptr(), st)),
+       flop=2.0 * B * 7975 * 251 * 80)
+# ---- implicit-GEMM layers ------------------------------------------------------------------
+convgemm("conv1_pool", B, 2658, 80, 60, 5, 1, _lib.EPI_POOL3, Npad=64, pro=True, pool=True)
+convgemm("conv2_pool", B, 884, 64, 60, 5, 1, _lib.EPI_POOL3, Npad=64, pro=True, pool=True)
+convgemm("lstm_proj0", B, F, 64, 1024, 1, 1, _lib.EPI_BIAS, pro=True)
+convgemm("lstm_proj", 1, B * F, 256, 1024, 1, 1, _lib.EPI_BIAS)
+convgemm("seg_mlp0", 1, B * F, 256, 128, 1, 1, _lib.EPI_BIAS_LEAKY)
+convgemm("tdnn1", B, 293, 64, 512, 5, 1, _lib.EPI_TDNN, pro=True)
+convgemm("tdnn2", B, 289, 512, 512, 3, 2, _lib.EPI_TDNN)
+convgemm("tdnn3", B, 285, 512, 512, 3, 3, _lib.EPI_TDNN)
+convgemm("tdnn4", B, 279, 512, 512, 1, 1, _lib.EPI_TDNN)
+convgemm("tdnn5", B, 279, 512, 1500, 1, 1, _lib.EPI_TDNN, Npad=1536)
+convgemm("emb_linear", 1, B * 3, 3008, 512, 1, 1, _lib.EPI_BIAS, ksplit=16)
+# ---- stats pooling ----------------------------------------------------------------------------
+x5 = torch.randn(B, 279, 1536, device=dev)
+w = torch.rand(B * 3, F, device=dev)
+pooled = torch.empty(B * 3, 3008, device=dev)
+timeit("stats_pool", lambda: _lib.check(lib.dz_k_stats_pool(ctx, x5.data_ptr(), 279, 1500, 1536, w.data_ptr(), F, B * 3, 3,
+                                                           pooled.data_ptr(), 3008, st)),
+       bytes_=B * 279 * 1536 * 4.0)
+out = Path("gpurun_out")
+out.mkdir(exist_ok=True)
+(out / "kbench.json").write_text(json.dumps(results, indent=1))
