@@ -93,7 +93,7 @@ class ConvGemmDesc(C.Structure):
         (n, C.c_int) for n in ("B", "Tin", "Tout", "Cin", "taps", "dil", "K", "Kpad", "Npad",
                                "Nstore", "ldx", "ldy", "nld", "Tstore")] + [
         ("xbs", C.c_longlong), ("ybs", C.c_longlong), ("norm_on_load", C.c_int), ("epi", C.c_int),
-        ("ksplit", C.c_int), ("ysplit", C.c_longlong)]
+        ("ksplit", C.c_int), ("ysplit", C.c_longlong), ("agroup", C.c_int)]
 
 
 EPI_BIAS, EPI_BIAS_LEAKY, EPI_BIAS_SIGMOID, EPI_TDNN, EPI_POOL3 = range(5)

@@ -159,6 +159,7 @@ typedef struct {
     int ksplit;           /* 0/1: off.  >1 (DZ_EPI_BIAS only): split z of the K loop writes its
                              partial sums to Y + z*ysplit (bias in split 0); the caller reduces */
     long long ysplit;     /* floats between the partial outputs of consecutive splits */
+    int agroup;           /* activation tiles swept together per XCD (0 = default 4)  */
 } dz_convgemm_desc;
 int dz_k_convgemm(dz_ctx* ctx, const dz_convgemm_desc* desc, void* stream);
 int dz_k_convgemm_ntile(int t_out);

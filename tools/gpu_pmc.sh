@@ -1,0 +1,16 @@
+#!/bin/bash
+# HBM traffic of every kernel from the TCC counters, collected as MI355X_MICROARCH.md §HBM
+# prescribes: separate --pmc passes (FETCH_SIZE takes 3 of the 4 TCC slots, WRITE_SIZE 2), no
+# trace domains besides --kernel-trace.  usage: tools/gpu_pmc.sh <tag>
+TAG=${1:-r1}
+REPO=$PWD
+export PYTHONDONTWRITEBYTECODE=1 TMPDIR=/tmp
+cd /tmp
+for C in FETCH_SIZE WRITE_SIZE; do
+  timeout 280 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $REPO/gpurun_out/pmc_${TAG}_$C -o pmc -- \
+      python $REPO/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $REPO/gpurun_out/pmc_${TAG}_$C.log 2>&1
+  echo "$C exit $?"
+done
+cd $REPO
+ls -la gpurun_out/pmc_${TAG}_*/ | head -20
+python tools/pmc_summary.py gpurun_out/pmc_${TAG}_FETCH_SIZE gpurun_out/pmc_${TAG}_WRITE_SIZE gpurun_out/traffic_${TAG}.json

@@ -17,6 +17,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--batch", type=int, default=64)
 ap.add_argument("--only", type=str, default="")
 ap.add_argument("--reps", type=int, default=20)
+ap.add_argument("--agroup", type=int, default=0)
 args = ap.parse_args()
 only = set(filter(None, args.only.split(",")))
 dev = torch.device("cuda", 0)
@@ -76,6 +77,7 @@ def convgemm(name, Bn, Tin, Cin, N, taps, dil, epi, Npad=None, pro=False, pool=F
     d.K, d.Kpad, d.Npad, d.Nstore, d.ldx, d.ldy, d.Tstore = K, Kpad, Npad, Npad, Cin, Npad, Tstore
     d.xbs, d.ybs, d.epi = Tin * Cin, Tstore * Npad, epi
     d.ksplit, d.ysplit = ksplit, Bn * Tstore * Npad
+    d.agroup = args.agroup
     flop = 2.0 * Bn * Tout * K * N
     timeit(name, lambda: _lib.check(lib.dz_k_convgemm(ctx, C.byref(d), st), name), flop=flop)
     return keep
