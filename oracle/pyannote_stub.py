@@ -43,12 +43,71 @@ class SlidingWindow:
         return Segment(s, s + self.duration)
 
 
+    # --- pyannote.core.SlidingWindow.closest_frame / samples / crop (one Segment, ranges) -----
+    def closest_frame(self, t: float) -> int:
+        return int(np.rint((t - self.start - .5 * self.duration) / self.step))
+
+    def samples(self, from_duration: float, mode: str = "strict") -> int:
+        if mode == "strict":
+            return int(np.floor((from_duration - self.duration) / self.step)) + 1
+        elif mode == "loose":
+            return int(np.floor((from_duration + self.duration) / self.step))
+        elif mode == "center":
+            return int(np.rint((from_duration / self.step)))
+
+    def crop(self, focus: "Segment", mode: str = "loose", fixed=None, return_ranges: bool = True):
+        if mode == "loose":
+            i = int(np.ceil((focus.start - self.duration - self.start) / self.step))
+            if fixed is None:
+                j = int(np.floor((focus.end - self.start) / self.step))
+                rng = (i, j + 1)
+            else:
+                rng = (i, i + self.samples(fixed, mode="loose"))
+        elif mode == "strict":
+            i = int(np.ceil((focus.start - self.start) / self.step))
+            if fixed is None:
+                j = int(np.floor((focus.end - self.duration - self.start) / self.step))
+                rng = (i, j + 1)
+            else:
+                rng = (i, i + self.samples(fixed, mode="strict"))
+        elif mode == "center":
+            i = self.closest_frame(focus.start)
+            if fixed is None:
+                rng = (i, self.closest_frame(focus.end) + 1)
+            else:
+                rng = (i, i + self.samples(fixed, mode="center"))
+        else:
+            raise ValueError(mode)
+        return [rng]
+
+
 class SlidingWindowFeature:
     def __init__(self, data: np.ndarray, sliding_window: SlidingWindow):
         self.data, self.sliding_window = data, sliding_window
 
     def __getitem__(self, i):
         return self.data[i]
+
+    def crop(self, focus: Segment, mode: str = "loose", fixed=None, return_data: bool = True):
+        """pyannote.core.SlidingWindowFeature.crop for a Segment focus (returns the ndarray)."""
+        ranges = self.sliding_window.crop(focus, mode=mode, fixed=fixed, return_ranges=True)
+        n_samples = self.data.shape[0]
+        n_dimensions = len(self.data.shape) - 1
+        clipped_ranges, repeat_first, repeat_last = [], 0, 0
+        for start, end in ranges:
+            repeat_first += min(end, 0) - min(start, 0)
+            repeat_last += max(end, n_samples) - max(start, n_samples)
+            if end < 0 or start >= n_samples:
+                continue
+            clipped_ranges += [[max(start, 0), min(end, n_samples)]]
+        if clipped_ranges:
+            data = np.vstack([self.data[start:end, :] for start, end in clipped_ranges])
+        else:
+            data = np.empty((0,) + self.data.shape[1:])
+        if fixed is not None:
+            data = np.vstack([np.tile(self.data[0], (repeat_first,) + (1,) * n_dimensions), data,
+                              np.tile(self.data[n_samples - 1], (repeat_last,) + (1,) * n_dimensions)])
+        return data
 
     def __len__(self):
         return self.data.shape[0]
@@ -58,6 +117,23 @@ class SlidingWindowFeature:
         sw = self.sliding_window
         n = self.data.shape[0]
         return Segment(sw.start, sw.start + (n - 1) * sw.step + sw.duration)
+
+
+class Annotation:
+    """``annotation[segment, track] = label`` + ``itertracks`` (what Binarize / the pipelines use)."""
+
+    def __init__(self, uri=None, modality=None):
+        self.uri, self.modality = uri, modality
+        self.tracks = []
+
+    def __setitem__(self, key, label):
+        segment, track = key
+        if segment.end - segment.start > 1e-6:      # pyannote ignores empty segments
+            self.tracks.append((segment, track, label))
+
+    def itertracks(self, yield_label=False):
+        for seg, track, label in sorted(self.tracks, key=lambda t: (t[0].start, t[0].end, str(t[1]))):
+            yield (seg, track, label) if yield_label else (seg, track)
 
 
 def install() -> None:
@@ -70,6 +146,13 @@ def install() -> None:
     core = types.ModuleType("pyannote.core")
     core.__path__ = []
     core.SlidingWindow, core.SlidingWindowFeature, core.Segment = SlidingWindow, SlidingWindowFeature, Segment
+    core.Annotation = Annotation
+    if "torchaudio" not in sys.modules:   # blocks/utils.py imports torchaudio.transforms for Resample
+        ta = types.ModuleType("torchaudio")
+        ta.__path__ = []
+        tat = types.ModuleType("torchaudio.transforms")
+        ta.transforms = tat
+        sys.modules.update({"torchaudio": ta, "torchaudio.transforms": tat})
     utils = types.ModuleType("pyannote.core.utils")
     utils.__path__ = []
     dist = types.ModuleType("pyannote.core.utils.distance")
@@ -112,4 +195,6 @@ def load_reference(root: str = "/root/reference/src/diart"):
     ns.clustering = _load("blocks.clustering", "blocks/clustering.py")
     ns.embedding = _load("blocks.embedding", "blocks/embedding.py")
     ns.segmentation = _load("blocks.segmentation", "blocks/segmentation.py")
+    ns.aggregation = _load("blocks.aggregation", "blocks/aggregation.py")
+    ns.blocks_utils = _load("blocks.utils", "blocks/utils.py")
     return ns

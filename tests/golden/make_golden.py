@@ -96,5 +96,48 @@ def main():
         print(name, "steps", T, "final speakers", int(active[-1].sum()), "raised", int(raised.sum()))
 
 
+def tail(ref):
+    """blocks/aggregation.py DelayedAggregation + blocks/utils.py Binarize, driven by the buffer
+    logic of blocks/diarization.py:203-232, for four latencies and two stream origins."""
+    out = {}
+    for start_time in (0.0, 7.5):
+        scores, starts, res = scenarios.tail_inputs(start_time)
+        tag0 = f"s{start_time:g}"
+        for latency in scenarios.TAIL_LATENCIES:
+            pred = ref.aggregation.DelayedAggregation(scenarios.TAIL_STEP, latency, strategy="hamming",
+                                                      cropping_mode="loose")
+            audio = ref.aggregation.DelayedAggregation(scenarios.TAIL_STEP, latency, strategy="first",
+                                                       cropping_mode="center")
+            mean = ref.aggregation.DelayedAggregation(scenarios.TAIL_STEP, latency, strategy="mean",
+                                                      cropping_mode="strict")
+            binarize = ref.blocks_utils.Binarize(0.5)
+            pbuf, abuf = [], []
+            for i in range(scores.shape[0]):
+                sw = SlidingWindow(start=starts[i], duration=res, step=res)
+                pbuf.append(SlidingWindowFeature(scores[i], sw))
+                wav = (np.arange(80000, dtype=np.float64) + 8000.0 * i)[:, None]   # sample index ramp
+                abuf.append(SlidingWindowFeature(wav, SlidingWindow(start=starts[i], duration=1 / 16000,
+                                                                    step=1 / 16000)))
+                agg, aud, mn = pred(pbuf), audio(abuf), mean(pbuf)
+                ann = binarize(agg)
+                turns = np.array([[seg.start, seg.end, spk] for seg, spk, _ in ann.itertracks(yield_label=True)],
+                                 dtype=np.float64).reshape(-1, 3)
+                tag = f"{tag0}_l{latency:g}_t{i}"
+                out[tag + "_agg"] = agg.data
+                out[tag + "_aggsw"] = np.array([agg.sliding_window.start, agg.sliding_window.step])
+                out[tag + "_mean"] = mn.data
+                out[tag + "_turns"] = turns
+                out[tag + "_aud"] = np.array([aud.data.shape[0], aud.data[0, 0], aud.data[-1, 0],
+                                              aud.sliding_window.start, aud.sliding_window.step])
+                if len(pbuf) == pred.num_overlapping_windows:
+                    pbuf, abuf = pbuf[1:], abuf[1:]
+    np.savez_compressed(HERE / "tail.npz", **out)
+    print("tail:", len(out), "arrays")
+
+
 if __name__ == "__main__":
-    main()
+    if "--tail-only" in sys.argv:
+        tail(load_reference())
+    else:
+        main()
+        tail(load_reference())

@@ -52,3 +52,33 @@ def functional_inputs():
     emb = rng.standard_normal((4, 3, 64)).astype(np.float32)
     emb[1, 2] = 0.0   # zero embedding -> NaN after normalisation (functional.py:26-27)
     return seg, emb
+
+
+# ---- aggregation / binarize tail (blocks/aggregation.py, blocks/utils.py) ---------------------
+TAIL_LATENCIES = (0.5, 1.0, 2.5, 5.0)
+TAIL_STEPS, TAIL_FRAMES, TAIL_SPEAKERS, TAIL_STEP, TAIL_DURATION = 16, 293, 5, 0.5, 5.0
+
+
+def tail_inputs(start_time: float = 0.0):
+    """Permuted score windows of one stream: smooth per-speaker activity that persists across the
+    overlapping windows (so the Hamming average is not trivially noise), some all-zero columns
+    (unassigned global speakers), values exactly at the threshold, windows starting at
+    ``start_time + 0.5 i``."""
+    rng = np.random.default_rng(77)
+    res = TAIL_DURATION / TAIL_FRAMES
+    total = int(round((TAIL_DURATION + TAIL_STEP * TAIL_STEPS) / res)) + 8
+    track = np.zeros((total, TAIL_SPEAKERS))
+    for k in range(TAIL_SPEAKERS - 1):
+        state, t = rng.random() < 0.5, 0
+        while t < total:
+            n = int(rng.integers(20, 140))
+            track[t:t + n, k] = (0.7 + 0.3 * rng.random()) if state else 0.1 * rng.random()
+            state, t = not state, t + n
+    scores = np.zeros((TAIL_STEPS, TAIL_FRAMES, TAIL_SPEAKERS))
+    for i in range(TAIL_STEPS):
+        off = int(round(i * TAIL_STEP / res))
+        scores[i] = np.clip(track[off:off + TAIL_FRAMES] + 0.08 * rng.standard_normal((TAIL_FRAMES, TAIL_SPEAKERS)), 0, 1)
+        scores[i][:, TAIL_SPEAKERS - 1] = 0.0
+    scores[3, 100:110, 0] = 0.5            # exactly tau: Binarize is strict (>)
+    starts = start_time + TAIL_STEP * np.arange(TAIL_STEPS)
+    return scores, starts, res

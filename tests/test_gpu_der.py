@@ -1,0 +1,142 @@
+"""RTTM / DER parity of the whole pipeline (BASELINE.json config 1 shape: one 30 s 16 kHz stream,
+5 s window, 500 ms step, Benchmark's batch of 32): ``diart_amd.blocks.SpeakerDiarization`` on the
+GPU vs the all-CPU chain (oracle networks -> oracle clustering -> oracle aggregation/binarise).
+
+Gate (north-star: "DER within 0.5 pt of reference"): DER of the GPU hypothesis scored against the
+CPU-chain hypothesis <= 0.5 %, for latency = 0.5 s and 5 s; batch_size 1 and 32 give identical
+RTTMs (README.md:430).  Same for the VoiceActivityDetection pipeline (config 5, step 0.25 s).
+"""
+import numpy as np
+import pytest
+import torch
+
+from diart_amd import models as M
+from diart_amd.blocks import (SpeakerDiarization, SpeakerDiarizationConfig, VoiceActivityDetection,
+                              VoiceActivityDetectionConfig)
+from diart_amd.features import Annotation, Segment, SlidingWindow, SlidingWindowFeature
+from diart_amd.metrics import DetectionErrorRate, DiarizationErrorRate
+from diart_amd.synth import synth_embedding_state, synth_segmentation_state, synth_stream
+
+pytestmark = pytest.mark.gpu
+SR = 16000
+
+
+def rolling_chunks(stream: np.ndarray, duration=5.0, step=0.5):
+    """What rearrange_audio_stream emits (operators.py:44-100): (samples, 1) windows with timestamps."""
+    S, H = int(round(duration * SR)), int(round(step * SR))
+    out = []
+    for i in range((len(stream) - S) // H + 1):
+        sw = SlidingWindow(start=i * step, duration=1 / SR, step=1 / SR)
+        out.append(SlidingWindowFeature(stream[i * H:i * H + S, None], sw))
+    return out
+
+
+def accumulate(outputs, uri="stream") -> Annotation:
+    """PredictionAccumulator (sinks.py:59-88): update() then support(0.05)."""
+    total = Annotation(uri)
+    for ann, _ in outputs:
+        total.update(ann)
+    return total.support(0.05)
+
+
+def cpu_chain(stream, latency, tau=0.6, rho=0.3, delta=1.0, step=0.5):
+    from oracle.clustering_ref import OnlineSpeakerClusteringRef
+    from oracle.functional_ref import normalize_embeddings_ref, overlapped_speech_penalty_ref
+    from oracle.models_ref import PyanNetRef, XVectorSincNetRef
+    from oracle.pyannote_stub import SlidingWindow as SW, SlidingWindowFeature as SWF
+    from oracle.tail_ref import TailRef
+    seg_m, emb_m = PyanNetRef().eval(), XVectorSincNetRef().eval()
+    seg_m.load_state_dict(synth_segmentation_state())
+    emb_m.load_state_dict(synth_embedding_state())
+    clu, tail = OnlineSpeakerClusteringRef(tau, rho, delta, "cosine", 20), TailRef(step, latency, tau)
+    total = Annotation("stream")
+    chunks = rolling_chunks(stream, 5.0, step)
+    x = torch.from_numpy(np.stack([c.data[:, 0] for c in chunks]))[:, None, :]
+    with torch.no_grad():
+        seg = torch.cat([seg_m(x[i:i + 8]) for i in range(0, len(chunks), 8)])
+        emb = torch.cat([normalize_embeddings_ref(emb_m.forward_multi(x[i:i + 8], overlapped_speech_penalty_ref(seg[i:i + 8])))
+                         for i in range(0, len(chunks), 8)])
+    for i, c in enumerate(chunks):
+        scores, _ = clu(seg[i].numpy(), emb[i].numpy())
+        res = 5.0 / seg.shape[1]
+        _, turns = tail(SWF(scores, SW(start=i * step, duration=res, step=res)))
+        for n, (s, e, spk) in enumerate(turns):
+            total[Segment(s, e), (i, n)] = f"speaker{spk}"
+    return total.support(0.05), seg.numpy()
+
+
+@pytest.fixture(scope="module")
+def stream():
+    return synth_stream(2024, 30.0)
+
+
+@pytest.fixture(scope="module")
+def models():
+    return (M.SegmentationModel.from_state(synth_segmentation_state(), max_batch=32),
+            M.EmbeddingModel.from_state(synth_embedding_state(), max_batch=32))
+
+
+@pytest.mark.parametrize("latency", [0.5, 5.0])
+def test_diarization_rttm_matches_cpu_chain(gpu, stream, models, latency):
+    cfg = SpeakerDiarizationConfig(segmentation=models[0], embedding=models[1], latency=latency, device=gpu)
+    chunks = rolling_chunks(stream)
+    assert len(chunks) == 51                                       # ceil((30-5+0.5)/0.5), inference.py:81-83
+    hyps = {}
+    for bs in (32, 1):
+        pipe = SpeakerDiarization(cfg)
+        outs = []
+        for i in range(0, len(chunks), bs):
+            outs += pipe(chunks[i:i + bs])
+        assert len(outs) == len(chunks)
+        hyps[bs] = accumulate(outs)
+        # audio aggregation returns the `step` seconds of audio that the prediction is about
+        assert all(w.data.shape[1] == 1 for _, w in outs)
+    assert hyps[32].to_rttm() == hyps[1].to_rttm(), "batch size changed the output"
+    ref, seg = cpu_chain(stream, latency)
+    assert len(ref) > 0 and seg.max() > 0.6, "degenerate scenario: nobody ever speaks"
+    der = DiarizationErrorRate()
+    d = der(ref, hyps[32], detailed=True)
+    print(f"latency {latency}: DER(GPU vs CPU chain) = {100 * d['diarization error rate']:.3f} % "
+          f"of {d['total']:.1f} s; turns {len(hyps[32])} vs {len(ref)}")
+    assert d["diarization error rate"] <= 0.005
+
+
+def test_vad_matches_cpu_chain(gpu, stream, models):
+    from oracle.models_ref import PyanNetRef
+    from oracle.pyannote_stub import SlidingWindow as SW, SlidingWindowFeature as SWF
+    from oracle.tail_ref import TailRef
+    step = 0.25
+    cfg = VoiceActivityDetectionConfig(segmentation=models[0], step=step, latency=step, device=gpu)
+    pipe = VoiceActivityDetection(cfg)
+    chunks = rolling_chunks(stream, 5.0, step)
+    outs = []
+    for i in range(0, len(chunks), 16):
+        outs += pipe(chunks[i:i + 16])
+    hyp = accumulate(outs)
+    assert set(hyp.labels()) <= {"speech"}
+    seg_m = PyanNetRef().eval()
+    seg_m.load_state_dict(synth_segmentation_state())
+    tail, ref = TailRef(step, step, 0.6), Annotation("stream")
+    for i, c in enumerate(chunks):
+        with torch.no_grad():
+            s = seg_m(torch.from_numpy(c.data[:, 0])[None, None, :])[0].max(dim=-1, keepdim=True)[0].numpy()
+        _, turns = tail(SWF(s, SW(start=i * step, duration=5.0 / 293, step=5.0 / 293)))
+        for n, (a, b, _) in enumerate(turns):
+            ref[Segment(a, b), (i, n)] = "speech"
+    d = DetectionErrorRate()(ref.support(0.05), hyp, detailed=True)
+    print(f"VAD: DetER(GPU vs CPU chain) = {100 * d['detection error rate']:.3f} % of {d['total']:.1f} s")
+    assert d["total"] > 1.0 and d["detection error rate"] <= 0.005
+
+
+def test_pipeline_asserts_like_the_reference(gpu, models):
+    cfg = SpeakerDiarizationConfig(segmentation=models[0], embedding=models[1], device=gpu)
+    pipe = SpeakerDiarization(cfg)
+    with pytest.raises(AssertionError):
+        pipe([])
+    bad = SlidingWindowFeature(np.zeros((100, 1), dtype=np.float32), SlidingWindow(start=0, duration=1 / SR, step=1 / SR))
+    with pytest.raises(AssertionError):
+        pipe([bad])
+    with pytest.raises(AssertionError):
+        SpeakerDiarization(SpeakerDiarizationConfig(segmentation=models[0], embedding=models[1], latency=7, device=gpu))
+    assert [h.name for h in SpeakerDiarization.hyper_parameters()] == ["tau_active", "rho_update", "delta_new"]
+    assert SpeakerDiarization.get_config_class() is SpeakerDiarizationConfig
