@@ -37,6 +37,19 @@ class EmbWeights(C.Structure):
                 ("th", vp * 5), ("emb_w", vp), ("emb_b", vp), ("dimension", C.c_int)]
 
 
+class Layer(C.Structure):
+    _fields_ = [("w", vp), ("b", vp), ("s", vp), ("h", vp)]
+
+
+class SeRes2Net(C.Structure):
+    _fields_ = [("tdnn1", Layer), ("res", Layer * 7), ("tdnn2", Layer), ("se1", Layer), ("se2", Layer)]
+
+
+class EcapaWeights(C.Structure):
+    _fields_ = [("dft", vp), ("mel", vp), ("block0", Layer), ("ser", SeRes2Net * 3), ("mfa", Layer),
+                ("asp_tdnn", Layer), ("asp_wms", vp), ("asp_conv", Layer), ("fc", Layer), ("zeros", vp)]
+
+
 # name -> (restype, argtypes); must list every function of include/diart_amd.h
 SIGNATURES = {
     "dz_last_error": (C.c_char_p, []),
@@ -55,6 +68,11 @@ SIGNATURES = {
     "dz_emb_frames": (C.c_int, [vp, vp, C.c_longlong, C.c_int, vp]),
     "dz_emb_pool": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]),
     "dz_emb_destroy": (C.c_int, [vp]),
+    "dz_ecapa_frames_for": (C.c_int, [C.c_int]),
+    "dz_ecapa_create": (C.c_int, [vp, C.POINTER(EcapaWeights), C.c_int, C.c_int, C.POINTER(vp)]),
+    "dz_ecapa_forward": (C.c_int, [vp, vp, C.c_longlong, vp, C.c_int, C.c_int, vp, vp]),
+    "dz_ecapa_peek": (C.c_int, [vp, C.c_int, C.POINTER(vp), C.POINTER(C.c_longlong), C.POINTER(C.c_int)]),
+    "dz_ecapa_destroy": (C.c_int, [vp]),
     "dz_prof_enable": (C.c_int, [C.c_int]),
     "dz_prof_collect": (C.c_int, []),
     "dz_prof_get": (C.c_int, [C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_double),
@@ -93,10 +111,12 @@ class ConvGemmDesc(C.Structure):
         (n, C.c_int) for n in ("B", "Tin", "Tout", "Cin", "taps", "dil", "K", "Kpad", "Npad",
                                "Nstore", "ldx", "ldy", "nld", "Tstore")] + [
         ("xbs", C.c_longlong), ("ybs", C.c_longlong), ("norm_on_load", C.c_int), ("epi", C.c_int),
-        ("ksplit", C.c_int), ("ysplit", C.c_longlong), ("agroup", C.c_int)]
+        ("ksplit", C.c_int), ("ysplit", C.c_longlong), ("agroup", C.c_int), ("pad", C.c_int),
+        ("X2", vp), ("rowbias", vp)]
 
 
-EPI_BIAS, EPI_BIAS_LEAKY, EPI_BIAS_SIGMOID, EPI_TDNN, EPI_POOL3 = range(5)
+(EPI_BIAS, EPI_BIAS_LEAKY, EPI_BIAS_SIGMOID, EPI_TDNN, EPI_POOL3, EPI_BIAS_RELU, EPI_RELU_BN,
+ EPI_RELU_BN_TANH) = range(8)
 
 
 class DiartAmdError(RuntimeError):

@@ -15,7 +15,8 @@ from pathlib import Path
 HERE = Path(__file__).resolve().parent
 CSRC = HERE / "csrc"
 LIB = HERE / "libdiart_amd.so"
-SOURCES = ["api.hip", "k_front.hip", "k_convgemm.hip", "k_lstm.hip", "k_pool.hip", "cluster.cpp"]
+SOURCES = ["api.hip", "ecapa_api.hip", "k_front.hip", "k_convgemm.hip", "k_lstm.hip", "k_pool.hip",
+           "k_ecapa.hip", "cluster.cpp"]
 ARCH = "gfx950"
 
 

@@ -23,10 +23,6 @@ extern "C" int dz_version(void) { return DZ_VERSION; }
 // ---------------------------------------------------------------------------
 // context + scratch arena
 // ---------------------------------------------------------------------------
-struct dz_ctx {
-    int device;
-};
-
 struct Arena {
     char* base = nullptr;
     size_t size = 0, used = 0;

@@ -74,3 +74,23 @@ int dz_launch_powerset(const float* logp, int rows, int classes, int speakers, f
                        hipStream_t st);
 int dz_launch_cdist(const float* emb, const double* centers, int n, int k, int g, int dim,
                     double* out, hipStream_t st);
+
+// k_ecapa.hip ---------------------------------------------------------------
+int dz_launch_mask_compact(const float* wave, long long stride, int S, const float* masks, int Fw,
+                           int rows, float* sig, long long sig_stride, int* lens, hipStream_t st);
+int dz_launch_power(const float* spec, int lds, long long rows, float* pw, hipStream_t st);
+int dz_launch_fbank_post(const float* melp, int T, int rows, const int* nvalid, float* feats,
+                         hipStream_t st);
+int dz_launch_se_mean(const float* x, int T, int C, int ldx, int rows, const int* nmask, float* s,
+                      hipStream_t st);
+int dz_launch_se_apply(const float* x, int ldx, const float* gate, const float* resid, int ldr,
+                       float* out, int ldo, int rows, int T, int C, hipStream_t st);
+int dz_launch_asp_gstats(const float* x, int T, int C, int rows, const int* nmask, float* g,
+                         hipStream_t st);
+int dz_launch_asp_pool(const float* x, const float* logit, int T, int C, int rows, const int* nmask,
+                       float* pooled, hipStream_t st);
+int dz_launch_nan_rows(float* out, int rows, int dim, const int* flags, hipStream_t st);
+
+struct dz_ctx {
+    int device;
+};

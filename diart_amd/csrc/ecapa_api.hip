@@ -1,0 +1,271 @@
+// dz_ecapa_*: launch sequence of the ECAPA-TDNN embedding (include/diart_amd.h).  Host code.
+#include "dz_common.h"
+
+#include <math.h>
+#include <string.h>
+#include <new>
+#include <vector>
+
+namespace {
+
+enum { MIN_NUM_SAMPLES = 640, HOP = 160, NFFT = 400, C1 = 1024, C3 = 3072, EMB = 192, FC_SPLIT = 16 };
+
+struct Carve {
+    char* base = nullptr;
+    size_t used = 0;
+    template <typename T>
+    T* take(size_t n) {
+        const size_t bytes = (n * sizeof(T) + 255) & ~size_t(255);
+        T* p = base ? reinterpret_cast<T*>(base + used) : nullptr;
+        used += bytes;
+        return p;
+    }
+};
+
+}  // namespace
+
+struct dz_ecapa {
+    dz_ctx* ctx;
+    dz_ecapa_weights w;
+    int Nm, S, Tc;
+    long long lstride;
+    char* arena;
+    int* h_pin;  // pinned host: lens[Nm] | nvalid[Nm] | nmask[Nm] | tooshort[Nm]
+    // device buffers
+    float *sig, *spec, *pw, *melp, *feats, *b0, *t1, *res, *t2, *cat, *mfa, *a1;
+    float *smean, *sfc1, *gate, *gstat, *rb, *pooled, *parts;
+    int *lens, *nvalid, *nmask, *tooshort;
+    int lastN, lastT;
+};
+
+static void ecapa_carve(dz_ecapa* e, Carve& a) {
+    const size_t N = e->Nm, NT = N * e->Tc;
+    e->sig = a.take<float>(N * e->lstride);
+    e->spec = a.take<float>(NT * 404);
+    e->pw = a.take<float>(NT * 204);
+    e->melp = a.take<float>(NT * 80);
+    e->feats = a.take<float>(NT * 80);
+    e->b0 = a.take<float>(NT * C1);
+    e->t1 = a.take<float>(NT * C1);
+    e->res = a.take<float>(NT * C1);
+    e->t2 = a.take<float>(NT * C1);
+    e->cat = a.take<float>(NT * C3);   // after the MFA convolution it is reused for the logits
+    e->mfa = a.take<float>(NT * C3);
+    e->a1 = a.take<float>(NT * 128);
+    e->smean = a.take<float>(N * C1);
+    e->sfc1 = a.take<float>(N * 128);
+    e->gate = a.take<float>(N * C1);
+    e->gstat = a.take<float>(N * 2 * C3);
+    e->rb = a.take<float>(N * 128);
+    e->pooled = a.take<float>(N * 2 * C3);
+    e->parts = a.take<float>((size_t)FC_SPLIT * N * EMB);
+    e->lens = a.take<int>(N);
+    e->nvalid = a.take<int>(N);
+    e->nmask = a.take<int>(N);
+    e->tooshort = a.take<int>(N);
+}
+
+extern "C" int dz_ecapa_frames_for(int num_samples) { return num_samples > 0 ? 1 + num_samples / HOP : 0; }
+
+extern "C" int dz_ecapa_create(dz_ctx* ctx, const dz_ecapa_weights* w, int max_rows, int num_samples,
+                               dz_ecapa** out) {
+    DZ_REQUIRE(ctx && w && out, "dz_ecapa_create: NULL argument");
+    DZ_REQUIRE(max_rows >= 1 && num_samples >= MIN_NUM_SAMPLES, "dz_ecapa_create: max_rows %d, %d samples",
+               max_rows, num_samples);
+    DZ_HIP(hipSetDevice(ctx->device));
+    dz_ecapa* e = new (std::nothrow) dz_ecapa;
+    DZ_REQUIRE(e != nullptr, "dz_ecapa_create: out of memory");
+    memset(e, 0, sizeof(*e));
+    e->ctx = ctx; e->w = *w; e->Nm = max_rows; e->S = num_samples;
+    e->Tc = 1 + num_samples / HOP;
+    e->lstride = ((long long)num_samples + NFFT + 3) / 4 * 4;
+    Carve measure;
+    ecapa_carve(e, measure);
+    hipError_t err = hipMalloc((void**)&e->arena, measure.used);
+    if (err != hipSuccess) {
+        dz_set_error("dz_ecapa_create: hipMalloc(%zu) failed: %s", measure.used, hipGetErrorString(err));
+        delete e;
+        return 1;
+    }
+    err = hipHostMalloc((void**)&e->h_pin, sizeof(int) * 4 * max_rows, hipHostMallocDefault);
+    if (err != hipSuccess) {
+        dz_set_error("dz_ecapa_create: hipHostMalloc failed: %s", hipGetErrorString(err));
+        (void)hipFree(e->arena);
+        delete e;
+        return 1;
+    }
+    Carve real;
+    real.base = e->arena;
+    ecapa_carve(e, real);
+    *out = e;
+    return 0;
+}
+
+extern "C" int dz_ecapa_destroy(dz_ecapa* e) {
+    if (e) {
+        if (e->arena) (void)hipFree(e->arena);
+        if (e->h_pin) (void)hipHostFree(e->h_pin);
+        delete e;
+    }
+    return 0;
+}
+
+// one convgemm launch; X is [B][Tin][ldx] with Cin channels used, Y [B][Tin or flat][ldy]
+static int gemm(hipStream_t st, const float* X, int ldx, long long xbs, int B, int T, int Cin, int taps,
+                int dil, int pad, const dz_layer& L, const float* bias, int Kpad, int Npad, int Nstore,
+                float* Y, int ldy, long long ybs, int epi, const float* X2 = nullptr,
+                const float* rowbias = nullptr, int ksplit = 0, long long ysplit = 0) {
+    DzConvGemm p;
+    memset(&p, 0, sizeof(p));
+    p.X = X; p.W = L.w; p.bias = bias ? bias : L.b; p.e0 = L.s; p.e1 = L.h; p.Y = Y;
+    p.B = B; p.Tin = T; p.Tout = pad ? T : T - (taps - 1) * dil; p.Tstore = p.Tout;
+    p.Cin = Cin; p.taps = taps; p.dil = dil; p.pad = pad; p.K = taps * Cin; p.Kpad = Kpad;
+    p.Npad = Npad; p.Nstore = Nstore; p.ldx = ldx; p.ldy = ldy; p.xbs = xbs; p.ybs = ybs;
+    p.epi = epi; p.X2 = X2; p.rowbias = rowbias; p.ksplit = ksplit; p.ysplit = ysplit;
+    return dz_launch_convgemm(p, st);
+}
+
+extern "C" int dz_ecapa_forward(dz_ecapa* e, const float* d_wave, long long wave_stride,
+                                const float* d_masks, int N, int mask_frames, float* d_out,
+                                void* stream) {
+    DZ_REQUIRE(e && d_wave && d_out, "dz_ecapa_forward: NULL argument");
+    DZ_REQUIRE(N >= 1 && N <= e->Nm, "dz_ecapa_forward: %d rows outside [1, %d]", N, e->Nm);
+    DZ_REQUIRE(d_masks == nullptr || mask_frames >= 1, "dz_ecapa_forward: mask_frames %d", mask_frames);
+    DZ_REQUIRE(wave_stride >= 0, "dz_ecapa_forward: negative stride");
+    DZ_HIP(hipSetDevice(e->ctx->device));
+    hipStream_t st = (hipStream_t)stream;
+    int rc;
+    const dz_ecapa_weights& w = e->w;
+
+    // ---- 1. mask -> kept samples, zero padded rows (200 leading zeros = centred STFT) ---------
+    DZ_HIP(hipMemsetAsync(e->sig, 0, sizeof(float) * (size_t)N * e->lstride, st));
+    if ((rc = dz_launch_mask_compact(d_wave, wave_stride, e->S, d_masks, mask_frames, N, e->sig,
+                                     e->lstride, e->lens, st)))
+        return rc;
+    int* h_lens = e->h_pin;
+    int* h_nvalid = h_lens + e->Nm;
+    int* h_nmask = h_nvalid + e->Nm;
+    int* h_short = h_nmask + e->Nm;
+    DZ_HIP(hipMemcpyAsync(h_lens, e->lens, sizeof(int) * N, hipMemcpyDeviceToHost, st));
+    DZ_HIP(hipStreamSynchronize(st));   // the batch geometry (frames) depends on the longest row
+    int lmax = 0;
+    for (int i = 0; i < N; ++i) lmax = h_lens[i] > lmax ? h_lens[i] : lmax;
+    e->lastN = N;
+    if (lmax < MIN_NUM_SAMPLES) {       // "every signal is too short": all NaN
+        for (int i = 0; i < N; ++i) h_short[i] = 1;
+        DZ_HIP(hipMemcpyAsync(e->tooshort, h_short, sizeof(int) * N, hipMemcpyHostToDevice, st));
+        e->lastT = 0;
+        return dz_launch_nan_rows(d_out, N, EMB, e->tooshort, st);
+    }
+    const int T = 1 + lmax / HOP;
+    e->lastT = T;
+    for (int i = 0; i < N; ++i) {
+        h_short[i] = h_lens[i] < MIN_NUM_SAMPLES;
+        // float32 arithmetic of torch: wav_lens / max_len, then * T
+        const float rel = h_short[i] ? 1.0f : (float)h_lens[i] / (float)lmax;
+        const float v = rel * (float)T;
+        int nv = (int)nearbyintf(v);            // torch.round: half to even
+        nv = nv < 1 ? 1 : (nv > T ? T : nv);
+        h_nvalid[i] = nv;
+        int nm = (int)ceilf(v);                 // #{t : (float)t < v}
+        nm = nm < 1 ? 1 : (nm > T ? T : nm);
+        h_nmask[i] = nm;
+    }
+    DZ_HIP(hipMemcpyAsync(e->nvalid, h_nvalid, sizeof(int) * N, hipMemcpyHostToDevice, st));
+    DZ_HIP(hipMemcpyAsync(e->nmask, h_nmask, sizeof(int) * N, hipMemcpyHostToDevice, st));
+    DZ_HIP(hipMemcpyAsync(e->tooshort, h_short, sizeof(int) * N, hipMemcpyHostToDevice, st));
+    const long long NT = (long long)N * T;
+
+    // ---- 2. Fbank: STFT as one GEMM over overlapping rows (hop 160 < window 400) ---------------
+    dz_layer dft = {w.dft, w.zeros, nullptr, nullptr};
+    if ((rc = gemm(st, e->sig, HOP, e->lstride, N, T, NFFT, 1, 1, 0, dft, nullptr, 416, 448, 402, e->spec,
+                   404, (long long)T * 404, DZ_EPI_BIAS)))
+        return rc;
+    if ((rc = dz_launch_power(e->spec, 404, NT, e->pw, st))) return rc;
+    dz_layer mel = {w.mel, w.zeros, nullptr, nullptr};
+    if ((rc = gemm(st, e->pw, 204, 0, 1, (int)NT, 204, 1, 1, 0, mel, nullptr, 224, 128, 80, e->melp, 80, 0,
+                   DZ_EPI_BIAS)))
+        return rc;
+    if ((rc = dz_launch_fbank_post(e->melp, T, N, e->nvalid, e->feats, st))) return rc;
+
+    // ---- 3. ECAPA-TDNN -------------------------------------------------------------------------
+    // block 0: Conv1d(80 -> 1024, k5) -> ReLU -> BN
+    if ((rc = gemm(st, e->feats, 80, (long long)T * 80, N, T, 80, 5, 1, 2, w.block0, nullptr, 416, C1, C1,
+                   e->b0, C1, (long long)T * C1, DZ_EPI_RELU_BN)))
+        return rc;
+    const int dil[3] = {2, 3, 4};
+    for (int i = 0; i < 3; ++i) {
+        const dz_seres2net& b = w.ser[i];
+        const float* xin = i == 0 ? e->b0 : e->cat + (size_t)(i - 1) * C1;
+        const int ldin = i == 0 ? C1 : C3;
+        // tdnn1 (1x1)
+        if ((rc = gemm(st, xin, ldin, 0, 1, (int)NT, C1, 1, 1, 0, b.tdnn1, nullptr, C1, C1, C1, e->t1, C1, 0,
+                       DZ_EPI_RELU_BN)))
+            return rc;
+        // Res2Net: y0 = x0; y1 = f1(x1); yi = fi(xi + y(i-1))
+        DZ_HIP(hipMemcpy2DAsync(e->res, sizeof(float) * C1, e->t1, sizeof(float) * C1, sizeof(float) * 128,
+                                (size_t)NT, hipMemcpyDeviceToDevice, st));
+        for (int j = 1; j < 8; ++j) {
+            const float* x2 = j >= 2 ? e->res + (j - 1) * 128 : nullptr;
+            if ((rc = gemm(st, e->t1 + j * 128, C1, (long long)T * C1, N, T, 128, 3, dil[i], dil[i], b.res[j - 1],
+                           nullptr, 384, 128, 128, e->res + j * 128, C1, (long long)T * C1, DZ_EPI_RELU_BN,
+                           x2)))
+                return rc;
+        }
+        // tdnn2 (1x1)
+        if ((rc = gemm(st, e->res, C1, 0, 1, (int)NT, C1, 1, 1, 0, b.tdnn2, nullptr, C1, C1, C1, e->t2, C1, 0,
+                       DZ_EPI_RELU_BN)))
+            return rc;
+        // squeeze-excitation + residual, written straight into its slice of the concatenation
+        if ((rc = dz_launch_se_mean(e->t2, T, C1, C1, N, e->nmask, e->smean, st))) return rc;
+        if ((rc = gemm(st, e->smean, C1, 0, 1, N, C1, 1, 1, 0, b.se1, nullptr, C1, 128, 128, e->sfc1, 128, 0,
+                       DZ_EPI_BIAS_RELU)))
+            return rc;
+        if ((rc = gemm(st, e->sfc1, 128, 0, 1, N, 128, 1, 1, 0, b.se2, nullptr, 128, C1, C1, e->gate, C1, 0,
+                       DZ_EPI_BIAS_SIGMOID)))
+            return rc;
+        if ((rc = dz_launch_se_apply(e->t2, C1, e->gate, xin, ldin, e->cat + (size_t)i * C1, C3, N, T, C1, st)))
+            return rc;
+    }
+    // multi-layer feature aggregation
+    if ((rc = gemm(st, e->cat, C3, 0, 1, (int)NT, C3, 1, 1, 0, w.mfa, nullptr, C3, C3, C3, e->mfa, C3, 0,
+                   DZ_EPI_RELU_BN)))
+        return rc;
+    // attentive statistics pooling with global context: W [x; mean; std] = Wx x + Wms [mean; std]
+    if ((rc = dz_launch_asp_gstats(e->mfa, T, C3, N, e->nmask, e->gstat, st))) return rc;
+    dz_layer wms = {w.asp_wms, w.zeros, nullptr, nullptr};
+    if ((rc = gemm(st, e->gstat, 2 * C3, 0, 1, N, 2 * C3, 1, 1, 0, wms, nullptr, 2 * C3, 128, 128, e->rb, 128, 0,
+                   DZ_EPI_BIAS)))
+        return rc;
+    if ((rc = gemm(st, e->mfa, C3, (long long)T * C3, N, T, C3, 1, 1, 0, w.asp_tdnn, nullptr, C3, 128, 128, e->a1,
+                   128, (long long)T * 128, DZ_EPI_RELU_BN_TANH, nullptr, e->rb)))
+        return rc;
+    float* logits = e->cat;   // the concatenation is dead once the MFA layer has consumed it
+    if ((rc = gemm(st, e->a1, 128, 0, 1, (int)NT, 128, 1, 1, 0, w.asp_conv, nullptr, 128, C3, C3, logits, C3, 0,
+                   DZ_EPI_BIAS)))
+        return rc;
+    if ((rc = dz_launch_asp_pool(e->mfa, logits, T, C3, N, e->nmask, e->pooled, st))) return rc;
+    // asp_bn (folded) + fc, split-K with a fixed-order reduce
+    const long long ysplit = (long long)N * EMB;
+    if ((rc = gemm(st, e->pooled, 2 * C3, 0, 1, N, 2 * C3, 1, 1, 0, w.fc, nullptr, 2 * C3, EMB, EMB, e->parts, EMB,
+                   0, DZ_EPI_BIAS, nullptr, nullptr, FC_SPLIT, ysplit)))
+        return rc;
+    if ((rc = dz_launch_splitk_finish(e->parts, FC_SPLIT, ysplit, N, EMB, 0, d_out, st))) return rc;
+    return dz_launch_nan_rows(d_out, N, EMB, e->tooshort, st);
+}
+
+extern "C" int dz_ecapa_peek(dz_ecapa* e, int which, const void** d_ptr, long long* count, int* frames) {
+    DZ_REQUIRE(e && d_ptr && count, "dz_ecapa_peek: NULL argument");
+    const long long N = e->lastN, T = e->lastT;
+    if (frames) *frames = (int)T;
+    switch (which) {
+        case 0: *d_ptr = e->feats; *count = N * T * 80; return 0;
+        case 1: *d_ptr = e->b0; *count = N * T * C1; return 0;
+        case 2: *d_ptr = e->cat; *count = N * T * C3; return 0;   // holds the logits after a forward
+        case 3: *d_ptr = e->mfa; *count = N * T * C3; return 0;
+        case 4: *d_ptr = e->pooled; *count = N * 2 * C3; return 0;
+        case 5: *d_ptr = e->lens; *count = N; return 0;
+    }
+    dz_set_error("dz_ecapa_peek: unknown buffer %d", which);
+    return 2;
+}

@@ -80,12 +80,12 @@ __global__ __launch_bounds__(256) void convgemm_kernel(DzConvGemm p) {
     const float* Xb = p.X + (long long)b * p.xbs;
     const float* nsc = PRO ? p.nscale + (long long)b * p.nld : nullptr;
     const float* nsh = PRO ? p.nshift + (long long)b * p.nld : nullptr;
-    long long arow[C::A_F4];
+    const float* X2b = p.X2 ? p.X2 + (long long)b * p.xbs : nullptr;
+    int trow[C::A_F4];
 #pragma unroll
     for (int a = 0; a < C::A_F4; ++a) {
-        int t = t0 + lrow + 32 * a;
-        t = t < p.Tout ? t : p.Tout - 1;
-        arow[a] = (long long)t * p.ldx;
+        const int t = t0 + lrow + 32 * a;
+        trow[a] = t < p.Tout ? t : p.Tout - 1;
     }
     const float* Wt = p.W + (long long)(n0 + lrow) * p.Kpad + lkq * 4;
 
@@ -103,12 +103,23 @@ __global__ __launch_bounds__(256) void convgemm_kernel(DzConvGemm p) {
             sc = *reinterpret_cast<const f32x4*>(nsc + c);
             sh = *reinterpret_cast<const f32x4*>(nsh + c);
         }
-        const long long koff = (long long)tap * p.dil * p.ldx + c;
+        const int toff = tap * p.dil - p.pad;
 #pragma unroll
         for (int a = 0; a < C::A_F4; ++a) {
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
             if (kvalid) {
-                v = *reinterpret_cast<const f32x4*>(Xb + arow[a] + koff);
+                int tt = trow[a] + toff;
+                if (p.pad) {  // "same" convolution with reflect padding (ECAPA TDNN blocks)
+                    tt = tt < 0 ? -tt : tt;
+                    tt = tt >= p.Tin ? 2 * (p.Tin - 1) - tt : tt;
+                }
+                const long long off = (long long)tt * p.ldx + c;
+                v = *reinterpret_cast<const f32x4*>(Xb + off);
+                if (X2b) {    // Res2Net: the convolution input is x_i + y_{i-1}
+                    const f32x4 v2 = *reinterpret_cast<const f32x4*>(X2b + off);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] += v2[e];
+                }
                 if (PRO) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = leaky(v[e] * sc[e] + sh[e]);
@@ -221,9 +232,10 @@ __global__ __launch_bounds__(256) void convgemm_kernel(DzConvGemm p) {
 #pragma unroll
     for (int nt = 0; nt < C::NT; ++nt) {
         const int n = n0 + wn * (BN / 2) + nt * 16 + li;
-        const float bv = ks == 0 ? p.bias[n] : 0.f;
+        float bv = ks == 0 ? p.bias[n] : 0.f;
+        if (p.rowbias) bv += p.rowbias[(long long)b * p.Npad + n];
         float e0 = 1.f, e1 = 0.f;
-        if (EPI == DZ_EPI_TDNN) {
+        if (EPI == DZ_EPI_TDNN || EPI == DZ_EPI_RELU_BN || EPI == DZ_EPI_RELU_BN_TANH) {
             e0 = p.e0[n];
             e1 = p.e1[n];
         }
@@ -238,6 +250,9 @@ __global__ __launch_bounds__(256) void convgemm_kernel(DzConvGemm p) {
                         if (EPI == DZ_EPI_BIAS_LEAKY) v = leaky(v);
                         if (EPI == DZ_EPI_BIAS_SIGMOID) v = 1.f / (1.f + expf(-v));
                         if (EPI == DZ_EPI_TDNN) v = leaky(v) * e0 + e1;
+                        if (EPI == DZ_EPI_BIAS_RELU) v = fmaxf(v, 0.f);
+                        if (EPI == DZ_EPI_RELU_BN) v = fmaxf(v, 0.f) * e0 + e1;
+                        if (EPI == DZ_EPI_RELU_BN_TANH) v = tanhf(fmaxf(v, 0.f) * e0 + e1);
                         Yb[(long long)t * p.ldy + n] = v;
                     }
                 }
@@ -267,7 +282,11 @@ int dz_convgemm_ntile(int Tout) { return (Tout + BM - 1) / BM; }
 int dz_launch_convgemm(const DzConvGemm& p, hipStream_t st) {
     DZ_REQUIRE(p.Kpad % KT == 0 && p.Cin % 4 == 0 && p.ldx % 4 == 0, "convgemm: bad K/Cin/ldx");
     DZ_REQUIRE(p.K <= p.Kpad && p.K == p.taps * p.Cin, "convgemm: K mismatch");
-    DZ_REQUIRE(p.Tout == p.Tin - (p.taps - 1) * p.dil && p.Tout > 0, "convgemm: Tout mismatch");
+    DZ_REQUIRE(p.pad >= 0 && p.Tout > 0 &&
+                   p.Tout == (p.pad ? p.Tin : p.Tin - (p.taps - 1) * p.dil),
+               "convgemm: Tout mismatch");
+    DZ_REQUIRE(p.pad == 0 || (2 * p.pad == (p.taps - 1) * p.dil && p.pad < p.Tin),
+               "convgemm: reflect 'same' padding needs 2*pad == (taps-1)*dil and pad < Tin");
     DZ_REQUIRE(p.ksplit <= 1 || (p.epi == DZ_EPI_BIAS && p.ksplit <= p.Kpad / KT),
                "convgemm: split-K needs the plain bias epilogue and ksplit <= k-tiles");
     const bool wide = (p.Npad % 128 == 0);
@@ -293,8 +312,18 @@ int dz_launch_convgemm(const DzConvGemm& p, hipStream_t st) {
             DZ_REQUIRE(wide && !pro, "convgemm: BIAS_LEAKY is BN=128, no norm-on-load");
             DZ_CG(128, false, DZ_EPI_BIAS_LEAKY);
         case DZ_EPI_BIAS_SIGMOID:
-            DZ_REQUIRE(!wide && !pro, "convgemm: BIAS_SIGMOID is BN=64, no norm-on-load");
+            DZ_REQUIRE(!pro, "convgemm: BIAS_SIGMOID has no norm-on-load instance");
+            if (wide) DZ_CG(128, false, DZ_EPI_BIAS_SIGMOID);
             DZ_CG(64, false, DZ_EPI_BIAS_SIGMOID);
+        case DZ_EPI_BIAS_RELU:
+            DZ_REQUIRE(wide && !pro, "convgemm: BIAS_RELU is BN=128, no norm-on-load");
+            DZ_CG(128, false, DZ_EPI_BIAS_RELU);
+        case DZ_EPI_RELU_BN:
+            DZ_REQUIRE(wide && !pro, "convgemm: RELU_BN is BN=128, no norm-on-load");
+            DZ_CG(128, false, DZ_EPI_RELU_BN);
+        case DZ_EPI_RELU_BN_TANH:
+            DZ_REQUIRE(wide && !pro, "convgemm: RELU_BN_TANH is BN=128, no norm-on-load");
+            DZ_CG(128, false, DZ_EPI_RELU_BN_TANH);
     }
 #undef DZ_CG
     dz_set_error("convgemm: unknown epilogue %d", p.epi);

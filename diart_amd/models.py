@@ -29,7 +29,7 @@ import torch
 import torch.nn as nn
 
 from . import _lib
-from .weights import PackedEmbedding, PackedSegmentation
+from .weights import PackedEcapa, PackedEmbedding, PackedSegmentation
 
 StateSource = Union[str, Path, Dict[str, torch.Tensor]]
 
@@ -243,6 +243,68 @@ class HipEmbedding(_HipModule):
         return out
 
 
+class HipEcapaEmbedding(_HipModule):
+    """speechbrain ECAPA-TDNN behind pyannote's ``PretrainedSpeakerEmbedding`` contract
+    (BASELINE.json config 3): ``(waveform (N,1,S), masks (N,F) | None) -> (N,192)``; a row whose
+    mask keeps fewer than 640 samples is NaN.  The reference reaches this model through the
+    fallback at models.py:59 and calls it at :262; it returns numpy there, a device tensor here
+    (``EmbeddingModel`` accepts both, models.py:263-264)."""
+
+    dimension = 192
+
+    def __init__(self, state: Dict[str, torch.Tensor], max_batch: int = 192):
+        super().__init__(state, max_batch)
+
+    def _extra_state(self):
+        return {}
+
+    def _pack(self, device):
+        return PackedEcapa(self._state, device)
+
+    def _create(self, num_samples, cap):
+        h = _lib.vp()
+        _lib.check(_lib.load().dz_ecapa_create(_lib.context(self.device.index),
+                                               C.byref(self._packed.struct), cap, num_samples,
+                                               C.byref(h)), "dz_ecapa_create")
+        return h
+
+    def _destroy(self, h):
+        _lib.load().dz_ecapa_destroy(h)
+
+    def __call__(self, waveform: torch.Tensor, masks: Optional[torch.Tensor] = None) -> torch.Tensor:
+        if self.device is None:
+            self.to(waveform.device)
+        rows = _as_rows(waveform.to(self.device))
+        N, S = rows.shape
+        mptr, fw = None, 0
+        if masks is not None:
+            masks = masks.to(self.device, torch.float32).contiguous()
+            if masks.ndim != 2 or masks.shape[0] != N:
+                raise ValueError(f"masks must be (batch, frames), got {tuple(masks.shape)}")
+            mptr, fw = masks.data_ptr(), masks.shape[1]
+        handle = self._need(S, N)
+        out = torch.empty((N, self.dimension), dtype=torch.float32, device=self.device)
+        _lib.check(_lib.load().dz_ecapa_forward(handle, rows.data_ptr(), rows.stride(0) if N > 1 else S,
+                                                mptr, N, fw, out.data_ptr(), _stream_ptr(self.device)),
+                   "dz_ecapa_forward")
+        return out
+
+    def peek(self, num_samples: int, which: int) -> torch.Tensor:
+        """Intermediate of the last forward (parity tests): see ``dz_ecapa_peek``."""
+        ptr, cnt, frames = _lib.vp(), C.c_longlong(), C.c_int()
+        _lib.check(_lib.load().dz_ecapa_peek(self._handles[num_samples][0], which, C.byref(ptr),
+                                             C.byref(cnt), C.byref(frames)), "dz_ecapa_peek")
+        dtype = torch.int32 if which == 5 else torch.float32
+        out = torch.empty(cnt.value, dtype=dtype, device=self.device)
+        torch.cuda.synchronize(self.device)
+        import ctypes
+        hip = ctypes.CDLL("libamdhip64.so")
+        rc = hip.hipMemcpy(ctypes.c_void_p(out.data_ptr()), ptr, ctypes.c_size_t(cnt.value * 4), 3)
+        if rc != 0:
+            raise _lib.DiartAmdError(f"hipMemcpy failed ({rc})")
+        return out, frames.value
+
+
 # --------------------------------------------------------------------------- #
 # loaders (picklable, no HIP state)
 # --------------------------------------------------------------------------- #
@@ -255,11 +317,18 @@ class SegmentationLoader:
 
 
 class EmbeddingLoader:
-    def __init__(self, state: StateSource, max_batch: int = 64):
-        self.state, self.max_batch = state, max_batch
+    """``arch``: "xvector" (pyannote/embedding) or "ecapa" (speechbrain/spkrec-ecapa-voxceleb);
+    None = decide from the checkpoint keys."""
 
-    def __call__(self) -> HipEmbedding:
-        return HipEmbedding(_read_state(self.state), self.max_batch)
+    def __init__(self, state: StateSource, max_batch: int = 64, arch: Optional[str] = None):
+        self.state, self.max_batch, self.arch = state, max_batch, arch
+
+    def __call__(self):
+        sd = _read_state(self.state)
+        arch = self.arch or ("ecapa" if any(k.startswith("asp.") for k in sd) else "xvector")
+        if arch == "ecapa":
+            return HipEcapaEmbedding(sd, self.max_batch)
+        return HipEmbedding(sd, self.max_batch)
 
 
 # --------------------------------------------------------------------------- #
@@ -339,8 +408,8 @@ class EmbeddingModel(LazyModel):
     from_onnx = staticmethod(_no_onnx)
 
     @staticmethod
-    def from_state(state: StateSource, max_batch: int = 64) -> "EmbeddingModel":
-        return EmbeddingModel(EmbeddingLoader(state, max_batch))
+    def from_state(state: StateSource, max_batch: int = 64, arch: Optional[str] = None) -> "EmbeddingModel":
+        return EmbeddingModel(EmbeddingLoader(state, max_batch, arch))
 
     @staticmethod
     def from_pyannote(model, use_hf_token=True) -> "EmbeddingModel":

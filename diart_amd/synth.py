@@ -158,3 +158,45 @@ def synth_embedding_state(seed: int = 4321, dimension: int = 512) -> Dict[str, t
     sd["embedding.weight"] = _u(g, (dimension, 3000), 1.0 / math.sqrt(3000))
     sd["embedding.bias"] = _u(g, (dimension,), 1.0 / math.sqrt(3000))
     return sd
+
+
+def synth_ecapa_state(seed: int = 777, channels: int = 1024, lin_neurons: int = 192) -> Dict[str, torch.Tensor]:
+    """Random-init weights of speechbrain's ECAPA-TDNN (spkrec-ecapa-voxceleb geometry), keyed like
+    its checkpoint (``blocks.0.conv.conv.weight``, ``blocks.1.res2net_block.blocks.0.norm.norm.
+    running_var``, ``asp.tdnn...``, ``fc.conv.weight``).  He-style bounds keep the ReLU stacks at
+    unit scale so that every layer contributes to the output."""
+    g = torch.Generator().manual_seed(seed)
+    sd: Dict[str, torch.Tensor] = {}
+    c = channels
+
+    def conv(prefix, cin, cout, k, gain=1.0):
+        b = gain * math.sqrt(6.0 / (cin * k))
+        sd[prefix + ".conv.weight"] = _u(g, (cout, cin, k), b)
+        sd[prefix + ".conv.bias"] = _u(g, (cout,), 0.1)
+
+    def bn(prefix, n):
+        sd[prefix + ".norm.weight"] = 1.0 + 0.2 * _u(g, (n,), 1.0)
+        sd[prefix + ".norm.bias"] = 0.1 * _u(g, (n,), 1.0)
+        sd[prefix + ".norm.running_mean"] = 0.3 + 0.1 * _u(g, (n,), 1.0)
+        sd[prefix + ".norm.running_var"] = 0.8 + 0.8 * torch.rand((n,), generator=g)
+        sd[prefix + ".norm.num_batches_tracked"] = torch.tensor(1000)
+
+    def tdnn(prefix, cin, cout, k, gain=0.55):
+        conv(prefix + ".conv", cin, cout, k, gain)
+        bn(prefix + ".norm", cout)
+
+    tdnn("blocks.0", 80, c, 5, gain=0.08)            # input is log-mel in dB (tens of units)
+    for i in (1, 2, 3):
+        p = f"blocks.{i}"
+        tdnn(p + ".tdnn1", c, c, 1)
+        for j in range(7):
+            tdnn(p + f".res2net_block.blocks.{j}", c // 8, c // 8, 3)
+        tdnn(p + ".tdnn2", c, c, 1)
+        conv(p + ".se_block.conv1", c, 128, 1)
+        conv(p + ".se_block.conv2", 128, c, 1)
+    tdnn("mfa", 3 * c, 3 * c, 1)
+    tdnn("asp.tdnn", 9 * c, 128, 1, gain=0.3)
+    conv("asp.conv", 128, 3 * c, 1, gain=1.5)
+    bn("asp_bn", 6 * c)
+    conv("fc", 6 * c, lin_neurons, 1)
+    return sd

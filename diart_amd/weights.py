@@ -165,3 +165,74 @@ class PackedEmbedding:
         w.emb_w, w.emb_b = pk.put(_pad2(ew, 512, 3008)), pk.put(g("embedding.bias"))
         w.dimension = 512
         self.struct, self.pack = w, pk
+
+
+class PackedEcapa:
+    """``dz_ecapa_weights`` + the tensors behind it (speechbrain ECAPA_TDNN checkpoint keys:
+    ``blocks.0.conv.conv.weight`` ... ``fc.conv.weight``).
+
+    * the Hamming window is folded into the DFT matrix, so the STFT is one GEMM over the
+      overlapping 400-sample rows of the signal (hop 160);
+    * BatchNorm1d (eval) after ReLU is folded to scale / shift; ``asp_bn`` is folded into ``fc``;
+    * the 9216-wide attention TDNN is split into the 3072 columns that see x and the 6144 columns
+      that see the per-row global (mean | std), which become a per-row bias."""
+
+    def __init__(self, sd: Dict[str, torch.Tensor], device: torch.device):
+        pk = _Packed(device)
+        g = lambda k: sd[k].detach().cpu().float()
+        w = _lib.EcapaWeights()
+
+        def bn(prefix, npad):
+            scale = g(prefix + ".norm.weight") / torch.sqrt(g(prefix + ".norm.running_var") + BN_EPS)
+            shift = g(prefix + ".norm.bias") - g(prefix + ".norm.running_mean") * scale
+            return _pad1(scale, npad), _pad1(shift, npad)
+
+        def layer(dst, prefix, cin_pad, npad, kpad, norm=True, weight=None):
+            cw = g(prefix + ".conv.weight") if weight is None else weight
+            dst.w = pk.put(_conv_pack(cw, cin_pad, npad, kpad))
+            dst.b = pk.put(_pad1(g(prefix + ".conv.bias"), npad))
+            if norm:
+                sc, sh = bn(prefix.rsplit(".conv", 1)[0] + ".norm", npad)
+                dst.s, dst.h = pk.put(sc), pk.put(sh)
+
+        # ---- features ------------------------------------------------------------------
+        n = torch.arange(400, dtype=torch.float64)
+        win = torch.hamming_window(400, dtype=torch.float64)          # periodic, like torch.stft callers
+        k = torch.arange(201, dtype=torch.float64)[:, None]
+        ang = 2.0 * math.pi * k * n[None, :] / 400.0
+        dft = torch.cat([torch.cos(ang) * win, torch.sin(ang) * win], 0)   # (402, 400)
+        w.dft = pk.put(_pad2(dft.float(), 448, 416))
+        w.mel = pk.put(_pad2(ecapa_mel_filterbank().t().contiguous(), 128, 224))
+        # ---- network -------------------------------------------------------------------
+        layer(w.block0, "blocks.0.conv", 80, 1024, 416)
+        for i in range(3):
+            p, b = f"blocks.{i + 1}", w.ser[i]
+            layer(b.tdnn1, p + ".tdnn1.conv", 1024, 1024, 1024)
+            for j in range(7):
+                layer(b.res[j], p + f".res2net_block.blocks.{j}.conv", 128, 128, 384)
+            layer(b.tdnn2, p + ".tdnn2.conv", 1024, 1024, 1024)
+            layer(b.se1, p + ".se_block.conv1", 1024, 128, 1024, norm=False)
+            layer(b.se2, p + ".se_block.conv2", 128, 1024, 128, norm=False)
+        layer(w.mfa, "mfa.conv", 3072, 3072, 3072)
+        aw = g("asp.tdnn.conv.conv.weight")                           # (128, 9216, 1)
+        layer(w.asp_tdnn, "asp.tdnn.conv", 3072, 128, 3072, weight=aw[:, :3072])
+        w.asp_wms = pk.put(aw[:, 3072:, 0].contiguous())             # (128, 6144)
+        layer(w.asp_conv, "asp.conv", 128, 3072, 128, norm=False)
+        sc, sh = bn("asp_bn", 6144)
+        fw, fb = g("fc.conv.weight")[:, :, 0], g("fc.conv.bias")     # (192, 6144)
+        w.fc.w = pk.put((fw * sc[None, :]).contiguous())
+        w.fc.b = pk.put(fb + fw @ sh)
+        w.zeros = pk.put(torch.zeros(6144))
+        self.struct, self.pack = w, pk
+
+
+def ecapa_mel_filterbank(n_mels: int = 80, n_fft: int = 400, sample_rate: int = 16000) -> torch.Tensor:
+    """speechbrain Filterbank (triangular, f_min = 0, f_max = sr / 2): (n_fft // 2 + 1, n_mels)."""
+    to_mel = lambda hz: 2595.0 * math.log10(1.0 + hz / 700.0)
+    mel = torch.linspace(to_mel(0.0), to_mel(sample_rate / 2), n_mels + 2)
+    hz = 700.0 * (10.0 ** (mel / 2595.0) - 1.0)
+    band = (hz[1:] - hz[:-1])[:-1]
+    f_central = hz[1:-1]
+    all_freqs = torch.linspace(0, sample_rate // 2, n_fft // 2 + 1)
+    slope = (all_freqs.repeat(n_mels, 1) - f_central[:, None]) / band[:, None]
+    return torch.max(torch.zeros(1), torch.min(slope + 1.0, -slope + 1.0)).t().contiguous()

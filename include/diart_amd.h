@@ -120,6 +120,52 @@ int dz_emb_pool(dz_emb* emb, const float* d_weights, int batch, int num_speakers
                 int weight_frames, int normalize, float* d_out, void* stream);
 int dz_emb_destroy(dz_emb* emb);
 
+/* ---- ECAPA-TDNN embedding (BASELINE.json config 3): replaces the callable behind
+ * EmbeddingModel.__call__ when the embedding is speechbrain/spkrec-ecapa-voxceleb, i.e.
+ * pyannote's PretrainedSpeakerEmbedding.__call__(waveforms, masks) reached through the fallback
+ * of /root/reference/src/diart/models.py:59 and called at :262.
+ * waveform (N,1,S), masks (N,Fw) or NULL -> (N,192); rows whose mask keeps fewer than 640
+ * samples come back as NaN (they are dropped by clustering.py:143-145).  The mask selects
+ * samples (nearest resampling, > 0.5), rows are zero padded to the longest row of the call and
+ * the relative lengths drive the sentence normalisation, the squeeze-excitation means and the
+ * attentive statistics pooling exactly as speechbrain's encode_batch does.                  */
+typedef struct {
+    const float* w;   /* [Npad][Kpad] packed like every convgemm weight                      */
+    const float* b;   /* [Npad] bias                                                          */
+    const float* s;   /* [Npad] folded BatchNorm scale (NULL if the layer has no norm)        */
+    const float* h;   /* [Npad] folded BatchNorm shift                                        */
+} dz_layer;
+typedef struct {
+    dz_layer tdnn1;    /* 1x1, 1024 -> 1024                                                   */
+    dz_layer res[7];   /* Res2Net: 128 -> 128, k = 3, dilation d, reflect "same" padding      */
+    dz_layer tdnn2;    /* 1x1                                                                  */
+    dz_layer se1;      /* [128][1024]  squeeze                                                 */
+    dz_layer se2;      /* [1024][128]  excite                                                  */
+} dz_seres2net;
+typedef struct {
+    const float* dft;      /* [448][416] hamming-windowed DFT: rows 0..200 cos, 201..401 sin  */
+    const float* mel;      /* [128][224] triangular mel bank, [mel][bin], zero padded         */
+    dz_layer block0;       /* [1024][416], k = tap*80 + mel                                    */
+    dz_seres2net ser[3];   /* dilations 2, 3, 4                                                */
+    dz_layer mfa;          /* [3072][3072]                                                     */
+    dz_layer asp_tdnn;     /* w = columns of the 9216-wide input that multiply x: [128][3072]  */
+    const float* asp_wms;  /* [128][6144] columns that multiply the global (mean | std)        */
+    dz_layer asp_conv;     /* [3072][128]                                                      */
+    dz_layer fc;           /* [192][6144] with asp_bn folded in                                */
+    const float* zeros;    /* [6144] zeros                                                     */
+} dz_ecapa_weights;
+typedef struct dz_ecapa dz_ecapa;
+int dz_ecapa_frames_for(int num_samples);   /* 1 + S / 160 */
+int dz_ecapa_create(dz_ctx* ctx, const dz_ecapa_weights* w, int max_rows, int num_samples,
+                    dz_ecapa** out);
+int dz_ecapa_forward(dz_ecapa* e, const float* d_wave, long long wave_stride, const float* d_masks,
+                     int n_rows, int mask_frames, float* d_out, void* stream);
+/* device pointer + element count of an intermediate of the LAST forward (parity tests):
+ * 0 features (N,T,80)  1 block0 (N,T,1024)  2 cat (N,T,3072)  3 mfa (N,T,3072)
+ * 4 pooled (N,6144)    5 kept-sample counts (N) as int32;  *frames receives T            */
+int dz_ecapa_peek(dz_ecapa* e, int which, const void** d_ptr, long long* count, int* frames);
+int dz_ecapa_destroy(dz_ecapa* e);
+
 /* ---- OverlappedSpeechPenalty: functional.py:6-13 + blocks/embedding.py:98-107
  * d_seg (B,F,K) -> weights.  speaker_major=0: (B,F,K) like the reference block;
  * speaker_major=1: (B,K,F), the layout dz_emb_forward_multi consumes.           */
@@ -141,7 +187,7 @@ int dz_cdist_cosine(dz_ctx* ctx, const float* d_emb, const double* d_centers,
  * kernel can be parity-tested on its own against a torch fp32 restatement of the same
  * op (tests/test_gpu_kernels.py).  Layouts: DESIGN.md §3.                          */
 enum { DZ_EPI_BIAS = 0, DZ_EPI_BIAS_LEAKY = 1, DZ_EPI_BIAS_SIGMOID = 2, DZ_EPI_TDNN = 3,
-       DZ_EPI_POOL3 = 4 };
+       DZ_EPI_POOL3 = 4, DZ_EPI_BIAS_RELU = 5, DZ_EPI_RELU_BN = 6, DZ_EPI_RELU_BN_TANH = 7 };
 typedef struct {
     const float* X;       /* [B][Tin][ldx] channels-last input                       */
     const float* W;       /* [Npad][Kpad], k = tap*Cin + c, zero padded              */
@@ -160,6 +206,9 @@ typedef struct {
                              partial sums to Y + z*ysplit (bias in split 0); the caller reduces */
     long long ysplit;     /* floats between the partial outputs of consecutive splits */
     int agroup;           /* activation tiles swept together per XCD (0 = default 4)  */
+    int pad;              /* >0: "same" convolution, reflect padding of `pad` frames  */
+    const float* X2;      /* optional second input with X's geometry, added on load   */
+    const float* rowbias; /* optional [B][Npad] per-batch-item bias added to `bias`   */
 } dz_convgemm_desc;
 int dz_k_convgemm(dz_ctx* ctx, const dz_convgemm_desc* desc, void* stream);
 int dz_k_convgemm_ntile(int t_out);
