@@ -140,3 +140,70 @@ def test_pipeline_asserts_like_the_reference(gpu, models):
         SpeakerDiarization(SpeakerDiarizationConfig(segmentation=models[0], embedding=models[1], latency=7, device=gpu))
     assert [h.name for h in SpeakerDiarization.hyper_parameters()] == ["tau_active", "rho_update", "delta_new"]
     assert SpeakerDiarization.get_config_class() is SpeakerDiarizationConfig
+
+
+def test_config3_powerset_ecapa_pipeline_matches_cpu_chain(gpu):
+    """BASELINE.json config 3: segmentation-3.0 (powerset -> hard multilabel) + ECAPA-TDNN with
+    normalised OSP weights, 12 s stream, Benchmark-style batches; RTTM vs the all-CPU chain."""
+    from oracle.clustering_ref import OnlineSpeakerClusteringRef
+    from oracle.ecapa_ref import PretrainedSpeakerEmbeddingRef
+    from oracle.functional_ref import normalize_embeddings_ref, overlapped_speech_penalty_ref
+    from oracle.models_ref import PyanNetRef, powerset_to_multilabel
+    from oracle.pyannote_stub import SlidingWindow as SW, SlidingWindowFeature as SWF
+    from oracle.tail_ref import TailRef
+    from diart_amd.synth import synth_ecapa_state
+    stream = synth_stream(31, 12.0)
+    seg_sd, emb_sd = synth_segmentation_state(seed=77, powerset=True), synth_ecapa_state()
+    cfg = SpeakerDiarizationConfig(
+        segmentation=M.SegmentationModel.from_state(seg_sd, max_batch=16, powerset=True),
+        embedding=M.EmbeddingModel.from_state(emb_sd, max_batch=48), latency=0.5, tau_active=0.5,
+        normalize_embedding_weights=True, device=gpu)
+    pipe = SpeakerDiarization(cfg)
+    chunks = rolling_chunks(stream)
+    outs = []
+    for i in range(0, len(chunks), 8):
+        outs += pipe(chunks[i:i + 8])
+    hyp = accumulate(outs)
+    # ---- all-CPU chain ------------------------------------------------------------------
+    seg_m = PyanNetRef(powerset=True).eval()
+    seg_m.load_state_dict(seg_sd)
+    emb_m = PretrainedSpeakerEmbeddingRef(emb_sd)
+    clu, tail, ref = OnlineSpeakerClusteringRef(0.5, 0.3, 1.0, "cosine", 20), TailRef(0.5, 0.5, 0.5), Annotation("stream")
+    # Hard powerset decisions flip where the two best classes are within fp32 noise of each other
+    # (random weights produce many such near-ties).  Those flips are checked on their own — they
+    # may only happen at near-ties — and the rest of the chain (OSP -> masks -> ECAPA ->
+    # clustering -> aggregation) is then compared on the SAME hard segmentation.
+    flips = near_ties = 0
+    for i0 in range(0, len(chunks), 8):
+        # the reference hands the embedding model all (chunk, speaker) rows of a batch at once, and
+        # ECAPA's padding makes a row depend on the longest row of its call: batch like the GPU run
+        batch = chunks[i0:i0 + 8]
+        x = torch.from_numpy(np.stack([c.data[:, 0] for c in batch]))[:, None, :]
+        with torch.no_grad():
+            logp = seg_m(x)
+        cpu_seg = powerset_to_multilabel(logp)                                      # (B,293,3) in {0,1}
+        seg = cfg.segmentation(x.to(gpu)).cpu()
+        top2 = logp.topk(2, dim=-1).values
+        margin = top2[..., 0] - top2[..., 1]
+        differ = (seg != cpu_seg).any(dim=-1)
+        assert (margin[differ] < 1e-3).all(), "a hard decision flipped away from a near-tie"
+        flips += int(differ.sum())
+        near_ties += int((margin < 1e-3).sum())
+        w = overlapped_speech_penalty_ref(seg)
+        mn, mx = w.min(dim=1, keepdim=True).values, w.max(dim=1, keepdim=True).values
+        w = ((w - mn) / (mx - mn)).nan_to_num(1e-8)
+        B = len(batch)
+        rows = x.repeat(1, 3, 1).reshape(B * 3, 1, -1)
+        emb = torch.from_numpy(emb_m(rows, w.permute(0, 2, 1).reshape(B * 3, -1))).view(B, 3, -1)
+        emb = normalize_embeddings_ref(emb)
+        for j in range(B):
+            i = i0 + j
+            scores, _ = clu(seg[j].numpy(), emb[j].numpy())
+            _, turns = tail(SWF(scores, SW(start=i * 0.5, duration=5 / 293, step=5 / 293)))
+            for n, (a, b, spk) in enumerate(turns):
+                ref[Segment(a, b), (i, n)] = f"speaker{spk}"
+    ref = ref.support(0.05)
+    d = DiarizationErrorRate()(ref, hyp, detailed=True)
+    print(f"config 3: DER(GPU vs CPU chain) = {100 * d['diarization error rate']:.3f} % of {d['total']:.1f} s; "
+          f"{flips} hard-decision flips at {near_ties} near-tie frames of {293 * len(chunks)}")
+    assert d["total"] > 1.0 and d["diarization error rate"] <= 0.005
