@@ -92,17 +92,8 @@ def kernel_table(lib, chunks_per_launch):
 
 
 def _usable_cores():
-    """Cores this process may really use: affinity mask capped by the cgroup CPU quota (a box can
-    show 256 logical CPUs while the container is limited to a handful; OpenMP teams larger than the
-    quota spin against each other in torch's per-timestep LSTM barriers)."""
-    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    try:
-        quota, period = Path("/sys/fs/cgroup/cpu.max").read_text().split()
-        if quota != "max":
-            n = min(n, max(1, int(float(quota) / float(period))))
-    except Exception:
-        pass
-    return max(1, n)
+    from diart_amd.hostinfo import usable_cores
+    return usable_cores()
 
 
 def cpu_baseline_worker(n_chunks, threads, budget_s):
@@ -194,6 +185,8 @@ def main():
     from diart_amd.synth import synth_embedding_state, synth_segmentation_state, synth_streams
 
     log("start")
+    from diart_amd.hostinfo import limit_host_threads
+    limit_host_threads()
     rank, world, local = D.init_from_env()
     assert world == args.gpus or world == 1, f"WORLD_SIZE={world} but --gpus {args.gpus}"
     if not torch.cuda.is_available():

@@ -9,6 +9,12 @@ if str(ROOT) not in sys.path:
     sys.path.insert(0, str(ROOT))
 
 
+def pytest_sessionstart(session):
+    # a GPU box shows 256 logical CPUs and grants 16: keep ATen's host thread team sane
+    from diart_amd.hostinfo import limit_host_threads
+    limit_host_threads()
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
