@@ -4,7 +4,9 @@
 A "step" = one pass of the hot path over one batch of synthetic input: the current 5 s window of
 each of the 64 concurrent 16 kHz streams of one GPU (BASELINE.json configs[1]) goes through
 SpeakerSegmentation -> OverlappedSpeechPenalty -> SpeakerEmbedding (x3 speakers) -> normalisation
--> OnlineSpeakerClustering, exactly the lines 186-203 of the reference's SpeakerDiarization.__call__.
+-> OnlineSpeakerClustering -> DelayedAggregation -> Binarize: lines 186-232 of the reference's
+SpeakerDiarization.__call__ for every stream (the audio passthrough of :205 aside — the audio
+stays in HBM), down to the speech turns of the 500 ms region each step finalises.
 Windows advance by 500 ms per step and are read in place from the streams, which are resident in
 HBM before the timed region starts.
 
@@ -38,6 +40,8 @@ MMAC = {  # algorithmic MACs per 5 s chunk per launch, launches
     "tdnn1": 289 * 512 * 300, "tdnn2": 285 * 512 * 1536, "tdnn3": 279 * 512 * 1536,
     "tdnn4": 279 * 512 * 512, "tdnn5": 279 * 1500 * 512, "emb_linear": 3 * 3000 * 512,
 }
+# sinc_conv0 folds the (anti)symmetric FIR bank: 42 tiles x 192 frames x 96 columns x 128 taps
+EXECUTED_MMAC = {"sinc_conv0": 42 * 192 * 96 * 128}
 # bench tag -> the device kernel (rocprofv3 symbol) that runs it: the roofline is reported per
 # device kernel, so the four TDNN layers that share one instantiation are one entry
 SYMBOL = {
@@ -66,6 +70,8 @@ def parse():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--streams", type=int, default=64, help="concurrent streams per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-tail", action="store_true",
+                    help="stop after clustering (skip the C++ aggregation + binarisation tail)")
     ap.add_argument("--cpu-chunks", type=int, default=8, help="chunks in the bounded CPU sample")
     ap.add_argument("--cpu-worker", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--cpu-threads", type=int, default=8, help=argparse.SUPPRESS)
@@ -87,6 +93,8 @@ def kernel_table(lib, chunks_per_launch):
             flop = 2.0 * MMAC[nm] * chunks_per_launch
             row["alg_gflop_per_launch"] = round(flop / 1e9, 3)
             row["tflops"] = round(flop / (avg_ms * 1e-3) / 1e12, 2)
+            if nm in EXECUTED_MMAC:   # the kernel does less arithmetic than the textbook form
+                row["executed_gflop_per_launch"] = round(2.0 * EXECUTED_MMAC[nm] * chunks_per_launch / 1e9, 3)
         rows.append(row)
     return rows
 
@@ -216,7 +224,8 @@ def main():
     assert audio.stride(0) % 4 == 0
 
     pipe = StreamBatch(HipSegmentation(seg_state, max_batch=n), HipEmbedding(emb_state, max_batch=n),
-                       n, device=device, cluster_threads=min(8, os.cpu_count() or 1))
+                       n, device=device, cluster_threads=min(8, os.cpu_count() or 1),
+                       tail=not args.no_tail)
 
     def window(t):
         return audio[:, t * hop: t * hop + S]

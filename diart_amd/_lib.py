@@ -92,6 +92,20 @@ SIGNATURES = {
     "dz_clu_set_state": (C.c_int, [vp, vp, vp, C.c_int]),
     "dz_clu_destroy": (C.c_int, [vp]),
     "dz_lsap": (C.c_int, [vp, C.c_int, C.c_int, vp]),
+    "dz_ring_create": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(vp)]),
+    "dz_ring_reset": (C.c_int, [vp]),
+    "dz_ring_destroy": (C.c_int, [vp]),
+    "dz_ring_push": (C.c_int, [vp, vp, C.c_longlong, C.c_int, vp]),
+    "dz_ring_window": (C.c_int, [vp, C.POINTER(vp), C.POINTER(C.c_longlong), C.POINTER(C.c_int)]),
+    "dz_ring_read": (C.c_int, [vp, vp, vp]),
+    "dz_tail_create": (C.c_int, [C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, C.c_int,
+                                 C.c_int, vp, C.POINTER(vp)]),
+    "dz_tail_reset": (C.c_int, [vp]),
+    "dz_tail_destroy": (C.c_int, [vp]),
+    "dz_tail_max_rows": (C.c_int, [vp]),
+    "dz_tail_step": (C.c_int, [vp, vp, C.c_double, C.c_double, vp, vp, vp, vp, vp, C.c_int, vp]),
+    "dz_tail_step_batch": (C.c_int, [C.POINTER(vp), C.c_int, vp, vp, vp, vp, vp, vp, vp, vp,
+                                     C.c_int, vp, C.c_int]),
     # kernel-level entry points
     "dz_k_convgemm": (C.c_int, [vp, vp, vp]),
     "dz_k_convgemm_ntile": (C.c_int, [C.c_int]),

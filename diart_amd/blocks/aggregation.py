@@ -87,3 +87,84 @@ class DelayedAggregation:
         start = buffers[-1].extent.end - self.latency
         region = Segment(start, start + self.step)
         return self._prepend(self.aggregate(buffers, region), region, buffers)
+
+
+_STRATEGY = {"hamming": 0, "mean": 1, "first": 2}
+_MODE = {"strict": 0, "loose": 1, "center": 2}
+
+
+class BatchedOutputTail:
+    """``DelayedAggregation`` + ``Binarize`` of N independent streams in C++ (``dz_tail_step_batch``,
+    host threads, fp64): what ``SpeakerDiarization.__call__`` does after clustering for one stream
+    (reference ``blocks/diarization.py:203-232``), for all the streams of a ``StreamBatch`` at once
+    and bit-identical to the Python blocks above (``tests/test_tail.py``).
+
+    ``__call__(scores (N,F,G) f64, chunk_start (N,), resolution (N,) | float)`` ->
+    ``(aggregated, rows, t0, res, turns, nturns)``: ``aggregated[i, :rows[i]]`` are the scores of the
+    region ``[t0[i], t0[i] + rows[i] * res[i])``; ``turns[i, :nturns[i]]`` = (start, end, speaker)."""
+
+    def __init__(self, num_streams: int, frames: int, speakers: int, step: float,
+                 latency: Optional[float] = None, threshold: float = 0.5, strategy: str = "hamming",
+                 cropping_mode: str = "loose", num_threads: int = 8, max_turns: Optional[int] = None):
+        from .. import _lib
+        import ctypes as C
+        self._lib, self._C = _lib, C
+        latency = step if latency is None else latency
+        assert step <= latency, "Invalid latency requested"
+        assert strategy in _STRATEGY and cropping_mode in _MODE
+        self.n, self.F, self.G = num_streams, frames, speakers
+        self.num_threads = num_threads
+        self.num_overlapping_windows = int(round(latency / step))
+        hamming = np.ascontiguousarray(np.hamming(frames), dtype=np.float64)
+        lib = _lib.load()
+        hs = []
+        for _ in range(num_streams):
+            h = _lib.vp()
+            _lib.check(lib.dz_tail_create(frames, speakers, float(step), float(latency), float(threshold),
+                                          _STRATEGY[strategy], _MODE[cropping_mode],
+                                          hamming.ctypes.data, C.byref(h)), "dz_tail_create")
+            hs.append(h)
+        self._hs = hs
+        self._handles = (_lib.vp * num_streams)(*hs)
+        self.max_rows = frames + 2
+        self.max_turns = max_turns if max_turns is not None else speakers * (self.max_rows // 2 + 1)
+        n = num_streams
+        self._agg = np.empty((n, self.max_rows, speakers), dtype=np.float64)
+        self._rows = np.empty(n, dtype=np.int32)
+        self._t0 = np.empty(n, dtype=np.float64)
+        self._res = np.empty(n, dtype=np.float64)
+        self._turns = np.empty((n, self.max_turns, 3), dtype=np.float64)
+        self._nturns = np.empty(n, dtype=np.int32)
+
+    def reset(self):
+        for h in self._hs:
+            self._lib.check(self._lib.load().dz_tail_reset(h), "dz_tail_reset")
+
+    def __del__(self):
+        try:
+            lib = self._lib.load()
+            for h in self._hs:
+                lib.dz_tail_destroy(h)
+        except Exception:
+            pass
+
+    def __call__(self, scores: np.ndarray, chunk_start, resolution):
+        scores = np.ascontiguousarray(scores, dtype=np.float64)
+        assert scores.shape == (self.n, self.F, self.G), scores.shape
+        start = np.ascontiguousarray(np.broadcast_to(np.asarray(chunk_start, dtype=np.float64), (self.n,)))
+        res = np.ascontiguousarray(np.broadcast_to(np.asarray(resolution, dtype=np.float64), (self.n,)))
+        self._lib.check(self._lib.load().dz_tail_step_batch(
+            self._handles, self.n, scores.ctypes.data, start.ctypes.data, res.ctypes.data,
+            self._agg.ctypes.data, self._rows.ctypes.data, self._t0.ctypes.data, self._res.ctypes.data,
+            self._turns.ctypes.data, self.max_turns, self._nturns.ctypes.data, self.num_threads),
+            "dz_tail_step_batch")
+        return self._agg, self._rows, self._t0, self._res, self._turns, self._nturns
+
+    @staticmethod
+    def annotation(turns: np.ndarray, nturns: int, uri=None, shift: float = 0.0):
+        """Speech turns of one stream as the ``Annotation`` ``Binarize`` builds (utils.py:47-58)."""
+        from ..features import Annotation
+        ann = Annotation(uri=uri, modality="speech")
+        for s, e, g in turns[:nturns]:
+            ann[Segment(s + shift, e + shift), int(g)] = f"speaker{int(g)}"
+        return ann

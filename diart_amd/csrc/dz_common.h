@@ -6,6 +6,7 @@
 #include "../../include/diart_amd.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 // v_mfma_f32_16x16x4_f32: exact-f32 matrix FMA, 32 cycles/SIMD issue (MI355X_MICROARCH.md).
 // Lane l supplies A[i=l&15][k=l>>4] and B[k=l>>4][j=l&15]; D: col j=l&15, rows 4*(l>>4)+r.

@@ -1,6 +1,6 @@
 // SincNet front-end kernels (shared by the segmentation and embedding networks):
 //   wave_stats     per-chunk mean / rstd of the raw 5 s window   (InstanceNorm1d(1))
-//   sinc_conv0     normalise-on-load + 80x251 sinc FIR bank (stride 10) on fp32 MFMA
+//   sinc_conv0     normalise-on-load + 80x251 sinc FIR bank (stride 10, symmetric fold) on fp32 MFMA
 //                  + abs + MaxPool1d(3) + per-tile (sum, sumsq) partials
 //   finalize_norm  partials -> per (chunk, channel) scale / shift of InstanceNorm1d(C, affine)
 // Restates pyannote.audio SincNet.forward (third party; called from
@@ -62,17 +62,27 @@ int dz_launch_wave_stats(const float* wave, long long stride, int B, int S, floa
 }
 
 // ---------------------------------------------------------------------------
-// sinc_conv0.  As a GEMM per chunk: out[t][c] = sum_k xn[10 t + k] * filt[k][c],
-// M = 7975 frames, N = 80 filters, K = 251 (+1 zero tap).  One workgroup = 192 conv
-// frames (= 64 pooled) x 80 filters; 4 waves x (3 M-frags x 5 N-frags) of 16x16x4 f32 MFMA.
-// LDS: the whole filter bank k-major (conflict-free B reads: bank = 16*(k&1) + j) and the
-// 2162-sample window slice the tile touches (A reads at stride 10 dwords: 10*i + q hits
-// 32 distinct banks per half-wave).  Every sample is read from HBM once per tile and reused
-// 25x from LDS.
+// sinc_conv0.  As a GEMM per chunk: out[t][c] = sum_k xn[10 t + k] * filt[c][k],
+// M = 7975 frames, N = 80 filters, K = 251.  ParamSincFB's filters are symmetric by
+// construction (cos filters right = flip(left), sin filters right = -flip(left)),
+// so with the centre tap at 10 t + 125 and j the distance from it
+//     cos:  out = sum_{j=0..125} hc[j] * (x[c + j] + x[c - j])      (hc[0] = centre / 2)
+//     sin:  out = sum_{j=1..125} hs[j] * (x[c + j] - x[c - j])
+// i.e. two GEMMs with K = 126 instead of one with K = 251: half the MFMA work, the price being
+// one add + one sub per A element (VALU, hidden under the 32-cycle f32 MFMAs).
+// One workgroup = 192 conv frames (= 64 pooled) x (48 cos | 48 sin) padded filter columns;
+// 4 waves x (3 M-frags x 6 N-frags) of 16x16x4 f32 MFMA, K padded to 128 (taps 126, 127 = 0).
+// LDS: folded bank [128][96] k-major, column XOR 16*(k&1) (B reads: bank = i + 16*((nt^k)&1),
+// conflict-free per half-wave) + the 2165-sample slice the tile touches (A reads at stride 10
+// dwords: 10 i +- q hits 32 distinct banks per half-wave).  58 KiB -> two workgroups per CU, so
+// one's prologue / pooling epilogue runs under the other's MFMAs.  Every sample is read from
+// HBM once per tile and reused ~25x from LDS.
 // ---------------------------------------------------------------------------
 #define C0_FR 192
-#define C0_XS (C0_FR * 10 + 256)
-#define C0_K4 63
+#define C0_LP 2                       /* samples kept left of the tile start (taps 126/127)  */
+#define C0_XS (C0_FR * 10 + 256)      /* >= 10*191 + 127 + 127 + 1                            */
+#define C0_KS 32                      /* k-steps of 4                                         */
+#define C0_NP 96                      /* padded filter columns: 48 cos | 48 sin              */
 #define C0_OLD 81
 
 __global__ __launch_bounds__(256) void sinc_conv0_kernel(
@@ -80,55 +90,69 @@ __global__ __launch_bounds__(256) void sinc_conv0_kernel(
     float gamma, float beta, const float* __restrict__ filt, float* __restrict__ y0, int P0,
     float* __restrict__ partials, int ntile) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* filt_s = smem;             // [252][80]
-    float* xs = smem + 252 * 80;      // [C0_XS]
-    float* out_s = smem;              // [192][81], aliases filt_s after the K loop
+    float* filt_s = smem;                    // [128][96], swizzled
+    float* xs = smem + 4 * C0_KS * C0_NP;    // [C0_XS]
+    float* out_s = smem;                     // [192][81], aliases both after the K loop
     const int b = blockIdx.y, tile = blockIdx.x, tid = threadIdx.x;
 
-    for (int i = tid; i < 252 * 80 / 4; i += 256)
-        reinterpret_cast<float4*>(filt_s)[i] = reinterpret_cast<const float4*>(filt)[i];
+    for (int i4 = tid; i4 < 4 * C0_KS * C0_NP / 4; i4 += 256) {
+        const int k = i4 / (C0_NP / 4), c4 = i4 - k * (C0_NP / 4);
+        reinterpret_cast<float4*>(filt_s)[k * (C0_NP / 4) + (c4 ^ ((k & 1) << 2))] =
+            reinterpret_cast<const float4*>(filt)[i4];
+    }
     {
         const float mean = stats[2 * b], rstd = stats[2 * b + 1];
         const float* wb = wave + (long long)b * stride;
-        const int s0 = tile * (C0_FR * 10);
+        const int s0 = tile * (C0_FR * 10) - C0_LP;
         for (int i = tid; i < C0_XS; i += 256) {
             const int s = s0 + i;
-            xs[i] = (s < S) ? ((wb[s] - mean) * rstd) * gamma + beta : 0.f;
+            xs[i] = (s >= 0 && s < S) ? ((wb[s] - mean) * rstd) * gamma + beta : 0.f;
         }
     }
     __syncthreads();
 
     const int w = tid >> 6, l = tid & 63, i = l & 15, q = l >> 4;
-    f32x4 acc[3][5];
+    f32x4 acc[3][6];
 #pragma unroll
     for (int mt = 0; mt < 3; ++mt)
 #pragma unroll
-        for (int nt = 0; nt < 5; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int nt = 0; nt < 6; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    const float* xa = xs + 10 * (48 * w + i) + q;
-    const float* fb = filt_s + q * 80 + i;
-#pragma unroll 7
-    for (int ks = 0; ks < C0_K4; ++ks) {
-        float a[3], bb[5];
+    // centre tap of frame t sits at xs[10 t + 125 + C0_LP]; this lane's k is 4 ks + q
+    const float* xp = xs + 10 * (48 * w + i) + 125 + C0_LP + q;   // x[c + j]
+    const float* xm = xs + 10 * (48 * w + i) + 125 + C0_LP - q;   // x[c - j]
+    const float* fb = filt_s + q * C0_NP + (i ^ ((q & 1) << 4));
+#pragma unroll 8
+    for (int ks = 0; ks < C0_KS; ++ks) {
+        float ac[3], as[3], bb[6];
 #pragma unroll
-        for (int mt = 0; mt < 3; ++mt) a[mt] = xa[4 * ks + 160 * mt];
+        for (int mt = 0; mt < 3; ++mt) {
+            const float hi = xp[4 * ks + 160 * mt], lo = xm[160 * mt - 4 * ks];
+            ac[mt] = hi + lo;
+            as[mt] = hi - lo;
+        }
 #pragma unroll
-        for (int nt = 0; nt < 5; ++nt) bb[nt] = fb[320 * ks + 16 * nt];
+        for (int nt = 0; nt < 6; ++nt) bb[nt] = fb[4 * C0_NP * ks + 16 * nt];
 #pragma unroll
         for (int mt = 0; mt < 3; ++mt)
 #pragma unroll
-            for (int nt = 0; nt < 5; ++nt) acc[mt][nt] = DZ_MFMA(a[mt], bb[nt], acc[mt][nt]);
+            for (int nt = 0; nt < 6; ++nt)
+                acc[mt][nt] = DZ_MFMA(nt < 3 ? ac[mt] : as[mt], bb[nt], acc[mt][nt]);
     }
-    __syncthreads();  // filt_s is dead from here: reuse as the output tile
+    __syncthreads();  // filt_s / xs are dead from here: reuse as the output tile
 
 #pragma unroll
-    for (int mt = 0; mt < 3; ++mt)
+    for (int nt = 0; nt < 6; ++nt) {
+        const int cl = 16 * (nt % 3) + i;            // column inside the cos / sin half
+        if (cl < 40) {
+            const int ch = (nt < 3 ? 0 : 40) + cl;   // output channel: 40 cos then 40 sin
 #pragma unroll
-        for (int nt = 0; nt < 5; ++nt)
+            for (int mt = 0; mt < 3; ++mt)
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
-                out_s[(48 * w + 16 * mt + 4 * q + r) * C0_OLD + 16 * nt + i] =
-                    fabsf(acc[mt][nt][r]);
+                for (int r = 0; r < 4; ++r)
+                    out_s[(48 * w + 16 * mt + 4 * q + r) * C0_OLD + ch] = fabsf(acc[mt][nt][r]);
+        }
+    }
     __syncthreads();
 
     const int p0 = tile * 64;
@@ -157,7 +181,9 @@ __global__ __launch_bounds__(256) void sinc_conv0_kernel(
 int dz_launch_sinc_conv0(const float* wave, long long stride, int B, int S, const float* stats,
                          float gamma, float beta, const float* filt, float* y0, int P0,
                          float* partials, int ntile, hipStream_t st) {
-    const size_t lds = (252 * 80 + C0_XS) * sizeof(float);
+    const size_t k_loop = (4 * C0_KS * C0_NP + C0_XS) * sizeof(float);
+    const size_t epi = (size_t)C0_FR * C0_OLD * sizeof(float);
+    const size_t lds = k_loop > epi ? k_loop : epi;
     static bool attr_set = false;
     if (!attr_set) {
         DZ_HIP(hipFuncSetAttribute((const void*)sinc_conv0_kernel,

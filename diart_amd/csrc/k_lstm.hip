@@ -11,7 +11,7 @@
 //   lane (u, p): hidden unit u = 16*wave + lane/4, k-quarter p = lane%4
 //                holds W[gate][u][16*jj + 4*p + e] for the 4 gates, jj < 8, e < 4
 //   step:  h_{t-1} is read from LDS as 8 x ds_read_b128 (the 4 lanes of a quad read one
-//          64-byte line: conflict-free), 128 v_fma_f32 per lane, 3 DPP adds fold the four
+//          64-byte line: conflict-free), 64 v_pk_fma_f32 per lane, 3 DPP adds fold the four
 //          k-quarters so that lane p ends with the complete pre-activation of gate p, one
 //          exp+rcp per lane, a quad broadcast (4 DPP moves) gives every lane i,f,g,o.
 //
@@ -55,8 +55,11 @@ __global__ __launch_bounds__(512) void lstm_rec_kernel(const float* __restrict__
     const int b = blockIdx.x, dir = blockIdx.y;
     const int tid = threadIdx.x, p = tid & 3, u = tid >> 2;
 
-    // slot j of lane p holds gate (j ^ p): the three DPP adds below then need no selects
-    float wreg[4][32];
+    // slot j of lane p holds gate (j ^ p): the three DPP adds below then need no selects.
+    // Weights are kept as k-PAIRS (f32x2 in an even-aligned register pair) so the contraction is
+    // 64 v_pk_fma_f32 per step instead of 128 v_fma_f32: the 157 TFLOP/s f32 vector peak of
+    // gfx950 is the packed rate, scalar v_fma_f32 tops out at half of it.
+    f32x2 wreg[4][16];
     {
         const float* Wd = whh + (long long)dir * 512 * 128;
 #pragma unroll
@@ -65,10 +68,8 @@ __global__ __launch_bounds__(512) void lstm_rec_kernel(const float* __restrict__
 #pragma unroll
             for (int jj = 0; jj < 8; ++jj) {
                 const float4 v = *reinterpret_cast<const float4*>(row + 16 * jj);
-                wreg[j][4 * jj + 0] = v.x;
-                wreg[j][4 * jj + 1] = v.y;
-                wreg[j][4 * jj + 2] = v.z;
-                wreg[j][4 * jj + 3] = v.w;
+                wreg[j][2 * jj + 0] = (f32x2){v.x, v.y};
+                wreg[j][2 * jj + 1] = (f32x2){v.z, v.w};
             }
         }
     }
@@ -87,19 +88,26 @@ __global__ __launch_bounds__(512) void lstm_rec_kernel(const float* __restrict__
     float c = 0.f;
     auto gload = [&](int s) { return gptr[(long long)(s < T ? s : T - 1) * tstep]; };
     auto step = [&](int s, float gcur) {
-        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        // acc[j] = (sum over even k, sum over odd k) of gate slot j
+        f32x2 acc[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[j] = (f32x2){0.f, 0.f};
         const float* hp = &hs[s & (RING - 1)][4 * p];
 #pragma unroll
         for (int jj = 0; jj < 8; ++jj) {
             const f32x4 hv = *reinterpret_cast<const f32x4*>(hp + 16 * jj);
+            const f32x2 h01 = {hv[0], hv[1]}, h23 = {hv[2], hv[3]};
 #pragma unroll
-            for (int e = 0; e < 4; ++e)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) acc[j] = fmaf(wreg[j][4 * jj + e], hv[e], acc[j]);
+            for (int j = 0; j < 4; ++j) {
+                acc[j] = __builtin_elementwise_fma(wreg[j][2 * jj + 0], h01, acc[j]);
+                acc[j] = __builtin_elementwise_fma(wreg[j][2 * jj + 1], h23, acc[j]);
+            }
         }
+        const float s0_ = acc[0][0] + acc[0][1], s1_ = acc[1][0] + acc[1][1],
+                    s2_ = acc[2][0] + acc[2][1], s3_ = acc[3][0] + acc[3][1];
         // fold the k-quarters: lane p ends with gate p (slot j of lane q is gate j ^ q)
-        const float a0 = acc[0] + dpp<DPP_XOR1>(acc[1]);
-        const float a1 = acc[2] + dpp<DPP_XOR1>(acc[3]);
+        const float a0 = s0_ + dpp<DPP_XOR1>(s1_);
+        const float a1 = s2_ + dpp<DPP_XOR1>(s3_);
         const float pre = a0 + dpp<DPP_XOR2>(a1) + gcur;
         const float act = act_scale * fast_sigmoid(act_scale * pre) + act_shift;
         const float ig = dpp<0x00>(act), fg = dpp<0x55>(act), gg = dpp<0xAA>(act),

@@ -1,0 +1,115 @@
+// Device-resident rolling window of N audio streams.
+//
+// Replaces, for the N-stream driver, rearrange_audio_stream
+// (/root/reference/src/diart/operators.py:44-100: accumulate blocks until `duration` seconds are
+// buffered, then emit the last `duration` seconds every `step` seconds) and the per-step upload
+// of the whole window that follows it (blocks/segmentation.py:47 / blocks/embedding.py:52: the
+// reference moves 320 KB per chunk to the device although only 32 KB of it are new).
+//
+// Layout: one row of 2*P floats per stream, P = W + slack*hop (W = window samples).  A new
+// block of `hop` samples is written at positions p and p + P (p advances modulo P), so the newest
+// W samples are ALWAYS one contiguous span [q, q + W) of the row, q = (p + slack*hop) mod P: the
+// segmentation / embedding kernels read the rolling window in place through (base pointer +
+// offset, row stride 2*P) with their usual coalesced 16-byte loads — no wrap-around logic in any
+// kernel, nothing is copied or repeated.  Only the new samples cross PCIe (one strided H2D copy)
+// plus one device-side mirror copy.  The slack keeps a push from overwriting samples a forward
+// pass of the previous `slack` windows may still be reading: block t+1 lands on the slot of
+// block t+1-W/hop-slack, which belongs to windows <= t-slack only.
+#include "dz_common.h"
+
+#include <new>
+
+struct dz_ring {
+    dz_ctx* ctx;
+    int n, W, hop, P;
+    float* buf;        // [n][2P]
+    long long pushed;  // blocks pushed so far
+    int pos;           // write position of the NEXT block, in [0, P)
+};
+
+extern "C" int dz_ring_create(dz_ctx* ctx, int n_streams, int window, int hop, int slack_blocks,
+                              dz_ring** out) {
+    DZ_REQUIRE(ctx && out, "dz_ring_create: NULL argument");
+    DZ_REQUIRE(n_streams >= 1 && window >= 4 && hop >= 4 && slack_blocks >= 0,
+               "dz_ring_create: empty geometry");
+    DZ_REQUIRE(window % hop == 0 && hop % 4 == 0,
+               "dz_ring_create: window (%d) must be a multiple of hop (%d) and hop a multiple of 4 "
+               "samples (16-byte aligned rows)", window, hop);
+    DZ_HIP(hipSetDevice(ctx->device));
+    dz_ring* r = new (std::nothrow) dz_ring;
+    DZ_REQUIRE(r != nullptr, "dz_ring_create: out of memory");
+    r->ctx = ctx; r->n = n_streams; r->W = window; r->hop = hop; r->buf = nullptr;
+    r->P = window + slack_blocks * hop;
+    r->pushed = 0; r->pos = 0;
+    const size_t bytes = (size_t)n_streams * 2 * r->P * sizeof(float);
+    hipError_t e = hipMalloc((void**)&r->buf, bytes);
+    if (e != hipSuccess) {
+        dz_set_error("dz_ring_create: hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+        delete r;
+        return 1;
+    }
+    DZ_HIP(hipMemset(r->buf, 0, bytes));
+    *out = r;
+    return 0;
+}
+
+extern "C" int dz_ring_destroy(dz_ring* r) {
+    if (r) {
+        if (r->buf) (void)hipFree(r->buf);
+        delete r;
+    }
+    return 0;
+}
+
+extern "C" int dz_ring_reset(dz_ring* r) {
+    DZ_REQUIRE(r, "dz_ring_reset: NULL argument");
+    r->pushed = 0;
+    r->pos = 0;
+    return 0;
+}
+
+// block: [n][hop] floats with `block_stride` floats between rows; on the host (pinned memory makes
+// the copy asynchronous) when on_device == 0, in device memory otherwise.
+extern "C" int dz_ring_push(dz_ring* r, const float* block, long long block_stride, int on_device,
+                            void* stream) {
+    DZ_REQUIRE(r && block, "dz_ring_push: NULL argument");
+    DZ_REQUIRE(block_stride >= r->hop, "dz_ring_push: block_stride %lld < hop %d", block_stride,
+               r->hop);
+    DZ_HIP(hipSetDevice(r->ctx->device));
+    hipStream_t st = (hipStream_t)stream;
+    const size_t pitch = (size_t)2 * r->P * sizeof(float), width = (size_t)r->hop * sizeof(float);
+    float* lo = r->buf + r->pos;
+    DZ_HIP(hipMemcpy2DAsync(lo, pitch, block, (size_t)block_stride * sizeof(float), width, r->n,
+                            on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st));
+    DZ_HIP(hipMemcpy2DAsync(lo + r->P, pitch, lo, pitch, width, r->n, hipMemcpyDeviceToDevice, st));
+    r->pos = (r->pos + r->hop) % r->P;
+    r->pushed += 1;
+    return 0;
+}
+
+// The rolling window as the forward passes take it: *d_wave + i * *stride is the window of stream
+// i.  *filled = samples received so far, capped at W: the window is complete (what
+// rearrange_audio_stream would emit) once *filled == W.
+extern "C" int dz_ring_window(const dz_ring* r, const float** d_wave, long long* stride,
+                              int* filled) {
+    DZ_REQUIRE(r && d_wave && stride, "dz_ring_window: NULL argument");
+    *d_wave = r->buf + (r->pos + r->P - r->W) % r->P;
+    *stride = 2LL * r->P;
+    if (filled) {
+        const long long got = r->pushed * r->hop;
+        *filled = got >= r->W ? r->W : (int)got;
+    }
+    return 0;
+}
+
+// contiguous copy (n, W) of the current window (tests; a consumer that wants the window the way
+// rearrange_audio_stream emits it).  The forward passes do not need it.
+extern "C" int dz_ring_read(const dz_ring* r, float* d_out, void* stream) {
+    DZ_REQUIRE(r && d_out, "dz_ring_read: NULL argument");
+    DZ_HIP(hipSetDevice(r->ctx->device));
+    const float* src = r->buf + (r->pos + r->P - r->W) % r->P;
+    DZ_HIP(hipMemcpy2DAsync(d_out, (size_t)r->W * sizeof(float), src,
+                            (size_t)2 * r->P * sizeof(float), (size_t)r->W * sizeof(float), r->n,
+                            hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return 0;
+}

@@ -18,14 +18,87 @@ GPU schedule per step (two HIP streams):
 """
 from __future__ import annotations
 
+import ctypes as C
+import os
 from typing import List, Optional, Tuple
 
 import numpy as np
 import torch
 
 from . import _lib
+from .blocks.aggregation import BatchedOutputTail
 from .blocks.clustering import BatchedSpeakerClustering
 from .models import HipEmbedding, HipSegmentation, _as_rows
+
+
+class AudioRing:
+    """Device-resident rolling window of N streams (``dz_ring_*``): per step only the ``hop`` new
+    samples of every stream are uploaded (32 KB instead of the 320 KB window the reference moves
+    per chunk, ``blocks/segmentation.py:47``); ``StreamBatch.launch`` reads the window in place.
+    The role of ``rearrange_audio_stream`` (reference ``operators.py:44-100``) for N streams."""
+
+    def __init__(self, num_streams: int, window: int = 80000, hop: int = 8000, slack_blocks: int = 2,
+                 device: Optional[torch.device] = None):
+        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else device
+        self.n, self.window, self.hop, self.slack = num_streams, window, hop, slack_blocks
+        self._lib = _lib.load()
+        self._h = _lib.vp()
+        _lib.check(self._lib.dz_ring_create(_lib.context(self.device.index), num_streams, window, hop,
+                                            slack_blocks, C.byref(self._h)), "dz_ring_create")
+        self._keep: List[torch.Tensor] = []          # pinned blocks of in-flight copies
+        self._readers: List[torch.cuda.Event] = []   # `done` events of the steps reading the ring
+
+    def __del__(self):
+        try:
+            self._lib.dz_ring_destroy(self._h)
+        except Exception:
+            pass
+
+    def reset(self):
+        _lib.check(self._lib.dz_ring_reset(self._h), "dz_ring_reset")
+        self._readers = []
+
+    def push(self, block) -> bool:
+        """``block``: (N, hop) float32 — a CPU tensor / ndarray (pinned memory makes the copy
+        asynchronous) or a tensor on the ring's GPU.  Enqueued on the current HIP stream, after the
+        forward passes of the window it is about to overwrite.  True once the window is complete."""
+        if isinstance(block, np.ndarray):
+            block = torch.from_numpy(block)
+        assert block.dtype == torch.float32 and tuple(block.shape) == (self.n, self.hop), block.shape
+        assert block.stride(1) == 1, "rows of the block must be contiguous"
+        cur = torch.cuda.current_stream(self.device)
+        # block t+1 overwrites samples of windows <= t - slack: wait for that window's readers
+        while len(self._readers) > self.slack + 1:
+            self._readers.pop(0)
+        if len(self._readers) == self.slack + 1:
+            cur.wait_event(self._readers[0])
+        on_dev = block.is_cuda
+        _lib.check(self._lib.dz_ring_push(self._h, block.data_ptr(), block.stride(0), int(on_dev),
+                                          cur.cuda_stream), "dz_ring_push")
+        self._keep = (self._keep + [block])[-4:]
+        return self.filled == self.window
+
+    def _read_by(self, done: torch.cuda.Event):
+        self._readers.append(done)
+
+    def raw(self) -> Tuple[int, int]:
+        ptr, stride = _lib.vp(), C.c_longlong()
+        _lib.check(self._lib.dz_ring_window(self._h, C.byref(ptr), C.byref(stride), None), "dz_ring_window")
+        return int(ptr.value), int(stride.value)
+
+    @property
+    def filled(self) -> int:
+        ptr, stride, f = _lib.vp(), C.c_longlong(), C.c_int()
+        _lib.check(self._lib.dz_ring_window(self._h, C.byref(ptr), C.byref(stride), C.byref(f)), "dz_ring_window")
+        return int(f.value)
+
+    def snapshot(self) -> torch.Tensor:
+        """Contiguous copy (N, window) of the current window (what ``rearrange_audio_stream`` would
+        emit); the forward passes do not need it, they read the ring in place."""
+        out = torch.empty((self.n, self.window), dtype=torch.float32, device=self.device)
+        _lib.check(self._lib.dz_ring_read(self._h, out.data_ptr(),
+                                          torch.cuda.current_stream(self.device).cuda_stream), "dz_ring_read")
+        return out
 
 
 class StreamBatch:
@@ -33,7 +106,10 @@ class StreamBatch:
                  tau_active: float = 0.6, rho_update: float = 0.3, delta_new: float = 1.0,
                  gamma: float = 3, beta: float = 10, max_speakers: int = 20,
                  normalize_embedding_weights: bool = False,
-                 device: Optional[torch.device] = None, cluster_threads: int = 8):
+                 device: Optional[torch.device] = None, cluster_threads: int = 8,
+                 seg_split: Optional[int] = None, emb_split: Optional[int] = None,
+                 tail: bool = False, duration: float = 5.0, step: float = 0.5,
+                 latency: Optional[float] = None):
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else device
         self.seg, self.emb = segmentation.to(self.device), embedding.to(self.device)
         self.device = self.seg.device
@@ -42,14 +118,30 @@ class StreamBatch:
         self.clustering = BatchedSpeakerClustering(num_streams, tau_active, rho_update, delta_new,
                                                    max_speakers, cluster_threads)
         self.max_speakers = max_speakers
-        self.stream_a = torch.cuda.Stream(self.device)
-        self.stream_b = torch.cuda.Stream(self.device)
+        # optional output tail (DelayedAggregation + Binarize of every stream, C++): built on the
+        # first step, when the number of frames per chunk is known
+        self.with_tail, self.duration, self.step = bool(tail), float(duration), float(step)
+        self.latency = self.step if latency is None else float(latency)
+        self.tau_active, self.cluster_threads = tau_active, cluster_threads
+        self.tail: Optional[BatchedOutputTail] = None
+        self._t = 0
+        # sub-batches per network, each on its own HIP stream with its own scratch arena: the
+        # x-projection GEMM of one sub-batch runs under the latency-bound recurrence of another
+        self.seg_split = max(1, min(int(os.environ.get("DZ_SEG_SPLIT", "1") if seg_split is None else seg_split), num_streams))
+        self.emb_split = max(1, min(int(os.environ.get("DZ_EMB_SPLIT", "1") if emb_split is None else emb_split), num_streams))
+        self.streams_a = [torch.cuda.Stream(self.device) for _ in range(self.seg_split)]
+        self.streams_b = [torch.cuda.Stream(self.device) for _ in range(self.emb_split)]
+        self.stream_a, self.stream_b = self.streams_a[0], self.streams_b[0]
+        self._sub: dict = {}
         self._slots: List[dict] = []
         self._lib = _lib.load()
         self._ctx = _lib.context(self.device.index)
 
     def reset(self):
         self.clustering.reset()
+        self._t = 0
+        if self.tail is not None:
+            self.tail.reset()
 
     # ------------------------------------------------------------------ GPU half
     def _slot(self, F: int, K: int, D: int) -> dict:
@@ -63,41 +155,98 @@ class StreamBatch:
                  emb=torch.empty((n, K, D), dtype=torch.float32, device=dev),
                  seg_h=torch.empty((n, F, K), dtype=torch.float32).pin_memory(),
                  emb_h=torch.empty((n, K, D), dtype=torch.float32).pin_memory(),
-                 ev_seg=torch.cuda.Event(), ev_in=torch.cuda.Event(), done=torch.cuda.Event())
+                 ev_seg=[torch.cuda.Event() for _ in range(self.seg_split)],
+                 ev_emb=[torch.cuda.Event() for _ in range(self.emb_split - 1)],
+                 ev_in=torch.cuda.Event(), done=torch.cuda.Event())
         self._slots.append(s)
         return s
 
-    def launch(self, waves: torch.Tensor) -> dict:
-        """Enqueue the GPU work for one step.  ``waves``: (N, S) or (N, 1, S) float32 on the GPU;
-        a strided rolling-window view is used in place.  Returns a ticket for ``finish``."""
-        rows = _as_rows(waves)
-        N, S = rows.shape
+    @staticmethod
+    def _ranges(n: int, parts: int) -> List[Tuple[int, int]]:
+        return [(n * i // parts, n * (i + 1) // parts) for i in range(parts)]
+
+    def _handles(self, S: int):
+        """C handles (one scratch arena each) of the sub-batches for windows of S samples."""
+        got = self._sub.get(S)
+        if got is None:
+            sa, sb = self._ranges(self.n, self.seg_split), self._ranges(self.n, self.emb_split)
+            if self.seg_split == 1:
+                hs = [self.seg._need(S, self.n)]
+            else:
+                hs = [self.seg._create(S, i1 - i0) for i0, i1 in sa]
+            if self.emb_split == 1:
+                he = [self.emb._need(S, self.n)]
+            else:
+                he = [self.emb._create(S, i1 - i0) for i0, i1 in sb]
+            got = self._sub[S] = (hs, he, sa, sb)
+        return got
+
+    def __del__(self):
+        try:
+            for hs, he, _, _ in self._sub.values():
+                if self.seg_split > 1:
+                    for h in hs:
+                        self.seg._destroy(h)
+                if self.emb_split > 1:
+                    for h in he:
+                        self.emb._destroy(h)
+        except Exception:
+            pass
+
+    def launch(self, waves, starts=None) -> dict:
+        """Enqueue the GPU work for one step.  ``waves``: (N, S) or (N, 1, S) float32 on the GPU
+        (a strided rolling-window view is used in place) or an ``AudioRing`` holding a complete
+        window.  ``starts``: start time in seconds of each
+        stream's window (default: step index x ``step``), used by the output tail only.
+        Returns a ticket for ``finish``."""
+        ring = waves if isinstance(waves, AudioRing) else None
+        if ring is not None:
+            assert ring.filled == ring.window, "the ring does not hold a complete window yet"
+            rows, N, S = None, ring.n, ring.window
+            base, stride = ring.raw()
+        else:
+            rows = _as_rows(waves)
+            N, S = rows.shape
+            base, stride = rows.data_ptr(), (rows.stride(0) if N > 1 else S)
         assert N == self.n, f"expected {self.n} streams, got {N}"
         F, K, D = self.seg.num_frames(S), None, self.emb.dimension
-        hseg, hemb = self.seg._need(S, N), self.emb._need(S, N)
+        hsegs, hembs, sa, sb = self._handles(S)
         K = self.seg.num_speakers
         slot = self._slot(F, K, D)
         slot["busy"] = True
-        lib, stride = self._lib, (rows.stride(0) if N > 1 else S)
+        lib, esz = self._lib, 4
         cur = torch.cuda.current_stream(self.device)
         slot["ev_in"].record(cur)                       # inputs produced on the caller's stream
-        a, b = self.stream_a, self.stream_b
-        a.wait_event(slot["ev_in"])
-        b.wait_event(slot["ev_in"])
-        _lib.check(lib.dz_seg_forward(hseg, rows.data_ptr(), stride, N, slot["seg"].data_ptr(),
-                                      a.cuda_stream), "dz_seg_forward")
-        _lib.check(lib.dz_osp(self._ctx, slot["seg"].data_ptr(), N, F, K, self.gamma, self.beta,
-                              int(self.norm_w), 1, slot["w"].data_ptr(), a.cuda_stream), "dz_osp")
-        slot["ev_seg"].record(a)
-        _lib.check(lib.dz_emb_frames(hemb, rows.data_ptr(), stride, N, b.cuda_stream), "dz_emb_frames")
-        b.wait_event(slot["ev_seg"])
-        _lib.check(lib.dz_emb_pool(hemb, slot["w"].data_ptr(), N, K, F, 1, slot["emb"].data_ptr(),
-                                   b.cuda_stream), "dz_emb_pool")
-        with torch.cuda.stream(b):
+        for (i0, i1), h, a, ev in zip(sa, hsegs, self.streams_a, slot["ev_seg"]):
+            a.wait_event(slot["ev_in"])
+            _lib.check(lib.dz_seg_forward(h, base + i0 * stride * esz, stride, i1 - i0,
+                                          slot["seg"][i0:i1].data_ptr(), a.cuda_stream), "dz_seg_forward")
+            _lib.check(lib.dz_osp(self._ctx, slot["seg"][i0:i1].data_ptr(), i1 - i0, F, K, self.gamma,
+                                  self.beta, int(self.norm_w), 1, slot["w"][i0:i1].data_ptr(),
+                                  a.cuda_stream), "dz_osp")
+            ev.record(a)
+        for (i0, i1), h, b in zip(sb, hembs, self.streams_b):
+            b.wait_event(slot["ev_in"])
+            _lib.check(lib.dz_emb_frames(h, base + i0 * stride * esz, stride, i1 - i0, b.cuda_stream),
+                       "dz_emb_frames")
+            for (j0, j1), ev in zip(sa, slot["ev_seg"]):
+                if j0 < i1 and i0 < j1:
+                    b.wait_event(ev)
+            _lib.check(lib.dz_emb_pool(h, slot["w"][i0:i1].data_ptr(), i1 - i0, K, F, 1,
+                                       slot["emb"][i0:i1].data_ptr(), b.cuda_stream), "dz_emb_pool")
+        b0 = self.streams_b[0]
+        for b, ev in zip(self.streams_b[1:], slot["ev_emb"]):
+            ev.record(b)
+            b0.wait_event(ev)
+        with torch.cuda.stream(b0):
             slot["seg_h"].copy_(slot["seg"], non_blocking=True)
             slot["emb_h"].copy_(slot["emb"], non_blocking=True)
-        slot["done"].record(b)
+        slot["done"].record(b0)
         slot["keep"] = rows                              # keep the view alive until the GPU is done
+        if ring is not None:
+            ring._read_by(slot["done"])                  # pushes `slack` steps from now wait for this
+        slot["starts"] = self._t * self.step if starts is None else starts
+        self._t += 1
         return slot
 
     # ------------------------------------------------------------------ host half
@@ -107,10 +256,28 @@ class StreamBatch:
         ticket["done"].synchronize()
         seg = ticket["seg_h"].numpy()
         emb = ticket["emb_h"].numpy()
-        scores, assign = self.clustering(seg, emb, want_scores)
+        scores, assign = self.clustering(seg, emb, want_scores or self.with_tail)
+        if self.with_tail:
+            # diarization.py:190,203-232 for every stream: aggregate the overlapping windows of the
+            # region [t - latency, t - latency + step) and binarise it
+            if self.tail is None:
+                self.tail = BatchedOutputTail(self.n, seg.shape[1], self.max_speakers, self.step,
+                                              self.latency, self.tau_active,
+                                              num_threads=self.cluster_threads)
+            ticket["tail"] = self.tail(scores, ticket["starts"], self.duration / seg.shape[1])
         ticket["busy"] = False
         ticket["keep"] = None
         return seg, emb, scores, assign
 
     def __call__(self, waves: torch.Tensor):
         return self.finish(self.launch(waves))
+
+    def diarize(self, waves: torch.Tensor, starts=None):
+        """One step of every stream, end to end: -> list of N ``Annotation`` (the speech turns of the
+        region this step finalises, what ``SpeakerDiarization.__call__`` returns per chunk) —
+        requires ``tail=True``."""
+        assert self.with_tail, "construct StreamBatch(tail=True)"
+        ticket = self.launch(waves, starts)
+        self.finish(ticket, want_scores=False)
+        _, _, _, _, turns, nturns = ticket["tail"]
+        return [BatchedOutputTail.annotation(turns[i], int(nturns[i])) for i in range(self.n)]

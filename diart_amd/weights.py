@@ -49,6 +49,29 @@ def sinc_filters(low_hz_: torch.Tensor, band_hz_: torch.Tensor, window_: torch.T
     return torch.cat(out, dim=0)
 
 
+def fold_sinc_filters(filt: torch.Tensor) -> torch.Tensor:
+    """[80][251] symmetric bank -> the folded k-major image ``[128][96]`` ``sinc_conv0`` consumes.
+
+    Row ``j`` is the tap at distance ``j`` from the centre (tap 125); columns 0..39 the cos (even)
+    filters, 48..87 the sin (odd) filters, the rest zero.  ``conv = sum_j cos_j (x[c+j] + x[c-j])
+    + sin_j (x[c+j] - x[c-j])``: the centre tap of the even filters is halved (exact), that of
+    the odd filters is zero.  The symmetry is what ``ParamSincFB.filters`` builds (``right =
+    flip(left)`` / ``-flip(left)``); a bank that does not have it is refused."""
+    assert filt.shape == (80, 251), filt.shape
+    f = filt.detach().float().cpu()
+    left, right = torch.flip(f[:, :125], dims=[1]), f[:, 126:]
+    scale = float(f.abs().max()) + 1e-30
+    if float((right[:40] - left[:40]).abs().max()) > 1e-6 * scale or \
+            float((right[40:] + left[40:]).abs().max()) > 1e-6 * scale or \
+            float(f[40:, 125].abs().max()) > 1e-6 * scale:
+        raise ValueError("sinc filter bank is not (anti)symmetric around its centre tap")
+    out = torch.zeros(128, 96, dtype=torch.float32)
+    out[0, :40] = 0.5 * f[:40, 125]
+    out[1:126, :40] = right[:40].t()
+    out[1:126, 48:88] = right[40:].t()
+    return out
+
+
 def _pad2(w: torch.Tensor, rows: int, cols: int) -> torch.Tensor:
     out = torch.zeros(rows, cols, dtype=torch.float32)
     out[: w.shape[0], : w.shape[1]] = w
@@ -93,7 +116,7 @@ def _pack_sincnet(sd: Dict[str, torch.Tensor], pk: _Packed, prefix: str = "sincn
     w = _lib.SincNetWeights()
     w.wav_gamma = float(g("wav_norm1d.weight").reshape(-1)[0])
     w.wav_beta = float(g("wav_norm1d.bias").reshape(-1)[0])
-    w.filt = pk.put(_pad2(filt.t().contiguous(), 252, 80))
+    w.filt = pk.put(fold_sinc_filters(filt))
     w.in0_g, w.in0_b = pk.put(g("norm1d.0.weight")), pk.put(g("norm1d.0.bias"))
     w.w1 = pk.put(_conv_pack(g("conv1d.1.weight"), 80, 64, 416))
     w.b1 = pk.put(_pad1(g("conv1d.1.bias"), 64))

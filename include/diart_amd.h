@@ -46,7 +46,7 @@ int dz_emb_frames_for(int num_samples);
 /* ---- packed weights (device pointers, fp32; layouts in DESIGN.md §3) ------- */
 typedef struct {
     float wav_gamma, wav_beta;   /* InstanceNorm1d(1, affine) on the waveform        */
-    const float* filt;           /* [252][80]  sinc FIR bank, k-major, tap 251 = 0   */
+    const float* filt;           /* [128][96]  folded sinc FIR bank (weights.py fold_sinc_filters) */
     const float* in0_g;          /* [80]  InstanceNorm1d(80) gamma                   */
     const float* in0_b;          /* [80]                     beta                    */
     const float* w1;             /* [64][416]  conv1 [co][tap*80+ci], zero padded    */
@@ -214,7 +214,8 @@ int dz_k_convgemm(dz_ctx* ctx, const dz_convgemm_desc* desc, void* stream);
 int dz_k_convgemm_ntile(int t_out);
 int dz_k_wave_stats(dz_ctx* ctx, const float* d_wave, long long stride, int batch, int samples,
                     float* d_stats, void* stream);
-/* y0 (B, P0, 80) with P0 = ((S-251)/10+1)/3; partials (B, ntile0, 80, 2), ntile0 = ceil(F0/192) */
+/* y0 (B, P0, 80) with P0 = ((S-251)/10+1)/3; partials (B, ntile0, 80, 2), ntile0 = ceil(F0/192);
+ * d_filt (128, 96): the folded symmetric bank, see dz_sincnet_weights.filt */
 int dz_k_sinc_conv0(dz_ctx* ctx, const float* d_wave, long long stride, int batch, int samples,
                     const float* d_stats, float gamma, float beta, const float* d_filt,
                     float* d_y0, float* d_partials, void* stream);
@@ -260,6 +261,59 @@ int dz_clu_destroy(dz_clu* clu);
 int dz_prof_enable(int on);
 int dz_prof_collect(void);
 int dz_prof_get(int tag, const char** name, double* total_ms, long long* launches);
+
+/* ---- device-resident rolling window of N streams ------------------------------------------
+ * Replaces rearrange_audio_stream (/root/reference/src/diart/operators.py:44-100) plus the
+ * per-chunk upload of the full window (blocks/segmentation.py:47, blocks/embedding.py:52) for the
+ * N-stream driver: every step only the `hop` new samples of each stream are pushed (32 KB
+ * instead of 320 KB per stream at 5 s / 500 ms); dz_ring_window returns the (pointer, row
+ * stride) pair dz_seg_forward / dz_emb_frames read in place.  window % hop == 0, hop % 4 == 0.
+ * slack_blocks extra blocks of history are kept so that pushing block t+1 never overwrites a
+ * sample of windows t-slack_blocks+1 .. t (forward passes of those may still be in flight).     */
+typedef struct dz_ring dz_ring;
+int dz_ring_create(dz_ctx* ctx, int n_streams, int window, int hop, int slack_blocks, dz_ring** out);
+int dz_ring_reset(dz_ring* r);
+int dz_ring_destroy(dz_ring* r);
+/* block (n_streams, hop) with block_stride floats between rows; host memory (on_device = 0;
+ * pinned memory makes the copy asynchronous) or device memory (on_device = 1).              */
+int dz_ring_push(dz_ring* r, const float* block, long long block_stride, int on_device, void* stream);
+/* *filled = min(window, samples pushed): the window is complete once *filled == window.     */
+int dz_ring_window(const dz_ring* r, const float** d_wave, long long* stride, int* filled);
+/* contiguous (n_streams, window) copy of the current window, device to device.               */
+int dz_ring_read(const dz_ring* r, float* d_out, void* stream);
+
+/* ---- output tail of one stream: DelayedAggregation + Binarize, host fp64 -------------------
+ * Replaces, for the N-stream driver, the per-chunk Python tail of SpeakerDiarization.__call__
+ * (/root/reference/src/diart/blocks/diarization.py:203-232): DelayedAggregation
+ * (blocks/aggregation.py:120-218; strategies :60-118; first-chunk prepend :188-211) followed by
+ * Binarize (blocks/utils.py:11-59).  State: the last round(latency/step) permuted score
+ * buffers of the stream.  dz_tail_step consumes the (frames, speakers) fp64 scores of the newest
+ * chunk (what dz_clu_step wrote), whose frame grid starts at chunk_start seconds with
+ * `resolution` seconds per frame (diarization.py:190,195-199), and returns
+ *   agg_out  (rows, speakers) aggregated scores of the region [t0, t0 + rows*res), rows <=
+ *            dz_tail_max_rows() = frames + 2 (the first chunk of a stream outputs everything up
+ *            to the end of its region);
+ *   turns_out (nturns, 3) = (start, end, speaker index) of `score > threshold` runs, ordered by
+ *            speaker then time; turns_out may be NULL.  More than max_turns turns -> error 5.  */
+enum { DZ_AGG_HAMMING = 0, DZ_AGG_MEAN = 1, DZ_AGG_FIRST = 2 };
+enum { DZ_CROP_STRICT = 0, DZ_CROP_LOOSE = 1, DZ_CROP_CENTER = 2 };
+typedef struct dz_tail dz_tail;
+int dz_tail_create(int frames, int speakers, double step, double latency, double threshold,
+                   int strategy, int cropping_mode, const double* hamming /* [frames] */,
+                   dz_tail** out);
+int dz_tail_reset(dz_tail* t);
+int dz_tail_destroy(dz_tail* t);
+int dz_tail_max_rows(const dz_tail* t);
+int dz_tail_step(dz_tail* t, const double* scores, double chunk_start, double resolution,
+                 double* agg_out, int* rows_out, double* t0_out, double* res_out,
+                 double* turns_out, int max_turns, int* nturns_out);
+/* n streams on host threads: scores (n, frames, speakers); chunk_start, resolution (n);
+ * agg_out (n, frames + 2, speakers); rows_out, t0_out, res_out, nturns_out (n);
+ * turns_out (n, max_turns, 3) or NULL.                                                        */
+int dz_tail_step_batch(dz_tail** tails, int n, const double* scores, const double* chunk_start,
+                       const double* resolution, double* agg_out, int* rows_out, double* t0_out,
+                       double* res_out, double* turns_out, int max_turns, int* nturns_out,
+                       int num_threads);
 
 /* exposed for tests: scipy.optimize.linear_sum_assignment (minimise), rows<=cols
  * or transposed internally; col4row (nr) gets the column of each row.            */

@@ -48,7 +48,7 @@ def test_wave_stats(gpu):
 
 def test_sinc_conv0(gpu):
     from diart_amd.synth import synth_segmentation_state, synth_stream, sliding_chunks
-    from diart_amd.weights import sinc_filters
+    from diart_amd.weights import fold_sinc_filters, sinc_filters
     sd = synth_segmentation_state()
     p = "sincnet.conv1d.0.filterbank."
     filt = sinc_filters(sd[p + "low_hz_"], sd[p + "band_hz_"], sd[p + "window_"], sd[p + "n_"])
@@ -63,9 +63,7 @@ def test_sinc_conv0(gpu):
     d = x.to(gpu)
     st = torch.empty(B, 2, device=gpu)
     _lib.check(lib.dz_k_wave_stats(_ctx(gpu), d.data_ptr(), d.stride(0), B, S, st.data_ptr(), None))
-    fk = torch.zeros(252, 80)
-    fk[:251] = filt.t()
-    fk = fk.to(gpu)
+    fk = fold_sinc_filters(filt).to(gpu)
     nt = (7975 + 191) // 192
     y0 = torch.full((B, P0, 80), float("nan"), device=gpu)
     part = torch.full((B, nt, 80, 2), float("nan"), device=gpu)

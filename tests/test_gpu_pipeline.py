@@ -135,3 +135,69 @@ def test_full_size_properties_64_streams(gpu):
         assert torch.equal(e_all[i:i + 16], emb.forward_multi(view[i:i + 16, None, :], w[i:i + 16], normalize=True))
     # different streams give different embeddings (the batch is not aliased)
     assert (e_all[0] - e_all[1]).abs().max().item() > 1e-3
+
+
+def test_audio_ring_is_the_rolling_window(gpu):
+    """dz_ring_*: pushing 500 ms blocks reproduces the windows rearrange_audio_stream emits
+    (operators.py:44-100: the last `duration` seconds after every block, from the first complete
+    window on), from pinned host blocks and from device blocks, across several wrap-arounds."""
+    from diart_amd.pipeline import AudioRing
+    n, W, hop, steps = 3, 80000, 8000, 37
+    audio = torch.from_numpy(synth_streams(n, (W + hop * steps) / 16000.0, seed0=40))
+    ring = AudioRing(n, W, hop, slack_blocks=2, device=gpu)
+    emitted = 0
+    for b in range(W // hop + steps):
+        blk = audio[:, b * hop:(b + 1) * hop]
+        blk = blk.contiguous().pin_memory() if b % 2 == 0 else blk.to(gpu)
+        full = ring.push(blk)
+        assert full == (b + 1 >= W // hop)
+        if full:
+            t = b + 1 - W // hop
+            assert torch.equal(ring.snapshot().cpu(), audio[:, t * hop:t * hop + W]), f"window {t}"
+            emitted += 1
+    assert emitted == steps + 1
+    ring.reset()
+    assert ring.filled == 0
+
+
+def test_stream_batch_on_ring_with_splits_and_tail(gpu):
+    """StreamBatch reading the device ring, with the networks split into sub-batches on separate
+    HIP streams, and the C++ output tail: identical segmentation / embeddings / clustering to the
+    plain resident-audio single-batch run, and the speech turns equal the Python
+    DelayedAggregation + Binarize blocks (pinned to the reference's goldens) on the same scores."""
+    from diart_amd.blocks import Binarize, DelayedAggregation
+    from diart_amd.pipeline import AudioRing
+    n, W, hop, steps, latency = 6, 80000, 8000, 9, 1.5
+    audio = torch.from_numpy(synth_streams(n, (W + hop * steps) / 16000.0, seed0=700))
+    d_audio = audio.to(gpu)
+    seg_sd, emb_sd = synth_segmentation_state(), synth_embedding_state()
+    plain = StreamBatch(M.HipSegmentation(seg_sd, max_batch=n), M.HipEmbedding(emb_sd, max_batch=n), n,
+                        device=gpu, seg_split=1, emb_split=1)
+    split = StreamBatch(M.HipSegmentation(seg_sd, max_batch=n), M.HipEmbedding(emb_sd, max_batch=n), n,
+                        device=gpu, seg_split=3, emb_split=2, tail=True, latency=latency)
+    ring = AudioRing(n, W, hop, device=gpu)
+    for b in range(W // hop - 1):
+        ring.push(audio[:, b * hop:(b + 1) * hop].contiguous().pin_memory())
+    aggs = [DelayedAggregation(0.5, latency, "hamming", "loose") for _ in range(n)]
+    binarize = Binarize(0.6)
+    bufs = [[] for _ in range(n)]
+    res = 5.0 / 293
+    for t in range(steps):
+        b = W // hop - 1 + t
+        assert ring.push(audio[:, b * hop:(b + 1) * hop].contiguous().pin_memory())
+        seg0, emb0, sc0, as0 = plain(d_audio[:, t * hop:t * hop + W])
+        ticket = split.launch(ring)
+        seg1, emb1, sc1, as1 = split.finish(ticket)
+        assert np.array_equal(seg0, seg1) and np.array_equal(emb0, emb1)
+        assert np.array_equal(sc0, sc1) and np.array_equal(as0, as1)
+        agg, rows, t0, r, turns, nturns = ticket["tail"]
+        for i in range(n):
+            bufs[i].append(SlidingWindowFeature(sc1[i], SlidingWindow(start=t * 0.5, duration=res, step=res)))
+            want = aggs[i](bufs[i])
+            assert np.array_equal(agg[i, :rows[i]], want.data)
+            assert abs(t0[i] - want.sliding_window.start) < 1e-12 and abs(r[i] - want.sliding_window.step) < 1e-12
+            wt = sorted((s.start, s.end, float(k)) for s, k, _ in binarize(want).itertracks(yield_label=True))
+            got = sorted(map(tuple, turns[i, :nturns[i]]))
+            assert np.allclose(np.array(got).reshape(-1, 3), np.array(wt).reshape(-1, 3), rtol=0, atol=1e-12)
+            if len(bufs[i]) == aggs[i].num_overlapping_windows:
+                bufs[i] = bufs[i][1:]

@@ -120,3 +120,31 @@ def test_weight_broadcast_world_size_2_gloo(tmp_path):
     for rank, (p, o) in enumerate(zip(procs, outs)):
         assert p.returncode == 0, o
         assert f"rank {rank} ok" in o
+
+
+def test_sinc_fold_identity():
+    """The folded bank sinc_conv0 consumes reproduces the plain 251-tap convolution
+    (cos filters even, sin filters odd: SURVEY.md A.1), and an asymmetric bank is refused."""
+    import pytest
+    import torch.nn.functional as F
+    from diart_amd.synth import synth_segmentation_state
+    from diart_amd.weights import fold_sinc_filters, sinc_filters
+    sd = synth_segmentation_state()
+    p = "sincnet.conv1d.0.filterbank."
+    filt = sinc_filters(sd[p + "low_hz_"], sd[p + "band_hz_"], sd[p + "window_"], sd[p + "n_"])
+    fold = fold_sinc_filters(filt)
+    assert fold.shape == (128, 96) and float(fold[126:].abs().max()) == 0.0
+    x = torch.randn(1, 1, 4000, dtype=torch.float64)
+    ref = F.conv1d(x, filt.double()[:, None, :], stride=10)[0]            # (80, T)
+    T = ref.shape[1]
+    c = 10 * torch.arange(T) + 125
+    j = torch.arange(126)
+    xp = x[0, 0][c[:, None] + j[None, :]]
+    xm = x[0, 0][c[:, None] - j[None, :]]
+    fd = fold.double()
+    got = torch.cat([((xp + xm) @ fd[:126, :40]).t(), ((xp - xm) @ fd[:126, 48:88]).t()])
+    assert torch.allclose(got, ref, rtol=1e-9, atol=1e-9)
+    bad = filt.clone()
+    bad[3, 10] += 0.01
+    with pytest.raises(ValueError):
+        fold_sinc_filters(bad)

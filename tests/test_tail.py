@@ -72,6 +72,45 @@ def test_oracle_tail_matches_reference_golden(start_time, latency):
         _check(i, f"s{start_time:g}", latency, agg, aud, mn, tr)
 
 
+@pytest.mark.parametrize("latency", scenarios.TAIL_LATENCIES)
+def test_cpp_batched_tail_matches_reference_golden(latency):
+    """dz_tail_step_batch (C++, what StreamBatch uses for N streams) against the same goldens of
+    the reference's aggregation.py + utils.py: two streams (starting at 0 s and 7.5 s) stepped
+    together; hamming/loose aggregation + turns, mean/strict aggregation, first/center audio."""
+    from diart_amd.blocks.aggregation import BatchedOutputTail
+    starts_of = (0.0, 7.5)
+    inputs = [scenarios.tail_inputs(s0) for s0 in starts_of]
+    T, F, G = inputs[0][0].shape
+    res = inputs[0][2]
+    pred = BatchedOutputTail(2, F, G, 0.5, latency, threshold=0.5, num_threads=2)
+    mean = BatchedOutputTail(2, F, G, 0.5, latency, strategy="mean", cropping_mode="strict", num_threads=1)
+    audio = BatchedOutputTail(2, 80000, 1, 0.5, latency, strategy="first", cropping_mode="center",
+                              max_turns=4)
+    assert pred.num_overlapping_windows == int(round(latency / 0.5))
+    for i in range(T):
+        scores = np.stack([inp[0][i] for inp in inputs])
+        starts = np.array([inp[1][i] for inp in inputs])
+        agg, rows, t0, r, turns, nturns = pred(scores, starts, res)
+        magg, mrows, _, _, _, _ = mean(scores, starts, res)
+        wav = np.repeat((np.arange(80000, dtype=np.float64) + 8000.0 * i)[None, :, None], 2, axis=0)
+        aagg, arows, at0, ar, _, _ = audio(wav, starts, 1 / 16000)
+        for k, s0 in enumerate(starts_of):
+            tag = f"s{s0:g}_l{latency:g}_t{i}"
+            want = GOLD[tag + "_agg"]
+            assert rows[k] == want.shape[0] and np.array_equal(agg[k, :rows[k]], want), tag
+            assert np.allclose([t0[k], r[k]], GOLD[tag + "_aggsw"], rtol=0, atol=1e-12), tag
+            assert np.array_equal(magg[k, :mrows[k]], GOLD[tag + "_mean"]), tag
+            wt = GOLD[tag + "_turns"]
+            got = np.array(sorted(map(tuple, turns[k, :nturns[k]])), dtype=np.float64).reshape(-1, 3)
+            assert got.shape == wt.shape and np.allclose(got, wt, rtol=0, atol=1e-12), tag
+            a = GOLD[tag + "_aud"]
+            assert arows[k] == int(a[0]) and aagg[k, 0, 0] == a[1] and aagg[k, arows[k] - 1, 0] == a[2], tag
+            assert np.allclose([at0[k], ar[k]], a[3:], rtol=0, atol=1e-12), tag
+    pred.reset()
+    agg, rows, *_ = pred(np.stack([inp[0][0] for inp in inputs]), np.array([0.0, 7.5]), res)
+    assert np.array_equal(agg[0, :rows[0]], GOLD[f"s0_l{latency:g}_t0_agg"])
+
+
 def test_docstring_example_of_the_reference():
     """aggregation.py:141-161: 5 s / 500 frames / step 0.5 / latency 2 -> 4 windows, (51, 2)."""
     from diart_amd.blocks import DelayedAggregation

@@ -94,7 +94,7 @@ timeit("lstm", lambda: _lib.check(lib.dz_k_lstm(ctx, gx.data_ptr(), whh.data_ptr
 wave = torch.randn(B, 80000, device=dev) * 0.1
 stats = torch.zeros(B, 2, device=dev)
 stats[:, 1] = 1.0
-filt = torch.randn(252, 80, device=dev) * 0.05
+filt = torch.randn(128, 96, device=dev) * 0.05
 y0 = torch.empty(B, 2658, 80, device=dev)
 part0 = torch.empty(B, 42, 80, 2, device=dev)
 timeit("wave_stats", lambda: _lib.check(lib.dz_k_wave_stats(ctx, wave.data_ptr(), 80000, B, 80000, stats.data_ptr(), st)),
