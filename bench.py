@@ -230,12 +230,18 @@ def main():
     def window(t):
         return audio[:, t * hop: t * hop + S]
 
+    host = {"launch": 0.0, "finish": 0.0}
+
     def run(t_first, count):
         prev = None
         for t in range(t_first, t_first + count):
+            h0 = time.perf_counter()
             tk = pipe.launch(window(t))
+            h1 = time.perf_counter()
             if prev is not None:
                 pipe.finish(prev, want_scores=True)
+            host["launch"] += h1 - h0
+            host["finish"] += time.perf_counter() - h1
             prev = tk
         pipe.finish(prev, want_scores=True)
 
@@ -246,7 +252,8 @@ def main():
     run(0, args.warmup)
     torch.cuda.synchronize()
     log("warm-up done")
-    lib.dz_prof_enable(1)
+    lib.dz_prof_enable(0 if os.environ.get("DZ_NO_PROF") else 1)
+    host["launch"] = host["finish"] = 0.0
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -254,7 +261,9 @@ def main():
     torch.cuda.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0
-    log(f"timed region done: {elapsed:.3f}s for {args.steps} steps")
+    log(f"timed region done: {elapsed:.3f}s for {args.steps} steps; host time per step: launch "
+        f"{1e3 * host['launch'] / args.steps:.3f} ms, finish (wait + clustering + tail) "
+        f"{1e3 * host['finish'] / args.steps:.3f} ms")
     lib.dz_prof_collect()
 
     if world > 1:

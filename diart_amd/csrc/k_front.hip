@@ -121,7 +121,11 @@ __global__ __launch_bounds__(256) void sinc_conv0_kernel(
     // centre tap of frame t sits at xs[10 t + 125 + C0_LP]; this lane's k is 4 ks + q
     const float* xp = xs + 10 * (48 * w + i) + 125 + C0_LP + q;   // x[c + j]
     const float* xm = xs + 10 * (48 * w + i) + 125 + C0_LP - q;   // x[c - j]
-    const float* fb = filt_s + q * C0_NP + (i ^ ((q & 1) << 4));
+    // column block nt of row k lives at block nt ^ (k & 1); k & 1 == q & 1 for this lane
+    const float* fb = filt_s + q * C0_NP + i;
+    int fo[6];
+#pragma unroll
+    for (int nt = 0; nt < 6; ++nt) fo[nt] = 16 * (nt ^ (q & 1));
 #pragma unroll 8
     for (int ks = 0; ks < C0_KS; ++ks) {
         float ac[3], as[3], bb[6];
@@ -132,7 +136,7 @@ __global__ __launch_bounds__(256) void sinc_conv0_kernel(
             as[mt] = hi - lo;
         }
 #pragma unroll
-        for (int nt = 0; nt < 6; ++nt) bb[nt] = fb[4 * C0_NP * ks + 16 * nt];
+        for (int nt = 0; nt < 6; ++nt) bb[nt] = fb[4 * C0_NP * ks + fo[nt]];
 #pragma unroll
         for (int mt = 0; mt < 3; ++mt)
 #pragma unroll

@@ -129,8 +129,12 @@ class StreamBatch:
         # x-projection GEMM of one sub-batch runs under the latency-bound recurrence of another
         self.seg_split = max(1, min(int(os.environ.get("DZ_SEG_SPLIT", "1") if seg_split is None else seg_split), num_streams))
         self.emb_split = max(1, min(int(os.environ.get("DZ_EMB_SPLIT", "1") if emb_split is None else emb_split), num_streams))
-        self.streams_a = [torch.cuda.Stream(self.device) for _ in range(self.seg_split)]
-        self.streams_b = [torch.cuda.Stream(self.device) for _ in range(self.emb_split)]
+        # the segmentation chain (4 x {GEMM, latency-bound recurrence}) is the critical path of a
+        # step: its stream gets the higher HIP priority so its GEMMs are not queued behind the
+        # TDNN workgroups of the embedding stream
+        pa, pb = int(os.environ.get("DZ_PRIO_A", "-1")), int(os.environ.get("DZ_PRIO_B", "0"))
+        self.streams_a = [torch.cuda.Stream(self.device, priority=pa) for _ in range(self.seg_split)]
+        self.streams_b = [torch.cuda.Stream(self.device, priority=pb) for _ in range(self.emb_split)]
         self.stream_a, self.stream_b = self.streams_a[0], self.streams_b[0]
         self._sub: dict = {}
         self._slots: List[dict] = []

@@ -207,3 +207,33 @@ def test_config3_powerset_ecapa_pipeline_matches_cpu_chain(gpu):
     print(f"config 3: DER(GPU vs CPU chain) = {100 * d['diarization error rate']:.3f} % of {d['total']:.1f} s; "
           f"{flips} hard-decision flips at {near_ties} near-tie frames of {293 * len(chunks)}")
     assert d["total"] > 1.0 and d["diarization error rate"] <= 0.005
+
+
+def test_benchmark_over_wav_files_matches_cpu_chain(gpu, models, tmp_path):
+    """BASELINE.json config 1 as the reference runs it: WAV files in a directory ->
+    ``Benchmark(speech, reference, output, batch_size=32)(SpeakerDiarization, config)`` ->
+    one RTTM per file + the DER report.  The reference RTTMs here are the all-CPU chain's
+    hypotheses on the same (16-bit) audio, so the reported DER IS the GPU-vs-CPU parity figure
+    (north-star gate: within 0.5 pt)."""
+    from diart_amd.inference import Benchmark, DistributedBenchmark, read_wav, write_wav
+    speech, refs, out = tmp_path / "wav", tmp_path / "ref", tmp_path / "out"
+    speech.mkdir()
+    refs.mkdir()
+    for name, seed, dur in (("meeting_a", 2024, 30.0), ("meeting_b", 7, 12.0)):
+        write_wav(speech / f"{name}.wav", synth_stream(seed, dur), SR)
+        audio, sr = read_wav(speech / f"{name}.wav")
+        assert sr == SR
+        ref, _ = cpu_chain(audio, 0.5)
+        ref.uri = name
+        with open(refs / f"{name}.rttm", "w") as f:
+            ref.write_rttm(f)
+    cfg = SpeakerDiarizationConfig(segmentation=models[0], embedding=models[1], latency=0.5, device=gpu)
+    metric = Benchmark(speech, refs, out, show_report=False, batch_size=32)(SpeakerDiarization, cfg)
+    print(metric.report())
+    assert [u for u, _ in metric.results] == ["meeting_a", "meeting_b"]
+    assert metric.accumulated["total"] > 5.0 and abs(metric) <= 0.005
+    assert sorted(p.name for p in out.iterdir()) == ["meeting_a.rttm", "meeting_b.rttm"]
+    # single-rank DistributedBenchmark is the same run
+    m2 = DistributedBenchmark(Benchmark(speech, refs, tmp_path / "out2", show_report=False))(SpeakerDiarization, cfg)
+    assert m2.accumulated == metric.accumulated
+    assert (tmp_path / "out2" / "meeting_a.rttm").read_text() == (out / "meeting_a.rttm").read_text()
