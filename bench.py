@@ -54,6 +54,8 @@ SYMBOL = {
 }
 ALG_GFLOP_PER_CHUNK = 3.352   # 1.312 seg + 2.039 emb de-duplicated
 PEAK_F32_MATRIX_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, dense
+PEAK_F32_FMA_TFLOPS = 78.6      # 256 CUs x 64 lanes x 2 FLOP x 2.4 GHz: v_fma_f32 (the packed form
+                                # measured no faster in the recurrence)
 
 
 _T0 = time.monotonic()
@@ -285,23 +287,50 @@ def main():
             g["launches"] += r["launches"]
             g["gflop"] += r["alg_gflop_per_launch"] * r["launches"]
             g["tags"].append(r["kernel"])
-        sym, dom = max(groups.items(), key=lambda kv: kv[1]["ms"])
+        # the dominant kernel = the MFMA-bound device kernel with the largest total time; the
+        # recurrence (f32 VALU chains, one per CU, latency bound) is priced against the FMA rate
+        # of the CUs it occupies and listed with every other kernel in `roofline_kernels`
+        mfma_groups = {k: v for k, v in groups.items() if k != "lstm_rec_kernel"}
+        sym, dom = max(mfma_groups.items(), key=lambda kv: kv[1]["ms"])
         tflops = dom["gflop"] / dom["ms"]               # GFLOP / ms = TFLOP/s
-        traffic = None
+        traffic_of, mfma_util_of = {}, {}
         tfile = ROOT / "profiles" / "traffic.json"      # rocprofv3 --pmc passes of this command
         if tfile.exists():
             for name, v in json.loads(tfile.read_text())["kernels"].items():
-                if sym in name:
-                    traffic = v["hbm_bytes_per_launch"]
+                for g in groups:
+                    if g in name:
+                        traffic_of[g] = v["hbm_bytes_per_launch"]
+        mfile = ROOT / "profiles" / "mfma_util.json"
+        if mfile.exists():
+            for name, v in json.loads(mfile.read_text())["kernels"].items():
+                for g in groups:
+                    if g in name:
+                        mfma_util_of[g] = v.get("mfma_util")
+        traffic = traffic_of.get(sym)
+        per_kernel = []
+        for g, v in sorted(groups.items(), key=lambda kv: -kv[1]["ms"]):
+            ach = v["gflop"] / v["ms"]
+            if g == "lstm_rec_kernel":
+                cus = min(256, 2 * n)                    # one (chunk, direction) chain per workgroup / CU
+                peak, bound = PEAK_F32_FMA_TFLOPS * cus / 256.0, "valu"
+            else:
+                peak, bound = PEAK_F32_MATRIX_TFLOPS, "mfma"
+            per_kernel.append({"kernel": g, "layers": v["tags"], "bound": bound, "achieved": round(ach, 2),
+                               "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(ach / peak, 4),
+                               "avg_launch_us": round(1e3 * v["ms"] / v["launches"], 2),
+                               "launches_per_step": round(v["launches"] / args.steps, 2),
+                               "traffic": traffic_of.get(g), "mfma_util_pmc": mfma_util_of.get(g)})
         roof = {"bound": "mfma", "kernel": sym, "layers": dom["tags"], "achieved": round(tflops, 2),
                 "peak": PEAK_F32_MATRIX_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(tflops / PEAK_F32_MATRIX_TFLOPS, 4), "traffic": traffic,
                 "traffic_source": "profiles/traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes "
                                   "of `bench.py --steps 3`, avg bytes per launch, FETCH doubled per the "
                                   "gfx950 correction)" if traffic is not None else None,
+                "mfma_util_pmc": mfma_util_of.get(sym),
                 "alg_gflop_per_launch": round(dom["gflop"] / dom["launches"], 3),
                 "avg_launch_us": round(1e3 * dom["ms"] / dom["launches"], 2),
-                "whole_path_tflops": round(cps / world * ALG_GFLOP_PER_CHUNK / 1e3, 2)}
+                "whole_path_tflops": round(cps / world * ALG_GFLOP_PER_CHUNK / 1e3, 2),
+                "whole_path_frac": round(cps / world * ALG_GFLOP_PER_CHUNK / 1e3 / PEAK_F32_MATRIX_TFLOPS, 4)}
         out = {
             "metric": "real-time-factor xRT streams/GPU @500ms step", "value": round(cps / 2, 2),
             "unit": "xRT 16 kHz streams (chunks/s / 2)", "n_gpus": world, "steps": args.steps,
@@ -312,7 +341,7 @@ def main():
                                    "pyannote/segmentation + pyannote/embedding architectures "
                                    "(random-init weights), %d concurrent synthetic 16 kHz streams per GPU" % n,
                        "streams_per_gpu": n, "chunks_per_step": world * n, "parallelism": f"streams x{world}"},
-            "roofline": roof,
+            "roofline": roof, "roofline_kernels": per_kernel,
         }
         if args.kernel_table:
             Path(args.kernel_table).parent.mkdir(parents=True, exist_ok=True)

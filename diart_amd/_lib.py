@@ -108,6 +108,7 @@ SIGNATURES = {
                                      C.c_int, vp, C.c_int]),
     # kernel-level entry points
     "dz_k_convgemm": (C.c_int, [vp, vp, vp]),
+    "dz_k_gemm_bx3": (C.c_int, [vp, vp, vp]),
     "dz_k_convgemm_ntile": (C.c_int, [C.c_int]),
     "dz_k_wave_stats": (C.c_int, [vp, vp, C.c_longlong, C.c_int, C.c_int, vp, vp]),
     "dz_k_sinc_conv0": (C.c_int, [vp, vp, C.c_longlong, C.c_int, C.c_int, vp, C.c_float,
@@ -126,7 +127,7 @@ class ConvGemmDesc(C.Structure):
                                "Nstore", "ldx", "ldy", "nld", "Tstore")] + [
         ("xbs", C.c_longlong), ("ybs", C.c_longlong), ("norm_on_load", C.c_int), ("epi", C.c_int),
         ("ksplit", C.c_int), ("ysplit", C.c_longlong), ("agroup", C.c_int), ("pad", C.c_int),
-        ("X2", vp), ("rowbias", vp)]
+        ("X2", vp), ("rowbias", vp), ("Wsplit", vp)]
 
 
 (EPI_BIAS, EPI_BIAS_LEAKY, EPI_BIAS_SIGMOID, EPI_TDNN, EPI_POOL3, EPI_BIAS_RELU, EPI_RELU_BN,

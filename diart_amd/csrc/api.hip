@@ -561,6 +561,11 @@ extern "C" int dz_k_convgemm(dz_ctx* ctx, const dz_convgemm_desc* d, void* strea
     DZ_HIP(hipSetDevice(ctx->device));
     return dz_launch_convgemm(*d, (hipStream_t)stream);
 }
+extern "C" int dz_k_gemm_bx3(dz_ctx* ctx, const dz_convgemm_desc* d, void* stream) {
+    DZ_REQUIRE(ctx && d, "dz_k_gemm_bx3: NULL argument");
+    DZ_HIP(hipSetDevice(ctx->device));
+    return dz_launch_gemm_bx3(*d, (hipStream_t)stream);
+}
 extern "C" int dz_k_convgemm_ntile(int t_out) { return dz_convgemm_ntile(t_out); }
 extern "C" int dz_k_wave_stats(dz_ctx* ctx, const float* d_wave, long long stride, int batch,
                                int samples, float* d_stats, void* stream) {

@@ -15,6 +15,36 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 #define DZ_LEAKY_SLOPE 0.01f
 
 // ---------------------------------------------------------------------------
+// XCD-aware tile order shared by the GEMM kernels (grid = (M-tiles, N-tiles, batch)).
+// Workgroups are dealt round-robin to the 8 XCDs, each with a private 4 MiB L2.  With the
+// plain (x, y, z) order the N-tiles that share one activation tile land on 8 different
+// XCDs and every L2 fetches it again (rocprofv3 FETCH_SIZE of the TDNN layers was 4.7x the
+// algorithmic bytes).  Re-order so that XCD r owns activation tiles a = r, r+8, ...; inside
+// an XCD, groups of AG activation tiles sweep the N-tiles together (weight slice reuse).
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void dz_tile_map(int agroup, int& bx, int& by, int& bz) {
+    const int gx = gridDim.x, gy = gridDim.y;
+    const int L = blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z);
+    const int NA = gx * gridDim.z, NA8 = NA & ~7;
+    int a;
+    if (L < NA8 * gy) {
+        const int xcd = L & 7, j = L >> 3;          // j-th workgroup of this XCD
+        const int per = NA8 >> 3;                   // activation tiles per XCD
+        const int AG = agroup > 0 ? agroup : 4;
+        const int g = j / (AG * gy), r = j - g * (AG * gy);
+        const int gsz = per - g * AG < AG ? per - g * AG : AG;  // last group may be short
+        by = r / gsz;
+        a = (g * AG + (r - by * gsz)) * 8 + xcd;
+    } else {
+        const int r = L - NA8 * gy;
+        a = NA8 + r / gy;
+        by = r - (r / gy) * gy;
+    }
+    bz = a / gx;
+    bx = a - bz * gx;
+}
+
+// ---------------------------------------------------------------------------
 // error plumbing (api.hip)
 // ---------------------------------------------------------------------------
 void dz_set_error(const char* fmt, ...);
@@ -54,6 +84,9 @@ int dz_launch_finalize_norm(const float* partials, int B, int ntile, int C, int 
 // k_convgemm.hip ------------------------------------------------------------
 typedef dz_convgemm_desc DzConvGemm;
 int dz_launch_convgemm(const DzConvGemm& p, hipStream_t st);
+// k_gemm_bx3.hip: the same contraction on the bf16 matrix cores with both operands split into
+// (hi, lo) bf16 pairs — 3 MFMAs per product, f32 accumulation
+int dz_launch_gemm_bx3(const DzConvGemm& p, hipStream_t st);
 int dz_convgemm_ntile(int Tout);
 
 // k_lstm.hip ----------------------------------------------------------------

@@ -41,34 +41,8 @@ __global__ __launch_bounds__(256) void convgemm_kernel(DzConvGemm p) {
     using C = Cfg<BN>;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x;
-    // ---- XCD-aware tile order -------------------------------------------------------
-    // Workgroups are dealt round-robin to the 8 XCDs, each with a private 4 MiB L2.  With the
-    // plain (x, y, z) order the N-tiles that share one activation tile land on 8 different
-    // XCDs and every L2 fetches it again (rocprofv3 FETCH_SIZE of the TDNN layers was 4.7x the
-    // algorithmic bytes).  Re-order so that XCD r owns activation tiles a = r, r+8, ...; inside
-    // an XCD, groups of AG activation tiles sweep the N-tiles together (weight slice reuse).
-    const int gx = gridDim.x, gy = gridDim.y;
     int bx, by, bz;
-    {
-        const int L = blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z);
-        const int NA = gx * gridDim.z, NA8 = NA & ~7;
-        int a;
-        if (L < NA8 * gy) {
-            const int xcd = L & 7, j = L >> 3;          // j-th workgroup of this XCD
-            const int per = NA8 >> 3;                   // activation tiles per XCD
-            const int AG = p.agroup > 0 ? p.agroup : 4;
-            const int g = j / (AG * gy), r = j - g * (AG * gy);
-            const int gsz = per - g * AG < AG ? per - g * AG : AG;  // last group may be short
-            by = r / gsz;
-            a = (g * AG + (r - by * gsz)) * 8 + xcd;
-        } else {
-            const int r = L - NA8 * gy;
-            a = NA8 + r / gy;
-            by = r - (r / gy) * gy;
-        }
-        bz = a / gx;
-        bx = a - bz * gx;
-    }
+    dz_tile_map(p.agroup, bx, by, bz);
     const int nsplit = p.ksplit > 1 ? p.ksplit : 1;
     const int b = bz / nsplit, ks = bz - b * nsplit;
     const int t0 = bx * BM;
@@ -221,7 +195,7 @@ __global__ __launch_bounds__(256) void convgemm_kernel(DzConvGemm p) {
                 ss += v * v;
             }
             float* pp = p.partials +
-                        (((long long)b * gx + bx) * p.Npad + n0 + tid) * 2;
+                        (((long long)b * gridDim.x + bx) * p.Npad + n0 + tid) * 2;
             pp[0] = s;
             pp[1] = ss;
         }

@@ -1,0 +1,258 @@
+// Implicit-GEMM 1-D convolution / linear layer on the bf16 matrix cores with split operands.
+//
+//   Y[b][t][n] = epi( sum_{tap,c} pro(X[b][t + tap*dil][c]) * W[n][tap*Cin + c] + bias[n] )
+//
+// Same contraction, descriptor and epilogues as k_convgemm.hip (exact-f32 MFMA, 157 TFLOP/s peak),
+// computed 5.3x closer to the metal: every f32 operand is split into two bf16 numbers
+//     x = hi + lo,   hi = bf16_rne(x),   lo = bf16_rne(x - hi)          (16 mantissa bits kept)
+// and the product is accumulated in f32 from three bf16 MFMAs
+//     x*w ~= hi_x*hi_w + hi_x*lo_w + lo_x*hi_w                          (lo*lo ~ 2^-18 dropped)
+// on v_mfma_f32_32x32x16_bf16 (2.5 PFLOP/s dense -> 833 TFLOP/s of split products).  Relative
+// error per product <= 2^-16: 50x tighter than the TF32 (10-bit mantissa) arithmetic PyTorch's
+// cuDNN convolutions and LSTMs use by default on the reference's own GPU path.
+//
+// Tile: 128 rows x 128 cols x 32 k per step, 8 waves (4 x 2), wave tile 32 x 64 = 1 x 2 MFMA
+// blocks; per k-step of 16 a wave reads 2 A and 4 B fragments (hi / lo, one ds_read_b128 each)
+// and issues 6 MFMAs.  Two workgroups per CU = 4 waves per SIMD: the MFMAs of three waves cover
+// the global-load latency of the fourth (with 4 waves per workgroup the kernel sat in s_waitcnt
+// for 39 % of its wave cycles; rocprofv3 SQ_WAIT_ANY).  LDS holds four bf16 planes per stage (A hi, A lo,
+// B hi, B lo; [row][32 k] = 64 B rows, 16-byte chunks XOR-swizzled with (row >> 2) & 3 so the 16
+// lanes of a ds_read_b128 phase hit 16 distinct 16-byte slots), double buffered: 64 KiB, two
+// workgroups per CU.  Activations are f32 in HBM: they are split on the way into LDS
+// (v_cvt_pk_bf16_f32, 3 VALU ops per element, hidden under the MFMAs of the other waves); weights
+// are split once on the host (weights.py split_bf16) and arrive as two bf16 planes.
+// The (lane -> k) assignment inside a fragment is the same for A and B (8 consecutive k per lane,
+// lanes 32..63 take the upper 8 of a 16-wide k-step), so the contraction is correct for any
+// hardware k-ordering; the C/D map is cdna_hip_programming.md "Fragment layout".
+#include "dz_common.h"
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int BM = 128, BN = 128, KT = 32;
+constexpr int PLANE = 128 * 64;              // bytes of one bf16 plane of a stage
+constexpr int STAGE = 4 * PLANE;             // A hi | A lo | B hi | B lo
+constexpr size_t LDS_BYTES = 2 * STAGE;
+
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+__device__ __forceinline__ float leaky(float v) { return v > 0.f ? v : v * DZ_LEAKY_SLOPE; }
+__device__ __forceinline__ int chunk_off(int row, int cidx) {
+    return row * 64 + ((cidx ^ ((row >> 2) & 3)) << 4);
+}
+__device__ __forceinline__ unsigned pack_bf16(float a, float b) {
+    const f32x2 v = {a, b};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+}
+// 8 floats -> 8 bf16 hi + 8 bf16 lo
+__device__ __forceinline__ void split8(const float* v, u32x4& hi, u32x4& lo) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const unsigned ph = pack_bf16(v[2 * e], v[2 * e + 1]);
+        const float f0 = __uint_as_float(ph << 16), f1 = __uint_as_float(ph & 0xffff0000u);
+        hi[e] = ph;
+        lo[e] = pack_bf16(v[2 * e] - f0, v[2 * e + 1] - f1);
+    }
+}
+
+template <bool PRO, int EPI>
+__global__ __launch_bounds__(512) void gemm_bx3_kernel(DzConvGemm p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    int bx, by, b;
+    dz_tile_map(p.agroup, bx, by, b);
+    const int t0 = bx * BM, n0 = by * BN;
+
+    // ---- staging coordinates: thread -> row tid >> 2 (0..127), 8-wide k chunk tid & 3 ----------
+    const int crow = tid >> 2, cidx = tid & 3;
+    const float* Xb = p.X + (long long)b * p.xbs;
+    const float* nsc = PRO ? p.nscale + (long long)b * p.nld : nullptr;
+    const float* nsh = PRO ? p.nshift + (long long)b * p.nld : nullptr;
+    const int trow = (t0 + crow) < p.Tout ? (t0 + crow) : p.Tout - 1;
+    const unsigned short* Whi = reinterpret_cast<const unsigned short*>(p.Wsplit);
+    const unsigned short* Wlo = Whi + (long long)p.Npad * p.Kpad;
+    const long long wofs = (long long)(n0 + crow) * p.Kpad + cidx * 8;
+
+    struct Regs {
+        f32x4 ra[2];
+        u32x4 rbh, rbl;
+    };
+    Regs R0;
+    auto load_tile = [&](Regs& R, int kt) {
+        const int k = kt * KT + cidx * 8;
+        const bool kvalid = k < p.K;
+        int tap = 0, c = k;
+        if (p.taps > 1) {
+            tap = k / p.Cin;
+            c = k - tap * p.Cin;
+        }
+        const int toff = tap * p.dil;
+        {
+            f32x4 v0 = {0.f, 0.f, 0.f, 0.f}, v1 = {0.f, 0.f, 0.f, 0.f};
+            if (kvalid) {
+                const float* src = Xb + (long long)(trow + toff) * p.ldx + c;
+                v0 = *reinterpret_cast<const f32x4*>(src);
+                v1 = *reinterpret_cast<const f32x4*>(src + 4);
+                if (PRO) {
+                    const f32x4 s0 = *reinterpret_cast<const f32x4*>(nsc + c);
+                    const f32x4 s1 = *reinterpret_cast<const f32x4*>(nsc + c + 4);
+                    const f32x4 h0 = *reinterpret_cast<const f32x4*>(nsh + c);
+                    const f32x4 h1 = *reinterpret_cast<const f32x4*>(nsh + c + 4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        v0[e] = leaky(v0[e] * s0[e] + h0[e]);
+                        v1[e] = leaky(v1[e] * s1[e] + h1[e]);
+                    }
+                }
+            }
+            R.ra[0] = v0;
+            R.ra[1] = v1;
+        }
+        const long long o = wofs + kt * KT;
+        R.rbh = *reinterpret_cast<const u32x4*>(Whi + o);
+        R.rbl = *reinterpret_cast<const u32x4*>(Wlo + o);
+    };
+    auto store_tile = [&](const Regs& R, int buf) {
+        char* st = smem + buf * STAGE;
+        const int off = chunk_off(crow, cidx);
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            v[e] = R.ra[0][e];
+            v[4 + e] = R.ra[1][e];
+        }
+        u32x4 hi, lo;
+        split8(v, hi, lo);
+        *reinterpret_cast<u32x4*>(st + off) = hi;
+        *reinterpret_cast<u32x4*>(st + PLANE + off) = lo;
+        *reinterpret_cast<u32x4*>(st + 2 * PLANE + off) = R.rbh;
+        *reinterpret_cast<u32x4*>(st + 3 * PLANE + off) = R.rbl;
+    };
+
+    // ---- MFMA coordinates ------------------------------------------------------------
+    const int w = tid >> 6, l = tid & 63, li = l & 31, g = l >> 5;
+    const int wm = w >> 1, wn = w & 1;       // 4 x 2 waves, wave tile 32 x 64
+    f32x16 acc[2];
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[nb][r] = 0.f;
+
+    const int nk = p.Kpad / KT;
+    auto compute = [&](int buf) {
+        const char* st = smem + buf * STAGE;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 ah, al, bh[2], bl[2];
+            {
+                const int off = chunk_off(wm * 32 + li, 2 * ks + g);
+                ah = *reinterpret_cast<const bf16x8*>(st + off);
+                al = *reinterpret_cast<const bf16x8*>(st + PLANE + off);
+            }
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb) {
+                const int off = chunk_off(wn * 64 + nb * 32 + li, 2 * ks + g);
+                bh[nb] = *reinterpret_cast<const bf16x8*>(st + 2 * PLANE + off);
+                bl[nb] = *reinterpret_cast<const bf16x8*>(st + 3 * PLANE + off);
+            }
+            // small cross terms first, the dominant hi*hi term last
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb)
+                acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[nb], acc[nb], 0, 0, 0);
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb)
+                acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[nb], acc[nb], 0, 0, 0);
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb)
+                acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[nb], acc[nb], 0, 0, 0);
+        }
+    };
+    // one k-tile per step: the global loads of tile kt + 1 are issued before the MFMAs of tile kt
+    // and parked in LDS after them.  The step barrier only has to publish LDS (s_waitcnt lgkmcnt +
+    // s_barrier): __syncthreads() would also drain vmcnt.  (Running the loads two tiles ahead
+    // through a second register set measured SLOWER: 128-register budget spills, 140 registers
+    // halve the occupancy.)
+    load_tile(R0, 0);
+    store_tile(R0, 0);
+    lds_barrier();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) load_tile(R0, kt + 1);
+        compute(buf);
+        if (kt + 1 < nk) store_tile(R0, buf ^ 1);
+        lds_barrier();
+    }
+
+    // ---- epilogue: C/D map col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5) -----
+    float* Yb = p.Y + (long long)b * p.ybs;
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb) {
+        const int n = n0 + wn * 64 + nb * 32 + li;
+        const float bv = p.bias[n];
+        float e0 = 1.f, e1 = 0.f;
+        if (EPI == DZ_EPI_TDNN) {
+            e0 = p.e0[n];
+            e1 = p.e1[n];
+        }
+        if (n < p.Nstore) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int t = t0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
+                if (t < p.Tout) {
+                    float v = acc[nb][r] + bv;
+                    if (EPI == DZ_EPI_BIAS_LEAKY) v = leaky(v);
+                    if (EPI == DZ_EPI_TDNN) v = leaky(v) * e0 + e1;
+                    Yb[(long long)t * p.ldy + n] = v;
+                }
+            }
+        }
+    }
+}
+
+template <bool PRO, int EPI>
+int launch(const DzConvGemm& p, hipStream_t st) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        DZ_HIP(hipFuncSetAttribute((const void*)gemm_bx3_kernel<PRO, EPI>,
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES));
+        attr_set = true;
+    }
+    dim3 grid((p.Tout + BM - 1) / BM, p.Npad / BN, p.B);
+    hipLaunchKernelGGL((gemm_bx3_kernel<PRO, EPI>), grid, dim3(512), LDS_BYTES, st, p);
+    DZ_HIP(hipGetLastError());
+    return 0;
+}
+
+}  // namespace
+
+int dz_launch_gemm_bx3(const DzConvGemm& p, hipStream_t st) {
+    DZ_REQUIRE(p.Wsplit != nullptr, "gemm_bx3: Wsplit (bf16 hi/lo planes of W) is NULL");
+    DZ_REQUIRE(p.Kpad % KT == 0 && p.Cin % 8 == 0 && p.ldx % 4 == 0 && p.K % 8 == 0,
+               "gemm_bx3: bad K/Cin/ldx (Cin and K must be multiples of 8)");
+    DZ_REQUIRE(p.K <= p.Kpad && p.K == p.taps * p.Cin, "gemm_bx3: K mismatch");
+    DZ_REQUIRE(p.pad == 0 && p.X2 == nullptr && p.rowbias == nullptr && p.ksplit <= 1,
+               "gemm_bx3: padding / second input / row bias / split-K are f32-path features");
+    DZ_REQUIRE(p.Tout > 0 && p.Tout == p.Tin - (p.taps - 1) * p.dil, "gemm_bx3: Tout mismatch");
+    DZ_REQUIRE(p.Npad % BN == 0, "gemm_bx3: Npad must be a multiple of 128");
+    const bool pro = p.norm_on_load != 0;
+#define DZ_BX(PRO, EPI) return launch<PRO, EPI>(p, st)
+    switch (p.epi) {
+        case DZ_EPI_TDNN:
+            if (pro) DZ_BX(true, DZ_EPI_TDNN);
+            DZ_BX(false, DZ_EPI_TDNN);
+        case DZ_EPI_BIAS:
+            if (pro) DZ_BX(true, DZ_EPI_BIAS);
+            DZ_BX(false, DZ_EPI_BIAS);
+        case DZ_EPI_BIAS_LEAKY:
+            DZ_REQUIRE(!pro, "gemm_bx3: BIAS_LEAKY has no norm-on-load instance");
+            DZ_BX(false, DZ_EPI_BIAS_LEAKY);
+    }
+#undef DZ_BX
+    dz_set_error("gemm_bx3: epilogue %d is not built on the split-bf16 path", p.epi);
+    return 2;
+}

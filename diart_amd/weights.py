@@ -72,6 +72,16 @@ def fold_sinc_filters(filt: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def split_bf16(w: torch.Tensor) -> torch.Tensor:
+    """f32 matrix ``[N][K]`` -> int16 ``[2][N][K]``: plane 0 = bf16(w) (round to nearest even),
+    plane 1 = bf16(w - plane 0) — the two-term split ``k_gemm_bx3.hip`` multiplies with
+    (``w = hi + lo`` to 16 mantissa bits)."""
+    w = w.detach().float().cpu().contiguous()
+    hi = w.to(torch.bfloat16)
+    lo = (w - hi.float()).to(torch.bfloat16)
+    return torch.stack([hi, lo]).view(torch.int16).contiguous()
+
+
 def _pad2(w: torch.Tensor, rows: int, cols: int) -> torch.Tensor:
     out = torch.zeros(rows, cols, dtype=torch.float32)
     out[: w.shape[0], : w.shape[1]] = w

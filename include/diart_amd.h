@@ -209,8 +209,12 @@ typedef struct {
     int pad;              /* >0: "same" convolution, reflect padding of `pad` frames  */
     const float* X2;      /* optional second input with X's geometry, added on load   */
     const float* rowbias; /* optional [B][Npad] per-batch-item bias added to `bias`   */
+    const void* Wsplit;   /* split-bf16 path: W as two bf16 planes [2][Npad][Kpad], hi = bf16(W),
+                             lo = bf16(W - hi) (weights.py split_bf16); NULL on the f32 path   */
 } dz_convgemm_desc;
 int dz_k_convgemm(dz_ctx* ctx, const dz_convgemm_desc* desc, void* stream);
+/* the same layer on the split-bf16 matrix-core path (desc->Wsplit must be set)       */
+int dz_k_gemm_bx3(dz_ctx* ctx, const dz_convgemm_desc* desc, void* stream);
 int dz_k_convgemm_ntile(int t_out);
 int dz_k_wave_stats(dz_ctx* ctx, const float* d_wave, long long stride, int batch, int samples,
                     float* d_stats, void* stream);

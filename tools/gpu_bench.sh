@@ -10,6 +10,7 @@ REPO=$PWD
 bash tools/gpu_pmc.sh $TAG > gpurun_out/pmc_$TAG.txt 2>&1
 tail -12 gpurun_out/pmc_$TAG.txt
 cp gpurun_out/traffic_$TAG.json profiles/traffic.json
+cp gpurun_out/mfma_$TAG.json profiles/mfma_util.json
 timeout 420 python bench.py --steps $STEPS --warmup 5 --kernel-table gpurun_out/kernels_$TAG.json \
     > gpurun_out/bench_$TAG.json 2> gpurun_out/bench_$TAG.err
 echo "bench exit $?"

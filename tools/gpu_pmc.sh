@@ -11,6 +11,12 @@ for C in FETCH_SIZE WRITE_SIZE; do
       python $REPO/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $REPO/gpurun_out/pmc_${TAG}_$C.log 2>&1
   echo "$C exit $?"
 done
+# matrix-core busy cycles (north-star: "MFMA utilisation against gfx950 peak"), own pass
+timeout 280 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv \
+    -d $REPO/gpurun_out/pmc_${TAG}_MFMA -o pmc -- python $REPO/bench.py --steps 3 --warmup 1 --no-cpu-baseline \
+    > $REPO/gpurun_out/pmc_${TAG}_MFMA.log 2>&1
+echo "MFMA exit $?"
 cd $REPO
+python tools/mfma_summary.py gpurun_out/pmc_${TAG}_MFMA gpurun_out/mfma_${TAG}.json | tail -14
 ls -la gpurun_out/pmc_${TAG}_*/ | head -20
 python tools/pmc_summary.py gpurun_out/pmc_${TAG}_FETCH_SIZE gpurun_out/pmc_${TAG}_WRITE_SIZE gpurun_out/traffic_${TAG}.json

@@ -30,9 +30,20 @@ if dbs and not csvs:
         rows.append((name, calls, tot / 1e3, tot / calls / 1e3, 0.0))
     total = sum(r[2] for r in rows)
     rows = [(n, c_, t, a, 100.0 * t / total) for n, c_, t, a, _ in rows]
+# medians from the raw trace (robust to a warm-up launch that sat behind an allocation)
+med = {}
+traces = sorted(glob.glob(str(src / "**/*kernel_trace.csv"), recursive=True))
+if traces:
+    import statistics
+    per = {}
+    for r in csv.DictReader(open(traces[0])):
+        per.setdefault(r["Kernel_Name"], []).append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+    med = {k: statistics.median(v) for k, v in per.items()}
 with open(out, "w") as f:
-    f.write(f"# {title}\n\nrocprofv3 --kernel-trace --stats (durations in microseconds)\n\n")
-    f.write("| kernel | calls | total us | avg us | % |\n|---|---:|---:|---:|---:|\n")
+    f.write(f"# {title}\n\nrocprofv3 --kernel-trace --stats (durations in microseconds; median from the raw "
+            f"kernel trace of the same run)\n\n")
+    f.write("| kernel | calls | total us | avg us | median us | % |\n|---|---:|---:|---:|---:|---:|\n")
     for n, c_, t, a, p in rows:
-        f.write(f"| `{n[:110]}` | {c_} | {t:.1f} | {a:.2f} | {p:.2f} |\n")
+        m = f"{med[n]:.2f}" if n in med else ""
+        f.write(f"| `{n[:110]}` | {c_} | {t:.1f} | {a:.2f} | {m} | {p:.2f} |\n")
 print(open(out).read())
