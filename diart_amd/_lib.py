@@ -29,12 +29,14 @@ class SegWeights(C.Structure):
     _fields_ = [("sinc", SincNetWeights), ("wih", vp * 4), ("bih", vp * 4), ("whh", vp * 4),
                 ("lin0_w", vp), ("lin0_b", vp), ("lin1_w", vp), ("lin1_b", vp),
                 ("cls_w", vp), ("cls_b", vp),
-                ("num_classes", C.c_int), ("powerset", C.c_int), ("num_speakers", C.c_int)]
+                ("num_classes", C.c_int), ("powerset", C.c_int), ("num_speakers", C.c_int),
+                ("wih_split", vp * 4), ("lin0_split", vp), ("lin1_split", vp)]
 
 
 class EmbWeights(C.Structure):
     _fields_ = [("sinc", SincNetWeights), ("tw", vp * 5), ("tb", vp * 5), ("ts", vp * 5),
-                ("th", vp * 5), ("emb_w", vp), ("emb_b", vp), ("dimension", C.c_int)]
+                ("th", vp * 5), ("emb_w", vp), ("emb_b", vp), ("dimension", C.c_int),
+                ("tw_split", vp * 5)]
 
 
 class Layer(C.Structure):
@@ -108,7 +110,7 @@ SIGNATURES = {
                                      C.c_int, vp, C.c_int]),
     # kernel-level entry points
     "dz_k_convgemm": (C.c_int, [vp, vp, vp]),
-    "dz_k_gemm_bx3": (C.c_int, [vp, vp, vp]),
+    "dz_k_gemm_split": (C.c_int, [vp, vp, vp]),
     "dz_k_convgemm_ntile": (C.c_int, [C.c_int]),
     "dz_k_wave_stats": (C.c_int, [vp, vp, C.c_longlong, C.c_int, C.c_int, vp, vp]),
     "dz_k_sinc_conv0": (C.c_int, [vp, vp, C.c_longlong, C.c_int, C.c_int, vp, C.c_float,

@@ -214,6 +214,15 @@ static int run_sincnet(const dz_sincnet_weights& w, const SincGeom& g, const Sin
     return dz_launch_finalize_norm(s.part2, B, g.nt2, 64, g.P2, w.in2_g, w.in2_b, s.sc2, s.sh2, st);
 }
 
+// exact-f32 MFMA kernel, or the split-f16 kernel when the layer came with split planes
+static int run_gemm(DzConvGemm& p, const void* split, hipStream_t st) {
+    if (split) {
+        p.Wsplit = split;
+        return dz_launch_gemm_split(p, st);
+    }
+    return dz_launch_convgemm(p, st);
+}
+
 static int check_wave(const char* who, const float* d_wave, long long stride, int S) {
     DZ_REQUIRE(d_wave != nullptr, "%s: d_wave is NULL", who);
     DZ_REQUIRE(((uintptr_t)d_wave & 15) == 0 && (stride & 3) == 0,
@@ -316,7 +325,7 @@ extern "C" int dz_seg_forward(dz_seg* s, const float* d_wave, long long wave_str
             p.B = 1; p.Tin = p.Tout = p.Tstore = B * F; p.Cin = 256; p.K = 256; p.Kpad = 256;
             p.ldx = 256;
         }
-        { ProfScope ps(T_PROJ, st); if ((rc = dz_launch_convgemm(p, st))) return rc; }
+        { ProfScope ps(T_PROJ, st); if ((rc = run_gemm(p, s->w.wih_split[layer], st))) return rc; }
         float* hout = (layer & 1) ? s->h1 : s->h0;
         { ProfScope ps(T_REC, st);
           if ((rc = dz_launch_lstm(s->gx, s->w.whh[layer], hout, B, F, st))) return rc; }
@@ -329,10 +338,11 @@ extern "C" int dz_seg_forward(dz_seg* s, const float* d_wave, long long wave_str
     p.X = lin; p.W = s->w.lin0_w; p.bias = s->w.lin0_b; p.Y = s->m0;
     p.Cin = 256; p.K = 256; p.Kpad = 256; p.ldx = 256; p.Npad = 128; p.Nstore = 128; p.ldy = 128;
     p.epi = DZ_EPI_BIAS_LEAKY;
-    { ProfScope ps(T_MLP, st); if ((rc = dz_launch_convgemm(p, st))) return rc; }
+    { ProfScope ps(T_MLP, st); if ((rc = run_gemm(p, s->w.lin0_split, st))) return rc; }
     p.X = s->m0; p.W = s->w.lin1_w; p.bias = s->w.lin1_b; p.Y = s->m1;
     p.Cin = 128; p.K = 128; p.Kpad = 128; p.ldx = 128;
-    { ProfScope ps(T_MLP, st); if ((rc = dz_launch_convgemm(p, st))) return rc; }
+    { ProfScope ps(T_MLP, st); if ((rc = run_gemm(p, s->w.lin1_split, st))) return rc; }
+    p.Wsplit = nullptr;
     p.X = s->m1; p.W = s->w.cls_w; p.bias = s->w.cls_b;
     p.Npad = 64; p.Nstore = s->w.num_classes; p.ldy = s->w.num_classes;
     if (s->w.powerset) {
@@ -367,9 +377,11 @@ static const int kEmbSplit = 16;  // split-K of Linear(3000, 512): 8 tiles -> 12
 
 static void emb_carve(dz_emb* e, Arena& a) {
     e->ss.carve(a, e->g, e->Bm);
-    e->a = a.take((size_t)e->Bm * e->T[0] * 512);
-    e->b = a.take((size_t)e->Bm * e->T[0] * 512);
-    e->x5 = a.take((size_t)e->Bm * e->T[4] * 1536);
+    // every TDNN activation keeps the row pitch of the network input (P2 = 293 frames per chunk,
+    // the first T[i] rows valid): layers 2..5 then run as ONE flattened GEMM over Bm * P2 rows
+    e->a = a.take((size_t)e->Bm * e->g.P2 * 512);
+    e->b = a.take((size_t)e->Bm * e->g.P2 * 512);
+    e->x5 = a.take((size_t)e->Bm * e->g.P2 * 1536);
     e->pooled = a.take((size_t)e->Bm * kMaxSpk * kPoolLd);
     e->parts = a.take((size_t)kEmbSplit * e->Bm * kMaxSpk * 512);
 }
@@ -420,25 +432,33 @@ static int emb_frames(dz_emb* e, const float* d_wave, long long stride, int B, h
     if ((rc = run_sincnet(e->w.sinc, e->g, e->ss, d_wave, stride, B, st))) return rc;
     const int cin[5] = {64, 512, 512, 512, 512};
     const int npad[5] = {512, 512, 512, 512, 1536};
+    // Row pitch P = P2 for every activation.  tdnn1 normalises on load with per-chunk statistics, so
+    // it runs per chunk; tdnn2..5 run flattened over all B * P rows: a row whose taps reach past
+    // the valid frames of its chunk (t >= T[i]) computes garbage that no valid row ever reads (a
+    // valid output row t < T[i] reads input rows t + tap * dil < T[i-1] of the same chunk), in
+    // exchange the M tiles are 95 % full instead of 73 % (279 rows in 3 x 128).
     const float* in = e->ss.y2;
-    int tin = e->g.P2;
+    const int P = e->g.P2;
     for (int i = 0; i < 5; ++i) {
         DzConvGemm p;
         memset(&p, 0, sizeof(p));
         float* outp = (i == 4) ? e->x5 : ((i & 1) ? e->b : e->a);
+        const int span = (kTdnnTaps[i] - 1) * kTdnnDil[i];
         p.X = in; p.W = e->w.tw[i]; p.bias = e->w.tb[i]; p.e0 = e->w.ts[i]; p.e1 = e->w.th[i];
         p.Y = outp;
-        p.B = B; p.Tin = tin; p.Tout = p.Tstore = e->T[i]; p.Cin = cin[i]; p.taps = kTdnnTaps[i];
+        p.Cin = cin[i]; p.taps = kTdnnTaps[i];
         p.dil = kTdnnDil[i]; p.K = cin[i] * kTdnnTaps[i]; p.Kpad = (p.K + 31) / 32 * 32;
         p.Npad = npad[i]; p.Nstore = npad[i]; p.ldx = cin[i]; p.ldy = npad[i];
-        p.xbs = (long long)tin * cin[i]; p.ybs = (long long)e->T[i] * npad[i];
         p.epi = DZ_EPI_TDNN;
         if (i == 0) {
+            p.B = B; p.Tin = P; p.Tout = p.Tstore = e->T[0];
+            p.xbs = (long long)P * cin[i]; p.ybs = (long long)P * npad[i];
             p.nscale = e->ss.sc2; p.nshift = e->ss.sh2; p.nld = 64; p.norm_on_load = 1;
+        } else {
+            p.B = 1; p.Tin = B * P; p.Tout = p.Tstore = B * P - span;
         }
-        { ProfScope ps(T_TDNN1 + i, st); if ((rc = dz_launch_convgemm(p, st))) return rc; }
+        { ProfScope ps(T_TDNN1 + i, st); if ((rc = run_gemm(p, e->w.tw_split[i], st))) return rc; }
         in = outp;
-        tin = e->T[i];
     }
     return 0;
 }
@@ -447,8 +467,8 @@ static int emb_head(dz_emb* e, const float* d_weights, int Fw, int rows, int row
                     int normalize, float* d_out, hipStream_t st) {
     int rc;
     { ProfScope ps(T_POOL, st);
-    if ((rc = dz_launch_stats_pool(e->x5, e->T[4], 1500, 1536, d_weights, Fw, rows, rows_per_x,
-                                   e->pooled, kPoolLd, st)))
+    if ((rc = dz_launch_stats_pool(e->x5, (long long)e->g.P2 * 1536, e->T[4], 1500, 1536, d_weights, Fw,
+                                   rows, rows_per_x, e->pooled, kPoolLd, st)))
         return rc; }
     DzConvGemm p;
     memset(&p, 0, sizeof(p));
@@ -561,10 +581,10 @@ extern "C" int dz_k_convgemm(dz_ctx* ctx, const dz_convgemm_desc* d, void* strea
     DZ_HIP(hipSetDevice(ctx->device));
     return dz_launch_convgemm(*d, (hipStream_t)stream);
 }
-extern "C" int dz_k_gemm_bx3(dz_ctx* ctx, const dz_convgemm_desc* d, void* stream) {
-    DZ_REQUIRE(ctx && d, "dz_k_gemm_bx3: NULL argument");
+extern "C" int dz_k_gemm_split(dz_ctx* ctx, const dz_convgemm_desc* d, void* stream) {
+    DZ_REQUIRE(ctx && d, "dz_k_gemm_split: NULL argument");
     DZ_HIP(hipSetDevice(ctx->device));
-    return dz_launch_gemm_bx3(*d, (hipStream_t)stream);
+    return dz_launch_gemm_split(*d, (hipStream_t)stream);
 }
 extern "C" int dz_k_convgemm_ntile(int t_out) { return dz_convgemm_ntile(t_out); }
 extern "C" int dz_k_wave_stats(dz_ctx* ctx, const float* d_wave, long long stride, int batch,
@@ -610,7 +630,7 @@ extern "C" int dz_k_stats_pool(dz_ctx* ctx, const float* d_x, int frames, int ch
     DZ_REQUIRE(ctx && d_x && d_out, "dz_k_stats_pool: NULL argument");
     DZ_REQUIRE(rows >= 1 && rows_per_x >= 1 && frames >= 2, "dz_k_stats_pool: empty input");
     DZ_HIP(hipSetDevice(ctx->device));
-    return dz_launch_stats_pool(d_x, frames, channels, ldx, d_weights,
+    return dz_launch_stats_pool(d_x, (long long)frames * ldx, frames, channels, ldx, d_weights,
                                 d_weights ? weight_frames : frames, rows, rows_per_x, d_out, ldo,
                                 (hipStream_t)stream);
 }

@@ -84,9 +84,9 @@ int dz_launch_finalize_norm(const float* partials, int B, int ntile, int C, int 
 // k_convgemm.hip ------------------------------------------------------------
 typedef dz_convgemm_desc DzConvGemm;
 int dz_launch_convgemm(const DzConvGemm& p, hipStream_t st);
-// k_gemm_bx3.hip: the same contraction on the bf16 matrix cores with both operands split into
-// (hi, lo) bf16 pairs — 3 MFMAs per product, f32 accumulation
-int dz_launch_gemm_bx3(const DzConvGemm& p, hipStream_t st);
+// k_gemm_split.hip: the same contraction on the f16 matrix cores with both operands split into
+// (hi, lo) f16 pairs — 3 MFMAs per product, f32 accumulation
+int dz_launch_gemm_split(const DzConvGemm& p, hipStream_t st);
 int dz_convgemm_ntile(int Tout);
 
 // k_lstm.hip ----------------------------------------------------------------
@@ -95,10 +95,12 @@ int dz_convgemm_ntile(int Tout);
 int dz_launch_lstm(const float* gx, const float* whh, float* hout, int B, int T, hipStream_t st);
 
 // k_pool.hip ----------------------------------------------------------------
-// weighted statistics pooling; X [nx][T][ldx] (C valid channels), weights [rows][Fw] or null,
-// row r pools X[r / rows_per_x]; out [rows][ldo] = mean | std (std at column C)
-int dz_launch_stats_pool(const float* X, int T, int C, int ldx, const float* weights, int Fw,
-                         int rows, int rows_per_x, float* out, int ldo, hipStream_t st);
+// weighted statistics pooling; X: nx chunks `xstride` floats apart, each [T][ldx] (C valid
+// channels), weights [rows][Fw] or null, row r pools chunk r / rows_per_x;
+// out [rows][ldo] = mean | std (std at column C)
+int dz_launch_stats_pool(const float* X, long long xstride, int T, int C, int ldx,
+                         const float* weights, int Fw, int rows, int rows_per_x, float* out, int ldo,
+                         hipStream_t st);
 int dz_launch_osp(const float* seg, int B, int F, int K, float gamma, float beta, int normalize,
                   int speaker_major, float* out, hipStream_t st);
 int dz_launch_l2norm(float* x, int rows, int dim, float norm, hipStream_t st);

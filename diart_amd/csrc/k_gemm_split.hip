@@ -1,26 +1,32 @@
-// Implicit-GEMM 1-D convolution / linear layer on the bf16 matrix cores with split operands.
+// Implicit-GEMM 1-D convolution / linear layer on the f16 matrix cores with split operands.
 //
 //   Y[b][t][n] = epi( sum_{tap,c} pro(X[b][t + tap*dil][c]) * W[n][tap*Cin + c] + bias[n] )
 //
-// Same contraction, descriptor and epilogues as k_convgemm.hip (exact-f32 MFMA, 157 TFLOP/s peak),
-// computed 5.3x closer to the metal: every f32 operand is split into two bf16 numbers
-//     x = hi + lo,   hi = bf16_rne(x),   lo = bf16_rne(x - hi)          (16 mantissa bits kept)
-// and the product is accumulated in f32 from three bf16 MFMAs
-//     x*w ~= hi_x*hi_w + hi_x*lo_w + lo_x*hi_w                          (lo*lo ~ 2^-18 dropped)
-// on v_mfma_f32_32x32x16_bf16 (2.5 PFLOP/s dense -> 833 TFLOP/s of split products).  Relative
-// error per product <= 2^-16: 50x tighter than the TF32 (10-bit mantissa) arithmetic PyTorch's
-// cuDNN convolutions and LSTMs use by default on the reference's own GPU path.
+// Same contraction, descriptor and epilogues as k_convgemm.hip (exact-f32 MFMA, 157 TFLOP/s peak)
+// on the 16x faster half-precision matrix pipe, without giving up f32-grade operands: every f32
+// operand is split into two f16 numbers
+//     x = hi + lo * 2^-11,   hi = f16(x),   lo = f16((x - hi) * 2^11)       (22 mantissa bits kept;
+//                                                        x - hi is exact, the scale is a power of 2)
+// and the product is accumulated in f32 from three f16 MFMAs into two accumulators
+//     main  += hi_x * hi_w
+//     cross += hi_x * lo_w + lo_x * hi_w        (lo*lo ~ 2^-22 relative, dropped)
+//     x*w   ~= main + cross * 2^-11
+// on v_mfma_f32_32x32x16_f16 (2.5 PFLOP/s dense -> 833 TFLOP/s of split products).  The scaled low
+// part keeps lo a NORMAL f16 for every |x| >= 2^-14 (an unscaled lo would be subnormal below
+// |x| = 0.125).  Operand error <= 2^-22 relative: the same order as f32's own rounding (2^-24) and
+// far below the summation-order noise of any f32 GEMM; inputs are clamped to the f16 range
+// (+-65504; the networks' GEMM inputs are normalised activations, |x| = O(1..10)).
 //
 // Tile: 128 rows x 128 cols x 32 k per step, 8 waves (4 x 2), wave tile 32 x 64 = 1 x 2 MFMA
 // blocks; per k-step of 16 a wave reads 2 A and 4 B fragments (hi / lo, one ds_read_b128 each)
 // and issues 6 MFMAs.  Two workgroups per CU = 4 waves per SIMD: the MFMAs of three waves cover
 // the global-load latency of the fourth (with 4 waves per workgroup the kernel sat in s_waitcnt
-// for 39 % of its wave cycles; rocprofv3 SQ_WAIT_ANY).  LDS holds four bf16 planes per stage (A hi, A lo,
-// B hi, B lo; [row][32 k] = 64 B rows, 16-byte chunks XOR-swizzled with (row >> 2) & 3 so the 16
-// lanes of a ds_read_b128 phase hit 16 distinct 16-byte slots), double buffered: 64 KiB, two
-// workgroups per CU.  Activations are f32 in HBM: they are split on the way into LDS
-// (v_cvt_pk_bf16_f32, 3 VALU ops per element, hidden under the MFMAs of the other waves); weights
-// are split once on the host (weights.py split_bf16) and arrive as two bf16 planes.
+// for 39 % of its wave cycles; rocprofv3 SQ_WAIT_ANY).  LDS holds four f16 planes per stage (A hi,
+// A lo, B hi, B lo; [row][32 k] = 64 B rows, 16-byte chunks XOR-swizzled with (row >> 2) & 3 so the
+// 16 lanes of a ds_read_b128 phase hit 16 distinct 16-byte slots: SQ_LDS_BANK_CONFLICT = 0),
+// double buffered: 64 KiB.  Activations are f32 in HBM: they are split on the way into LDS
+// (v_cvt_pk_f16_f32, ~4 VALU ops per element, hidden under the MFMAs of the other waves); weights
+// are split once on the host (weights.py split_f16) and arrive as two f16 planes.
 // The (lane -> k) assignment inside a fragment is the same for A and B (8 consecutive k per lane,
 // lanes 32..63 take the upper 8 of a 16-wide k-step), so the contraction is correct for any
 // hardware k-ordering; the C/D map is cdna_hip_programming.md "Fragment layout".
@@ -28,8 +34,8 @@
 
 namespace {
 
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
@@ -45,23 +51,23 @@ __device__ __forceinline__ float leaky(float v) { return v > 0.f ? v : v * DZ_LE
 __device__ __forceinline__ int chunk_off(int row, int cidx) {
     return row * 64 + ((cidx ^ ((row >> 2) & 3)) << 4);
 }
-__device__ __forceinline__ unsigned pack_bf16(float a, float b) {
-    const f32x2 v = {a, b};
-    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
-}
-// 8 floats -> 8 bf16 hi + 8 bf16 lo
+constexpr float LO_SCALE = 2048.f, LO_UNSCALE = 1.f / 2048.f;
+constexpr float F16_MAX = 65504.f;
+// 8 floats -> 8 f16 hi + 8 f16 lo (lo scaled by 2^11)
 __device__ __forceinline__ void split8(const float* v, u32x4& hi, u32x4& lo) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-        const unsigned ph = pack_bf16(v[2 * e], v[2 * e + 1]);
-        const float f0 = __uint_as_float(ph << 16), f1 = __uint_as_float(ph & 0xffff0000u);
-        hi[e] = ph;
-        lo[e] = pack_bf16(v[2 * e] - f0, v[2 * e + 1] - f1);
+        const f32x2 x = {__builtin_amdgcn_fmed3f(v[2 * e], -F16_MAX, F16_MAX),
+                         __builtin_amdgcn_fmed3f(v[2 * e + 1], -F16_MAX, F16_MAX)};
+        const f16x2 h = __builtin_convertvector(x, f16x2);
+        const f32x2 r = (x - __builtin_convertvector(h, f32x2)) * LO_SCALE;
+        hi[e] = __builtin_bit_cast(unsigned, h);
+        lo[e] = __builtin_bit_cast(unsigned, __builtin_convertvector(r, f16x2));
     }
 }
 
 template <bool PRO, int EPI>
-__global__ __launch_bounds__(512) void gemm_bx3_kernel(DzConvGemm p) {
+__global__ __launch_bounds__(512) void gemm_split_kernel(DzConvGemm p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     int bx, by, b;
@@ -137,39 +143,38 @@ __global__ __launch_bounds__(512) void gemm_bx3_kernel(DzConvGemm p) {
     // ---- MFMA coordinates ------------------------------------------------------------
     const int w = tid >> 6, l = tid & 63, li = l & 31, g = l >> 5;
     const int wm = w >> 1, wn = w & 1;       // 4 x 2 waves, wave tile 32 x 64
-    f32x16 acc[2];
+    f32x16 accm[2], accx[2];                 // hi*hi | cross terms (scaled by 2^11)
 #pragma unroll
     for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[nb][r] = 0.f;
+        for (int r = 0; r < 16; ++r) accm[nb][r] = accx[nb][r] = 0.f;
 
     const int nk = p.Kpad / KT;
     auto compute = [&](int buf) {
         const char* st = smem + buf * STAGE;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            bf16x8 ah, al, bh[2], bl[2];
+            f16x8 ah, al, bh[2], bl[2];
             {
                 const int off = chunk_off(wm * 32 + li, 2 * ks + g);
-                ah = *reinterpret_cast<const bf16x8*>(st + off);
-                al = *reinterpret_cast<const bf16x8*>(st + PLANE + off);
+                ah = *reinterpret_cast<const f16x8*>(st + off);
+                al = *reinterpret_cast<const f16x8*>(st + PLANE + off);
             }
 #pragma unroll
             for (int nb = 0; nb < 2; ++nb) {
                 const int off = chunk_off(wn * 64 + nb * 32 + li, 2 * ks + g);
-                bh[nb] = *reinterpret_cast<const bf16x8*>(st + 2 * PLANE + off);
-                bl[nb] = *reinterpret_cast<const bf16x8*>(st + 3 * PLANE + off);
+                bh[nb] = *reinterpret_cast<const f16x8*>(st + 2 * PLANE + off);
+                bl[nb] = *reinterpret_cast<const f16x8*>(st + 3 * PLANE + off);
             }
-            // small cross terms first, the dominant hi*hi term last
 #pragma unroll
             for (int nb = 0; nb < 2; ++nb)
-                acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[nb], acc[nb], 0, 0, 0);
+                accx[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[nb], accx[nb], 0, 0, 0);
 #pragma unroll
             for (int nb = 0; nb < 2; ++nb)
-                acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[nb], acc[nb], 0, 0, 0);
+                accm[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[nb], accm[nb], 0, 0, 0);
 #pragma unroll
             for (int nb = 0; nb < 2; ++nb)
-                acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[nb], acc[nb], 0, 0, 0);
+                accx[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[nb], accx[nb], 0, 0, 0);
         }
     };
     // one k-tile per step: the global loads of tile kt + 1 are issued before the MFMAs of tile kt
@@ -204,7 +209,7 @@ __global__ __launch_bounds__(512) void gemm_bx3_kernel(DzConvGemm p) {
             for (int r = 0; r < 16; ++r) {
                 const int t = t0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
                 if (t < p.Tout) {
-                    float v = acc[nb][r] + bv;
+                    float v = (accm[nb][r] + accx[nb][r] * LO_UNSCALE) + bv;
                     if (EPI == DZ_EPI_BIAS_LEAKY) v = leaky(v);
                     if (EPI == DZ_EPI_TDNN) v = leaky(v) * e0 + e1;
                     Yb[(long long)t * p.ldy + n] = v;
@@ -218,41 +223,41 @@ template <bool PRO, int EPI>
 int launch(const DzConvGemm& p, hipStream_t st) {
     static bool attr_set = false;
     if (!attr_set) {
-        DZ_HIP(hipFuncSetAttribute((const void*)gemm_bx3_kernel<PRO, EPI>,
+        DZ_HIP(hipFuncSetAttribute((const void*)gemm_split_kernel<PRO, EPI>,
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES));
         attr_set = true;
     }
     dim3 grid((p.Tout + BM - 1) / BM, p.Npad / BN, p.B);
-    hipLaunchKernelGGL((gemm_bx3_kernel<PRO, EPI>), grid, dim3(512), LDS_BYTES, st, p);
+    hipLaunchKernelGGL((gemm_split_kernel<PRO, EPI>), grid, dim3(512), LDS_BYTES, st, p);
     DZ_HIP(hipGetLastError());
     return 0;
 }
 
 }  // namespace
 
-int dz_launch_gemm_bx3(const DzConvGemm& p, hipStream_t st) {
-    DZ_REQUIRE(p.Wsplit != nullptr, "gemm_bx3: Wsplit (bf16 hi/lo planes of W) is NULL");
+int dz_launch_gemm_split(const DzConvGemm& p, hipStream_t st) {
+    DZ_REQUIRE(p.Wsplit != nullptr, "gemm_split: Wsplit (f16 hi/lo planes of W) is NULL");
     DZ_REQUIRE(p.Kpad % KT == 0 && p.Cin % 8 == 0 && p.ldx % 4 == 0 && p.K % 8 == 0,
-               "gemm_bx3: bad K/Cin/ldx (Cin and K must be multiples of 8)");
-    DZ_REQUIRE(p.K <= p.Kpad && p.K == p.taps * p.Cin, "gemm_bx3: K mismatch");
+               "gemm_split: bad K/Cin/ldx (Cin and K must be multiples of 8)");
+    DZ_REQUIRE(p.K <= p.Kpad && p.K == p.taps * p.Cin, "gemm_split: K mismatch");
     DZ_REQUIRE(p.pad == 0 && p.X2 == nullptr && p.rowbias == nullptr && p.ksplit <= 1,
-               "gemm_bx3: padding / second input / row bias / split-K are f32-path features");
-    DZ_REQUIRE(p.Tout > 0 && p.Tout == p.Tin - (p.taps - 1) * p.dil, "gemm_bx3: Tout mismatch");
-    DZ_REQUIRE(p.Npad % BN == 0, "gemm_bx3: Npad must be a multiple of 128");
+               "gemm_split: padding / second input / row bias / split-K are f32-path features");
+    DZ_REQUIRE(p.Tout > 0 && p.Tout == p.Tin - (p.taps - 1) * p.dil, "gemm_split: Tout mismatch");
+    DZ_REQUIRE(p.Npad % BN == 0, "gemm_split: Npad must be a multiple of 128");
     const bool pro = p.norm_on_load != 0;
-#define DZ_BX(PRO, EPI) return launch<PRO, EPI>(p, st)
+#define DZ_SP(PRO, EPI) return launch<PRO, EPI>(p, st)
     switch (p.epi) {
         case DZ_EPI_TDNN:
-            if (pro) DZ_BX(true, DZ_EPI_TDNN);
-            DZ_BX(false, DZ_EPI_TDNN);
+            if (pro) DZ_SP(true, DZ_EPI_TDNN);
+            DZ_SP(false, DZ_EPI_TDNN);
         case DZ_EPI_BIAS:
-            if (pro) DZ_BX(true, DZ_EPI_BIAS);
-            DZ_BX(false, DZ_EPI_BIAS);
+            if (pro) DZ_SP(true, DZ_EPI_BIAS);
+            DZ_SP(false, DZ_EPI_BIAS);
         case DZ_EPI_BIAS_LEAKY:
-            DZ_REQUIRE(!pro, "gemm_bx3: BIAS_LEAKY has no norm-on-load instance");
-            DZ_BX(false, DZ_EPI_BIAS_LEAKY);
+            DZ_REQUIRE(!pro, "gemm_split: BIAS_LEAKY has no norm-on-load instance");
+            DZ_SP(false, DZ_EPI_BIAS_LEAKY);
     }
-#undef DZ_BX
-    dz_set_error("gemm_bx3: epilogue %d is not built on the split-bf16 path", p.epi);
+#undef DZ_SP
+    dz_set_error("gemm_split: epilogue %d is not built on the split-f16 path", p.epi);
     return 2;
 }

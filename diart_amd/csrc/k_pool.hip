@@ -18,8 +18,8 @@ namespace {
 // ---------------------------------------------------------------------------
 template <int K>
 __global__ __launch_bounds__(256) void stats_pool_kernel(
-    const float* __restrict__ X, int T, int C, int ldx, const float* __restrict__ weights, int Fw,
-    int ktot, int kofs, float* __restrict__ out, int ldo) {
+    const float* __restrict__ X, long long xstride, int T, int C, int ldx,
+    const float* __restrict__ weights, int Fw, int ktot, int kofs, float* __restrict__ out, int ldo) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* xs = smem;                 // [T][64]
     float* wk = xs + T * 64;          // [K][T]
@@ -27,7 +27,7 @@ __global__ __launch_bounds__(256) void stats_pool_kernel(
     const int c0 = blockIdx.x * 64, xi = blockIdx.y, tid = threadIdx.x;
     const int c = tid & 63, ph = tid >> 6;
 
-    const float* Xb = X + (long long)xi * T * ldx;
+    const float* Xb = X + (long long)xi * xstride;   // chunks may sit on a wider row pitch than T
     for (int idx = tid; idx < T * 64; idx += 256) {
         const int t = idx >> 6, cc = idx & 63;
         xs[idx] = (c0 + cc < C) ? Xb[(long long)t * ldx + c0 + cc] : 0.f;
@@ -116,14 +116,14 @@ __global__ __launch_bounds__(256) void stats_pool_kernel(
 }
 
 template <int K>
-int launch_pool(const float* X, int T, int C, int ldx, const float* weights, int Fw, int nx,
+int launch_pool(const float* X, long long xstride, int T, int C, int ldx, const float* weights, int Fw, int nx,
                 int ktot, int kofs, float* out, int ldo, hipStream_t st) {
     const size_t lds = sizeof(float) * ((size_t)T * 64 + (size_t)K * T + 4 * K * 64);
     DZ_REQUIRE(lds <= 160 * 1024, "stats_pool: %d frames do not fit in LDS", T);
     DZ_HIP(hipFuncSetAttribute((const void*)stats_pool_kernel<K>,
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL((stats_pool_kernel<K>), dim3((C + 63) / 64, nx), dim3(256), lds, st, X, T, C,
-                       ldx, weights, Fw, ktot, kofs, out, ldo);
+    hipLaunchKernelGGL((stats_pool_kernel<K>), dim3((C + 63) / 64, nx), dim3(256), lds, st, X, xstride,
+                       T, C, ldx, weights, Fw, ktot, kofs, out, ldo);
     DZ_HIP(hipGetLastError());
     return 0;
 }
@@ -315,8 +315,9 @@ __global__ __launch_bounds__(256) void cdist_kernel(const float* __restrict__ em
 
 }  // namespace
 
-int dz_launch_stats_pool(const float* X, int T, int C, int ldx, const float* weights, int Fw,
-                         int rows, int rows_per_x, float* out, int ldo, hipStream_t st) {
+int dz_launch_stats_pool(const float* X, long long xstride, int T, int C, int ldx,
+                         const float* weights, int Fw, int rows, int rows_per_x, float* out, int ldo,
+                         hipStream_t st) {
     DZ_REQUIRE(rows % rows_per_x == 0, "stats_pool: rows %% rows_per_x != 0");
     const int nx = rows / rows_per_x;
     int kofs = 0;
@@ -324,10 +325,10 @@ int dz_launch_stats_pool(const float* X, int T, int C, int ldx, const float* wei
         const int kk = rows_per_x - kofs >= 4 ? 4 : rows_per_x - kofs;
         int rc;
         switch (kk) {
-            case 4: rc = launch_pool<4>(X, T, C, ldx, weights, Fw, nx, rows_per_x, kofs, out, ldo, st); break;
-            case 3: rc = launch_pool<3>(X, T, C, ldx, weights, Fw, nx, rows_per_x, kofs, out, ldo, st); break;
-            case 2: rc = launch_pool<2>(X, T, C, ldx, weights, Fw, nx, rows_per_x, kofs, out, ldo, st); break;
-            default: rc = launch_pool<1>(X, T, C, ldx, weights, Fw, nx, rows_per_x, kofs, out, ldo, st); break;
+            case 4: rc = launch_pool<4>(X, xstride, T, C, ldx, weights, Fw, nx, rows_per_x, kofs, out, ldo, st); break;
+            case 3: rc = launch_pool<3>(X, xstride, T, C, ldx, weights, Fw, nx, rows_per_x, kofs, out, ldo, st); break;
+            case 2: rc = launch_pool<2>(X, xstride, T, C, ldx, weights, Fw, nx, rows_per_x, kofs, out, ldo, st); break;
+            default: rc = launch_pool<1>(X, xstride, T, C, ldx, weights, Fw, nx, rows_per_x, kofs, out, ldo, st); break;
         }
         if (rc) return rc;
         kofs += kk;

@@ -34,6 +34,19 @@ from .weights import PackedEcapa, PackedEmbedding, PackedSegmentation
 StateSource = Union[str, Path, Dict[str, torch.Tensor]]
 
 
+def default_precision() -> str:
+    """Arithmetic of the GEMM-shaped layers when a model does not say: ``DZ_PRECISION`` or "f16x3"
+    (f32 operands split into two f16 numbers = 22 mantissa bits, three f16 MFMAs per product, f32
+    accumulation: measured against the f32 oracle it is indistinguishable from "f32", the exact-f32
+    MFMA path, and 2x faster; weights.PRECISIONS)."""
+    import os
+    from .weights import PRECISIONS
+    p = os.environ.get("DZ_PRECISION", "f16x3")
+    if p not in PRECISIONS:
+        raise ValueError(f"DZ_PRECISION={p!r}: expected one of {PRECISIONS}")
+    return p
+
+
 def _read_state(src: StateSource) -> Dict[str, torch.Tensor]:
     """A state dict, or a file holding one (plain, or a Lightning checkpoint's 'state_dict')."""
     if isinstance(src, dict):
@@ -131,16 +144,18 @@ class HipSegmentation(_HipModule):
     (hard {0,1} multilabel when ``powerset``) — the callable behind
     ``SegmentationModel.__call__`` (reference models.py:188-198)."""
 
-    def __init__(self, state: Dict[str, torch.Tensor], max_batch: int = 64, powerset: bool = False):
+    def __init__(self, state: Dict[str, torch.Tensor], max_batch: int = 64, powerset: bool = False,
+                 precision: Optional[str] = None):
         super().__init__(state, max_batch)
         self.powerset = bool(powerset)
+        self.precision = default_precision() if precision is None else precision
         self.num_speakers: Optional[int] = None
 
     def _extra_state(self):
-        return {"powerset": self.powerset}
+        return {"powerset": self.powerset, "precision": self.precision}
 
     def _pack(self, device):
-        p = PackedSegmentation(self._state, device, powerset=self.powerset)
+        p = PackedSegmentation(self._state, device, powerset=self.powerset, precision=self.precision)
         self.num_speakers = p.num_speakers
         return p
 
@@ -181,14 +196,15 @@ class HipEmbedding(_HipModule):
 
     dimension = 512
 
-    def __init__(self, state: Dict[str, torch.Tensor], max_batch: int = 64):
+    def __init__(self, state: Dict[str, torch.Tensor], max_batch: int = 64, precision: Optional[str] = None):
         super().__init__(state, max_batch)
+        self.precision = default_precision() if precision is None else precision
 
     def _extra_state(self):
-        return {}
+        return {"precision": self.precision}
 
     def _pack(self, device):
-        return PackedEmbedding(self._state, device)
+        return PackedEmbedding(self._state, device, precision=self.precision)
 
     def _create(self, num_samples, cap):
         h = _lib.vp()
@@ -309,26 +325,28 @@ class HipEcapaEmbedding(_HipModule):
 # loaders (picklable, no HIP state)
 # --------------------------------------------------------------------------- #
 class SegmentationLoader:
-    def __init__(self, state: StateSource, max_batch: int = 64, powerset: bool = False):
-        self.state, self.max_batch, self.powerset = state, max_batch, powerset
+    def __init__(self, state: StateSource, max_batch: int = 64, powerset: bool = False,
+                 precision: Optional[str] = None):
+        self.state, self.max_batch, self.powerset, self.precision = state, max_batch, powerset, precision
 
     def __call__(self) -> HipSegmentation:
-        return HipSegmentation(_read_state(self.state), self.max_batch, self.powerset)
+        return HipSegmentation(_read_state(self.state), self.max_batch, self.powerset, self.precision)
 
 
 class EmbeddingLoader:
     """``arch``: "xvector" (pyannote/embedding) or "ecapa" (speechbrain/spkrec-ecapa-voxceleb);
     None = decide from the checkpoint keys."""
 
-    def __init__(self, state: StateSource, max_batch: int = 64, arch: Optional[str] = None):
-        self.state, self.max_batch, self.arch = state, max_batch, arch
+    def __init__(self, state: StateSource, max_batch: int = 64, arch: Optional[str] = None,
+                 precision: Optional[str] = None):
+        self.state, self.max_batch, self.arch, self.precision = state, max_batch, arch, precision
 
     def __call__(self):
         sd = _read_state(self.state)
         arch = self.arch or ("ecapa" if any(k.startswith("asp.") for k in sd) else "xvector")
         if arch == "ecapa":
             return HipEcapaEmbedding(sd, self.max_batch)
-        return HipEmbedding(sd, self.max_batch)
+        return HipEmbedding(sd, self.max_batch, self.precision)
 
 
 # --------------------------------------------------------------------------- #
@@ -376,8 +394,9 @@ class SegmentationModel(LazyModel):
     from_onnx = staticmethod(_no_onnx)
 
     @staticmethod
-    def from_state(state: StateSource, max_batch: int = 64, powerset: bool = False) -> "SegmentationModel":
-        return SegmentationModel(SegmentationLoader(state, max_batch, powerset))
+    def from_state(state: StateSource, max_batch: int = 64, powerset: bool = False,
+                   precision: Optional[str] = None) -> "SegmentationModel":
+        return SegmentationModel(SegmentationLoader(state, max_batch, powerset, precision))
 
     @staticmethod
     def from_pyannote(model, use_hf_token=True) -> "SegmentationModel":
@@ -408,8 +427,9 @@ class EmbeddingModel(LazyModel):
     from_onnx = staticmethod(_no_onnx)
 
     @staticmethod
-    def from_state(state: StateSource, max_batch: int = 64, arch: Optional[str] = None) -> "EmbeddingModel":
-        return EmbeddingModel(EmbeddingLoader(state, max_batch, arch))
+    def from_state(state: StateSource, max_batch: int = 64, arch: Optional[str] = None,
+                   precision: Optional[str] = None) -> "EmbeddingModel":
+        return EmbeddingModel(EmbeddingLoader(state, max_batch, arch, precision))
 
     @staticmethod
     def from_pyannote(model, use_hf_token=True) -> "EmbeddingModel":

@@ -23,6 +23,10 @@ import torch
 from . import _lib
 
 BN_EPS = 1e-5
+# arithmetic of the GEMM-shaped layers: "f32" = exact-f32 MFMA (v_mfma_f32_16x16x4_f32);
+# "f16x3" = both operands split into (hi, lo) f16 pairs (22 mantissa bits), 3 f16 MFMAs per product, f32
+# accumulation (k_gemm_split.hip; ~2^-16 relative error per product)
+PRECISIONS = ("f32", "f16x3")
 
 
 def sinc_filters(low_hz_: torch.Tensor, band_hz_: torch.Tensor, window_: torch.Tensor,
@@ -72,13 +76,13 @@ def fold_sinc_filters(filt: torch.Tensor) -> torch.Tensor:
     return out
 
 
-def split_bf16(w: torch.Tensor) -> torch.Tensor:
-    """f32 matrix ``[N][K]`` -> int16 ``[2][N][K]``: plane 0 = bf16(w) (round to nearest even),
-    plane 1 = bf16(w - plane 0) — the two-term split ``k_gemm_bx3.hip`` multiplies with
-    (``w = hi + lo`` to 16 mantissa bits)."""
-    w = w.detach().float().cpu().contiguous()
-    hi = w.to(torch.bfloat16)
-    lo = (w - hi.float()).to(torch.bfloat16)
+def split_f16(w: torch.Tensor) -> torch.Tensor:
+    """f32 matrix ``[N][K]`` -> int16 ``[2][N][K]`` of IEEE f16 bit patterns: plane 0 ``hi = f16(w)``,
+    plane 1 ``lo = f16((w - hi) * 2^11)`` — the two-term split ``k_gemm_split.hip`` multiplies with
+    (``w = hi + lo * 2^-11`` to 22 mantissa bits; the scale keeps ``lo`` a normal f16)."""
+    w = w.detach().float().cpu().contiguous().clamp(-65504.0, 65504.0)
+    hi = w.to(torch.float16)
+    lo = ((w - hi.float()) * 2048.0).to(torch.float16)
     return torch.stack([hi, lo]).view(torch.int16).contiguous()
 
 
@@ -114,8 +118,14 @@ class _Packed:
         self.tensors.append(d)
         return d.data_ptr()
 
+    def put_split(self, t: torch.Tensor) -> int:
+        """The matrix as two f16 planes (hi, lo * 2^11) for the split-f16 GEMM path."""
+        d = split_f16(t).to(self.device)
+        self.tensors.append(d)
+        return d.data_ptr()
+
     def nbytes(self) -> int:
-        return sum(t.numel() * 4 for t in self.tensors)
+        return sum(t.numel() * t.element_size() for t in self.tensors)
 
 
 def _pack_sincnet(sd: Dict[str, torch.Tensor], pk: _Packed, prefix: str = "sincnet.") -> _lib.SincNetWeights:
@@ -141,7 +151,9 @@ class PackedSegmentation:
     """``dz_seg_weights`` + the tensors behind it."""
 
     def __init__(self, sd: Dict[str, torch.Tensor], device: torch.device, powerset: bool = False,
-                 num_speakers: int | None = None):
+                 num_speakers: int | None = None, precision: str = "f32"):
+        assert precision in PRECISIONS, precision
+        split = precision == "f16x3"
         pk = _Packed(device)
         g = lambda k: sd[k].detach().cpu().float()
         w = _lib.SegWeights()
@@ -150,6 +162,8 @@ class PackedSegmentation:
             wih = torch.cat([g(f"lstm.weight_ih_l{layer}"), g(f"lstm.weight_ih_l{layer}_reverse")], 0)
             kpad = 64 if layer == 0 else 256
             w.wih[layer] = pk.put(_pad2(wih, 1024, kpad))
+            if split:
+                w.wih_split[layer] = pk.put_split(_pad2(wih, 1024, kpad))
             bias = torch.cat([g(f"lstm.bias_ih_l{layer}") + g(f"lstm.bias_hh_l{layer}"),
                               g(f"lstm.bias_ih_l{layer}_reverse") + g(f"lstm.bias_hh_l{layer}_reverse")], 0)
             w.bih[layer] = pk.put(bias)
@@ -158,6 +172,8 @@ class PackedSegmentation:
             w.whh[layer] = pk.put(whh)
         w.lin0_w, w.lin0_b = pk.put(g("linear.0.weight")), pk.put(g("linear.0.bias"))
         w.lin1_w, w.lin1_b = pk.put(g("linear.1.weight")), pk.put(g("linear.1.bias"))
+        if split:
+            w.lin0_split, w.lin1_split = pk.put_split(g("linear.0.weight")), pk.put_split(g("linear.1.weight"))
         cls_w, cls_b = g("classifier.weight"), g("classifier.bias")
         ncls = cls_w.shape[0]
         w.cls_w, w.cls_b = pk.put(_pad2(cls_w, 64, 128)), pk.put(_pad1(cls_b, 64))
@@ -178,7 +194,9 @@ class PackedEmbedding:
 
     TDNN = [(64, 512, 512), (512, 512, 512), (512, 512, 512), (512, 512, 512), (512, 1500, 1536)]
 
-    def __init__(self, sd: Dict[str, torch.Tensor], device: torch.device):
+    def __init__(self, sd: Dict[str, torch.Tensor], device: torch.device, precision: str = "f32"):
+        assert precision in PRECISIONS, precision
+        split = precision == "f16x3"
         pk = _Packed(device)
         g = lambda k: sd[k].detach().cpu().float()
         w = _lib.EmbWeights()
@@ -188,6 +206,8 @@ class PackedEmbedding:
             assert cw.shape[0] == cout
             k = cw.shape[2] * cin_pad
             w.tw[i] = pk.put(_conv_pack(cw, cin_pad, npad, (k + 31) // 32 * 32))
+            if split:
+                w.tw_split[i] = pk.put_split(_conv_pack(cw, cin_pad, npad, (k + 31) // 32 * 32))
             w.tb[i] = pk.put(_pad1(g(f"tdnns.{3 * i}.bias"), npad))
             bn = f"tdnns.{3 * i + 2}."
             scale = g(bn + "weight") / torch.sqrt(g(bn + "running_var") + BN_EPS)

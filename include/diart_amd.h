@@ -73,6 +73,11 @@ typedef struct {
     int num_classes;             /* K (multilabel) or 7 (powerset)                   */
     int powerset;                /* 1: log-softmax -> hard multilabel (models.py:29-39) */
     int num_speakers;            /* speakers of the multilabel output (3)            */
+    /* split-f16 matrix path (optional; NULL = exact-f32 MFMA for that layer): the same matrices
+     * as two f16 planes [2][Npad][Kpad], hi = f16(W), lo = f16((W - hi) * 2^11) (weights.py split_f16) */
+    const void* wih_split[4];
+    const void* lin0_split;
+    const void* lin1_split;
 } dz_seg_weights;
 
 typedef struct {
@@ -84,6 +89,7 @@ typedef struct {
     const float* emb_w;          /* [512][3008]  Linear(3000, D), zero padded        */
     const float* emb_b;          /* [512] */
     int dimension;               /* D = 512 */
+    const void* tw_split[5];     /* split-f16 planes of tw[i] (optional, NULL = exact f32)     */
 } dz_emb_weights;
 
 /* ---- segmentation: replaces the callable behind SegmentationModel.__call__ --
@@ -209,12 +215,12 @@ typedef struct {
     int pad;              /* >0: "same" convolution, reflect padding of `pad` frames  */
     const float* X2;      /* optional second input with X's geometry, added on load   */
     const float* rowbias; /* optional [B][Npad] per-batch-item bias added to `bias`   */
-    const void* Wsplit;   /* split-bf16 path: W as two bf16 planes [2][Npad][Kpad], hi = bf16(W),
-                             lo = bf16(W - hi) (weights.py split_bf16); NULL on the f32 path   */
+    const void* Wsplit;   /* split-f16 path: W as two f16 planes [2][Npad][Kpad], hi = f16(W),
+                             lo = f16((W - hi) * 2^11) (weights.py split_f16); NULL on the f32 path   */
 } dz_convgemm_desc;
 int dz_k_convgemm(dz_ctx* ctx, const dz_convgemm_desc* desc, void* stream);
-/* the same layer on the split-bf16 matrix-core path (desc->Wsplit must be set)       */
-int dz_k_gemm_bx3(dz_ctx* ctx, const dz_convgemm_desc* desc, void* stream);
+/* the same layer on the split-f16 matrix-core path (desc->Wsplit must be set)       */
+int dz_k_gemm_split(dz_ctx* ctx, const dz_convgemm_desc* desc, void* stream);
 int dz_k_convgemm_ntile(int t_out);
 int dz_k_wave_stats(dz_ctx* ctx, const float* d_wave, long long stride, int batch, int samples,
                     float* d_stats, void* stream);

@@ -35,8 +35,11 @@ def oracle_models():
     return s, e
 
 
-def test_segmentation_forward(gpu, chunks, oracle_models):
-    seg = M.SegmentationModel.from_state(synth_segmentation_state(), max_batch=8)
+@pytest.mark.parametrize("precision", ["f32", "f16x3"])
+def test_segmentation_forward(gpu, chunks, oracle_models, precision):
+    """Both arithmetic modes against the SAME gate: "f16x3" (split-f16 products on the half-precision
+    matrix cores for the LSTM projections and the MLP) is not given a looser tolerance."""
+    seg = M.SegmentationModel.from_state(synth_segmentation_state(), max_batch=8, precision=precision)
     seg.to(gpu)
     x = chunks[:7]
     with torch.no_grad():
@@ -44,7 +47,7 @@ def test_segmentation_forward(gpu, chunks, oracle_models):
     got = seg(x.to(gpu)).cpu()
     assert got.shape == ref.shape == (7, 293, 3)
     d = (got - ref).abs()
-    print("seg max|d|", d.max().item(), "mean|d|", d.mean().item())
+    print(precision, "seg max|d|", d.max().item(), "mean|d|", d.mean().item())
     assert d.max().item() < SEG_MAX and d.mean().item() < SEG_MEAN
     # batch invariance (README.md:430): B=1 and a strided rolling-window view give the same rows
     one = seg(x[3:4].to(gpu)).cpu()
@@ -56,8 +59,9 @@ def test_segmentation_forward(gpu, chunks, oracle_models):
     assert (got2 - got).abs().max().item() < 1e-6
 
 
-def test_embedding_forward_both_forms(gpu, chunks, oracle_models):
-    emb = M.EmbeddingModel.from_state(synth_embedding_state(), max_batch=16)
+@pytest.mark.parametrize("precision", ["f32", "f16x3"])
+def test_embedding_forward_both_forms(gpu, chunks, oracle_models, precision):
+    emb = M.EmbeddingModel.from_state(synth_embedding_state(), max_batch=16, precision=precision)
     emb.to(gpu)
     x = chunks[:4]
     g = torch.Generator().manual_seed(0)
@@ -73,7 +77,7 @@ def test_embedding_forward_both_forms(gpu, chunks, oracle_models):
     for got in (got_rows, got_multi):
         cos = torch.nn.functional.cosine_similarity(got.double(), ref.double(), dim=-1)
         rel = ((got - ref).norm(dim=-1) / ref.norm(dim=-1)).max().item()
-        print("emb cos min", cos.min().item(), "rel", rel)
+        print(precision, "emb cos min", cos.min().item(), "rel", rel)
         assert cos.min().item() >= EMB_COS and rel < 1e-4
     assert (got_rows - got_multi).abs().max().item() < 1e-5
     # no weights -> plain mean / unbiased std pooling

@@ -80,22 +80,22 @@ def convgemm(name, Bn, Tin, Cin, N, taps, dil, epi, Npad=None, pro=False, pool=F
     d.agroup = args.agroup
     flop = 2.0 * Bn * Tout * K * N
     timeit(name, lambda: _lib.check(lib.dz_k_convgemm(ctx, C.byref(d), st), name), flop=flop)
-    if not pool and not ksplit and Npad % 128 == 0 and (not only or name + "_bx3" in only or name in only):
-        from diart_amd.weights import split_bf16
-        ws = split_bf16(W.cpu()).to(dev)
+    if not pool and not ksplit and Npad % 128 == 0 and (not only or name + "_split" in only or name in only):
+        from diart_amd.weights import split_f16
+        ws = split_f16(W.cpu()).to(dev)
         y32 = Y.clone()
         Y.zero_()
         d.Wsplit = ws.data_ptr()
         keep.append(ws)
         only_saved = set(only)
         only.clear()
-        timeit(name + "_bx3", lambda: _lib.check(lib.dz_k_gemm_bx3(ctx, C.byref(d), st), name + "_bx3"), flop=flop)
+        timeit(name + "_split", lambda: _lib.check(lib.dz_k_gemm_split(ctx, C.byref(d), st), name + "_split"), flop=flop)
         only.update(only_saved)
         torch.cuda.synchronize()
         err = ((Y - y32).norm() / y32.norm()).item()
         mx = ((Y - y32).abs().max() / y32.abs().max()).item()
-        results[name + "_bx3"]["rel_l2_vs_f32"] = err
-        print(f"    {name}_bx3 vs f32 kernel: rel L2 {err:.2e}, max|d|/max|y| {mx:.2e}", flush=True)
+        results[name + "_split"]["rel_l2_vs_f32"] = err
+        print(f"    {name}_split vs f32 kernel: rel L2 {err:.2e}, max|d|/max|y| {mx:.2e}", flush=True)
     return keep
 
 
