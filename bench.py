@@ -52,7 +52,17 @@ SYMBOL = {
     "tdnn2": "convgemm_kernel<128, false, 3>", "tdnn3": "convgemm_kernel<128, false, 3>",
     "tdnn4": "convgemm_kernel<128, false, 3>", "tdnn5": "convgemm_kernel<128, false, 3>",
 }
+# the same layers on the split-f16 path (precision "f16x3", the default): k_gemm_split.hip
+SYMBOL_SPLIT = {
+    "conv1_pool": "gemm_split_kernel<3, 1, true, 4>", "conv2_pool": "gemm_split_kernel<3, 1, true, 4>",
+    "lstm_proj": "gemm_split_kernel<4, 2, false, 0>", "seg_mlp": "gemm_split_kernel<4, 2, false, 1>",
+    "tdnn1": "gemm_split_kernel<4, 2, true, 3>", "tdnn2": "gemm_split_kernel<4, 2, false, 3>",
+    "tdnn3": "gemm_split_kernel<4, 2, false, 3>", "tdnn4": "gemm_split_kernel<4, 2, false, 3>",
+    "tdnn5": "gemm_split_kernel<4, 2, false, 3>",
+}
 ALG_GFLOP_PER_CHUNK = 3.352   # 1.312 seg + 2.039 emb de-duplicated
+PEAK_F16_MATRIX_TFLOPS = 2500.0  # MI355X_MICROARCH.md: v_mfma_f32_32x32x16_f16, dense
+SPLIT_PRODUCTS = 3               # f16 MFMAs per algorithmic product on the split path
 PEAK_F32_MATRIX_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, dense
 PEAK_F32_FMA_TFLOPS = 78.6      # 256 CUs x 64 lanes x 2 FLOP x 2.4 GHz: v_fma_f32 (the packed form
                                 # measured no faster in the recurrence)
@@ -78,6 +88,9 @@ def parse():
     ap.add_argument("--cpu-worker", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--cpu-threads", type=int, default=8, help=argparse.SUPPRESS)
     ap.add_argument("--kernel-table", type=str, default="", help="write the per-kernel table here")
+    ap.add_argument("--precision", type=str, default="", help="f16x3 | f32 (default: DZ_PRECISION or f16x3)")
+    ap.add_argument("--no-exact-f32", action="store_true",
+                    help="skip the second, untimed-for-`value` pass on the exact-f32 MFMA path")
     return ap.parse_args()
 
 
@@ -190,11 +203,13 @@ def main():
     if args.cpu_worker:
         return cpu_baseline_worker(args.cpu_chunks, args.cpu_threads, 12.0)
     from diart_amd import _lib, distributed as D
-    from diart_amd.models import HipEmbedding, HipSegmentation
+    from diart_amd.models import HipEmbedding, HipSegmentation, default_precision
     from diart_amd.pipeline import StreamBatch
     from diart_amd.synth import synth_embedding_state, synth_segmentation_state, synth_streams
 
-    log("start")
+    precision = args.precision or default_precision()
+    symbol = dict(SYMBOL, **(SYMBOL_SPLIT if precision == "f16x3" else {}))
+    log(f"start (precision {precision})")
     from diart_amd.hostinfo import limit_host_threads
     limit_host_threads()
     rank, world, local = D.init_from_env()
@@ -225,16 +240,21 @@ def main():
     log("streams resident in HBM")
     assert audio.stride(0) % 4 == 0
 
-    pipe = StreamBatch(HipSegmentation(seg_state, max_batch=n), HipEmbedding(emb_state, max_batch=n),
-                       n, device=device, cluster_threads=min(8, os.cpu_count() or 1),
-                       tail=not args.no_tail)
+    def make_pipe(prec):
+        return StreamBatch(HipSegmentation(seg_state, max_batch=n, precision=prec),
+                           HipEmbedding(emb_state, max_batch=n, precision=prec),
+                           n, device=device, cluster_threads=min(8, os.cpu_count() or 1),
+                           tail=not args.no_tail)
+
+    pipe = make_pipe(precision)
 
     def window(t):
         return audio[:, t * hop: t * hop + S]
 
     host = {"launch": 0.0, "finish": 0.0}
 
-    def run(t_first, count):
+    def run(t_first, count, pipe=None):
+        pipe = pipe or main_pipe[0]
         prev = None
         for t in range(t_first, t_first + count):
             h0 = time.perf_counter()
@@ -246,6 +266,8 @@ def main():
             host["finish"] += time.perf_counter() - h1
             prev = tk
         pipe.finish(prev, want_scores=True)
+
+    main_pipe = [pipe]
 
     def barrier():
         if world > 1:
@@ -267,6 +289,29 @@ def main():
         f"{1e3 * host['launch'] / args.steps:.3f} ms, finish (wait + clustering + tail) "
         f"{1e3 * host['finish'] / args.steps:.3f} ms")
     lib.dz_prof_collect()
+    table = kernel_table(lib, n)          # read before dz_prof_enable(0) clears the accumulators
+    lib.dz_prof_enable(0)
+
+    # ---- the same job on the exact-f32 MFMA path, for the record (not `value`) -----------------
+    exact = None
+    if precision != "f32" and not args.no_exact_f32:
+        p32 = make_pipe("f32")
+        run(0, args.warmup, p32)
+        torch.cuda.synchronize()
+        barrier()
+        t1 = time.perf_counter()
+        run(args.warmup, args.steps, p32)
+        torch.cuda.synchronize()
+        barrier()
+        e32 = time.perf_counter() - t1
+        if world > 1:
+            t32 = torch.tensor([e32], dtype=torch.float64, device=device)
+            torch.distributed.all_reduce(t32, op=torch.distributed.ReduceOp.MAX)
+            e32 = float(t32.item())
+        exact = {"value": round(world * n * args.steps / e32 / 2, 2), "ms_per_step": round(1e3 * e32 / args.steps, 3),
+                 "note": "same job with precision='f32' (v_mfma_f32_16x16x4_f32 everywhere), no per-kernel "
+                         "event brackets in this pass"}
+        log(f"exact-f32 pass: {e32:.3f}s")
 
     if world > 1:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
@@ -276,12 +321,11 @@ def main():
     if rank == 0:
         chunks = world * n * args.steps
         cps = chunks / elapsed
-        table = kernel_table(lib, n)
         groups = {}
         for r in table:
             if "tflops" not in r:
                 continue
-            g = groups.setdefault(SYMBOL.get(r["kernel"], r["kernel"]),
+            g = groups.setdefault(symbol.get(r["kernel"], r["kernel"]),
                                   {"ms": 0.0, "launches": 0, "gflop": 0.0, "tags": []})
             g["ms"] += r["total_ms"]
             g["launches"] += r["launches"]
@@ -290,6 +334,14 @@ def main():
         # the dominant kernel = the MFMA-bound device kernel with the largest total time; the
         # recurrence (f32 VALU chains, one per CU, latency bound) is priced against the FMA rate
         # of the CUs it occupies and listed with every other kernel in `roofline_kernels`
+        def peak_of(g):
+            if g == "lstm_rec_kernel":
+                cus = min(256, 2 * n)                    # one (chunk, direction) chain per workgroup / CU
+                return PEAK_F32_FMA_TFLOPS * cus / 256.0, "valu"
+            if g.startswith("gemm_split_kernel"):        # 3 f16 MFMAs per algorithmic product
+                return PEAK_F16_MATRIX_TFLOPS / SPLIT_PRODUCTS, "mfma"
+            return PEAK_F32_MATRIX_TFLOPS, "mfma"
+
         mfma_groups = {k: v for k, v in groups.items() if k != "lstm_rec_kernel"}
         sym, dom = max(mfma_groups.items(), key=lambda kv: kv[1]["ms"])
         tflops = dom["gflop"] / dom["ms"]               # GFLOP / ms = TFLOP/s
@@ -310,38 +362,45 @@ def main():
         per_kernel = []
         for g, v in sorted(groups.items(), key=lambda kv: -kv[1]["ms"]):
             ach = v["gflop"] / v["ms"]
-            if g == "lstm_rec_kernel":
-                cus = min(256, 2 * n)                    # one (chunk, direction) chain per workgroup / CU
-                peak, bound = PEAK_F32_FMA_TFLOPS * cus / 256.0, "valu"
-            else:
-                peak, bound = PEAK_F32_MATRIX_TFLOPS, "mfma"
+            peak, bound = peak_of(g)
             per_kernel.append({"kernel": g, "layers": v["tags"], "bound": bound, "achieved": round(ach, 2),
                                "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(ach / peak, 4),
                                "avg_launch_us": round(1e3 * v["ms"] / v["launches"], 2),
                                "launches_per_step": round(v["launches"] / args.steps, 2),
                                "traffic": traffic_of.get(g), "mfma_util_pmc": mfma_util_of.get(g)})
+        dom_peak = peak_of(sym)[0]
         roof = {"bound": "mfma", "kernel": sym, "layers": dom["tags"], "achieved": round(tflops, 2),
-                "peak": PEAK_F32_MATRIX_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(tflops / PEAK_F32_MATRIX_TFLOPS, 4), "traffic": traffic,
+                "peak": round(dom_peak, 1), "unit": "TFLOP/s",
+                "peak_note": ("f16 matrix peak 2500 TFLOP/s / 3: the split-f16 path spends three f16 MFMAs "
+                              "per algorithmic product; `achieved` counts algorithmic FLOPs only"
+                              if sym.startswith("gemm_split_kernel") else "exact-f32 matrix peak"),
+                "frac": round(tflops / dom_peak, 4), "traffic": traffic,
                 "traffic_source": "profiles/traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes "
                                   "of `bench.py --steps 3`, avg bytes per launch, FETCH doubled per the "
                                   "gfx950 correction)" if traffic is not None else None,
                 "mfma_util_pmc": mfma_util_of.get(sym),
                 "alg_gflop_per_launch": round(dom["gflop"] / dom["launches"], 3),
                 "avg_launch_us": round(1e3 * dom["ms"] / dom["launches"], 2),
-                "whole_path_tflops": round(cps / world * ALG_GFLOP_PER_CHUNK / 1e3, 2),
-                "whole_path_frac": round(cps / world * ALG_GFLOP_PER_CHUNK / 1e3 / PEAK_F32_MATRIX_TFLOPS, 4)}
+                "whole_path_tflops": round(cps / world * ALG_GFLOP_PER_CHUNK / 1e3, 2)}
         out = {
             "metric": "real-time-factor xRT streams/GPU @500ms step", "value": round(cps / 2, 2),
             "unit": "xRT 16 kHz streams (chunks/s / 2)", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32" if precision == "f32" else "f16x3",
+            "dtype_note": ("exact-f32 MFMA (v_mfma_f32_16x16x4_f32), f32 VALU, f32 accumulation; clustering f64"
+                           if precision == "f32" else
+                           "GEMM-shaped layers: f32 operands split into two f16 numbers (hi + lo*2^-11 = 22 "
+                           "mantissa bits), three f16 MFMAs per product, f32 accumulation (k_gemm_split.hip); error "
+                           "vs the f32 oracle is the same as the exact-f32 path's (tests/test_gpu_models.py: seg "
+                           "8.7e-6 vs 8.8e-6, emb 4.7e-7 vs 5.0e-7); sinc conv0 and the LSTM recurrence exact "
+                           "f32; clustering f64.  The exact-f32 run of the same job is in `exact_f32`."),
             "data": "synthetic",
             "config": {"workload": "configs[1]: single MI355X, 5 s window / 500 ms step, "
                                    "pyannote/segmentation + pyannote/embedding architectures "
                                    "(random-init weights), %d concurrent synthetic 16 kHz streams per GPU" % n,
                        "streams_per_gpu": n, "chunks_per_step": world * n, "parallelism": f"streams x{world}"},
-            "roofline": roof, "roofline_kernels": per_kernel,
+            "roofline": roof, "roofline_kernels": per_kernel, "exact_f32": exact,
         }
         if args.kernel_table:
             Path(args.kernel_table).parent.mkdir(parents=True, exist_ok=True)

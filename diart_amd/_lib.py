@@ -22,7 +22,7 @@ vp = C.c_void_p
 class SincNetWeights(C.Structure):
     _fields_ = [("wav_gamma", C.c_float), ("wav_beta", C.c_float)] + [
         (n, vp) for n in ("filt", "in0_g", "in0_b", "w1", "b1", "in1_g", "in1_b",
-                          "w2", "b2", "in2_g", "in2_b")]
+                          "w2", "b2", "in2_g", "in2_b", "w1_split", "w2_split")]
 
 
 class SegWeights(C.Structure):

@@ -157,6 +157,15 @@ extern "C" int dz_emb_frames_for(int num_samples) {
     return f > 0 ? f : 0;
 }
 
+// exact-f32 MFMA kernel, or the split-f16 kernel when the layer came with split planes
+static int run_gemm(DzConvGemm& p, const void* split, hipStream_t st) {
+    if (split) {
+        p.Wsplit = split;
+        return dz_launch_gemm_split(p, st);
+    }
+    return dz_launch_convgemm(p, st);
+}
+
 struct SincScratch {
     float *stats, *y0, *part0, *sc0, *sh0, *y1, *part1, *sc1, *sh1, *y2, *part2, *sc2, *sh2;
     void carve(Arena& a, const SincGeom& g, int Bm) {
@@ -199,7 +208,7 @@ static int run_sincnet(const dz_sincnet_weights& w, const SincGeom& g, const Sin
     p.Kpad = 416; p.Npad = 64; p.Nstore = 64; p.ldx = 80; p.ldy = 64; p.Tstore = g.P1;
     p.xbs = (long long)g.P0 * 80; p.ybs = (long long)g.P1 * 64;
     p.norm_on_load = 1; p.epi = DZ_EPI_POOL3;
-    { ProfScope ps(T_CONV1, st); if ((rc = dz_launch_convgemm(p, st))) return rc; }
+    { ProfScope ps(T_CONV1, st); if ((rc = run_gemm(p, w.w1_split, st))) return rc; }
     { ProfScope ps(T_FIN, st);
     if ((rc = dz_launch_finalize_norm(s.part1, B, g.nt1, 64, g.P1, w.in1_g, w.in1_b, s.sc1, s.sh1,
                                       st)))
@@ -209,18 +218,9 @@ static int run_sincnet(const dz_sincnet_weights& w, const SincGeom& g, const Sin
     p.Y = s.y2; p.partials = s.part2;
     p.Tin = g.P1; p.Tout = g.T2; p.Cin = 64; p.K = 320; p.Kpad = 320; p.ldx = 64;
     p.Tstore = g.P2; p.xbs = (long long)g.P1 * 64; p.ybs = (long long)g.P2 * 64;
-    { ProfScope ps(T_CONV2, st); if ((rc = dz_launch_convgemm(p, st))) return rc; }
+    { ProfScope ps(T_CONV2, st); if ((rc = run_gemm(p, w.w2_split, st))) return rc; }
     ProfScope ps(T_FIN, st);
     return dz_launch_finalize_norm(s.part2, B, g.nt2, 64, g.P2, w.in2_g, w.in2_b, s.sc2, s.sh2, st);
-}
-
-// exact-f32 MFMA kernel, or the split-f16 kernel when the layer came with split planes
-static int run_gemm(DzConvGemm& p, const void* split, hipStream_t st) {
-    if (split) {
-        p.Wsplit = split;
-        return dz_launch_gemm_split(p, st);
-    }
-    return dz_launch_convgemm(p, st);
 }
 
 static int check_wave(const char* who, const float* d_wave, long long stride, int S) {

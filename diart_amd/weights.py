@@ -128,7 +128,8 @@ class _Packed:
         return sum(t.numel() * t.element_size() for t in self.tensors)
 
 
-def _pack_sincnet(sd: Dict[str, torch.Tensor], pk: _Packed, prefix: str = "sincnet.") -> _lib.SincNetWeights:
+def _pack_sincnet(sd: Dict[str, torch.Tensor], pk: _Packed, prefix: str = "sincnet.",
+                  split: bool = False) -> _lib.SincNetWeights:
     g = lambda k: sd[prefix + k].detach().cpu()
     filt = sinc_filters(g("conv1d.0.filterbank.low_hz_"), g("conv1d.0.filterbank.band_hz_"),
                         g("conv1d.0.filterbank.window_"), g("conv1d.0.filterbank.n_"))
@@ -139,6 +140,9 @@ def _pack_sincnet(sd: Dict[str, torch.Tensor], pk: _Packed, prefix: str = "sincn
     w.filt = pk.put(fold_sinc_filters(filt))
     w.in0_g, w.in0_b = pk.put(g("norm1d.0.weight")), pk.put(g("norm1d.0.bias"))
     w.w1 = pk.put(_conv_pack(g("conv1d.1.weight"), 80, 64, 416))
+    if split:
+        w.w1_split = pk.put_split(_conv_pack(g("conv1d.1.weight"), 80, 64, 416))
+        w.w2_split = pk.put_split(_conv_pack(g("conv1d.2.weight"), 64, 64, 320))
     w.b1 = pk.put(_pad1(g("conv1d.1.bias"), 64))
     w.in1_g, w.in1_b = pk.put(_pad1(g("norm1d.1.weight"), 64)), pk.put(_pad1(g("norm1d.1.bias"), 64))
     w.w2 = pk.put(_conv_pack(g("conv1d.2.weight"), 64, 64, 320))
@@ -157,7 +161,7 @@ class PackedSegmentation:
         pk = _Packed(device)
         g = lambda k: sd[k].detach().cpu().float()
         w = _lib.SegWeights()
-        w.sinc = _pack_sincnet(sd, pk)
+        w.sinc = _pack_sincnet(sd, pk, split=split)
         for layer in range(4):
             wih = torch.cat([g(f"lstm.weight_ih_l{layer}"), g(f"lstm.weight_ih_l{layer}_reverse")], 0)
             kpad = 64 if layer == 0 else 256
@@ -200,7 +204,7 @@ class PackedEmbedding:
         pk = _Packed(device)
         g = lambda k: sd[k].detach().cpu().float()
         w = _lib.EmbWeights()
-        w.sinc = _pack_sincnet(sd, pk)
+        w.sinc = _pack_sincnet(sd, pk, split=split)
         for i, (cin_pad, cout, npad) in enumerate(self.TDNN):
             cw = g(f"tdnns.{3 * i}.weight")
             assert cw.shape[0] == cout

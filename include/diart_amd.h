@@ -57,6 +57,8 @@ typedef struct {
     const float* b2;             /* [64]                                             */
     const float* in2_g;          /* [64]                                             */
     const float* in2_b;          /* [64]                                             */
+    const void* w1_split;        /* split-f16 planes of w1 / w2 (optional, NULL = exact f32)  */
+    const void* w2_split;
 } dz_sincnet_weights;
 
 typedef struct {

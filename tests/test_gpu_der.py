@@ -70,10 +70,13 @@ def stream():
     return synth_stream(2024, 30.0)
 
 
-@pytest.fixture(scope="module")
-def models():
-    return (M.SegmentationModel.from_state(synth_segmentation_state(), max_batch=32),
-            M.EmbeddingModel.from_state(synth_embedding_state(), max_batch=32))
+@pytest.fixture(scope="module", params=["f16x3", "f32"])
+def models(request):
+    """Every RTTM / DER gate below runs in both arithmetic modes of the GEMM-shaped layers: the
+    default split-f16 MFMA path and the exact-f32 MFMA path (weights.PRECISIONS)."""
+    p = request.param
+    return (M.SegmentationModel.from_state(synth_segmentation_state(), max_batch=32, precision=p),
+            M.EmbeddingModel.from_state(synth_embedding_state(), max_batch=32, precision=p))
 
 
 @pytest.mark.parametrize("latency", [0.5, 5.0])

@@ -90,8 +90,9 @@ def test_sinc_conv0(gpu):
 
 # --------------------------------------------------------------------------- #
 def _run_convgemm(gpu, X, W, bias, *, taps, dil, epi, Npad, Nstore, Kpad, e0=None, e1=None,
-                  nscale=None, nshift=None, Tstore=None, ldy=None, ksplit=0):
-    """X (B,Tin,Cin) channels-last; W (Npad,Kpad) packed."""
+                  nscale=None, nshift=None, Tstore=None, ldy=None, ksplit=0, split=False):
+    """X (B,Tin,Cin) channels-last; W (Npad,Kpad) packed.  ``split``: run the split-f16 MFMA kernel
+    (dz_k_gemm_split, weights as f16 hi/lo planes) instead of the exact-f32 one."""
     lib = _lib.load()
     B, Tin, Cin = X.shape
     Tout = Tin - (taps - 1) * dil
@@ -119,7 +120,14 @@ def _run_convgemm(gpu, X, W, bias, *, taps, dil, epi, Npad, Nstore, Kpad, e0=Non
     d.B, d.Tin, d.Tout, d.Cin, d.taps, d.dil = B, Tin, Tout, Cin, taps, dil
     d.K, d.Kpad, d.Npad, d.Nstore, d.ldx, d.ldy, d.Tstore = taps * Cin, Kpad, Npad, Nstore, Cin, ldy, Tstore
     d.xbs, d.ybs, d.epi = Tin * Cin, Tstore * ldy, epi
-    _lib.check(lib.dz_k_convgemm(_ctx(gpu), C.byref(d), None), "dz_k_convgemm")
+    if split:
+        from diart_amd.weights import split_f16
+        ws = split_f16(W).to(gpu)
+        d.Wsplit = ws.data_ptr()
+        keep.append(ws)
+        _lib.check(lib.dz_k_gemm_split(_ctx(gpu), C.byref(d), None), "dz_k_gemm_split")
+    else:
+        _lib.check(lib.dz_k_convgemm(_ctx(gpu), C.byref(d), None), "dz_k_convgemm")
     _sync()
     return Y.cpu(), (part.cpu() if part is not None else None)
 
@@ -132,8 +140,12 @@ def _pack(w, cin_pad, npad, kpad):
 @pytest.mark.parametrize("M,K,N,epi", [(293 * 2 + 5, 64, 1024, "bias"), (500, 256, 1024, "bias"),
                                        (97, 256, 128, "leaky"), (200, 128, 3, "sigmoid"),
                                        (192, 3008, 512, "bias64"), (192, 3008, 512, "split16"),
-                                       (7, 96, 128, "split3")])
+                                       (7, 96, 128, "split3"),
+                                       (293 * 2 + 5, 64, 1024, "bias/f16x3"), (500, 256, 1024, "bias/f16x3"),
+                                       (97, 256, 128, "leaky/f16x3"), (18752, 256, 1024, "bias/f16x3")])
 def test_convgemm_linear(gpu, M, K, N, epi):
+    epi, _, mode = epi.partition("/")
+    split = mode == "f16x3"
     g = torch.Generator().manual_seed(M + K)
     X = torch.randn(1, M, K, generator=g)
     W = torch.randn(N, K, generator=g) / math.sqrt(K)
@@ -149,7 +161,7 @@ def test_convgemm_linear(gpu, M, K, N, epi):
     code = {"bias": _lib.EPI_BIAS, "bias64": _lib.EPI_BIAS, "leaky": _lib.EPI_BIAS_LEAKY,
             "sigmoid": _lib.EPI_BIAS_SIGMOID}.get(epi, _lib.EPI_BIAS)
     Y, _ = _run_convgemm(gpu, X, Wp, bp, taps=1, dil=1, epi=code, Npad=Npad, Nstore=N, Kpad=K,
-                         ksplit=ksplit)
+                         ksplit=ksplit, split=split)
     if ksplit:   # partial sums of the K slices, bias in slice 0
         assert not torch.isnan(Y).any()
         Y = Y.double().sum(0, keepdim=True).float()
@@ -164,7 +176,8 @@ def test_convgemm_linear(gpu, M, K, N, epi):
 
 @pytest.mark.parametrize("Cin,Cout,taps,dil,Tin", [(60, 512, 5, 1, 293), (512, 512, 3, 2, 289),
                                                    (512, 512, 3, 3, 285), (512, 1500, 1, 1, 279)])
-def test_convgemm_tdnn(gpu, Cin, Cout, taps, dil, Tin):
+@pytest.mark.parametrize("split", [False, True], ids=["f32", "f16x3"])
+def test_convgemm_tdnn(gpu, Cin, Cout, taps, dil, Tin, split):
     g = torch.Generator().manual_seed(Cin + taps)
     B = 2
     cin_pad = 64 if Cin == 60 else Cin
@@ -187,7 +200,8 @@ def test_convgemm_tdnn(gpu, Cin, Cout, taps, dil, Tin):
         nshift[:, :60] = torch.randn(B, 60, generator=g) * 0.2
         xin = F.leaky_relu(x * nscale[:, :60, None] + nshift[:, :60, None], 0.01)
     Y, _ = _run_convgemm(gpu, X, Wp, pad1(bias), taps=taps, dil=dil, epi=_lib.EPI_TDNN, Npad=npad,
-                         Nstore=npad, Kpad=kpad, e0=pad1(s0), e1=pad1(s1), nscale=nscale, nshift=nshift)
+                         Nstore=npad, Kpad=kpad, e0=pad1(s0), e1=pad1(s1), nscale=nscale, nshift=nshift,
+                         split=split)
     ref = F.leaky_relu(F.conv1d(xin.double(), w.double(), bias.double(), dilation=dil), 0.01)
     ref = ref * s0.double()[None, :, None] + s1.double()[None, :, None]
     got = Y[:, :, :Cout].permute(0, 2, 1).double()
@@ -197,7 +211,8 @@ def test_convgemm_tdnn(gpu, Cin, Cout, taps, dil, Tin):
 
 
 @pytest.mark.parametrize("Cin,Tin", [(80, 2658), (60, 884)])
-def test_convgemm_pool3(gpu, Cin, Tin):
+@pytest.mark.parametrize("split", [False, True], ids=["f32", "f16x3"])
+def test_convgemm_pool3(gpu, Cin, Tin, split):
     g = torch.Generator().manual_seed(Cin)
     B, Cout, taps = 2, 60, 5
     cin_pad = 80 if Cin == 80 else 64
@@ -216,7 +231,7 @@ def test_convgemm_pool3(gpu, Cin, Tin):
     Tp = ref.shape[2]
     bp = torch.cat([bias, torch.zeros(4)])
     Y, part = _run_convgemm(gpu, X, Wp, bp, taps=taps, dil=1, epi=_lib.EPI_POOL3, Npad=64, Nstore=64,
-                            Kpad=kpad, nscale=nscale, nshift=nshift, Tstore=Tp, ldy=64)
+                            Kpad=kpad, nscale=nscale, nshift=nshift, Tstore=Tp, ldy=64, split=split)
     got = Y[:, :, :Cout].permute(0, 2, 1).double()
     assert not torch.isnan(Y).any() and not torch.isnan(part).any()
     assert (Y[:, :, Cout:] == 0).all()

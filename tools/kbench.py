@@ -80,7 +80,7 @@ def convgemm(name, Bn, Tin, Cin, N, taps, dil, epi, Npad=None, pro=False, pool=F
     d.agroup = args.agroup
     flop = 2.0 * Bn * Tout * K * N
     timeit(name, lambda: _lib.check(lib.dz_k_convgemm(ctx, C.byref(d), st), name), flop=flop)
-    if not pool and not ksplit and Npad % 128 == 0 and (not only or name + "_split" in only or name in only):
+    if not ksplit and (Npad % 128 == 0 or pool) and (not only or name + "_split" in only or name in only):
         from diart_amd.weights import split_f16
         ws = split_f16(W.cpu()).to(dev)
         y32 = Y.clone()
