@@ -17,9 +17,10 @@
 // far below the summation-order noise of any f32 GEMM; inputs are clamped to the f16 range
 // (+-65504; the networks' GEMM inputs are normalised activations, |x| = O(1..10)).
 //
-// Tile: 128 rows x 128 cols x 32 k per step, 8 waves (4 x 2), wave tile 32 x 64 = 1 x 2 MFMA
-// blocks; per k-step of 16 a wave reads 2 A and 4 B fragments (hi / lo, one ds_read_b128 each)
-// and issues 6 MFMAs.  Two workgroups per CU = 4 waves per SIMD: the MFMAs of three waves cover
+// Tile: (32 WM) rows x (64 NB) cols x 32 k per step, WM x 2 waves, wave tile 32 x 32 NB; the wide
+// layers use WM = 4, NB = 2 (128 x 128, 8 waves: per k-step of 16 a wave reads 2 A and 4 B
+// fragments (hi / lo, one ds_read_b128 each) and issues 6 MFMAs), the SincNet convolutions
+// (60 -> 64 output channels, MaxPool1d(3) fused) use WM = 3, NB = 1 (96 x 64, 6 waves).  Two workgroups per CU = 4 waves per SIMD: the MFMAs of three waves cover
 // the global-load latency of the fourth (with 4 waves per workgroup the kernel sat in s_waitcnt
 // for 39 % of its wave cycles; rocprofv3 SQ_WAIT_ANY).  LDS holds four f16 planes per stage (A hi,
 // A lo, B hi, B lo; [row][32 k] = 64 B rows, 16-byte chunks XOR-swizzled with (row >> 2) & 3 so the
@@ -39,10 +40,7 @@ typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int BM = 128, BN = 128, KT = 32;
-constexpr int PLANE = 128 * 64;              // bytes of one bf16 plane of a stage
-constexpr int STAGE = 4 * PLANE;             // A hi | A lo | B hi | B lo
-constexpr size_t LDS_BYTES = 2 * STAGE;
+constexpr int KT = 32;
 
 __device__ __forceinline__ void lds_barrier() {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -66,23 +64,37 @@ __device__ __forceinline__ void split8(const float* v, u32x4& hi, u32x4& lo) {
     }
 }
 
-template <bool PRO, int EPI>
-__global__ __launch_bounds__(512) void gemm_split_kernel(DzConvGemm p) {
+template <int WM, int NB>
+struct Cfg {
+    static constexpr int BM = 32 * WM, BN = 64 * NB, T = 128 * WM;
+    static constexpr int APLANE = BM * 64, BPLANE = BN * 64;      // bytes of one f16 plane
+    static constexpr int STAGE = 2 * APLANE + 2 * BPLANE;         // A hi | A lo | B hi | B lo
+    static constexpr int OLD = BN + 1;                            // pooled epilogue staging pitch
+    static constexpr size_t LDS =
+        2 * STAGE > 4 * BM * OLD ? 2 * STAGE : 4 * BM * OLD;
+    static_assert(BN * 4 <= T, "one B chunk per thread at most");
+};
+
+template <int WM, int NB, bool PRO, int EPI>
+__global__ __launch_bounds__(128 * WM) void gemm_split_kernel(DzConvGemm p) {
+    using C = Cfg<WM, NB>;
+    constexpr int BM = C::BM, BN = C::BN;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     int bx, by, b;
     dz_tile_map(p.agroup, bx, by, b);
     const int t0 = bx * BM, n0 = by * BN;
 
-    // ---- staging coordinates: thread -> row tid >> 2 (0..127), 8-wide k chunk tid & 3 ----------
+    // ---- staging coordinates: thread -> row tid >> 2, 8-wide k chunk tid & 3 ------------------
     const int crow = tid >> 2, cidx = tid & 3;
+    const bool has_b = tid < BN * 4;
     const float* Xb = p.X + (long long)b * p.xbs;
     const float* nsc = PRO ? p.nscale + (long long)b * p.nld : nullptr;
     const float* nsh = PRO ? p.nshift + (long long)b * p.nld : nullptr;
     const int trow = (t0 + crow) < p.Tout ? (t0 + crow) : p.Tout - 1;
     const unsigned short* Whi = reinterpret_cast<const unsigned short*>(p.Wsplit);
     const unsigned short* Wlo = Whi + (long long)p.Npad * p.Kpad;
-    const long long wofs = (long long)(n0 + crow) * p.Kpad + cidx * 8;
+    const long long wofs = (long long)(n0 + (has_b ? crow : 0)) * p.Kpad + cidx * 8;
 
     struct Regs {
         f32x4 ra[2];
@@ -119,12 +131,14 @@ __global__ __launch_bounds__(512) void gemm_split_kernel(DzConvGemm p) {
             R.ra[0] = v0;
             R.ra[1] = v1;
         }
-        const long long o = wofs + kt * KT;
-        R.rbh = *reinterpret_cast<const u32x4*>(Whi + o);
-        R.rbl = *reinterpret_cast<const u32x4*>(Wlo + o);
+        if (has_b) {
+            const long long o = wofs + kt * KT;
+            R.rbh = *reinterpret_cast<const u32x4*>(Whi + o);
+            R.rbl = *reinterpret_cast<const u32x4*>(Wlo + o);
+        }
     };
     auto store_tile = [&](const Regs& R, int buf) {
-        char* st = smem + buf * STAGE;
+        char* st = smem + buf * C::STAGE;
         const int off = chunk_off(crow, cidx);
         float v[8];
 #pragma unroll
@@ -135,53 +149,56 @@ __global__ __launch_bounds__(512) void gemm_split_kernel(DzConvGemm p) {
         u32x4 hi, lo;
         split8(v, hi, lo);
         *reinterpret_cast<u32x4*>(st + off) = hi;
-        *reinterpret_cast<u32x4*>(st + PLANE + off) = lo;
-        *reinterpret_cast<u32x4*>(st + 2 * PLANE + off) = R.rbh;
-        *reinterpret_cast<u32x4*>(st + 3 * PLANE + off) = R.rbl;
+        *reinterpret_cast<u32x4*>(st + C::APLANE + off) = lo;
+        if (has_b) {
+            *reinterpret_cast<u32x4*>(st + 2 * C::APLANE + off) = R.rbh;
+            *reinterpret_cast<u32x4*>(st + 2 * C::APLANE + C::BPLANE + off) = R.rbl;
+        }
     };
 
-    // ---- MFMA coordinates ------------------------------------------------------------
+    // ---- MFMA coordinates: WM x 2 waves, wave tile 32 x (32 NB) ---------------------------------
     const int w = tid >> 6, l = tid & 63, li = l & 31, g = l >> 5;
-    const int wm = w >> 1, wn = w & 1;       // 4 x 2 waves, wave tile 32 x 64
-    f32x16 accm[2], accx[2];                 // hi*hi | cross terms (scaled by 2^11)
+    const int wm = w >> 1, wn = w & 1;
+    f32x16 accm[NB], accx[NB];                 // hi*hi | cross terms (scaled by 2^11)
 #pragma unroll
-    for (int nb = 0; nb < 2; ++nb)
+    for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
         for (int r = 0; r < 16; ++r) accm[nb][r] = accx[nb][r] = 0.f;
 
     const int nk = p.Kpad / KT;
     auto compute = [&](int buf) {
-        const char* st = smem + buf * STAGE;
+        const char* st = smem + buf * C::STAGE;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            f16x8 ah, al, bh[2], bl[2];
+            f16x8 ah, al, bh[NB], bl[NB];
             {
                 const int off = chunk_off(wm * 32 + li, 2 * ks + g);
                 ah = *reinterpret_cast<const f16x8*>(st + off);
-                al = *reinterpret_cast<const f16x8*>(st + PLANE + off);
+                al = *reinterpret_cast<const f16x8*>(st + C::APLANE + off);
             }
 #pragma unroll
-            for (int nb = 0; nb < 2; ++nb) {
-                const int off = chunk_off(wn * 64 + nb * 32 + li, 2 * ks + g);
-                bh[nb] = *reinterpret_cast<const f16x8*>(st + 2 * PLANE + off);
-                bl[nb] = *reinterpret_cast<const f16x8*>(st + 3 * PLANE + off);
+            for (int nb = 0; nb < NB; ++nb) {
+                const int off = chunk_off(wn * 32 * NB + nb * 32 + li, 2 * ks + g);
+                bh[nb] = *reinterpret_cast<const f16x8*>(st + 2 * C::APLANE + off);
+                bl[nb] = *reinterpret_cast<const f16x8*>(st + 2 * C::APLANE + C::BPLANE + off);
             }
 #pragma unroll
-            for (int nb = 0; nb < 2; ++nb)
+            for (int nb = 0; nb < NB; ++nb)
                 accx[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[nb], accx[nb], 0, 0, 0);
 #pragma unroll
-            for (int nb = 0; nb < 2; ++nb)
+            for (int nb = 0; nb < NB; ++nb)
                 accm[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[nb], accm[nb], 0, 0, 0);
 #pragma unroll
-            for (int nb = 0; nb < 2; ++nb)
+            for (int nb = 0; nb < NB; ++nb)
                 accx[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[nb], accx[nb], 0, 0, 0);
         }
     };
     // one k-tile per step: the global loads of tile kt + 1 are issued before the MFMAs of tile kt
     // and parked in LDS after them.  The step barrier only has to publish LDS (s_waitcnt lgkmcnt +
-    // s_barrier): __syncthreads() would also drain vmcnt.  (Running the loads two tiles ahead
-    // through a second register set measured SLOWER: 128-register budget spills, 140 registers
-    // halve the occupancy.)
+    // s_barrier): __syncthreads() would also drain vmcnt.  Measured and rejected: global loads two
+    // tiles ahead through a second register set (spills inside a 128-register budget, 140
+    // registers halve the occupancy) and register-double-buffered fragments on a 96 x 128 / 6-wave
+    // tile (160 registers, 3 waves per SIMD: 20-70 % slower per layer).
     load_tile(R0, 0);
     store_tile(R0, 0);
     lds_barrier();
@@ -194,10 +211,48 @@ __global__ __launch_bounds__(512) void gemm_split_kernel(DzConvGemm p) {
     }
 
     // ---- epilogue: C/D map col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5) -----
+    if (EPI == DZ_EPI_POOL3) {
+        // conv (+bias) -> LDS tile -> MaxPool1d(3,3) over time -> pooled rows + stats partials
+        float* out_s = reinterpret_cast<float*>(smem);  // all waves are past the last barrier
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+            const int n = wn * 32 * NB + nb * 32 + li;
+            const float bv = p.bias[n0 + n];
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                out_s[(wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * g) * C::OLD + n] =
+                    (accm[nb][r] + accx[nb][r] * LO_UNSCALE) + bv;
+        }
+        __syncthreads();
+        constexpr int PR = BM / 3;                     // pooled rows per tile
+        const int p0 = t0 / 3;
+        float* Yb = p.Y + (long long)b * p.ybs;
+        for (int idx = tid; idx < PR * BN; idx += C::T) {
+            const int pr = idx / BN, n = idx - pr * BN;
+            const float* o = out_s + (3 * pr) * C::OLD + n;
+            const float v = fmaxf(fmaxf(o[0], o[C::OLD]), o[2 * C::OLD]);
+            const bool valid = (p0 + pr) < p.Tstore;
+            if (valid && (n0 + n) < p.Nstore) Yb[(long long)(p0 + pr) * p.ldy + n0 + n] = v;
+            out_s[(3 * pr) * C::OLD + n] = valid ? v : 0.f;
+        }
+        __syncthreads();
+        if (tid < BN) {
+            float s = 0.f, ss = 0.f;
+            for (int pr = 0; pr < PR; ++pr) {
+                const float v = out_s[(3 * pr) * C::OLD + tid];
+                s += v;
+                ss += v * v;
+            }
+            float* pp = p.partials + (((long long)b * gridDim.x + bx) * p.Npad + n0 + tid) * 2;
+            pp[0] = s;
+            pp[1] = ss;
+        }
+        return;
+    }
     float* Yb = p.Y + (long long)b * p.ybs;
 #pragma unroll
-    for (int nb = 0; nb < 2; ++nb) {
-        const int n = n0 + wn * 64 + nb * 32 + li;
+    for (int nb = 0; nb < NB; ++nb) {
+        const int n = n0 + wn * 32 * NB + nb * 32 + li;
         const float bv = p.bias[n];
         float e0 = 1.f, e1 = 0.f;
         if (EPI == DZ_EPI_TDNN) {
@@ -219,16 +274,17 @@ __global__ __launch_bounds__(512) void gemm_split_kernel(DzConvGemm p) {
     }
 }
 
-template <bool PRO, int EPI>
+template <int WM, int NB, bool PRO, int EPI>
 int launch(const DzConvGemm& p, hipStream_t st) {
+    using C = Cfg<WM, NB>;
     static bool attr_set = false;
     if (!attr_set) {
-        DZ_HIP(hipFuncSetAttribute((const void*)gemm_split_kernel<PRO, EPI>,
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES));
+        DZ_HIP(hipFuncSetAttribute((const void*)gemm_split_kernel<WM, NB, PRO, EPI>,
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS));
         attr_set = true;
     }
-    dim3 grid((p.Tout + BM - 1) / BM, p.Npad / BN, p.B);
-    hipLaunchKernelGGL((gemm_split_kernel<PRO, EPI>), grid, dim3(512), LDS_BYTES, st, p);
+    dim3 grid((p.Tout + C::BM - 1) / C::BM, p.Npad / C::BN, p.B);
+    hipLaunchKernelGGL((gemm_split_kernel<WM, NB, PRO, EPI>), grid, dim3(C::T), C::LDS, st, p);
     DZ_HIP(hipGetLastError());
     return 0;
 }
@@ -243,19 +299,24 @@ int dz_launch_gemm_split(const DzConvGemm& p, hipStream_t st) {
     DZ_REQUIRE(p.pad == 0 && p.X2 == nullptr && p.rowbias == nullptr && p.ksplit <= 1,
                "gemm_split: padding / second input / row bias / split-K are f32-path features");
     DZ_REQUIRE(p.Tout > 0 && p.Tout == p.Tin - (p.taps - 1) * p.dil, "gemm_split: Tout mismatch");
-    DZ_REQUIRE(p.Npad % BN == 0, "gemm_split: Npad must be a multiple of 128");
     const bool pro = p.norm_on_load != 0;
-#define DZ_SP(PRO, EPI) return launch<PRO, EPI>(p, st)
+#define DZ_SP(WM, NB, PRO, EPI) return launch<WM, NB, PRO, EPI>(p, st)
+    if (p.epi == DZ_EPI_POOL3) {
+        // the pooled tile is 96 conv rows = 32 pooled rows, like the f32 kernel (same partials grid)
+        DZ_REQUIRE(pro && p.Npad == 64, "gemm_split: POOL3 is built for norm-on-load, Npad = 64");
+        DZ_SP(3, 1, true, DZ_EPI_POOL3);
+    }
+    DZ_REQUIRE(p.Npad % 128 == 0, "gemm_split: Npad must be a multiple of 128");
     switch (p.epi) {
         case DZ_EPI_TDNN:
-            if (pro) DZ_SP(true, DZ_EPI_TDNN);
-            DZ_SP(false, DZ_EPI_TDNN);
+            if (pro) DZ_SP(4, 2, true, DZ_EPI_TDNN);
+            DZ_SP(4, 2, false, DZ_EPI_TDNN);
         case DZ_EPI_BIAS:
-            if (pro) DZ_SP(true, DZ_EPI_BIAS);
-            DZ_SP(false, DZ_EPI_BIAS);
+            if (pro) DZ_SP(4, 2, true, DZ_EPI_BIAS);
+            DZ_SP(4, 2, false, DZ_EPI_BIAS);
         case DZ_EPI_BIAS_LEAKY:
             DZ_REQUIRE(!pro, "gemm_split: BIAS_LEAKY has no norm-on-load instance");
-            DZ_SP(false, DZ_EPI_BIAS_LEAKY);
+            DZ_SP(4, 2, false, DZ_EPI_BIAS_LEAKY);
     }
 #undef DZ_SP
     dz_set_error("gemm_split: epilogue %d is not built on the split-f16 path", p.epi);
