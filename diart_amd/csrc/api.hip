@@ -57,21 +57,24 @@ extern "C" int dz_ctx_destroy(dz_ctx* ctx) {
 }
 
 // ---------------------------------------------------------------------------
-// per-kernel timing with HIP events on the launch stream (bench.py's roofline leg).
-// Off by default; when on, every launch issued by the forward passes is bracketed by an
-// event pair taken from a fixed pool; dz_prof_collect() synchronises and accumulates.
+// per-kernel timing (bench.py's roofline leg).  Off by default; when on, every launch issued by
+// the forward passes carries a (start, stop) event pair from a fixed pool that the runtime fills
+// with the dispatch's own timestamps (DZ_LAUNCH / hipExtLaunchKernelGGL): kernel execution time on
+// whatever stream it ran, no marker packets between kernels.  dz_prof_collect() synchronises and
+// accumulates.
 // ---------------------------------------------------------------------------
 enum { PROF_POOL = 8192, PROF_TAGS = 24 };
 static const char* kProfNames[PROF_TAGS] = {
     "wave_stats", "sinc_conv0", "finalize_norm", "conv1_pool", "conv2_pool", "lstm_proj",
     "lstm_rec", "seg_mlp", "seg_classifier", "tdnn1", "tdnn2", "tdnn3", "tdnn4", "tdnn5",
-    "stats_pool", "emb_linear", "l2norm", "osp", "powerset", "cdist", "", "", "", ""};
+    "stats_pool", "emb_linear", "l2norm", "osp", "powerset", "cdist", "lstm_proj0", "", "", ""};
 enum { T_WAVE = 0, T_CONV0, T_FIN, T_CONV1, T_CONV2, T_PROJ, T_REC, T_MLP, T_CLS, T_TDNN1, T_TDNN2,
-       T_TDNN3, T_TDNN4, T_TDNN5, T_POOL, T_EMBLIN, T_L2, T_OSP, T_PSET, T_CDIST };
+       T_TDNN3, T_TDNN4, T_TDNN5, T_POOL, T_EMBLIN, T_L2, T_OSP, T_PSET, T_CDIST, T_PROJ0 };
+thread_local DzLaunchProf* dz_launch_prof = nullptr;
 struct Prof {
     bool on = false;
     int used = 0;
-    hipEvent_t ev[PROF_POOL][2];
+    DzLaunchProf ev[PROF_POOL];
     int tag[PROF_POOL];
     bool made = false;
     double ms[PROF_TAGS];
@@ -79,24 +82,20 @@ struct Prof {
 };
 static Prof g_prof;
 struct ProfScope {
-    int slot = -1;
-    hipStream_t st;
-    ProfScope(int tag, hipStream_t s) : st(s) {
+    ProfScope(int tag, hipStream_t) {
         if (g_prof.on && g_prof.used < PROF_POOL) {
-            slot = g_prof.used++;
+            const int slot = g_prof.used++;
             g_prof.tag[slot] = tag;
-            (void)hipEventRecord(g_prof.ev[slot][0], st);
+            dz_launch_prof = &g_prof.ev[slot];   // consumed by the next DZ_LAUNCH
         }
     }
-    ~ProfScope() {
-        if (slot >= 0) (void)hipEventRecord(g_prof.ev[slot][1], st);
-    }
+    ~ProfScope() { dz_launch_prof = nullptr; }
 };
 extern "C" int dz_prof_enable(int on) {
     if (on && !g_prof.made) {
         for (int i = 0; i < PROF_POOL; ++i) {
-            DZ_HIP(hipEventCreate(&g_prof.ev[i][0]));
-            DZ_HIP(hipEventCreate(&g_prof.ev[i][1]));
+            DZ_HIP(hipEventCreate(&g_prof.ev[i].start));
+            DZ_HIP(hipEventCreate(&g_prof.ev[i].stop));
         }
         g_prof.made = true;
     }
@@ -110,7 +109,7 @@ extern "C" int dz_prof_collect(void) {
     DZ_HIP(hipDeviceSynchronize());
     for (int i = 0; i < g_prof.used; ++i) {
         float ms = 0.f;
-        if (hipEventElapsedTime(&ms, g_prof.ev[i][0], g_prof.ev[i][1]) == hipSuccess) {
+        if (hipEventElapsedTime(&ms, g_prof.ev[i].start, g_prof.ev[i].stop) == hipSuccess) {
             g_prof.ms[g_prof.tag[i]] += ms;
             g_prof.n[g_prof.tag[i]] += 1;
         }
@@ -325,7 +324,8 @@ extern "C" int dz_seg_forward(dz_seg* s, const float* d_wave, long long wave_str
             p.B = 1; p.Tin = p.Tout = p.Tstore = B * F; p.Cin = 256; p.K = 256; p.Kpad = 256;
             p.ldx = 256;
         }
-        { ProfScope ps(T_PROJ, st); if ((rc = run_gemm(p, s->w.wih_split[layer], st))) return rc; }
+        { ProfScope ps(layer == 0 ? T_PROJ0 : T_PROJ, st);
+          if ((rc = run_gemm(p, s->w.wih_split[layer], st))) return rc; }
         float* hout = (layer & 1) ? s->h1 : s->h0;
         { ProfScope ps(T_REC, st);
           if ((rc = dz_launch_lstm(s->gx, s->w.whh[layer], hout, B, F, st))) return rc; }

@@ -1,6 +1,7 @@
 // Shared declarations for libdiart_amd (gfx950 only).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 #include <stddef.h>
 #include "../../include/diart_amd.h"
@@ -13,6 +14,25 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 #define DZ_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 
 #define DZ_LEAKY_SLOPE 0.01f
+
+// Every kernel of the library is launched through DZ_LAUNCH.  When the per-kernel profiler of
+// api.hip is on, the launch carries a (start, stop) event pair that the runtime fills with the
+// dispatch's own begin / end timestamps (hipExtLaunchKernelGGL) — the same numbers rocprofv3's
+// kernel trace reports, with no extra marker packets in the stream.  Otherwise a plain launch.
+struct DzLaunchProf {
+    hipEvent_t start, stop;
+};
+extern thread_local DzLaunchProf* dz_launch_prof;
+#define DZ_LAUNCH(kernel, grid, block, lds, st, ...)                                          \
+    do {                                                                                      \
+        if (dz_launch_prof) {                                                                 \
+            hipExtLaunchKernelGGL(kernel, grid, block, lds, st, dz_launch_prof->start,        \
+                                  dz_launch_prof->stop, 0, __VA_ARGS__);                      \
+            dz_launch_prof = nullptr; /* one launch per bracket */                            \
+        } else {                                                                              \
+            hipLaunchKernelGGL(kernel, grid, block, lds, st, __VA_ARGS__);                    \
+        }                                                                                     \
+    } while (0)
 
 // ---------------------------------------------------------------------------
 // XCD-aware tile order shared by the GEMM kernels (grid = (M-tiles, N-tiles, batch)).

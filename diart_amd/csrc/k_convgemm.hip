@@ -244,7 +244,7 @@ int launch(const DzConvGemm& p, hipStream_t st) {
         attr_set = true;
     }
     dim3 grid((p.Tout + BM - 1) / BM, p.Npad / BN, p.B * (p.ksplit > 1 ? p.ksplit : 1));
-    hipLaunchKernelGGL((convgemm_kernel<BN, PRO, EPI>), grid, dim3(256), C::LDS, st, p);
+    DZ_LAUNCH((convgemm_kernel<BN, PRO, EPI>), grid, dim3(256), C::LDS, st, p);
     DZ_HIP(hipGetLastError());
     return 0;
 }

@@ -210,27 +210,27 @@ __global__ void nan_rows_kernel(float* __restrict__ out, int rows, int dim,
 
 int dz_launch_mask_compact(const float* wave, long long stride, int S, const float* masks, int Fw,
                            int rows, float* sig, long long sig_stride, int* lens, hipStream_t st) {
-    hipLaunchKernelGGL(mask_compact_kernel, dim3(rows), dim3(256), 0, st, wave, stride, S, masks, Fw,
+    DZ_LAUNCH(mask_compact_kernel, dim3(rows), dim3(256), 0, st, wave, stride, S, masks, Fw,
                        sig, sig_stride, lens);
     DZ_HIP(hipGetLastError());
     return 0;
 }
 int dz_launch_power(const float* spec, int lds, long long rows, float* pw, hipStream_t st) {
     const long long n = rows * 204;
-    hipLaunchKernelGGL(power_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, spec, lds,
+    DZ_LAUNCH(power_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, spec, lds,
                        rows, pw);
     DZ_HIP(hipGetLastError());
     return 0;
 }
 int dz_launch_fbank_post(const float* melp, int T, int rows, const int* nvalid, float* feats,
                          hipStream_t st) {
-    hipLaunchKernelGGL(fbank_post_kernel, dim3(rows), dim3(256), 0, st, melp, T, nvalid, feats);
+    DZ_LAUNCH(fbank_post_kernel, dim3(rows), dim3(256), 0, st, melp, T, nvalid, feats);
     DZ_HIP(hipGetLastError());
     return 0;
 }
 int dz_launch_se_mean(const float* x, int T, int C, int ldx, int rows, const int* nmask, float* s,
                       hipStream_t st) {
-    hipLaunchKernelGGL(se_mean_kernel, dim3((C + 255) / 256, rows), dim3(256), 0, st, x, T, C, ldx,
+    DZ_LAUNCH(se_mean_kernel, dim3((C + 255) / 256, rows), dim3(256), 0, st, x, T, C, ldx,
                        nmask, s);
     DZ_HIP(hipGetLastError());
     return 0;
@@ -238,27 +238,27 @@ int dz_launch_se_mean(const float* x, int T, int C, int ldx, int rows, const int
 int dz_launch_se_apply(const float* x, int ldx, const float* gate, const float* resid, int ldr,
                        float* out, int ldo, int rows, int T, int C, hipStream_t st) {
     const long long total4 = (long long)rows * T * (C / 4);
-    hipLaunchKernelGGL(se_apply_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, st, x,
+    DZ_LAUNCH(se_apply_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, st, x,
                        ldx, gate, resid, ldr, out, ldo, T, C, total4);
     DZ_HIP(hipGetLastError());
     return 0;
 }
 int dz_launch_asp_gstats(const float* x, int T, int C, int rows, const int* nmask, float* g,
                          hipStream_t st) {
-    hipLaunchKernelGGL(asp_gstats_kernel, dim3((C + 255) / 256, rows), dim3(256), 0, st, x, T, C,
+    DZ_LAUNCH(asp_gstats_kernel, dim3((C + 255) / 256, rows), dim3(256), 0, st, x, T, C,
                        nmask, g);
     DZ_HIP(hipGetLastError());
     return 0;
 }
 int dz_launch_asp_pool(const float* x, const float* logit, int T, int C, int rows, const int* nmask,
                        float* pooled, hipStream_t st) {
-    hipLaunchKernelGGL(asp_pool_kernel, dim3((C + 255) / 256, rows), dim3(256), 0, st, x, logit, T, C,
+    DZ_LAUNCH(asp_pool_kernel, dim3((C + 255) / 256, rows), dim3(256), 0, st, x, logit, T, C,
                        nmask, pooled);
     DZ_HIP(hipGetLastError());
     return 0;
 }
 int dz_launch_nan_rows(float* out, int rows, int dim, const int* flags, hipStream_t st) {
-    hipLaunchKernelGGL(nan_rows_kernel, dim3((rows * dim + 255) / 256), dim3(256), 0, st, out, rows,
+    DZ_LAUNCH(nan_rows_kernel, dim3((rows * dim + 255) / 256), dim3(256), 0, st, out, rows,
                        dim, flags);
     DZ_HIP(hipGetLastError());
     return 0;

@@ -56,7 +56,7 @@ __global__ __launch_bounds__(256) void wave_stats_kernel(const float* __restrict
 
 int dz_launch_wave_stats(const float* wave, long long stride, int B, int S, float* stats,
                          hipStream_t st) {
-    hipLaunchKernelGGL(wave_stats_kernel, dim3(B), dim3(256), 0, st, wave, stride, S, stats);
+    DZ_LAUNCH(wave_stats_kernel, dim3(B), dim3(256), 0, st, wave, stride, S, stats);
     DZ_HIP(hipGetLastError());
     return 0;
 }
@@ -194,7 +194,7 @@ int dz_launch_sinc_conv0(const float* wave, long long stride, int B, int S, cons
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
-    hipLaunchKernelGGL(sinc_conv0_kernel, dim3(ntile, B), dim3(256), lds, st, wave, stride, S,
+    DZ_LAUNCH(sinc_conv0_kernel, dim3(ntile, B), dim3(256), lds, st, wave, stride, S,
                        stats, gamma, beta, filt, y0, P0, partials, ntile);
     DZ_HIP(hipGetLastError());
     return 0;
@@ -230,7 +230,7 @@ int dz_launch_finalize_norm(const float* partials, int B, int ntile, int C, int 
                             const float* gamma, const float* beta, float* scale, float* shift,
                             hipStream_t st) {
     const int n = B * C;
-    hipLaunchKernelGGL(finalize_norm_kernel, dim3((n + 255) / 256), dim3(256), 0, st, partials, B,
+    DZ_LAUNCH(finalize_norm_kernel, dim3((n + 255) / 256), dim3(256), 0, st, partials, B,
                        ntile, C, T, gamma, beta, scale, shift);
     DZ_HIP(hipGetLastError());
     return 0;

@@ -284,7 +284,7 @@ int launch(const DzConvGemm& p, hipStream_t st) {
         attr_set = true;
     }
     dim3 grid((p.Tout + C::BM - 1) / C::BM, p.Npad / C::BN, p.B);
-    hipLaunchKernelGGL((gemm_split_kernel<WM, NB, PRO, EPI>), grid, dim3(C::T), C::LDS, st, p);
+    DZ_LAUNCH((gemm_split_kernel<WM, NB, PRO, EPI>), grid, dim3(C::T), C::LDS, st, p);
     DZ_HIP(hipGetLastError());
     return 0;
 }

@@ -156,7 +156,7 @@ __global__ __launch_bounds__(512) void lstm_rec_kernel(const float* __restrict__
 
 int dz_launch_lstm(const float* gx, const float* whh, float* hout, int B, int T, hipStream_t st) {
     dim3 grid(B, 2);
-    hipLaunchKernelGGL(lstm_rec_kernel, grid, dim3(512), 0, st, gx, whh, hout, B, T);
+    DZ_LAUNCH(lstm_rec_kernel, grid, dim3(512), 0, st, gx, whh, hout, B, T);
     DZ_HIP(hipGetLastError());
     return 0;
 }

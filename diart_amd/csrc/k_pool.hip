@@ -122,7 +122,7 @@ int launch_pool(const float* X, long long xstride, int T, int C, int ldx, const 
     DZ_REQUIRE(lds <= 160 * 1024, "stats_pool: %d frames do not fit in LDS", T);
     DZ_HIP(hipFuncSetAttribute((const void*)stats_pool_kernel<K>,
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL((stats_pool_kernel<K>), dim3((C + 63) / 64, nx), dim3(256), lds, st, X, xstride,
+    DZ_LAUNCH((stats_pool_kernel<K>), dim3((C + 63) / 64, nx), dim3(256), lds, st, X, xstride,
                        T, C, ldx, weights, Fw, ktot, kofs, out, ldo);
     DZ_HIP(hipGetLastError());
     return 0;
@@ -341,14 +341,14 @@ int dz_launch_osp(const float* seg, int B, int F, int K, float gamma, float beta
     DZ_REQUIRE(K >= 1 && K <= 8, "osp: 1 <= speakers <= 8 (got %d)", K);
     const size_t lds = sizeof(float) * ((size_t)F * K + 2 * K);
     DZ_REQUIRE(lds <= 64 * 1024, "osp: %d frames x %d speakers do not fit in LDS", F, K);
-    hipLaunchKernelGGL(osp_kernel, dim3(B), dim3(256), lds, st, seg, F, K, gamma, beta, normalize,
+    DZ_LAUNCH(osp_kernel, dim3(B), dim3(256), lds, st, seg, F, K, gamma, beta, normalize,
                        speaker_major, out);
     DZ_HIP(hipGetLastError());
     return 0;
 }
 
 int dz_launch_l2norm(float* x, int rows, int dim, float norm, hipStream_t st) {
-    hipLaunchKernelGGL(l2norm_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, x, rows, dim, norm);
+    DZ_LAUNCH(l2norm_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, x, rows, dim, norm);
     DZ_HIP(hipGetLastError());
     return 0;
 }
@@ -356,7 +356,7 @@ int dz_launch_l2norm(float* x, int rows, int dim, float norm, hipStream_t st) {
 int dz_launch_splitk_finish(const float* parts, int nsplit, long long stride, int rows, int dim,
                             int normalize, float* out, hipStream_t st) {
     DZ_REQUIRE(dim <= 512, "splitk_finish: dim %d > 512", dim);
-    hipLaunchKernelGGL(splitk_finish_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, parts, nsplit,
+    DZ_LAUNCH(splitk_finish_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, parts, nsplit,
                        stride, rows, dim, normalize, out);
     DZ_HIP(hipGetLastError());
     return 0;
@@ -366,7 +366,7 @@ int dz_launch_powerset(const float* logp, int rows, int classes, int speakers, f
                        hipStream_t st) {
     DZ_REQUIRE(classes == 1 + speakers + speakers * (speakers - 1) / 2,
                "powerset: %d classes is not 'at most 2 of %d speakers'", classes, speakers);
-    hipLaunchKernelGGL(powerset_kernel, dim3((rows + 255) / 256), dim3(256), 0, st, logp, rows,
+    DZ_LAUNCH(powerset_kernel, dim3((rows + 255) / 256), dim3(256), 0, st, logp, rows,
                        classes, speakers, out);
     DZ_HIP(hipGetLastError());
     return 0;
@@ -374,7 +374,7 @@ int dz_launch_powerset(const float* logp, int rows, int classes, int speakers, f
 
 int dz_launch_cdist(const float* emb, const double* centers, int n, int k, int g, int dim,
                     double* out, hipStream_t st) {
-    hipLaunchKernelGGL(cdist_kernel, dim3(n * k), dim3(256), 0, st, emb, centers, k, g, dim, out);
+    DZ_LAUNCH(cdist_kernel, dim3(n * k), dim3(256), 0, st, emb, centers, k, g, dim, out);
     DZ_HIP(hipGetLastError());
     return 0;
 }
