@@ -37,8 +37,9 @@ StateSource = Union[str, Path, Dict[str, torch.Tensor]]
 def default_precision() -> str:
     """Arithmetic of the GEMM-shaped layers when a model does not say: ``DZ_PRECISION`` or "f16x3"
     (f32 operands split into two f16 numbers = 22 mantissa bits, three f16 MFMAs per product, f32
-    accumulation: measured against the f32 oracle it is indistinguishable from "f32", the exact-f32
-    MFMA path, and 2x faster; weights.PRECISIONS)."""
+    accumulation: measured against the f32 CPU restatement of the networks it is indistinguishable
+    from "f32", the exact-f32 MFMA path, and 1.4x faster end to end; weights.PRECISIONS,
+    DESIGN.md 4.4)."""
     import os
     from .weights import PRECISIONS
     p = os.environ.get("DZ_PRECISION", "f16x3")
