@@ -90,8 +90,10 @@ void dz_set_error(const char* fmt, ...);
 // ---------------------------------------------------------------------------
 // k_front.hip ---------------------------------------------------------------
 // per-chunk mean / rstd of the raw waveform -> stats[B][2]
+// scratch: dz_wave_stats_scratch_floats(B) floats, zero before the first launch
 int dz_launch_wave_stats(const float* wave, long long stride, int B, int S, float* stats,
-                         hipStream_t st);
+                         float* scratch, hipStream_t st);
+size_t dz_wave_stats_scratch_floats(int B);
 // InstanceNorm(1)+sinc conv(80x251, stride 10)+abs+maxpool3 -> y0[B][P0][80], partials
 int dz_launch_sinc_conv0(const float* wave, long long stride, int B, int S, const float* stats,
                          float gamma, float beta, const float* filt, float* y0, int P0,

@@ -8,55 +8,97 @@
 #include "dz_common.h"
 
 // ---------------------------------------------------------------------------
-// wave_stats: one workgroup per chunk; two passes (mean, then centred variance) so the
-// variance does not cancel; 16 B coalesced reads of the window, wave shuffles + LDS.
+// wave_stats: WS_G workgroups per chunk, each over one slice of the window.  A slice is read from
+// HBM ONCE (16 B coalesced loads, kept in registers), reduced in two passes (slice mean, then
+// centred second moment: no cancellation); the slice moments are combined with Chan's formula in
+// f64, in fixed slice order, by whichever workgroup of the chunk finishes last (a per-chunk
+// arrival counter in scratch, reset for the next launch).  One workgroup per chunk (the first
+// version) streamed 320 KB through 256 threads twice: 22 us alone, 65-90 us beside other kernels,
+// at the head of both networks' critical paths.
+// scratch per chunk: WS_G x (mean, M2) floats + 1 arrival counter (zero before the first launch).
 // ---------------------------------------------------------------------------
-__device__ __forceinline__ double dz_block_sum(double v, double* red) {
+#define WS_G 8
+#define WS_NV 10   /* float4 kept per thread: slices up to 256 * 10 * 4 = 10240 samples */
+
+__device__ __forceinline__ float dz_block_sum_f(float v, float* red) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
     const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
     __syncthreads();
     if (l == 0) red[w] = v;
     __syncthreads();
-    double t = 0.0;
-    const int nw = blockDim.x >> 6;
-    for (int i = 0; i < nw; ++i) t += red[i];
-    return t;
+    return (red[0] + red[1]) + (red[2] + red[3]);
 }
 
 __global__ __launch_bounds__(256) void wave_stats_kernel(const float* __restrict__ wave,
-                                                         long long stride, int S,
+                                                         long long stride, int S, int L,
+                                                         float* __restrict__ scratch,
                                                          float* __restrict__ stats) {
-    __shared__ double red[4];
-    const float* x = wave + (long long)blockIdx.x * stride;
-    const int n4 = S >> 2;
+    __shared__ float red[4];
+    __shared__ int last_s;
+    const int b = blockIdx.y, g = blockIdx.x, tid = threadIdx.x;
+    const int s0 = g * L, s1 = min(S, s0 + L), n = max(0, s1 - s0);
+    const float* x = wave + (long long)b * stride + s0;
+    const int n4 = n >> 2;
+    float4 v[WS_NV];
     float s = 0.f;
-    for (int i = threadIdx.x; i < n4; i += 256) {
-        const float4 v = reinterpret_cast<const float4*>(x)[i];
-        s += (v.x + v.y) + (v.z + v.w);
+#pragma unroll
+    for (int j = 0; j < WS_NV; ++j) {
+        const int i = tid + 256 * j;
+        v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (i < n4) {
+            v[j] = reinterpret_cast<const float4*>(x)[i];
+            s += (v[j].x + v[j].y) + (v[j].z + v[j].w);
+        }
     }
-    for (int i = (n4 << 2) + threadIdx.x; i < S; i += 256) s += x[i];
-    const double mean_d = dz_block_sum((double)s, red) / (double)S;
-    const float mean = (float)mean_d;
+    for (int i = (n4 << 2) + tid; i < n; i += 256) s += x[i];          // tail (< 4 samples)
+    const float mean = n > 0 ? dz_block_sum_f(s, red) / (float)n : 0.f;
     float ss = 0.f;
-    for (int i = threadIdx.x; i < n4; i += 256) {
-        const float4 v = reinterpret_cast<const float4*>(x)[i];
-        const float a = v.x - mean, b = v.y - mean, c = v.z - mean, d = v.w - mean;
-        ss += (a * a + b * b) + (c * c + d * d);
-    }
-    for (int i = (n4 << 2) + threadIdx.x; i < S; i += 256) {
+#pragma unroll
+    for (int j = 0; j < WS_NV; ++j)
+        if (tid + 256 * j < n4) {
+            const float a = v[j].x - mean, c = v[j].y - mean, d = v[j].z - mean, e = v[j].w - mean;
+            ss += (a * a + c * c) + (d * d + e * e);
+        }
+    for (int i = (n4 << 2) + tid; i < n; i += 256) {
         const float a = x[i] - mean;
         ss += a * a;
     }
-    const double var = dz_block_sum((double)ss, red) / (double)S;  // biased, like InstanceNorm
-    if (threadIdx.x == 0) {
-        stats[2 * blockIdx.x] = mean;
-        stats[2 * blockIdx.x + 1] = (float)(1.0 / sqrt(var + 1e-5));
+    const float m2 = dz_block_sum_f(ss, red);
+    float* part = scratch + (long long)b * (2 * WS_G + 1);
+    int* counter = reinterpret_cast<int*>(part + 2 * WS_G);
+    if (tid == 0) {
+        part[2 * g] = mean;
+        part[2 * g + 1] = m2;
+        __threadfence();                                   // publish the moments, then arrive
+        last_s = atomicAdd(counter, 1) == WS_G - 1;
+    }
+    __syncthreads();
+    if (last_s && tid == 0) {
+        __threadfence();
+        double tot = 0.0, M2 = 0.0;
+        double mu[WS_G], cnt[WS_G];
+        for (int i = 0; i < WS_G; ++i) {
+            cnt[i] = (double)max(0, min(S, (i + 1) * L) - i * L);
+            mu[i] = (double)__hip_atomic_load(part + 2 * i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            M2 += (double)__hip_atomic_load(part + 2 * i + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            tot += cnt[i] * mu[i];
+        }
+        const double m = tot / (double)S;
+        for (int i = 0; i < WS_G; ++i) M2 += cnt[i] * (mu[i] - m) * (mu[i] - m);
+        stats[2 * b] = (float)m;
+        stats[2 * b + 1] = (float)(1.0 / sqrt(M2 / (double)S + 1e-5));   // biased, like InstanceNorm
+        *counter = 0;                                                      // ready for the next launch
     }
 }
 
+size_t dz_wave_stats_scratch_floats(int B) { return (size_t)B * (2 * WS_G + 1); }
+
 int dz_launch_wave_stats(const float* wave, long long stride, int B, int S, float* stats,
-                         hipStream_t st) {
-    DZ_LAUNCH(wave_stats_kernel, dim3(B), dim3(256), 0, st, wave, stride, S, stats);
+                         float* scratch, hipStream_t st) {
+    int L = ((S + WS_G - 1) / WS_G + 3) & ~3;              // slice length, a multiple of 4 samples
+    DZ_REQUIRE(L <= 256 * WS_NV * 4, "wave_stats: %d samples per chunk exceed the %d-sample slices",
+               S, 256 * WS_NV * 4 * WS_G);
+    DZ_LAUNCH(wave_stats_kernel, dim3(WS_G, B), dim3(256), 0, st, wave, stride, S, L, scratch, stats);
     DZ_HIP(hipGetLastError());
     return 0;
 }

@@ -28,9 +28,18 @@ __global__ __launch_bounds__(256) void stats_pool_kernel(
     const int c = tid & 63, ph = tid >> 6;
 
     const float* Xb = X + (long long)xi * xstride;   // chunks may sit on a wider row pitch than T
-    for (int idx = tid; idx < T * 64; idx += 256) {
-        const int t = idx >> 6, cc = idx & 63;
-        xs[idx] = (c0 + cc < C) ? Xb[(long long)t * ldx + c0 + cc] : 0.f;
+    for (int i4 = tid; i4 < T * 16; i4 += 256) {           // 16 B per lane, 256 B rows
+        const int t = i4 >> 4, cc = (i4 & 15) << 2;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (c0 + cc + 3 < C) {
+            v = *reinterpret_cast<const float4*>(Xb + (long long)t * ldx + c0 + cc);
+        } else {
+            const float* src = Xb + (long long)t * ldx + c0 + cc;
+            if (c0 + cc < C) v.x = src[0];
+            if (c0 + cc + 1 < C) v.y = src[1];
+            if (c0 + cc + 2 < C) v.z = src[2];
+        }
+        reinterpret_cast<float4*>(xs)[i4] = v;
     }
     // temporal weights, resampled to T frames like F.interpolate(mode="linear",
     // align_corners=False) (ATen area_pixel_compute_source_index)
