@@ -166,10 +166,9 @@ static int run_gemm(DzConvGemm& p, const void* split, hipStream_t st) {
 }
 
 struct SincScratch {
-    float *stats, *wscratch, *y0, *part0, *sc0, *sh0, *y1, *part1, *sc1, *sh1, *y2, *part2, *sc2, *sh2;
+    float *stats, *y0, *part0, *sc0, *sh0, *y1, *part1, *sc1, *sh1, *y2, *part2, *sc2, *sh2;
     void carve(Arena& a, const SincGeom& g, int Bm) {
-        stats = a.take((size_t)Bm * 2);
-        wscratch = a.take(dz_wave_stats_scratch_floats(Bm));
+        stats = a.take((size_t)Bm * 2 * DZ_WS_G);   // slice moments of the waveform
         y0 = a.take((size_t)Bm * g.P0 * 80);
         part0 = a.take((size_t)Bm * g.nt0 * 80 * 2);
         sc0 = a.take((size_t)Bm * 80);
@@ -190,9 +189,9 @@ struct SincScratch {
 static int run_sincnet(const dz_sincnet_weights& w, const SincGeom& g, const SincScratch& s,
                        const float* wave, long long stride, int B, hipStream_t st) {
     int rc;
-    { ProfScope ps(T_WAVE, st); if ((rc = dz_launch_wave_stats(wave, stride, B, g.S, s.stats, s.wscratch, st))) return rc; }
+    { ProfScope ps(T_WAVE, st); if ((rc = dz_launch_wave_stats(wave, stride, B, g.S, s.stats, st))) return rc; }
     { ProfScope ps(T_CONV0, st);
-    if ((rc = dz_launch_sinc_conv0(wave, stride, B, g.S, s.stats, w.wav_gamma, w.wav_beta, w.filt,
+    if ((rc = dz_launch_sinc_conv0(wave, stride, B, g.S, s.stats, 1, w.wav_gamma, w.wav_beta, w.filt,
                                    s.y0, g.P0, s.part0, g.nt0, st)))
         return rc; }
     { ProfScope ps(T_FIN, st);
@@ -594,14 +593,13 @@ extern "C" int dz_k_wave_stats(dz_ctx* ctx, const float* d_wave, long long strid
     int rc;
     if ((rc = check_wave("dz_k_wave_stats", d_wave, stride, samples))) return rc;
     DZ_HIP(hipSetDevice(ctx->device));
-    // kernel-level test entry: a throw-away scratch (the forward passes carve theirs from the arena)
-    float* scratch = nullptr;
-    const size_t bytes = dz_wave_stats_scratch_floats(batch) * sizeof(float);
-    DZ_HIP(hipMalloc((void**)&scratch, bytes));
-    DZ_HIP(hipMemsetAsync(scratch, 0, bytes, (hipStream_t)stream));
-    rc = dz_launch_wave_stats(d_wave, stride, batch, samples, d_stats, scratch, (hipStream_t)stream);
+    // kernel-level entry: slice moments into a throw-away buffer, then the (mean, rstd) contract
+    float* mom = nullptr;
+    DZ_HIP(hipMalloc((void**)&mom, (size_t)batch * 2 * DZ_WS_G * sizeof(float)));
+    rc = dz_launch_wave_stats(d_wave, stride, batch, samples, mom, (hipStream_t)stream);
+    if (!rc) rc = dz_launch_wave_stats_combine(mom, batch, samples, d_stats, (hipStream_t)stream);
     (void)hipStreamSynchronize((hipStream_t)stream);
-    (void)hipFree(scratch);
+    (void)hipFree(mom);
     return rc;
 }
 extern "C" int dz_k_sinc_conv0(dz_ctx* ctx, const float* d_wave, long long stride, int batch,
@@ -613,7 +611,7 @@ extern "C" int dz_k_sinc_conv0(dz_ctx* ctx, const float* d_wave, long long strid
     const SincGeom g = sinc_geom(samples);
     DZ_REQUIRE(g.P0 > 0, "dz_k_sinc_conv0: %d samples is too short", samples);
     DZ_HIP(hipSetDevice(ctx->device));
-    return dz_launch_sinc_conv0(d_wave, stride, batch, samples, d_stats, gamma, beta, d_filt, d_y0,
+    return dz_launch_sinc_conv0(d_wave, stride, batch, samples, d_stats, 0, gamma, beta, d_filt, d_y0,
                                 g.P0, d_partials, g.nt0, (hipStream_t)stream);
 }
 extern "C" int dz_k_finalize_norm(dz_ctx* ctx, const float* d_partials, int batch, int ntile,

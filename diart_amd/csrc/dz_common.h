@@ -89,15 +89,18 @@ void dz_set_error(const char* fmt, ...);
 // kernel launch wrappers (one per .hip file)
 // ---------------------------------------------------------------------------
 // k_front.hip ---------------------------------------------------------------
-// per-chunk mean / rstd of the raw waveform -> stats[B][2]
-// scratch: dz_wave_stats_scratch_floats(B) floats, zero before the first launch
-int dz_launch_wave_stats(const float* wave, long long stride, int B, int S, float* stats,
-                         float* scratch, hipStream_t st);
-size_t dz_wave_stats_scratch_floats(int B);
-// InstanceNorm(1)+sinc conv(80x251, stride 10)+abs+maxpool3 -> y0[B][P0][80], partials
+// wave statistics in two steps: slice moments, then (mean, rstd) merged by the consumer
+#define DZ_WS_G 8   /* slices per chunk in wave_stats */
+// slice moments of the raw waveform -> mom[B][DZ_WS_G][2] (mean_i, M2_i)
+int dz_launch_wave_stats(const float* wave, long long stride, int B, int S, float* mom,
+                         hipStream_t st);
+// slice moments -> stats[B][2] = (mean, rstd)
+int dz_launch_wave_stats_combine(const float* mom, int B, int S, float* stats, hipStream_t st);
+// InstanceNorm(1)+sinc conv(80x251, stride 10)+abs+maxpool3 -> y0[B][P0][80], partials;
+// stats = (mean, rstd) per chunk, or wave_stats' slice moments when stats_are_moments
 int dz_launch_sinc_conv0(const float* wave, long long stride, int B, int S, const float* stats,
-                         float gamma, float beta, const float* filt, float* y0, int P0,
-                         float* partials, int ntile, hipStream_t st);
+                         int stats_are_moments, float gamma, float beta, const float* filt,
+                         float* y0, int P0, float* partials, int ntile, hipStream_t st);
 // partial (sum,sumsq) -> per (b,c) scale/shift of InstanceNorm1d(C, affine)
 int dz_launch_finalize_norm(const float* partials, int B, int ntile, int C, int T,
                             const float* gamma, const float* beta, float* scale, float* shift,

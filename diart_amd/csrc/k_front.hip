@@ -9,15 +9,16 @@
 
 // ---------------------------------------------------------------------------
 // wave_stats: WS_G workgroups per chunk, each over one slice of the window.  A slice is read from
-// HBM ONCE (16 B coalesced loads, kept in registers), reduced in two passes (slice mean, then
-// centred second moment: no cancellation); the slice moments are combined with Chan's formula in
-// f64, in fixed slice order, by whichever workgroup of the chunk finishes last (a per-chunk
-// arrival counter in scratch, reset for the next launch).  One workgroup per chunk (the first
-// version) streamed 320 KB through 256 threads twice: 22 us alone, 65-90 us beside other kernels,
-// at the head of both networks' critical paths.
-// scratch per chunk: WS_G x (mean, M2) floats + 1 arrival counter (zero before the first launch).
+// HBM ONCE (16 B coalesced loads, kept in registers) and reduced in two passes (slice mean, then
+// centred second moment: no cancellation) to (mean_i, M2_i).  The consumer (sinc_conv0's
+// prologue, or wave_stats_combine for the kernel-level entry point) merges the WS_G slice moments
+// with Chan's formula in f64, in fixed slice order — the kernel boundary is the only
+// synchronisation.  (One workgroup per chunk, the first version, streamed 320 KB through 256
+// threads twice: 22 us alone, 65-90 us beside other kernels, at the head of both networks'
+// critical paths.  A "last workgroup combines" variant needs a device-scope release per
+// workgroup, i.e. an L2 write-back across the 8 XCDs: measured slower.)
+// moments layout: [B][WS_G][2] floats.
 // ---------------------------------------------------------------------------
-#define WS_G 8
 #define WS_NV 10   /* float4 kept per thread: slices up to 256 * 10 * 4 = 10240 samples */
 
 __device__ __forceinline__ float dz_block_sum_f(float v, float* red) {
@@ -29,13 +30,35 @@ __device__ __forceinline__ float dz_block_sum_f(float v, float* red) {
     return (red[0] + red[1]) + (red[2] + red[3]);
 }
 
+__host__ __device__ __forceinline__ int dz_ws_slice(int S) { return ((S + DZ_WS_G - 1) / DZ_WS_G + 3) & ~3; }
+
+// (mean, rstd) of chunk b from its slice moments — fixed order, f64
+__device__ __forceinline__ void dz_ws_combine(const float* __restrict__ mom, int b, int S, float* mean,
+                                              float* rstd) {
+    const int L = dz_ws_slice(S);
+    const float* m = mom + (long long)b * 2 * DZ_WS_G;
+    double tot = 0.0, M2 = 0.0, mu[DZ_WS_G], cnt[DZ_WS_G];
+#pragma unroll
+    for (int i = 0; i < DZ_WS_G; ++i) {
+        const int n = min(S, (i + 1) * L) - i * L;
+        cnt[i] = (double)(n > 0 ? n : 0);
+        mu[i] = (double)m[2 * i];
+        M2 += (double)m[2 * i + 1];
+        tot += cnt[i] * mu[i];
+    }
+    const double mm = tot / (double)S;
+#pragma unroll
+    for (int i = 0; i < DZ_WS_G; ++i) M2 += cnt[i] * (mu[i] - mm) * (mu[i] - mm);
+    *mean = (float)mm;
+    *rstd = (float)(1.0 / sqrt(M2 / (double)S + 1e-5));   // biased variance, like InstanceNorm
+}
+
 __global__ __launch_bounds__(256) void wave_stats_kernel(const float* __restrict__ wave,
-                                                         long long stride, int S, int L,
-                                                         float* __restrict__ scratch,
-                                                         float* __restrict__ stats) {
+                                                         long long stride, int S,
+                                                         float* __restrict__ mom) {
     __shared__ float red[4];
-    __shared__ int last_s;
     const int b = blockIdx.y, g = blockIdx.x, tid = threadIdx.x;
+    const int L = dz_ws_slice(S);
     const int s0 = g * L, s1 = min(S, s0 + L), n = max(0, s1 - s0);
     const float* x = wave + (long long)b * stride + s0;
     const int n4 = n >> 2;
@@ -64,41 +87,31 @@ __global__ __launch_bounds__(256) void wave_stats_kernel(const float* __restrict
         ss += a * a;
     }
     const float m2 = dz_block_sum_f(ss, red);
-    float* part = scratch + (long long)b * (2 * WS_G + 1);
-    int* counter = reinterpret_cast<int*>(part + 2 * WS_G);
     if (tid == 0) {
-        part[2 * g] = mean;
-        part[2 * g + 1] = m2;
-        __threadfence();                                   // publish the moments, then arrive
-        last_s = atomicAdd(counter, 1) == WS_G - 1;
-    }
-    __syncthreads();
-    if (last_s && tid == 0) {
-        __threadfence();
-        double tot = 0.0, M2 = 0.0;
-        double mu[WS_G], cnt[WS_G];
-        for (int i = 0; i < WS_G; ++i) {
-            cnt[i] = (double)max(0, min(S, (i + 1) * L) - i * L);
-            mu[i] = (double)__hip_atomic_load(part + 2 * i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            M2 += (double)__hip_atomic_load(part + 2 * i + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            tot += cnt[i] * mu[i];
-        }
-        const double m = tot / (double)S;
-        for (int i = 0; i < WS_G; ++i) M2 += cnt[i] * (mu[i] - m) * (mu[i] - m);
-        stats[2 * b] = (float)m;
-        stats[2 * b + 1] = (float)(1.0 / sqrt(M2 / (double)S + 1e-5));   // biased, like InstanceNorm
-        *counter = 0;                                                      // ready for the next launch
+        float* out = mom + ((long long)b * DZ_WS_G + g) * 2;
+        out[0] = mean;
+        out[1] = m2;
     }
 }
 
-size_t dz_wave_stats_scratch_floats(int B) { return (size_t)B * (2 * WS_G + 1); }
+__global__ void wave_stats_combine_kernel(const float* __restrict__ mom, int B, int S,
+                                          float* __restrict__ stats) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < B) dz_ws_combine(mom, b, S, stats + 2 * b, stats + 2 * b + 1);
+}
 
-int dz_launch_wave_stats(const float* wave, long long stride, int B, int S, float* stats,
-                         float* scratch, hipStream_t st) {
-    int L = ((S + WS_G - 1) / WS_G + 3) & ~3;              // slice length, a multiple of 4 samples
-    DZ_REQUIRE(L <= 256 * WS_NV * 4, "wave_stats: %d samples per chunk exceed the %d-sample slices",
-               S, 256 * WS_NV * 4 * WS_G);
-    DZ_LAUNCH(wave_stats_kernel, dim3(WS_G, B), dim3(256), 0, st, wave, stride, S, L, scratch, stats);
+// mom: [B][DZ_WS_G][2] floats
+int dz_launch_wave_stats(const float* wave, long long stride, int B, int S, float* mom,
+                         hipStream_t st) {
+    DZ_REQUIRE(dz_ws_slice(S) <= 256 * WS_NV * 4, "wave_stats: %d samples per chunk exceed %d", S,
+               256 * WS_NV * 4 * DZ_WS_G);
+    DZ_LAUNCH(wave_stats_kernel, dim3(DZ_WS_G, B), dim3(256), 0, st, wave, stride, S, mom);
+    DZ_HIP(hipGetLastError());
+    return 0;
+}
+// (mean, rstd) per chunk from the slice moments: the kernel-level entry point's contract
+int dz_launch_wave_stats_combine(const float* mom, int B, int S, float* stats, hipStream_t st) {
+    DZ_LAUNCH(wave_stats_combine_kernel, dim3((B + 63) / 64), dim3(64), 0, st, mom, B, S, stats);
     DZ_HIP(hipGetLastError());
     return 0;
 }
@@ -129,8 +142,8 @@ int dz_launch_wave_stats(const float* wave, long long stride, int B, int S, floa
 
 __global__ __launch_bounds__(256) void sinc_conv0_kernel(
     const float* __restrict__ wave, long long stride, int S, const float* __restrict__ stats,
-    float gamma, float beta, const float* __restrict__ filt, float* __restrict__ y0, int P0,
-    float* __restrict__ partials, int ntile) {
+    int stats_are_moments, float gamma, float beta, const float* __restrict__ filt,
+    float* __restrict__ y0, int P0, float* __restrict__ partials, int ntile) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* filt_s = smem;                    // [128][96], swizzled
     float* xs = smem + 4 * C0_KS * C0_NP;    // [C0_XS]
@@ -143,7 +156,11 @@ __global__ __launch_bounds__(256) void sinc_conv0_kernel(
             reinterpret_cast<const float4*>(filt)[i4];
     }
     {
-        const float mean = stats[2 * b], rstd = stats[2 * b + 1];
+        float mean, rstd;
+        if (stats_are_moments)   // wave_stats' slice moments: merged here (fixed order, f64)
+            dz_ws_combine(stats, b, S, &mean, &rstd);
+        else
+            mean = stats[2 * b], rstd = stats[2 * b + 1];
         const float* wb = wave + (long long)b * stride;
         const int s0 = tile * (C0_FR * 10) - C0_LP;
         for (int i = tid; i < C0_XS; i += 256) {
@@ -225,8 +242,8 @@ __global__ __launch_bounds__(256) void sinc_conv0_kernel(
 }
 
 int dz_launch_sinc_conv0(const float* wave, long long stride, int B, int S, const float* stats,
-                         float gamma, float beta, const float* filt, float* y0, int P0,
-                         float* partials, int ntile, hipStream_t st) {
+                         int stats_are_moments, float gamma, float beta, const float* filt,
+                         float* y0, int P0, float* partials, int ntile, hipStream_t st) {
     const size_t k_loop = (4 * C0_KS * C0_NP + C0_XS) * sizeof(float);
     const size_t epi = (size_t)C0_FR * C0_OLD * sizeof(float);
     const size_t lds = k_loop > epi ? k_loop : epi;
@@ -237,7 +254,7 @@ int dz_launch_sinc_conv0(const float* wave, long long stride, int B, int S, cons
         attr_set = true;
     }
     DZ_LAUNCH(sinc_conv0_kernel, dim3(ntile, B), dim3(256), lds, st, wave, stride, S,
-                       stats, gamma, beta, filt, y0, P0, partials, ntile);
+                       stats, stats_are_moments, gamma, beta, filt, y0, P0, partials, ntile);
     DZ_HIP(hipGetLastError());
     return 0;
 }
