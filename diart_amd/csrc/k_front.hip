@@ -19,7 +19,7 @@
 // workgroup, i.e. an L2 write-back across the 8 XCDs: measured slower.)
 // moments layout: [B][WS_G][2] floats.
 // ---------------------------------------------------------------------------
-#define WS_NV 10   /* float4 kept per thread: slices up to 256 * 10 * 4 = 10240 samples */
+#define WS_NV 10   /* float4 kept per thread: slices up to 256 * 10 * 4 = 10240 samples stay in registers */
 
 __device__ __forceinline__ float dz_block_sum_f(float v, float* red) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
@@ -73,6 +73,10 @@ __global__ __launch_bounds__(256) void wave_stats_kernel(const float* __restrict
             s += (v[j].x + v[j].y) + (v[j].z + v[j].w);
         }
     }
+    for (int i = tid + 256 * WS_NV; i < n4; i += 256) {                  // longer windows: not cached
+        const float4 u = reinterpret_cast<const float4*>(x)[i];
+        s += (u.x + u.y) + (u.z + u.w);
+    }
     for (int i = (n4 << 2) + tid; i < n; i += 256) s += x[i];          // tail (< 4 samples)
     const float mean = n > 0 ? dz_block_sum_f(s, red) / (float)n : 0.f;
     float ss = 0.f;
@@ -82,6 +86,11 @@ __global__ __launch_bounds__(256) void wave_stats_kernel(const float* __restrict
             const float a = v[j].x - mean, c = v[j].y - mean, d = v[j].z - mean, e = v[j].w - mean;
             ss += (a * a + c * c) + (d * d + e * e);
         }
+    for (int i = tid + 256 * WS_NV; i < n4; i += 256) {                  // re-read what was not cached
+        const float4 u = reinterpret_cast<const float4*>(x)[i];
+        const float a = u.x - mean, c = u.y - mean, d = u.z - mean, e = u.w - mean;
+        ss += (a * a + c * c) + (d * d + e * e);
+    }
     for (int i = (n4 << 2) + tid; i < n; i += 256) {
         const float a = x[i] - mean;
         ss += a * a;
@@ -103,8 +112,6 @@ __global__ void wave_stats_combine_kernel(const float* __restrict__ mom, int B, 
 // mom: [B][DZ_WS_G][2] floats
 int dz_launch_wave_stats(const float* wave, long long stride, int B, int S, float* mom,
                          hipStream_t st) {
-    DZ_REQUIRE(dz_ws_slice(S) <= 256 * WS_NV * 4, "wave_stats: %d samples per chunk exceed %d", S,
-               256 * WS_NV * 4 * DZ_WS_G);
     DZ_LAUNCH(wave_stats_kernel, dim3(DZ_WS_G, B), dim3(256), 0, st, wave, stride, S, mom);
     DZ_HIP(hipGetLastError());
     return 0;

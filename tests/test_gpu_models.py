@@ -118,3 +118,51 @@ def test_errors_are_loud(gpu):
         seg(torch.zeros(1, 2, 80000, device=gpu))    # not mono
     with pytest.raises(DiartAmdError):
         M.HipSegmentation(synth_segmentation_state()).to(torch.device("cpu"))
+
+
+@pytest.mark.parametrize("precision", ["f16x3", "f32"])
+def test_other_geometries_10s_windows_4_speakers(gpu, precision):
+    """Edge geometries the reference supports through its config (duration, model variant):
+    10 s windows (160000 samples -> 589 frames, 575 x-vector frames), the 4-speaker multilabel head
+    (`@Interspeech2021`), batch 1 and a batch that outgrows ``max_batch`` (the handle
+    is re-created), a stream row that is only 16-byte aligned; both arithmetic modes."""
+    from oracle.models_ref import PyanNetRef, XVectorSincNetRef
+    seg_sd, emb_sd = synth_segmentation_state(seed=5, num_speakers=4), synth_embedding_state(seed=6)
+    ref_s, ref_e = PyanNetRef(num_speakers=4).eval(), XVectorSincNetRef().eval()
+    ref_s.load_state_dict(seg_sd)
+    ref_e.load_state_dict(emb_sd)
+    seg = M.HipSegmentation(seg_sd, max_batch=2, precision=precision).to(gpu)
+    emb = M.HipEmbedding(emb_sd, max_batch=2, precision=precision).to(gpu)
+    stream = torch.from_numpy(synth_stream(21, 13.0))
+    assert seg.num_frames(160000) == 589
+    for B in (1, 3):                                           # 3 > max_batch: handle grows
+        x = torch.stack([stream[4 + 8000 * i: 4 + 8000 * i + 160000] for i in range(B)])[:, None, :]
+        with torch.no_grad():
+            rs = ref_s(x)
+            w = torch.rand(B, 589, 4, generator=torch.Generator().manual_seed(B)) ** 2 + 1e-8
+            re = ref_e.forward_multi(x, w)
+        dx = stream.to(gpu)[4:].unfold(0, 160000, 8000)[:B]    # in-place view, offset 4 samples = 16 B
+        assert dx.data_ptr() % 16 == 0 and dx.stride(0) == 8000
+        gs = seg(dx[:, None, :]).cpu()
+        assert gs.shape == rs.shape == (B, 589, 4)
+        assert (gs - rs).abs().max().item() < SEG_MAX and (gs - rs).abs().mean().item() < SEG_MEAN
+        ge = emb.forward_multi(dx[:, None, :], w.permute(0, 2, 1).contiguous().to(gpu)).cpu()
+        assert ge.shape == re.shape == (B, 4, 512)
+        assert ((ge - re).norm(dim=-1) / re.norm(dim=-1)).max().item() < 1e-4
+
+
+def test_precisions_agree_with_each_other(gpu, chunks):
+    """f16x3 vs f32 directly: closer to each other than either is allowed to be to the oracle."""
+    x = chunks[:6].to(gpu)
+    out = {}
+    for p in ("f32", "f16x3"):
+        seg = M.HipSegmentation(synth_segmentation_state(), max_batch=8, precision=p).to(gpu)
+        emb = M.HipEmbedding(synth_embedding_state(), max_batch=8, precision=p).to(gpu)
+        s = seg(x)
+        from diart_amd.functional import overlapped_speech_penalty
+        w = overlapped_speech_penalty(s, 3, 10, speaker_major=True)
+        out[p] = (s.cpu(), emb.forward_multi(x, w, normalize=True).cpu())
+    ds = (out["f32"][0] - out["f16x3"][0]).abs().max().item()
+    de = (out["f32"][1] - out["f16x3"][1]).abs().max().item()
+    print("f32 vs f16x3: seg max|d|", ds, "normalised emb max|d|", de)
+    assert ds < 5e-5 and de < 5e-6
