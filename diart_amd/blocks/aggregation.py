@@ -136,8 +136,8 @@ class BatchedOutputTail:
         self._turns = np.empty((n, self.max_turns, 3), dtype=np.float64)
         self._nturns = np.empty(n, dtype=np.int32)
 
-    def reset(self):
-        for h in self._hs:
+    def reset(self, slot=None):
+        for h in (self._hs if slot is None else [self._hs[slot]]):
             self._lib.check(self._lib.load().dz_tail_reset(h), "dz_tail_reset")
 
     def __del__(self):
@@ -148,13 +148,17 @@ class BatchedOutputTail:
         except Exception:
             pass
 
-    def __call__(self, scores: np.ndarray, chunk_start, resolution):
+    def __call__(self, scores: np.ndarray, chunk_start, resolution, slots=None):
+        """``slots``: the streams the rows of ``scores`` belong to (default: all, in order); the
+        outputs are then indexed by row, not by slot."""
         scores = np.ascontiguousarray(scores, dtype=np.float64)
-        assert scores.shape == (self.n, self.F, self.G), scores.shape
-        start = np.ascontiguousarray(np.broadcast_to(np.asarray(chunk_start, dtype=np.float64), (self.n,)))
-        res = np.ascontiguousarray(np.broadcast_to(np.asarray(resolution, dtype=np.float64), (self.n,)))
+        n = self.n if slots is None else len(slots)
+        handles = self._handles if slots is None else (self._lib.vp * n)(*[self._hs[i] for i in slots])
+        assert scores.shape == (n, self.F, self.G), scores.shape
+        start = np.ascontiguousarray(np.broadcast_to(np.asarray(chunk_start, dtype=np.float64), (n,)))
+        res = np.ascontiguousarray(np.broadcast_to(np.asarray(resolution, dtype=np.float64), (n,)))
         self._lib.check(self._lib.load().dz_tail_step_batch(
-            self._handles, self.n, scores.ctypes.data, start.ctypes.data, res.ctypes.data,
+            handles, n, scores.ctypes.data, start.ctypes.data, res.ctypes.data,
             self._agg.ctypes.data, self._rows.ctypes.data, self._t0.ctypes.data, self._res.ctypes.data,
             self._turns.ctypes.data, self.max_turns, self._nturns.ctypes.data, self.num_threads),
             "dz_tail_step_batch")

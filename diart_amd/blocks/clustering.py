@@ -143,18 +143,22 @@ class BatchedSpeakerClustering:
         self.max_speakers, self.num_threads = max_speakers, num_threads
         self._handles = (_lib.vp * num_streams)(*[s._h for s in self.streams])
 
-    def reset(self):
-        for s in self.streams:
+    def reset(self, slot=None):
+        for s in (self.streams if slot is None else [self.streams[slot]]):
             s.reset()
 
-    def __call__(self, seg: np.ndarray, emb: np.ndarray, want_scores: bool = True):
+    def __call__(self, seg: np.ndarray, emb: np.ndarray, want_scores: bool = True, slots=None):
+        """``slots``: the streams the N rows belong to (default: all, in order)."""
         seg = np.ascontiguousarray(seg, dtype=np.float32)
         emb = np.ascontiguousarray(emb, dtype=np.float32)
         N, F, K = seg.shape
-        assert N == len(self.streams) and emb.shape[:2] == (N, K)
+        handles = self._handles
+        if slots is not None:
+            handles = (_lib.vp * N)(*[self.streams[i]._h for i in slots])
+        assert N == len(handles) and emb.shape[:2] == (N, K)
         scores = np.empty((N, F, self.max_speakers), dtype=np.float64) if want_scores else None
         assign = np.empty((N, K), dtype=np.int32)
-        rc = _lib.load().dz_clu_step_batch(self._handles, N, seg.ctypes.data, F, K, emb.ctypes.data,
+        rc = _lib.load().dz_clu_step_batch(handles, N, seg.ctypes.data, F, K, emb.ctypes.data,
                                            emb.shape[2], scores.ctypes.data if want_scores else None,
                                            assign.ctypes.data, self.num_threads)
         if rc == 3:

@@ -20,7 +20,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
-from typing import List, Optional, Tuple
+from typing import List, Optional, Sequence, Tuple
 
 import numpy as np
 import torch
@@ -141,11 +141,13 @@ class StreamBatch:
         self._lib = _lib.load()
         self._ctx = _lib.context(self.device.index)
 
-    def reset(self):
-        self.clustering.reset()
-        self._t = 0
+    def reset(self, slot: Optional[int] = None):
+        """Forget the clustering / aggregation state of every stream, or of one slot."""
+        self.clustering.reset(slot)
         if self.tail is not None:
-            self.tail.reset()
+            self.tail.reset(slot)
+        if slot is None:
+            self._t = 0
 
     # ------------------------------------------------------------------ GPU half
     def _slot(self, F: int, K: int, D: int) -> dict:
@@ -180,11 +182,11 @@ class StreamBatch:
             if self.seg_split == 1:
                 hs = [self.seg._need(S, self.n)]
             else:
-                hs = [self.seg._create(S, i1 - i0) for i0, i1 in sa]
+                hs = [self.seg._create(S, -(-self.n // self.seg_split)) for _ in sa]
             if self.emb_split == 1:
                 he = [self.emb._need(S, self.n)]
             else:
-                he = [self.emb._create(S, i1 - i0) for i0, i1 in sb]
+                he = [self.emb._create(S, -(-self.n // self.emb_split)) for _ in sb]
             got = self._sub[S] = (hs, he, sa, sb)
         return got
 
@@ -200,12 +202,14 @@ class StreamBatch:
         except Exception:
             pass
 
-    def launch(self, waves, starts=None) -> dict:
+    def launch(self, waves, starts=None, slots: Optional[Sequence[int]] = None) -> dict:
         """Enqueue the GPU work for one step.  ``waves``: (N, S) or (N, 1, S) float32 on the GPU
         (a strided rolling-window view is used in place) or an ``AudioRing`` holding a complete
         window.  ``starts``: start time in seconds of each
         stream's window (default: step index x ``step``), used by the output tail only.
-        Returns a ticket for ``finish``."""
+        ``slots``: which of the ``num_streams`` clustering / tail states the rows belong to, for a
+        step in which only some streams have a new window (``len(slots)`` rows; default: all, in
+        order).  Returns a ticket for ``finish``."""
         ring = waves if isinstance(waves, AudioRing) else None
         if ring is not None:
             assert ring.filled == ring.window, "the ring does not hold a complete window yet"
@@ -215,9 +219,16 @@ class StreamBatch:
             rows = _as_rows(waves)
             N, S = rows.shape
             base, stride = rows.data_ptr(), (rows.stride(0) if N > 1 else S)
-        assert N == self.n, f"expected {self.n} streams, got {N}"
+        if slots is None:
+            assert N == self.n, f"expected {self.n} streams, got {N}"
+        else:
+            slots = [int(i) for i in slots]
+            assert N == len(slots) and 1 <= N <= self.n and len(set(slots)) == N, "bad slots"
+            assert all(0 <= i < self.n for i in slots), "slot out of range"
         F, K, D = self.seg.num_frames(S), None, self.emb.dimension
-        hsegs, hembs, sa, sb = self._handles(S)
+        hsegs, hembs, _, _ = self._handles(S)
+        # sub-batch ranges of THIS step's rows (each at most the capacity its handle was built for)
+        sa, sb = self._ranges(N, self.seg_split), self._ranges(N, self.emb_split)
         K = self.seg.num_speakers
         if not any(s["shape"] == (F, K, D) for s in self._slots):
             # both in-flight slots up front: a pinned-memory allocation made while kernels are
@@ -232,6 +243,9 @@ class StreamBatch:
         slot["ev_in"].record(cur)                       # inputs produced on the caller's stream
         for (i0, i1), h, a, ev in zip(sa, hsegs, self.streams_a, slot["ev_seg"]):
             a.wait_event(slot["ev_in"])
+            if i1 == i0:                                 # fewer rows than sub-batches
+                ev.record(a)
+                continue
             _lib.check(lib.dz_seg_forward(h, base + i0 * stride * esz, stride, i1 - i0,
                                           slot["seg"][i0:i1].data_ptr(), a.cuda_stream), "dz_seg_forward")
             _lib.check(lib.dz_osp(self._ctx, slot["seg"][i0:i1].data_ptr(), i1 - i0, F, K, self.gamma,
@@ -240,6 +254,8 @@ class StreamBatch:
             ev.record(a)
         for (i0, i1), h, b in zip(sb, hembs, self.streams_b):
             b.wait_event(slot["ev_in"])
+            if i1 == i0:
+                continue
             _lib.check(lib.dz_emb_frames(h, base + i0 * stride * esz, stride, i1 - i0, b.cuda_stream),
                        "dz_emb_frames")
             for (j0, j1), ev in zip(sa, slot["ev_seg"]):
@@ -252,9 +268,10 @@ class StreamBatch:
             ev.record(b)
             b0.wait_event(ev)
         with torch.cuda.stream(b0):
-            slot["seg_h"].copy_(slot["seg"], non_blocking=True)
-            slot["emb_h"].copy_(slot["emb"], non_blocking=True)
+            slot["seg_h"][:N].copy_(slot["seg"][:N], non_blocking=True)
+            slot["emb_h"][:N].copy_(slot["emb"][:N], non_blocking=True)
         slot["done"].record(b0)
+        slot["rows"], slot["slots"] = N, slots
         slot["keep"] = rows                              # keep the view alive until the GPU is done
         if ring is not None:
             ring._read_by(slot["done"])                  # pushes `slack` steps from now wait for this
@@ -267,9 +284,10 @@ class StreamBatch:
         """Wait for the step's GPU work, run the N clustering updates.
         -> (segmentation (N,F,K) f32, embeddings (N,K,D) f32, scores (N,F,G) f64 | None, assign (N,K))."""
         ticket["done"].synchronize()
-        seg = ticket["seg_h"].numpy()
-        emb = ticket["emb_h"].numpy()
-        scores, assign = self.clustering(seg, emb, want_scores or self.with_tail)
+        N, slots = ticket["rows"], ticket["slots"]
+        seg = ticket["seg_h"].numpy()[:N]
+        emb = ticket["emb_h"].numpy()[:N]
+        scores, assign = self.clustering(seg, emb, want_scores or self.with_tail, slots=slots)
         if self.with_tail:
             # diarization.py:190,203-232 for every stream: aggregate the overlapping windows of the
             # region [t - latency, t - latency + step) and binarise it
@@ -277,7 +295,7 @@ class StreamBatch:
                 self.tail = BatchedOutputTail(self.n, seg.shape[1], self.max_speakers, self.step,
                                               self.latency, self.tau_active,
                                               num_threads=self.cluster_threads)
-            ticket["tail"] = self.tail(scores, ticket["starts"], self.duration / seg.shape[1])
+            ticket["tail"] = self.tail(scores, ticket["starts"], self.duration / seg.shape[1], slots=slots)
         ticket["busy"] = False
         ticket["keep"] = None
         return seg, emb, scores, assign

@@ -201,3 +201,44 @@ def test_stream_batch_on_ring_with_splits_and_tail(gpu):
             assert np.allclose(np.array(got).reshape(-1, 3), np.array(wt).reshape(-1, 3), rtol=0, atol=1e-12)
             if len(bufs[i]) == aggs[i].num_overlapping_windows:
                 bufs[i] = bufs[i][1:]
+
+
+def test_stream_server_equals_dedicated_pipelines(gpu):
+    """diart_amd.serve.StreamServer: 4 streams of different lengths that join at different times and
+    push audio in odd block sizes, windows batched ACROSS streams; every stream's accumulated RTTM is
+    exactly what its own SpeakerDiarization pipeline (blocks API, batch 1, same models) produces,
+    for latency = step and for a longer latency (aggregation over 3 windows)."""
+    from diart_amd.blocks import SpeakerDiarization, SpeakerDiarizationConfig
+    from diart_amd.inference import StreamingInference
+    from diart_amd.serve import StreamServer
+    seg_sd, emb_sd = synth_segmentation_state(), synth_embedding_state()
+    lengths = {"alice": 11.0, "bob": 8.5, "carol": 14.0, "dave": 6.0}
+    audio = {k: synth_streams(1, v, seed0=900 + i)[0] for i, (k, v) in enumerate(lengths.items())}
+    for latency in (0.5, 1.5):
+        srv = StreamServer(M.HipSegmentation(seg_sd, max_batch=4), M.HipEmbedding(emb_sd, max_batch=4),
+                           max_streams=4, latency=latency, device=gpu)
+        rng = np.random.default_rng(3)
+        pos = {k: 0 for k in audio}
+        join_at = {"alice": 0, "bob": 3, "carol": 3, "dave": 9}     # server ticks at which they open
+        tick, widths = 0, []
+        while any(pos[k] < len(audio[k]) for k in audio):
+            for k in audio:
+                if tick == join_at[k]:
+                    srv.open(k)
+                if tick >= join_at[k] and pos[k] < len(audio[k]):
+                    n = int(rng.integers(2000, 30000))
+                    srv.push(k, audio[k][pos[k]:pos[k] + n])
+                    pos[k] += n
+            out = srv.step()
+            widths.append(len(out))
+            tick += 1
+        srv.drain()
+        assert max(widths) >= 3, "windows of different streams were never batched together"
+        for k in audio:
+            got = srv.close(k)
+            cfg = SpeakerDiarizationConfig(
+                segmentation=M.SegmentationModel.from_state(seg_sd, max_batch=1),
+                embedding=M.EmbeddingModel.from_state(emb_sd, max_batch=1), latency=latency, device=gpu)
+            usable = len(audio[k]) // 8000 * 8000       # the server never sees a zero-padded last block
+            want = StreamingInference(SpeakerDiarization(cfg), audio[k][:usable], 16000, k, (0, 0), 1)()
+            assert want is not None and got.to_rttm() == want.to_rttm(), (k, latency)

@@ -1,0 +1,120 @@
+"""Host logic of the cross-stream server (diart_amd/serve.py) with a recording engine in place of
+the GPU: per-stream windowing == rearrange_audio_stream for arbitrary block sizes, one window per
+stream per step batched across streams, join / leave at any time, slot reuse, thread safety."""
+import threading
+
+import numpy as np
+import pytest
+
+from diart_amd.inference import file_blocks, rolling_windows
+from diart_amd.serve import StreamServer
+
+
+class Recorder:
+    """engine(windows, starts, slots): remembers every batch; one turn per window =
+    [start, start + 0.5) on 'speaker' = slot, if the window's newest sample is > 0."""
+
+    def __init__(self):
+        self.batches, self.resets = [], []
+
+    def reset(self, slot):
+        self.resets.append(slot)
+
+    def __call__(self, windows, starts, slots):
+        self.batches.append((windows.copy(), np.array(starts), list(slots)))
+        return [np.array([[s + 4.5, s + 5.0, float(slot)]]) if w[-1] > 0 else np.zeros((0, 3))
+                for w, s, slot in zip(windows, starts, slots)]
+
+
+def ramp(n, offset=0):
+    return (np.arange(n, dtype=np.float32) + offset + 1) / 1e6
+
+
+def test_windows_follow_rearrange_audio_stream_for_any_block_size():
+    rec = Recorder()
+    srv = StreamServer(None, None, max_streams=4, engine=rec)
+    audio = ramp(16000 * 9 + 1234)
+    srv.open("a")
+    pos, sizes = 0, [3000, 1, 7999, 16000, 40000, 123]
+    i = 0
+    while pos < len(audio):
+        n = sizes[i % len(sizes)]
+        srv.push("a", audio[pos:pos + n])
+        pos += n
+        i += 1
+        srv.drain()
+    want = list(rolling_windows(file_blocks(audio[:len(audio) // 8000 * 8000], 16000, (0, 0), 0.5), 5.0, 0.5, 16000))
+    got = [(w[0], s[0]) for w, s, _ in rec.batches]
+    assert len(got) == len(want) == (len(audio) - 80000) // 8000 + 1
+    for (w, s), ref in zip(got, want):
+        assert np.array_equal(w, ref.data[:, 0]) and abs(s - ref.sliding_window.start) < 1e-9
+    total = srv.close("a")
+    assert total.uri == "a" and len(total) == 1          # consecutive half-second turns are stitched
+    seg = next(iter(total.itertracks()))[0]
+    assert abs(seg.start - 4.5) < 1e-9 and abs(seg.end - (4.5 + 0.5 * len(want))) < 1e-9
+
+
+def test_batches_across_streams_and_join_leave():
+    rec = Recorder()
+    srv = StreamServer(None, None, max_streams=2, engine=rec)
+    srv.open("x")
+    srv.open("y")
+    with pytest.raises(RuntimeError):
+        srv.open("z")                                     # no free slot
+    with pytest.raises(ValueError):
+        srv.open("x")
+    assert rec.resets == [0, 1]
+    srv.push("x", ramp(80000 + 16000))                    # 3 windows pending
+    srv.push("y", ramp(80000, offset=5_000_000))          # 1 window pending
+    assert srv.step().keys() == {"x", "y"}                # one window of each, ONE batch
+    assert rec.batches[-1][0].shape == (2, 80000) and rec.batches[-1][2] == [0, 1]
+    assert srv.step().keys() == {"x"} and srv.step().keys() == {"x"} and srv.step() == {}
+    assert [b[2] for b in rec.batches] == [[0, 1], [0], [0]]
+    assert list(rec.batches[1][1]) == [0.5] and list(rec.batches[2][1]) == [1.0]
+    done = srv.close("y")
+    assert done.uri == "y" and srv.open_streams == ["x"]
+    srv.open("z")                                         # takes y's slot, state reset
+    assert rec.resets[-1] == 1
+    srv.push("z", ramp(80000))
+    srv.push("x", ramp(8000))
+    out = srv.step()
+    assert set(out) == {"x", "z"} and rec.batches[-1][2] == [0, 1]
+    assert list(rec.batches[-1][1]) == [1.5, 0.0]         # x is at its 4th window, z at its first
+    with pytest.raises(KeyError):
+        srv.push("y", ramp(10))
+
+
+def test_push_is_thread_safe():
+    rec = Recorder()
+    srv = StreamServer(None, None, max_streams=8, engine=rec)
+    ids = [f"s{i}" for i in range(8)]
+    for sid in ids:
+        srv.open(sid)
+
+    def client(sid, seed):
+        rng = np.random.default_rng(seed)
+        audio, pos = ramp(80000 + 8000 * 6, offset=seed * 1000), 0
+        while pos < len(audio):
+            n = int(rng.integers(100, 9000))
+            srv.push(sid, audio[pos:pos + n])
+            pos += n
+
+    worker = threading.Thread(target=srv.serve_forever, kwargs={"idle_sleep": 0.0005})
+    worker.start()
+    clients = [threading.Thread(target=client, args=(sid, i)) for i, sid in enumerate(ids)]
+    for c in clients:
+        c.start()
+    for c in clients:
+        c.join()
+    srv.shutdown()
+    worker.join(timeout=10)
+    srv.drain()
+    per_stream = {}
+    for w, s, slots in rec.batches:
+        for row, start, slot in zip(w, s, slots):
+            per_stream.setdefault(slot, []).append((start, row[0]))
+    assert len(per_stream) == 8
+    for slot, seq in per_stream.items():
+        assert [t for t, _ in seq] == [0.5 * i for i in range(7)]     # every window, in order
+        first = [v for _, v in seq]
+        assert np.allclose(np.diff(first), 8000 / 1e6, atol=1e-9)     # each window starts 8000 samples later
