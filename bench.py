@@ -220,7 +220,9 @@ def main():
     assert world == args.gpus or world == 1, f"WORLD_SIZE={world} but --gpus {args.gpus}"
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X GPU (the HIP path has no CPU fallback)")
-    device = torch.device("cuda", local)
+    # DZ_FORCE_DEVICE: every rank on one GPU (single-GPU rehearsal of the multi-rank path, with
+    # DZ_DIST_BACKEND=gloo); the driver's real runs use one GPU per rank over RCCL
+    device = torch.device("cuda", int(os.environ.get("DZ_FORCE_DEVICE", local)))
     torch.cuda.set_device(device)
     lib = _lib.load()
 

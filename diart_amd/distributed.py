@@ -23,10 +23,10 @@ def init_from_env(backend: Optional[str] = None) -> Tuple[int, int, int]:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend is None:   # DZ_DIST_BACKEND=gloo: rehearse the multi-rank path on ONE GPU
+            backend = os.environ.get("DZ_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl":
-            torch.cuda.set_device(local)
+            torch.cuda.set_device(int(os.environ.get("DZ_FORCE_DEVICE", local)))
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, world, local
 

@@ -37,7 +37,8 @@ args = ap.parse_args()
 
 limit_host_threads()
 rank, world, local = D.init_from_env()
-device = torch.device("cuda", local)
+import os  # noqa: E402
+device = torch.device("cuda", int(os.environ.get("DZ_FORCE_DEVICE", local)))   # see bench.py
 torch.cuda.set_device(device)
 work = Path(args.workdir)
 speech, out = work / "wav", work / f"rttm_w{world}"
