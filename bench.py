@@ -246,10 +246,16 @@ def main():
     log("streams resident in HBM")
     assert audio.stride(0) % 4 == 0
 
+    # host threads of the clustering / output tail: the usable cores are shared by the ranks of
+    # the node (every rank runs its own 64 clustering states between two GPU steps)
+    from diart_amd.hostinfo import usable_cores
+    host_threads = max(1, min(8, usable_cores() // max(1, world)))
+    log(f"host threads per rank for clustering / tail: {host_threads}")
+
     def make_pipe(prec):
         return StreamBatch(HipSegmentation(seg_state, max_batch=n, precision=prec),
                            HipEmbedding(emb_state, max_batch=n, precision=prec),
-                           n, device=device, cluster_threads=min(8, os.cpu_count() or 1),
+                           n, device=device, cluster_threads=host_threads,
                            tail=not args.no_tail)
 
     pipe = make_pipe(precision)
