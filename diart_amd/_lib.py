@@ -76,6 +76,7 @@ SIGNATURES = {
     "dz_ecapa_peek": (C.c_int, [vp, C.c_int, C.POINTER(vp), C.POINTER(C.c_longlong), C.POINTER(C.c_int)]),
     "dz_ecapa_destroy": (C.c_int, [vp]),
     "dz_prof_enable": (C.c_int, [C.c_int]),
+    "dz_prof_pause": (C.c_int, [C.c_int]),
     "dz_prof_collect": (C.c_int, []),
     "dz_prof_get": (C.c_int, [C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_double),
                               C.POINTER(C.c_longlong)]),

@@ -104,6 +104,13 @@ extern "C" int dz_prof_enable(int on) {
     for (int t = 0; t < PROF_TAGS; ++t) { g_prof.ms[t] = 0.0; g_prof.n[t] = 0; }
     return 0;
 }
+// suspend / resume the bracketing without touching what has been accumulated: bench.py instruments
+// every k-th step of its timed region only (a dispatch that carries profiling events costs the
+// runtime ~15 % of throughput when every launch has one)
+extern "C" int dz_prof_pause(int paused) {
+    if (g_prof.made) g_prof.on = !paused;
+    return 0;
+}
 // drains the event pool (device must be idle or will be synchronised); returns #tags
 extern "C" int dz_prof_collect(void) {
     DZ_HIP(hipDeviceSynchronize());

@@ -271,6 +271,7 @@ int dz_clu_destroy(dz_clu* clu);
  * dz_prof_enable(1) starts bracketing every kernel the forward passes launch; dz_prof_collect()
  * synchronises the device and accumulates; dz_prof_get(tag) reads name / total ms / launches. */
 int dz_prof_enable(int on);
+int dz_prof_pause(int paused);   /* suspend / resume bracketing, accumulators untouched */
 int dz_prof_collect(void);
 int dz_prof_get(int tag, const char** name, double* total_ms, long long* launches);
 
