@@ -265,7 +265,8 @@ def main():
 
     host = {"launch": 0.0, "finish": 0.0}
 
-    PROF_EVERY = 5       # every 5th step of the timed region carries the per-kernel event pairs
+    # every 5th step of the timed region carries the per-kernel event pairs (DZ_PROF_EVERY=1: all)
+    PROF_EVERY = max(1, int(os.environ.get("DZ_PROF_EVERY", "5")))
     sampled = [0]
 
     def run(t_first, count, pipe=None, profiled=False):

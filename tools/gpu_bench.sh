@@ -17,7 +17,7 @@ echo "bench exit $?"
 cat gpurun_out/bench_$TAG.json
 tail -3 gpurun_out/bench_$TAG.err
 cd /tmp
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $REPO/gpurun_out/prof_$TAG -o prof -- \
+DZ_PROF_EVERY=1 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $REPO/gpurun_out/prof_$TAG -o prof -- \
     python $REPO/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-exact-f32 --no-host-pass --kernel-table $REPO/gpurun_out/kernels_${TAG}_same_run.json > $REPO/gpurun_out/prof_$TAG.log 2>&1
 echo "rocprof exit $?"
 cd $REPO
