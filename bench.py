@@ -16,6 +16,13 @@ HBM before the timed region starts.
 N > 1 (launched by torch.distributed.run): every rank owns 64 streams of its own (weak scaling,
 streams are independent — no data-path collective); rank 0 synthesises the weights and broadcasts
 them over RCCL; timing is barrier + synchronize on both sides, max over ranks.
+
+Besides the contract's fields the JSON line carries: ``roofline`` (dominant MFMA-bound kernel) and
+``roofline_kernels`` (every kernel against its own bound) from per-kernel dispatch timestamps taken
+on every 5th timed step; ``exact_f32`` — the same job on the exact-f32 matrix path (the default
+arithmetic is "f16x3"); ``host_fed`` — the same job with each step's new audio
+uploaded from pinned host memory into the device ring (PCIe-inclusive); ``cpu_baseline`` — the
+oracle on the host cores (rank 0, N = 1).
 """
 from __future__ import annotations
 

@@ -3,18 +3,21 @@
 The reference batches consecutive windows of ONE stream (``inference.py:126-128``) and keeps one
 pipeline object per stream (``blocks/diarization.py:121-125``); 64 concurrent real-time streams
 (BASELINE.json config 2) therefore need a driver the reference does not have.  ``StreamBatch``
-stacks the current window of every stream into one segmentation / embedding call and steps N
-independent clustering states, producing for each stream exactly what its own
-``SpeakerDiarization.__call__`` computes at lines 186-203: segmentation, overlap-aware
-normalised embeddings and the permuted ``(frames, max_speakers)`` scores.
+stacks the current window of every stream into one segmentation / embedding launch sequence and
+steps N independent clustering states and (``tail=True``) N aggregation / binarisation states,
+producing for each stream exactly what its own ``SpeakerDiarization.__call__`` computes at lines
+186-232: segmentation, overlap-aware normalised embeddings, the permuted ``(frames,
+max_speakers)`` scores and the speech turns of the region the step finalises.  ``AudioRing`` keeps
+the rolling windows of host-fed streams on the device (only new samples are uploaded).
 
-GPU schedule per step (two HIP streams):
+GPU schedule per step (``seg_split`` + ``emb_split`` HIP streams, default 2 + 1):
 
-    stream A : dz_seg_forward (SincNet -> 4 x {x-projection GEMM, persistent LSTM} -> MLP)
-               -> dz_osp  --event-->
-    stream B : dz_emb_frames (SincNet -> 5 TDNN; independent of the segmentation, fills the
-               CUs the latency-bound LSTM leaves idle)  <--wait--  dz_emb_pool -> D2H (pinned)
-    host     : clustering of step t-1 (C++ threads, fp64) while the GPU runs step t
+    stream A_i : sub-batch i: dz_seg_forward (SincNet -> 4 x {x-projection GEMM, persistent
+                 LSTM} -> MLP) -> dz_osp  --event-->        (the GEMMs of one sub-batch run
+                 under the latency-bound recurrence of the other)
+    stream B   : dz_emb_frames (SincNet -> 5 TDNN; independent of the segmentation, fills the
+                 CUs the LSTM leaves idle)  <--wait all--  dz_emb_pool -> D2H (pinned)
+    host       : clustering + output tail of step t-1 (C++ threads, fp64) while the GPU runs step t
 """
 from __future__ import annotations
 

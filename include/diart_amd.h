@@ -224,6 +224,9 @@ int dz_k_convgemm(dz_ctx* ctx, const dz_convgemm_desc* desc, void* stream);
 /* the same layer on the split-f16 matrix-core path (desc->Wsplit must be set)       */
 int dz_k_gemm_split(dz_ctx* ctx, const dz_convgemm_desc* desc, void* stream);
 int dz_k_convgemm_ntile(int t_out);
+/* d_stats (B, 2) = (mean, 1/sqrt(biased var + 1e-5)) of each window: InstanceNorm1d(1).  Inside
+ * the forward passes the 8 slice moments stay separate and the consumer merges them; this entry
+ * point runs the slice kernel plus the merge and synchronises the stream.                     */
 int dz_k_wave_stats(dz_ctx* ctx, const float* d_wave, long long stride, int batch, int samples,
                     float* d_stats, void* stream);
 /* y0 (B, P0, 80) with P0 = ((S-251)/10+1)/3; partials (B, ntile0, 80, 2), ntile0 = ceil(F0/192);
