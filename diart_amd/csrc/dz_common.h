@@ -15,6 +15,21 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 #define DZ_LEAKY_SLOPE 0.01f
 
+// hipFuncSetAttribute is a per-device setting and a process may drive several GPUs (one dz_ctx
+// each): remember per device whether a kernel's dynamic-LDS limit has been raised.  (Two host
+// threads racing here would both set the same value: harmless.)
+struct DzAttrOnce {
+    bool done[64] = {};
+    bool need() {
+        int d = 0;
+        (void)hipGetDevice(&d);
+        if (d < 0 || d >= 64) return true;
+        if (done[d]) return false;
+        done[d] = true;
+        return true;
+    }
+};
+
 // Every kernel of the library is launched through DZ_LAUNCH.  When the per-kernel profiler of
 // api.hip is on, the launch carries a (start, stop) event pair that the runtime fills with the
 // dispatch's own begin / end timestamps (hipExtLaunchKernelGGL) — the same numbers rocprofv3's

@@ -237,11 +237,10 @@ __global__ __launch_bounds__(256) void convgemm_kernel(DzConvGemm p) {
 template <int BN, bool PRO, int EPI>
 int launch(const DzConvGemm& p, hipStream_t st) {
     using C = Cfg<BN>;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static DzAttrOnce attr_once;
+    if (attr_once.need()) {
         DZ_HIP(hipFuncSetAttribute((const void*)convgemm_kernel<BN, PRO, EPI>,
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS));
-        attr_set = true;
     }
     dim3 grid((p.Tout + BM - 1) / BM, p.Npad / BN, p.B * (p.ksplit > 1 ? p.ksplit : 1));
     DZ_LAUNCH((convgemm_kernel<BN, PRO, EPI>), grid, dim3(256), C::LDS, st, p);

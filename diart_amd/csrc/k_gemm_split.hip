@@ -277,11 +277,10 @@ __global__ __launch_bounds__(128 * WM) void gemm_split_kernel(DzConvGemm p) {
 template <int WM, int NB, bool PRO, int EPI>
 int launch(const DzConvGemm& p, hipStream_t st) {
     using C = Cfg<WM, NB>;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static DzAttrOnce attr_once;
+    if (attr_once.need()) {
         DZ_HIP(hipFuncSetAttribute((const void*)gemm_split_kernel<WM, NB, PRO, EPI>,
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS));
-        attr_set = true;
     }
     dim3 grid((p.Tout + C::BM - 1) / C::BM, p.Npad / C::BN, p.B);
     DZ_LAUNCH((gemm_split_kernel<WM, NB, PRO, EPI>), grid, dim3(C::T), C::LDS, st, p);
