@@ -104,20 +104,32 @@ print("rank", rank, "ok")
 '''
 
 
+def _two_ranks(script, args, attempts=3):
+    """Launch ``script`` as ranks 0 and 1 of a gloo group on 127.0.0.1.  The rendezvous port is
+    picked by binding port 0 and releasing it, which another process can win in between: a failed
+    rendezvous is retried on a fresh port."""
+    last = None
+    for _ in range(attempts):
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+        procs = []
+        for rank in range(2):
+            env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", LOCAL_RANK=str(rank),
+                       MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), PYTHONDONTWRITEBYTECODE="1")
+            procs.append(subprocess.Popen([sys.executable, str(script), *map(str, args)], env=env,
+                                          stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+        outs = [p.communicate(timeout=180)[0] for p in procs]
+        last = list(zip(procs, outs))
+        if all(p.returncode == 0 for p in procs):
+            break
+    return last
+
+
 def test_weight_broadcast_world_size_2_gloo(tmp_path):
     script = tmp_path / "worker.py"
     script.write_text(WORKER)
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
-    procs = []
-    for rank in range(2):
-        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", LOCAL_RANK=str(rank),
-                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), PYTHONDONTWRITEBYTECODE="1")
-        procs.append(subprocess.Popen([sys.executable, str(script), str(ROOT)], env=env,
-                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
-    outs = [p.communicate(timeout=180)[0] for p in procs]
-    for rank, (p, o) in enumerate(zip(procs, outs)):
+    for rank, (p, o) in enumerate(_two_ranks(script, [ROOT])):
         assert p.returncode == 0, o
         assert f"rank {rank} ok" in o
 

@@ -188,18 +188,9 @@ def test_distributed_benchmark_world_size_2_gloo(tmp_path):
     (tmp_path / "pipeline.py").write_text(PIPELINE_SRC)
     script = tmp_path / "worker.py"
     script.write_text(WORKER)
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
-    procs = []
-    for rank in range(2):
-        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", LOCAL_RANK=str(rank),
-                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), PYTHONDONTWRITEBYTECODE="1")
-        procs.append(subprocess.Popen([sys.executable, str(script), str(ROOT), str(speech), str(refs), str(out),
-                                       str(tmp_path / "pipeline.py")], env=env,
-                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
-    outs = [p.communicate(timeout=180)[0] for p in procs]
-    for rank, (p, o) in enumerate(zip(procs, outs)):
+    sys.path.insert(0, str(Path(__file__).resolve().parent))
+    from test_host_logic import _two_ranks
+    for rank, (p, o) in enumerate(_two_ranks(script, [ROOT, speech, refs, out, tmp_path / "pipeline.py"])):
         assert p.returncode == 0, o
         assert f"rank {rank} ok" in o
     # every file was written exactly once, by the rank that owned it
