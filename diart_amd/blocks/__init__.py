@@ -1,4 +1,5 @@
-from .aggregation import AggregationStrategy, DelayedAggregation
+from .aggregation import (AggregationStrategy, AverageStrategy, BatchedOutputTail, DelayedAggregation,
+                          FirstOnlyStrategy, HammingWeightedAverageStrategy)
 from .base import HyperParameter, Pipeline, PipelineConfig
 from .clustering import (BatchedSpeakerClustering, IncrementalSpeakerClustering,
                          OnlineSpeakerClustering)
@@ -12,6 +13,7 @@ from .vad import VoiceActivityDetection, VoiceActivityDetectionConfig
 __all__ = ["SpeakerSegmentation", "SpeakerEmbedding", "OverlappedSpeechPenalty",
            "EmbeddingNormalization", "OverlapAwareSpeakerEmbedding", "OnlineSpeakerClustering",
            "IncrementalSpeakerClustering", "BatchedSpeakerClustering", "DelayedAggregation",
-           "AggregationStrategy", "Binarize", "Pipeline", "PipelineConfig", "HyperParameter",
+           "AggregationStrategy", "HammingWeightedAverageStrategy", "AverageStrategy", "FirstOnlyStrategy",
+           "BatchedOutputTail", "Binarize", "Pipeline", "PipelineConfig", "HyperParameter",
            "SpeakerDiarization", "SpeakerDiarizationConfig", "VoiceActivityDetection",
            "VoiceActivityDetectionConfig"]

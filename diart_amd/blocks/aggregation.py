@@ -37,7 +37,10 @@ class AggregationStrategy:
 
     @staticmethod
     def build(name: str, cropping_mode: str = "loose") -> "AggregationStrategy":
-        return AggregationStrategy(name, cropping_mode)
+        """The strategy class of that name, like the reference's factory (aggregation.py:28-40)."""
+        assert name in ("mean", "hamming", "first")
+        return {"mean": AverageStrategy, "hamming": HammingWeightedAverageStrategy,
+                "first": FirstOnlyStrategy}[name](cropping_mode)
 
     def aggregate(self, buffers: List[SlidingWindowFeature], focus: Segment) -> np.ndarray:
         if self.name == "first":
@@ -56,6 +59,27 @@ class AggregationStrategy:
         aggregation = self.aggregate(buffers, focus)
         res = focus.duration / aggregation.shape[0]
         return SlidingWindowFeature(aggregation, SlidingWindow(start=focus.start, duration=res, step=res))
+
+
+class HammingWeightedAverageStrategy(AggregationStrategy):
+    """Average weighted by the Hamming window aligned to each buffer (aggregation.py:95-118)."""
+
+    def __init__(self, cropping_mode: str = "loose"):
+        super().__init__("hamming", cropping_mode)
+
+
+class AverageStrategy(AggregationStrategy):
+    """Simple average over the focus region (aggregation.py:73-92)."""
+
+    def __init__(self, cropping_mode: str = "loose"):
+        super().__init__("mean", cropping_mode)
+
+
+class FirstOnlyStrategy(AggregationStrategy):
+    """Keep the first buffer that covers the region (aggregation.py:60-70)."""
+
+    def __init__(self, cropping_mode: str = "loose"):
+        super().__init__("first", cropping_mode)
 
 
 class DelayedAggregation:
