@@ -225,26 +225,35 @@ __global__ __launch_bounds__(256) void sinc_conv0_kernel(
     }
     __syncthreads();
 
+    // MaxPool1d(3) over time + the tile's InstanceNorm partials in ONE pass: thread -> fixed channel
+    // n = tid % 80 and row group tid / 80 (3 groups; threads 240..255 idle), so every thread keeps
+    // its channel's running (sum, sumsq) in registers; the three group partials meet in LDS in fixed
+    // order.  (A separate pass in which 80 threads walked 64 pooled rows each cost ~6k cycles per
+    // tile with the matrix pipe idle.)
     const int p0 = tile * 64;
-    for (int idx = tid; idx < 64 * 80; idx += 256) {
-        const int pr = idx / 80, n = idx - pr * 80;
-        const float* o = out_s + (3 * pr) * C0_OLD + n;
-        const float v = fmaxf(fmaxf(o[0], o[C0_OLD]), o[2 * C0_OLD]);
-        const bool valid = (p0 + pr) < P0;
-        if (valid) y0[((long long)b * P0 + p0 + pr) * 80 + n] = v;
-        out_s[(3 * pr) * C0_OLD + n] = valid ? v : 0.f;
+    float s = 0.f, ss = 0.f;
+    const int n = tid % 80, rg = tid / 80;
+    if (rg < 3) {
+        for (int pr = rg; pr < 64; pr += 3) {
+            const float* o = out_s + (3 * pr) * C0_OLD + n;
+            const float v = fmaxf(fmaxf(o[0], o[C0_OLD]), o[2 * C0_OLD]);
+            if ((p0 + pr) < P0) {
+                y0[((long long)b * P0 + p0 + pr) * 80 + n] = v;
+                s += v;
+                ss += v * v;
+            }
+        }
+    }
+    __syncthreads();                       // every read of out_s is done: reuse its head
+    if (rg < 3) {
+        out_s[(rg * 80 + n) * 2] = s;
+        out_s[(rg * 80 + n) * 2 + 1] = ss;
     }
     __syncthreads();
     if (tid < 80) {
-        float s = 0.f, ss = 0.f;
-        for (int pr = 0; pr < 64; ++pr) {
-            const float v = out_s[(3 * pr) * C0_OLD + tid];
-            s += v;
-            ss += v * v;
-        }
         float* pp = partials + (((long long)b * ntile + tile) * 80 + tid) * 2;
-        pp[0] = s;
-        pp[1] = ss;
+        pp[0] = (out_s[tid * 2] + out_s[(80 + tid) * 2]) + out_s[(160 + tid) * 2];
+        pp[1] = (out_s[tid * 2 + 1] + out_s[(80 + tid) * 2 + 1]) + out_s[(160 + tid) * 2 + 1];
     }
 }
 
