@@ -56,6 +56,7 @@ class EcapaWeights(C.Structure):
 SIGNATURES = {
     "dz_last_error": (C.c_char_p, []),
     "dz_version": (C.c_int, []),
+    "dz_abi_struct_sizes": (C.c_int, [C.POINTER(C.c_int * 5)]),
     "dz_ctx_create": (C.c_int, [C.c_int, C.POINTER(vp)]),
     "dz_ctx_destroy": (C.c_int, [vp]),
     "dz_seg_frames_for": (C.c_int, [C.c_int]),
@@ -158,6 +159,12 @@ def load() -> C.CDLL:
             fn = getattr(lib, name)  # AttributeError if a declared symbol is missing
             fn.restype = res
             fn.argtypes = args
+        sizes = (C.c_int * 5)()
+        lib.dz_abi_struct_sizes(C.byref(sizes))
+        mine = [C.sizeof(t) for t in (SincNetWeights, SegWeights, EmbWeights, EcapaWeights, ConvGemmDesc)]
+        if list(sizes) != mine:
+            raise DiartAmdError(f"{_LIB_PATH} was built from a different include/diart_amd.h: struct sizes "
+                                f"{list(sizes)} (library) vs {mine} (this binding); rebuild it")
         _lib = lib
     return _lib
 

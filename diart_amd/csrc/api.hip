@@ -19,6 +19,15 @@ void dz_set_error(const char* fmt, ...) {
 }
 extern "C" const char* dz_last_error(void) { return g_err; }
 extern "C" int dz_version(void) { return DZ_VERSION; }
+extern "C" int dz_abi_struct_sizes(int out[5]) {
+    if (!out) return 2;
+    out[0] = (int)sizeof(dz_sincnet_weights);
+    out[1] = (int)sizeof(dz_seg_weights);
+    out[2] = (int)sizeof(dz_emb_weights);
+    out[3] = (int)sizeof(dz_ecapa_weights);
+    out[4] = (int)sizeof(dz_convgemm_desc);
+    return 0;
+}
 
 // ---------------------------------------------------------------------------
 // context + scratch arena

@@ -331,6 +331,11 @@ int dz_tail_step_batch(dz_tail** tails, int n, const double* scores, const doubl
                        double* res_out, double* turns_out, int max_turns, int* nturns_out,
                        int num_threads);
 
+/* sizeof() of the five structs that cross this boundary, in declaration order
+ * (dz_sincnet_weights, dz_seg_weights, dz_emb_weights, dz_ecapa_weights, dz_convgemm_desc): a
+ * binding checks its own mirror of the layouts against the library it loaded.            */
+int dz_abi_struct_sizes(int out[5]);
+
 /* exposed for tests: scipy.optimize.linear_sum_assignment (minimise), rows<=cols
  * or transposed internally; col4row (nr) gets the column of each row.            */
 int dz_lsap(const double* cost, int nr, int nc, int* col4row);

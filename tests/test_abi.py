@@ -52,3 +52,16 @@ def test_no_cpu_fallback():
 def test_product_never_imports_oracle():
     for f in (ROOT / "diart_amd").rglob("*.py"):
         assert "oracle" not in f.read_text().replace("the oracle", ""), f
+
+
+def test_struct_layouts_match_the_library():
+    """The ctypes mirrors of the structs that cross the C ABI have the sizes the library was
+    compiled with (load() refuses a mismatching library; this keeps the check itself honest)."""
+    import ctypes as C
+    from diart_amd import _lib
+    lib = _lib.load()
+    sizes = (C.c_int * 5)()
+    assert lib.dz_abi_struct_sizes(C.byref(sizes)) == 0
+    mine = [C.sizeof(t) for t in (_lib.SincNetWeights, _lib.SegWeights, _lib.EmbWeights,
+                                  _lib.EcapaWeights, _lib.ConvGemmDesc)]
+    assert list(sizes) == mine and all(v > 0 for v in mine)
