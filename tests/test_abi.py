@@ -65,3 +65,41 @@ def test_struct_layouts_match_the_library():
     mine = [C.sizeof(t) for t in (_lib.SincNetWeights, _lib.SegWeights, _lib.EmbWeights,
                                   _lib.EcapaWeights, _lib.ConvGemmDesc)]
     assert list(sizes) == mine and all(v > 0 for v in mine)
+
+
+def test_header_is_plain_c_and_links_without_python(tmp_path):
+    """include/diart_amd.h is a C header (C99, -pedantic clean) and a C program can call the library
+    through it with no Python / torch in sight: frame geometry, version, struct sizes, and the
+    error path of a call that needs a GPU context (NULL handle -> status 2 + message)."""
+    import shutil
+    import subprocess
+    from diart_amd import _lib
+    if shutil.which("gcc") is None:
+        import pytest
+        pytest.skip("gcc not available")
+    src = tmp_path / "abi_demo.c"
+    src.write_text(r'''
+#include <stdio.h>
+#include <string.h>
+#include "diart_amd.h"
+int main(void) {
+    int sizes[5];
+    if (dz_version() <= 0 || dz_abi_struct_sizes(sizes) != 0) return 1;
+    if (sizes[4] != (int)sizeof(dz_convgemm_desc) || sizes[1] != (int)sizeof(dz_seg_weights)) return 2;
+    if (dz_seg_frames_for(80000) != 293 || dz_emb_frames_for(80000) != 279) return 3;
+    if (dz_seg_frames_for(160000) != 589 || dz_seg_frames_for(100) != 0) return 4;
+    float out[4];
+    int rc = dz_seg_forward(NULL, NULL, 0, 1, out, NULL);          /* must fail loudly, not crash */
+    if (rc == 0 || strlen(dz_last_error()) == 0) return 5;
+    printf("abi ok v%d\n", dz_version());
+    return 0;
+}
+''')
+    exe = tmp_path / "abi_demo"
+    lib = _lib.lib_path()
+    cmd = ["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", f"-I{ROOT / 'include'}", str(src),
+           str(lib), f"-Wl,-rpath,{lib.parent}", "-Wl,-rpath,/opt/rocm/lib", "-o", str(exe)]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    r = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert r.returncode == 0 and "abi ok" in r.stdout, (r.returncode, r.stdout, r.stderr)
