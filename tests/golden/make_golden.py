@@ -1,6 +1,6 @@
 """Generate the golden fixtures from the REFERENCE'S OWN CODE (build container only).
 
-    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py [--out DIR]
 
 Runs /root/reference/src/diart/{functional.py, mapping.py, blocks/clustering.py,
 blocks/embedding.py} (loaded by path with the pyannote.core stand-in of oracle/pyannote_stub.py)
@@ -15,6 +15,9 @@ import numpy as np
 import torch
 
 HERE = Path(__file__).resolve().parent
+# --out DIR: write somewhere else (tests/test_oracle_golden.py regenerates into a scratch directory
+# and compares with the committed fixtures whenever /root/reference is present)
+OUT = Path(sys.argv[sys.argv.index("--out") + 1]) if "--out" in sys.argv else HERE
 sys.path.insert(0, str(HERE.parent.parent))
 sys.path.insert(0, str(HERE))
 
@@ -35,7 +38,7 @@ def main():
         out[f"osp_block_norm{int(norm)}"] = block(torch.from_numpy(seg)).numpy()
     out["normalize"] = ref.functional.normalize_embeddings(torch.from_numpy(emb)).numpy()
     out["normalize_2d"] = ref.functional.normalize_embeddings(torch.from_numpy(emb[0]), norm=2.5).numpy()
-    np.savez_compressed(HERE / "functional.npz", seg=seg, emb=emb, **out)
+    np.savez_compressed(OUT / "functional.npz", seg=seg, emb=emb, **out)
 
     # ---- blocks/embedding.py plumbing with a toy model (ordering / squeeze semantics) --------
     class Toy:  # custom-model contract of README.md:186-209: __call__ + .to(device)
@@ -58,7 +61,7 @@ def main():
     plumb["oase_b1"] = oase(torch.from_numpy(wav[:1]), torch.from_numpy(sg[:1])).numpy()
     se = ref.embedding.SpeakerEmbedding(model, torch.device("cpu"))
     plumb["se_noweights"] = se(torch.from_numpy(wav)).numpy()
-    np.savez_compressed(HERE / "embedding_plumbing.npz", **plumb)
+    np.savez_compressed(OUT / "embedding_plumbing.npz", **plumb)
 
     # ---- blocks/clustering.py ---------------------------------------------------------
     for name in scenarios.CLUSTERING:
@@ -89,7 +92,7 @@ def main():
             score_sum[t] = res.data.sum(0)
             active[t, sorted(clu.active_centers)] = 1
             centers_trace[t] = clu.centers.sum(1)
-        np.savez_compressed(HERE / f"clustering_{name}.npz", seg=inp["seg"], emb=inp["emb"],
+        np.savez_compressed(OUT / f"clustering_{name}.npz", seg=inp["seg"], emb=inp["emb"],
                             params=np.array([inp["tau"], inp["rho"], inp["delta"], inp["G"]]),
                             assign=assign, active=active, score_sum=score_sum, raised=raised,
                             centers_trace=centers_trace, centers=clu.centers)
@@ -131,7 +134,7 @@ def tail(ref):
                                               aud.sliding_window.start, aud.sliding_window.step])
                 if len(pbuf) == pred.num_overlapping_windows:
                     pbuf, abuf = pbuf[1:], abuf[1:]
-    np.savez_compressed(HERE / "tail.npz", **out)
+    np.savez_compressed(OUT / "tail.npz", **out)
     print("tail:", len(out), "arrays")
 
 
