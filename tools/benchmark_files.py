@@ -24,7 +24,8 @@ from diart_amd import models as M  # noqa: E402
 from diart_amd.blocks import SpeakerDiarization, SpeakerDiarizationConfig  # noqa: E402
 from diart_amd.hostinfo import limit_host_threads  # noqa: E402
 from diart_amd.inference import Benchmark, DistributedBenchmark, wav_duration, write_wav  # noqa: E402
-from diart_amd.synth import synth_embedding_state, synth_segmentation_state, synth_stream  # noqa: E402
+from diart_amd.synth import (synth_ecapa_state, synth_embedding_state, synth_segmentation_state,  # noqa: E402
+                             synth_stream)
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--files", type=int, default=1)
@@ -33,6 +34,9 @@ ap.add_argument("--batch-size", type=int, default=32)
 ap.add_argument("--latency", type=float, default=0.5)
 ap.add_argument("--workdir", type=str, default="gpurun_out/benchmark_files")
 ap.add_argument("--ami-hparams", action="store_true", help="tau/rho/delta of README.md:391")
+ap.add_argument("--config3", action="store_true",
+                help="BASELINE config 3: powerset segmentation-3.0 + speechbrain ECAPA-TDNN embedding, "
+                     "normalised OSP weights")
 args = ap.parse_args()
 
 limit_host_threads()
@@ -51,15 +55,20 @@ if rank == 0:
 if world > 1:
     torch.distributed.barrier()
 
-seg_sd = synth_segmentation_state() if rank == 0 else None
-emb_sd = synth_embedding_state() if rank == 0 else None
+make_seg = (lambda: synth_segmentation_state(seed=77, powerset=True)) if args.config3 else synth_segmentation_state
+make_emb = synth_ecapa_state if args.config3 else synth_embedding_state
+seg_sd = make_seg() if rank == 0 else None
+emb_sd = make_emb() if rank == 0 else None
 if world > 1:
-    seg_sd = D.broadcast_state(seg_sd, D.state_spec(synth_segmentation_state()), device)
-    emb_sd = D.broadcast_state(emb_sd, D.state_spec(synth_embedding_state()), device)
+    seg_sd = D.broadcast_state(seg_sd, D.state_spec(make_seg()), device)
+    emb_sd = D.broadcast_state(emb_sd, D.state_spec(make_emb()), device)
 hp = dict(tau_active=0.507, rho_update=0.006, delta_new=1.057) if args.ami_hparams else {}
-cfg = SpeakerDiarizationConfig(segmentation=M.SegmentationModel.from_state(seg_sd, max_batch=args.batch_size),
-                               embedding=M.EmbeddingModel.from_state(emb_sd, max_batch=args.batch_size),
-                               latency=args.latency, device=device, **hp)
+if args.config3:
+    hp.update(normalize_embedding_weights=True, tau_active=0.5)
+cfg = SpeakerDiarizationConfig(
+    segmentation=M.SegmentationModel.from_state(seg_sd, max_batch=args.batch_size, powerset=args.config3),
+    embedding=M.EmbeddingModel.from_state(emb_sd, max_batch=(3 if args.config3 else 1) * args.batch_size),
+    latency=args.latency, device=device, **hp)
 bench = DistributedBenchmark(Benchmark(speech, None, out, show_report=False, batch_size=args.batch_size))
 # warm-up: weights packed, arenas allocated, kernels loaded
 SpeakerDiarization(cfg)
@@ -77,7 +86,9 @@ if rank == 0:
     audio_s = sum(wav_duration(p) for p in sorted(speech.glob("*.wav"))[:args.files])
     chunks = sum(max(0, int((wav_duration(p) + args.latency - 0.5 - 5.0) / 0.5) + 1)
                  for p in sorted(speech.glob("*.wav"))[:args.files])
-    print(json.dumps({"workload": f"{args.files} synthetic 16 kHz files, {audio_s:.0f} s of audio, batch "
+    print(json.dumps({"models": "segmentation-3.0 (powerset) + ECAPA-TDNN" if args.config3 else
+                                "pyannote/segmentation + pyannote/embedding",
+                      "workload": f"{args.files} synthetic 16 kHz files, {audio_s:.0f} s of audio, batch "
                                   f"{args.batch_size}, latency {args.latency}", "n_gpus": world, "files": len(uris),
                       "wall_s": round(dt, 3), "audio_seconds_per_second": round(audio_s / dt, 1),
                       "chunks_per_second": round(chunks / dt, 1), "rttm_dir": str(out)}), flush=True)
