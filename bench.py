@@ -19,7 +19,7 @@ them over RCCL; timing is barrier + synchronize on both sides, max over ranks.
 
 Besides the contract's fields the JSON line carries: ``roofline`` (dominant MFMA-bound kernel) and
 ``roofline_kernels`` (every kernel against its own bound) from per-kernel dispatch timestamps taken
-on every 5th timed step; ``exact_f32`` — the same job on the exact-f32 matrix path (the default
+on every 10th timed step; ``exact_f32`` — the same job on the exact-f32 matrix path (the default
 arithmetic is "f16x3"); ``host_fed`` — the same job with each step's new audio
 uploaded from pinned host memory into the device ring (PCIe-inclusive); ``cpu_baseline`` — the
 oracle on the host cores (rank 0, N = 1).
@@ -272,8 +272,8 @@ def main():
 
     host = {"launch": 0.0, "finish": 0.0}
 
-    # every 5th step of the timed region carries the per-kernel event pairs (DZ_PROF_EVERY=1: all)
-    PROF_EVERY = max(1, int(os.environ.get("DZ_PROF_EVERY", "5")))
+    # every 10th step of the timed region carries the per-kernel event pairs (DZ_PROF_EVERY=1: all)
+    PROF_EVERY = max(1, int(os.environ.get("DZ_PROF_EVERY", "10")))
     sampled = [0]
 
     def run(t_first, count, pipe=None, profiled=False):
