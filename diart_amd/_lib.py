@@ -40,7 +40,7 @@ class EmbWeights(C.Structure):
 
 
 class Layer(C.Structure):
-    _fields_ = [("w", vp), ("b", vp), ("s", vp), ("h", vp)]
+    _fields_ = [("w", vp), ("b", vp), ("s", vp), ("h", vp), ("wsplit", vp)]
 
 
 class SeRes2Net(C.Structure):

@@ -122,6 +122,13 @@ static int gemm(hipStream_t st, const float* X, int ldx, long long xbs, int B, i
     p.Cin = Cin; p.taps = taps; p.dil = dil; p.pad = pad; p.K = taps * Cin; p.Kpad = Kpad;
     p.Npad = Npad; p.Nstore = Nstore; p.ldx = ldx; p.ldy = ldy; p.xbs = xbs; p.ybs = ybs;
     p.epi = epi; p.X2 = X2; p.rowbias = rowbias; p.ksplit = ksplit; p.ysplit = ysplit;
+    // the wide 1x1 layers (87 % of the network's FLOPs) come with split-f16 planes in the default
+    // precision: same contraction on the f16 matrix cores (k_gemm_split.hip)
+    if (L.wsplit && epi == DZ_EPI_RELU_BN && taps == 1 && pad == 0 && !X2 && !rowbias && ksplit <= 1 &&
+        Npad % 128 == 0 && Cin % 8 == 0) {
+        p.Wsplit = L.wsplit;
+        return dz_launch_gemm_split(p, st);
+    }
     return dz_launch_convgemm(p, st);
 }
 
@@ -177,12 +184,12 @@ extern "C" int dz_ecapa_forward(dz_ecapa* e, const float* d_wave, long long wave
     const long long NT = (long long)N * T;
 
     // ---- 2. Fbank: STFT as one GEMM over overlapping rows (hop 160 < window 400) ---------------
-    dz_layer dft = {w.dft, w.zeros, nullptr, nullptr};
+    dz_layer dft = {w.dft, w.zeros, nullptr, nullptr, nullptr};
     if ((rc = gemm(st, e->sig, HOP, e->lstride, N, T, NFFT, 1, 1, 0, dft, nullptr, 416, 448, 402, e->spec,
                    404, (long long)T * 404, DZ_EPI_BIAS)))
         return rc;
     if ((rc = dz_launch_power(e->spec, 404, NT, e->pw, st))) return rc;
-    dz_layer mel = {w.mel, w.zeros, nullptr, nullptr};
+    dz_layer mel = {w.mel, w.zeros, nullptr, nullptr, nullptr};
     if ((rc = gemm(st, e->pw, 204, 0, 1, (int)NT, 204, 1, 1, 0, mel, nullptr, 224, 128, 80, e->melp, 80, 0,
                    DZ_EPI_BIAS)))
         return rc;

@@ -255,7 +255,7 @@ __global__ __launch_bounds__(128 * WM) void gemm_split_kernel(DzConvGemm p) {
         const int n = n0 + wn * 32 * NB + nb * 32 + li;
         const float bv = p.bias[n];
         float e0 = 1.f, e1 = 0.f;
-        if (EPI == DZ_EPI_TDNN) {
+        if (EPI == DZ_EPI_TDNN || EPI == DZ_EPI_RELU_BN) {
             e0 = p.e0[n];
             e1 = p.e1[n];
         }
@@ -267,6 +267,7 @@ __global__ __launch_bounds__(128 * WM) void gemm_split_kernel(DzConvGemm p) {
                     float v = (accm[nb][r] + accx[nb][r] * LO_UNSCALE) + bv;
                     if (EPI == DZ_EPI_BIAS_LEAKY) v = leaky(v);
                     if (EPI == DZ_EPI_TDNN) v = leaky(v) * e0 + e1;
+                    if (EPI == DZ_EPI_RELU_BN) v = fmaxf(v, 0.f) * e0 + e1;
                     Yb[(long long)t * p.ldy + n] = v;
                 }
             }
@@ -316,6 +317,9 @@ int dz_launch_gemm_split(const DzConvGemm& p, hipStream_t st) {
         case DZ_EPI_BIAS_LEAKY:
             DZ_REQUIRE(!pro, "gemm_split: BIAS_LEAKY has no norm-on-load instance");
             DZ_SP(4, 2, false, DZ_EPI_BIAS_LEAKY);
+        case DZ_EPI_RELU_BN:   // ECAPA-TDNN's 1x1 layers: conv -> ReLU -> folded BatchNorm
+            DZ_REQUIRE(!pro, "gemm_split: RELU_BN has no norm-on-load instance");
+            DZ_SP(4, 2, false, DZ_EPI_RELU_BN);
     }
 #undef DZ_SP
     dz_set_error("gemm_split: epilogue %d is not built on the split-f16 path", p.epi);

@@ -269,14 +269,15 @@ class HipEcapaEmbedding(_HipModule):
 
     dimension = 192
 
-    def __init__(self, state: Dict[str, torch.Tensor], max_batch: int = 192):
+    def __init__(self, state: Dict[str, torch.Tensor], max_batch: int = 192, precision: Optional[str] = None):
         super().__init__(state, max_batch)
+        self.precision = default_precision() if precision is None else precision
 
     def _extra_state(self):
-        return {}
+        return {"precision": self.precision}
 
     def _pack(self, device):
-        return PackedEcapa(self._state, device)
+        return PackedEcapa(self._state, device, precision=self.precision)
 
     def _create(self, num_samples, cap):
         h = _lib.vp()
@@ -346,7 +347,7 @@ class EmbeddingLoader:
         sd = _read_state(self.state)
         arch = self.arch or ("ecapa" if any(k.startswith("asp.") for k in sd) else "xvector")
         if arch == "ecapa":
-            return HipEcapaEmbedding(sd, self.max_batch)
+            return HipEcapaEmbedding(sd, self.max_batch, self.precision)
         return HipEmbedding(sd, self.max_batch, self.precision)
 
 

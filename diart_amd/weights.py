@@ -234,7 +234,9 @@ class PackedEcapa:
     * the 9216-wide attention TDNN is split into the 3072 columns that see x and the 6144 columns
       that see the per-row global (mean | std), which become a per-row bias."""
 
-    def __init__(self, sd: Dict[str, torch.Tensor], device: torch.device):
+    def __init__(self, sd: Dict[str, torch.Tensor], device: torch.device, precision: str = "f32"):
+        assert precision in PRECISIONS, precision
+        split = precision == "f16x3"
         pk = _Packed(device)
         g = lambda k: sd[k].detach().cpu().float()
         w = _lib.EcapaWeights()
@@ -244,9 +246,11 @@ class PackedEcapa:
             shift = g(prefix + ".norm.bias") - g(prefix + ".norm.running_mean") * scale
             return _pad1(scale, npad), _pad1(shift, npad)
 
-        def layer(dst, prefix, cin_pad, npad, kpad, norm=True, weight=None):
+        def layer(dst, prefix, cin_pad, npad, kpad, norm=True, weight=None, wide=False):
             cw = g(prefix + ".conv.weight") if weight is None else weight
             dst.w = pk.put(_conv_pack(cw, cin_pad, npad, kpad))
+            if wide and split:   # 1x1, >= 1024 channels: also as split-f16 planes
+                dst.wsplit = pk.put_split(_conv_pack(cw, cin_pad, npad, kpad))
             dst.b = pk.put(_pad1(g(prefix + ".conv.bias"), npad))
             if norm:
                 sc, sh = bn(prefix.rsplit(".conv", 1)[0] + ".norm", npad)
@@ -264,13 +268,13 @@ class PackedEcapa:
         layer(w.block0, "blocks.0.conv", 80, 1024, 416)
         for i in range(3):
             p, b = f"blocks.{i + 1}", w.ser[i]
-            layer(b.tdnn1, p + ".tdnn1.conv", 1024, 1024, 1024)
+            layer(b.tdnn1, p + ".tdnn1.conv", 1024, 1024, 1024, wide=True)
             for j in range(7):
                 layer(b.res[j], p + f".res2net_block.blocks.{j}.conv", 128, 128, 384)
-            layer(b.tdnn2, p + ".tdnn2.conv", 1024, 1024, 1024)
+            layer(b.tdnn2, p + ".tdnn2.conv", 1024, 1024, 1024, wide=True)
             layer(b.se1, p + ".se_block.conv1", 1024, 128, 1024, norm=False)
             layer(b.se2, p + ".se_block.conv2", 128, 1024, 128, norm=False)
-        layer(w.mfa, "mfa.conv", 3072, 3072, 3072)
+        layer(w.mfa, "mfa.conv", 3072, 3072, 3072, wide=True)
         aw = g("asp.tdnn.conv.conv.weight")                           # (128, 9216, 1)
         layer(w.asp_tdnn, "asp.tdnn.conv", 3072, 128, 3072, weight=aw[:, :3072])
         w.asp_wms = pk.put(aw[:, 3072:, 0].contiguous())             # (128, 6144)

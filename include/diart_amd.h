@@ -142,6 +142,7 @@ typedef struct {
     const float* b;   /* [Npad] bias                                                          */
     const float* s;   /* [Npad] folded BatchNorm scale (NULL if the layer has no norm)        */
     const float* h;   /* [Npad] folded BatchNorm shift                                        */
+    const void* wsplit; /* optional split-f16 planes of w (the wide 1x1 layers: tdnn1, tdnn2, mfa)   */
 } dz_layer;
 typedef struct {
     dz_layer tdnn1;    /* 1x1, 1024 -> 1024                                                   */

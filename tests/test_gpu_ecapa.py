@@ -24,9 +24,11 @@ def oracle():
     return PretrainedSpeakerEmbeddingRef(synth_ecapa_state())
 
 
-@pytest.fixture(scope="module")
-def hip(gpu):
-    return M.HipEcapaEmbedding(synth_ecapa_state(), max_batch=8).to(gpu)
+@pytest.fixture(scope="module", params=["f16x3", "f32"])
+def hip(gpu, request):
+    """Both arithmetic modes against the same gates: "f16x3" runs the wide 1x1 layers (tdnn1, tdnn2,
+    mfa: 87 % of the FLOPs) on the split-f16 kernel, "f32" everything on exact-f32 MFMA."""
+    return M.HipEcapaEmbedding(synth_ecapa_state(), max_batch=8, precision=request.param).to(gpu)
 
 
 def test_stages_without_masks(gpu, oracle, hip):
