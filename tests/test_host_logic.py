@@ -160,3 +160,51 @@ def test_sinc_fold_identity():
     bad[3, 10] += 0.01
     with pytest.raises(ValueError):
         fold_sinc_filters(bad)
+
+
+def test_split_f16_arithmetic_is_f32_grade():
+    """The arithmetic of k_gemm_split.hip, emulated on the CPU: x = hi + lo * 2^-11 with
+    hi = f16(x), lo = f16((x - hi) * 2^11); a product is hi*hi + (hi*lo + lo*hi) * 2^-11 with f32
+    accumulation.  Against an f64 reference the result is as good as a plain f32 GEMM (the split
+    keeps 22 mantissa bits; what dominates either way is the f32 accumulation), it is far better
+    than a bf16 split or TF32-like 10-bit operands, and ``weights.split_f16`` produces exactly the
+    planes the kernel expects."""
+    from diart_amd.weights import split_f16
+    g = torch.Generator().manual_seed(0)
+    M_, K, N = 96, 1536, 64
+    X = torch.randn(M_, K, generator=g) * 2.0
+    W = torch.randn(N, K, generator=g) / K ** 0.5
+    X[:, ::7] *= 1e-3                      # small magnitudes too: lo stays a normal f16 thanks to the scale
+    ref = X.double() @ W.double().t()
+
+    def split(t):
+        hi = t.to(torch.float16)
+        lo = ((t - hi.float()) * 2048.0).to(torch.float16)
+        return hi.float(), lo.float()
+
+    xh, xl = split(X)
+    wh, wl = split(W)
+    main = xh @ wh.t()                                     # f32 accumulation
+    cross = xh @ wl.t() + xl @ wh.t()
+    got = main + cross * (1.0 / 2048.0)
+    plain = X @ W.t()                                      # an f32 GEMM
+    err = lambda y: ((y.double() - ref).norm() / ref.norm()).item()
+    e_split, e_f32 = err(got), err(plain)
+    # bf16 split (the first version of the kernel) and 10-bit operands for scale
+    bh = X.to(torch.bfloat16).float()
+    bl = (X - bh).to(torch.bfloat16).float()
+    vh = W.to(torch.bfloat16).float()
+    vl = (W - vh).to(torch.bfloat16).float()
+    e_bf16 = err(bh @ vh.t() + bh @ vl.t() + bl @ vh.t())
+    tf32 = lambda t: (t.view(torch.int32) & ~0x1FFF).view(torch.float32)   # keep 10 mantissa bits
+    e_tf32 = err(tf32(X.clone()) @ tf32(W.clone()).t())
+    print(f"rel L2 vs f64: split-f16 {e_split:.2e}, f32 {e_f32:.2e}, split-bf16 {e_bf16:.2e}, 10-bit {e_tf32:.2e}")
+    assert e_split < 2.0 * e_f32 + 1e-7
+    assert e_bf16 > 5 * e_split and e_tf32 > 100 * e_split
+    # the reconstruction keeps 22 bits: |x - (hi + lo / 2048)| <= 2^-22 |x| (away from f16 underflow)
+    rec = xh.double() + xl.double() / 2048.0
+    big = X.abs() > 1e-4
+    assert ((rec - X.double()).abs()[big] / X.double().abs()[big]).max().item() <= 2.0 ** -21.9
+    # the packed planes are those numbers
+    planes = split_f16(W).view(torch.float16)
+    assert torch.equal(planes[0].float(), wh) and torch.equal(planes[1].float(), wl)
