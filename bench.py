@@ -40,41 +40,70 @@ import torch
 ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
-MMAC = {  # algorithmic MACs per 5 s chunk per launch, launches per forward
-    "sinc_conv0": 160_138_000, "conv1_pool": 63_696_000, "conv2_pool": 15_840_000,
-    "lstm_proj0": 293 * 60 * 1024, "lstm_proj": 293 * 256 * 1024, "lstm_rec": 2 * 293 * 512 * 128,
-    "seg_mlp": (293 * 256 * 128 + 293 * 128 * 128) / 2, "seg_classifier": 293 * 128 * 3,
-    "tdnn1": 289 * 512 * 300, "tdnn2": 285 * 512 * 1536, "tdnn3": 279 * 512 * 1536,
-    "tdnn4": 279 * 512 * 512, "tdnn5": 279 * 1500 * 512, "emb_linear": 3 * 3000 * 512,
+F_SEG, F_E1, F_E2, F_E3 = 293, 289, 285, 279
+# Per launch tag: algorithmic MACs per 5 s chunk, algorithmic HBM bytes per chunk
+# (the layer's input + output read / written once, f32) and weight bytes per LAUNCH.
+KERNELS = {
+    "wave_stats": dict(mac=0, io=320_000, w=0, bound="hbm"),
+    "sinc_conv0": dict(mac=160_138_000, io=320_000 + 2658 * 80 * 4, w=128 * 96 * 4, bound="mfma_f32"),
+    "conv1_pool": dict(mac=63_696_000, io=(2658 * 80 + 884 * 64) * 4, w=64 * 416 * 4, bound="gemm"),
+    "conv2_pool": dict(mac=15_840_000, io=(884 * 64 + 293 * 64) * 4, w=64 * 320 * 4, bound="gemm"),
+    "lstm_proj0": dict(mac=F_SEG * 60 * 1024, io=F_SEG * (64 + 1024) * 4, w=1024 * 64 * 4, bound="gemm"),
+    "lstm_proj": dict(mac=F_SEG * 256 * 1024, io=F_SEG * (256 + 1024) * 4, w=1024 * 256 * 4, bound="gemm"),
+    "lstm_rec": dict(mac=2 * F_SEG * 512 * 128, io=F_SEG * (1024 + 256) * 4, w=2 * 512 * 128 * 4, bound="rec"),
+    "seg_mlp": dict(mac=(F_SEG * 256 * 128 + F_SEG * 128 * 128) / 2, io=F_SEG * (256 + 128 + 128 + 128) * 2,
+                    w=(128 * 256 + 128 * 128) * 2, bound="gemm"),
+    "seg_classifier": dict(mac=F_SEG * 128 * 3, io=F_SEG * (128 + 3) * 4, w=64 * 128 * 4, bound="mfma_f32"),
+    "seg_head": dict(mac=F_SEG * (256 * 128 + 128 * 128 + 128 * 3), io=F_SEG * (256 + 3 + 3) * 4,
+                     w=(128 * 256 + 128 * 128 + 8 * 128) * 4, bound="gemm"),
+    "tdnn1": dict(mac=F_E1 * 512 * 300, io=F_SEG * (64 + 512) * 4, w=512 * 320 * 4, bound="gemm"),
+    "tdnn2": dict(mac=F_E2 * 512 * 1536, io=F_SEG * 1024 * 4, w=512 * 1536 * 4, bound="gemm"),
+    "tdnn3": dict(mac=F_E3 * 512 * 1536, io=F_SEG * 1024 * 4, w=512 * 1536 * 4, bound="gemm"),
+    "tdnn4": dict(mac=F_E3 * 512 * 512, io=F_SEG * 1024 * 4, w=512 * 512 * 4, bound="gemm"),
+    "tdnn5": dict(mac=F_E3 * 1500 * 512, io=F_SEG * (512 + 1536) * 4, w=1536 * 512 * 4, bound="gemm"),
+    "stats_pool": dict(mac=0, io=F_E3 * 1536 * 4 + 3 * F_SEG * 4 + 3 * 3008 * 4, w=0, bound="hbm"),
+    "emb_linear": dict(mac=3 * 3000 * 512, io=3 * (3008 + 512) * 4, w=512 * 3008 * 4, bound="mfma_f32"),
 }
 # sinc_conv0 folds the (anti)symmetric FIR bank: 42 tiles x 192 frames x 96 columns x 128 taps
-EXECUTED_MMAC = {"sinc_conv0": 42 * 192 * 96 * 128}
-# bench tag -> the device kernel (rocprofv3 symbol) that runs it: the roofline is reported per
-# device kernel, so the four TDNN layers that share one instantiation are one entry
-SYMBOL = {
-    "sinc_conv0": "sinc_conv0_kernel", "conv1_pool": "convgemm_kernel<64, true, 4>",
-    "conv2_pool": "convgemm_kernel<64, true, 4>", "lstm_proj": "convgemm_kernel<128, false, 0>",
-    "lstm_proj0": "convgemm_kernel<128, true, 0>",
-    "lstm_rec": "lstm_rec_kernel", "seg_mlp": "convgemm_kernel<128, false, 1>",
-    "seg_classifier": "convgemm_kernel<64, false, 2>", "tdnn1": "convgemm_kernel<128, true, 3>",
-    "tdnn2": "convgemm_kernel<128, false, 3>", "tdnn3": "convgemm_kernel<128, false, 3>",
-    "tdnn4": "convgemm_kernel<128, false, 3>", "tdnn5": "convgemm_kernel<128, false, 3>",
-}
-# the same layers on the split-f16 path (precision "f16x3", the default): k_gemm_split.hip
-SYMBOL_SPLIT = {
-    "conv1_pool": "gemm_split_kernel<3, 1, true, 4>", "conv2_pool": "gemm_split_kernel<3, 1, true, 4>",
-    "lstm_proj": "gemm_split_kernel<4, 2, false, 0>", "lstm_proj0": "gemm_split_kernel<4, 2, true, 0>",
-    "seg_mlp": "gemm_split_kernel<4, 2, false, 1>",
-    "tdnn1": "gemm_split_kernel<4, 2, true, 3>", "tdnn2": "gemm_split_kernel<4, 2, false, 3>",
-    "tdnn3": "gemm_split_kernel<4, 2, false, 3>", "tdnn4": "gemm_split_kernel<4, 2, false, 3>",
-    "tdnn5": "gemm_split_kernel<4, 2, false, 3>",
-}
-ALG_GFLOP_PER_CHUNK = 3.352   # 1.312 seg + 2.039 emb de-duplicated (SURVEY.md §8d)
-PEAK_F16_MATRIX_TFLOPS = 2500.0  # MI355X_MICROARCH.md: v_mfma_f32_32x32x16_f16, dense
+EXECUTED_MAC = {"sinc_conv0": 42 * 192 * 96 * 128}
+ALG_GFLOP_PER_CHUNK = 3.352   # 1.312 seg + 2.039 emb de-duplicated (SURVEY.md 8d)
+# Peaks from /opt/skills/guides/MI355X_MICROARCH.md (chip level, 256 CUs @ 2.4 GHz):
+PEAK_F16_MATRIX_TFLOPS = 2500.0  # v_mfma_f32_32x32x16_f16 / 16x16x32_f16, dense
 SPLIT_PRODUCTS = 3               # f16 MFMAs per algorithmic product on the split path
-PEAK_F32_MATRIX_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, dense
-PEAK_F32_FMA_TFLOPS = 78.6      # 256 CUs x 64 lanes x 2 FLOP x 2.4 GHz: v_fma_f32 (the packed form
-                                # measured no faster in the recurrence)
+PEAK_F32_MATRIX_TFLOPS = 157.3   # v_mfma_f32_16x16x4_f32, dense
+PEAK_F32_VECTOR_TFLOPS = 157.3   # f32 vector peak (packed FMA); plain v_fma_f32 issues at half of it
+PEAK_HBM_GBPS = 8000.0
+
+
+def device_kernel(tag, precision):
+    """bench tag -> (rocprofv3 kernel symbol, bound, chip peak, unit): the roofline is reported per
+    DEVICE kernel, so the layers that share one instantiation are one entry."""
+    split = precision == "f16x3"
+    pre = split and os.environ.get("DZ_GEMM_PRE", "1") != "0"     # wide layers on k_gemm_pre.hip
+    lstm = os.environ.get("DZ_LSTM", "0")                          # weights.default_lstm_variant
+    k = KERNELS[tag]
+    if k["bound"] == "hbm":
+        return {"wave_stats": "wave_stats_kernel", "stats_pool": "stats_pool_kernel<3>"}[tag], "hbm", PEAK_HBM_GBPS, "GB/s"
+    if k["bound"] == "rec":
+        if split and lstm != "valu":
+            sym = "lstm_mfma_kernel<true>" if lstm == "0" else "lstm_mfma1_kernel<true, %d>" % (0 if lstm == "1" else 8)
+            return sym, "mfma", PEAK_F16_MATRIX_TFLOPS / SPLIT_PRODUCTS, "TFLOP/s"
+        return "lstm_rec_kernel<true>", "valu", PEAK_F32_VECTOR_TFLOPS, "TFLOP/s"
+    if k["bound"] == "mfma_f32" or not split:
+        sym = {"sinc_conv0": "sinc_conv0_kernel", "conv1_pool": "convgemm_kernel<64, true, 4>",
+               "conv2_pool": "convgemm_kernel<64, true, 4>", "lstm_proj": "convgemm_kernel<128, false, 0>",
+               "lstm_proj0": "convgemm_kernel<128, true, 0>", "seg_mlp": "convgemm_kernel<128, false, 1>",
+               "seg_classifier": "convgemm_kernel<64, false, 2>", "tdnn1": "convgemm_kernel<128, true, 3>",
+               "emb_linear": "convgemm_kernel<128, false, 0> (split-K)", "seg_head": "seg_head_kernel"}
+        return sym.get(tag, "convgemm_kernel<128, false, 3>"), "mfma", PEAK_F32_MATRIX_TFLOPS, "TFLOP/s"
+    if pre and tag in ("tdnn2", "tdnn3", "tdnn4", "tdnn5", "lstm_proj", "seg_mlp"):
+        sym = {"lstm_proj": "gemm_pre_kernel<0>", "seg_mlp": "gemm_pre_kernel<1>"}.get(tag, "gemm_pre_kernel<3>")
+        return sym, "mfma", PEAK_F16_MATRIX_TFLOPS / SPLIT_PRODUCTS, "TFLOP/s"
+    sym = {"conv1_pool": "gemm_split_kernel<3, 1, true, 4>", "conv2_pool": "gemm_split_kernel<3, 1, true, 4>",
+           "lstm_proj": "gemm_split_kernel<4, 2, false, 0>", "lstm_proj0": "gemm_split_kernel<4, 2, true, 0>",
+           "seg_mlp": "gemm_split_kernel<4, 2, false, 1>", "tdnn1": "gemm_split_kernel<4, 2, true, 3>",
+           "seg_head": "seg_head_kernel"}
+    return sym.get(tag, "gemm_split_kernel<4, 2, false, 3>"), "mfma", PEAK_F16_MATRIX_TFLOPS / SPLIT_PRODUCTS, "TFLOP/s"
 
 
 _T0 = time.monotonic()
@@ -105,22 +134,29 @@ def parse():
     return ap.parse_args()
 
 
-def kernel_table(lib, chunks_per_launch):
+def kernel_table(lib):
+    """Per launch tag: launches, total / average duration and the number of chunks those launches
+    worked on (recorded by the library next to every bracketed launch: a 32-chunk sub-batch launch
+    counts 32), hence algorithmic FLOP and HBM bytes PER LAUNCH at the launch's real batch."""
     rows = []
-    name, ms, n = C.c_char_p(), C.c_double(), C.c_longlong()
+    name, ms, n, ch = C.c_char_p(), C.c_double(), C.c_longlong(), C.c_longlong()
     for tag in range(24):
-        lib.dz_prof_get(tag, C.byref(name), C.byref(ms), C.byref(n))
+        lib.dz_prof_get(tag, C.byref(name), C.byref(ms), C.byref(n), C.byref(ch))
         if n.value == 0:
             continue
         nm = name.value.decode()
         avg_ms = ms.value / n.value
-        row = {"kernel": nm, "launches": n.value, "total_ms": round(ms.value, 3), "avg_us": round(avg_ms * 1e3, 2)}
-        if nm in MMAC:
-            flop = 2.0 * MMAC[nm] * chunks_per_launch
-            row["alg_gflop_per_launch"] = round(flop / 1e9, 3)
-            row["tflops"] = round(flop / (avg_ms * 1e-3) / 1e12, 2)
-            if nm in EXECUTED_MMAC:   # the kernel does less arithmetic than the textbook form
-                row["executed_gflop_per_launch"] = round(2.0 * EXECUTED_MMAC[nm] * chunks_per_launch / 1e9, 3)
+        cpl = ch.value / n.value
+        row = {"kernel": nm, "launches": n.value, "total_ms": round(ms.value, 3), "avg_us": round(avg_ms * 1e3, 2),
+               "chunks_per_launch": round(cpl, 2)}
+        k = KERNELS.get(nm)
+        if k:
+            row["alg_gflop_per_launch"] = round(2.0 * k["mac"] * cpl / 1e9, 3)
+            row["alg_bytes_per_launch"] = int(k["io"] * cpl + k["w"])
+            row["tflops"] = round(2.0 * k["mac"] * cpl / (avg_ms * 1e-3) / 1e12, 2)
+            row["gbps"] = round((k["io"] * cpl + k["w"]) / (avg_ms * 1e-3) / 1e9, 1)
+            if nm in EXECUTED_MAC:   # the kernel does less arithmetic than the textbook form
+                row["executed_gflop_per_launch"] = round(2.0 * EXECUTED_MAC[nm] * cpl / 1e9, 3)
         rows.append(row)
     return rows
 
@@ -219,7 +255,6 @@ def main():
     from diart_amd.synth import synth_embedding_state, synth_segmentation_state, synth_streams
 
     precision = args.precision or default_precision()
-    symbol = dict(SYMBOL, **(SYMBOL_SPLIT if precision == "f16x3" else {}))
     log(f"start (precision {precision})")
     from diart_amd.hostinfo import limit_host_threads
     limit_host_threads()
@@ -237,10 +272,11 @@ def main():
     seg_state = synth_segmentation_state() if rank == 0 or world == 1 else None
     emb_state = synth_embedding_state() if rank == 0 or world == 1 else None
     if world > 1:
-        seg_spec = D.state_spec(synth_segmentation_state()) if rank != 0 else D.state_spec(seg_state)
-        emb_spec = D.state_spec(synth_embedding_state()) if rank != 0 else D.state_spec(emb_state)
-        seg_state = D.broadcast_state(seg_state, seg_spec, device)
-        emb_state = D.broadcast_state(emb_state, emb_spec, device)
+        # only rank 0 holds weights; the others know the architecture (key, shape, dtype) and
+        # receive the values as one flat buffer over RCCL
+        from diart_amd.synth import embedding_spec, segmentation_spec
+        seg_state = D.broadcast_state(seg_state, segmentation_spec(), device)
+        emb_state = D.broadcast_state(emb_state, embedding_spec(), device)
 
     # ---- synthetic streams of this rank, resident in HBM -------------------------------
     n = args.streams
@@ -277,22 +313,24 @@ def main():
     sampled = [0]
 
     def run(t_first, count, pipe=None, profiled=False):
+        # pipe.depth steps are kept on the GPU (one per lane) while the host runs the clustering +
+        # output tail of the oldest one
         pipe = pipe or main_pipe[0]
-        prev = None
+        inflight = []
         for t in range(t_first, t_first + count):
             if profiled:
                 on = (t - t_first) % PROF_EVERY == 0
                 lib.dz_prof_pause(0 if on else 1)
                 sampled[0] += int(on)
             h0 = time.perf_counter()
-            tk = pipe.launch(window(t))
+            inflight.append(pipe.launch(window(t)))
             h1 = time.perf_counter()
-            if prev is not None:
-                pipe.finish(prev, want_scores=True)
+            if len(inflight) > pipe.depth:
+                pipe.finish(inflight.pop(0), want_scores=True)
             host["launch"] += h1 - h0
             host["finish"] += time.perf_counter() - h1
-            prev = tk
-        pipe.finish(prev, want_scores=True)
+        while inflight:
+            pipe.finish(inflight.pop(0), want_scores=True)
 
     main_pipe = [pipe]
 
@@ -320,7 +358,7 @@ def main():
         f"{1e3 * host['launch'] / args.steps:.3f} ms, finish (wait + clustering + tail) "
         f"{1e3 * host['finish'] / args.steps:.3f} ms")
     lib.dz_prof_collect()
-    table = kernel_table(lib, n)          # read before dz_prof_enable(0) clears the accumulators
+    table = kernel_table(lib)             # read before dz_prof_enable(0) clears the accumulators
     lib.dz_prof_enable(0)
 
     # ---- the same job on the exact-f32 MFMA path, for the record (not `value`) -----------------
@@ -349,21 +387,21 @@ def main():
     host_fed = None
     if not args.no_host_pass:
         from diart_amd.pipeline import AudioRing
-        ring = AudioRing(n, S, hop, device=device)
+        ring = AudioRing(n, S, hop, slack_blocks=pipe.depth + 1, device=device)
         blocks = audio_cpu.unfold(1, hop, hop)                     # (n, nblocks, hop) view
         pinned = [blocks[:, i].contiguous().pin_memory() for i in range(S // hop + total_steps)]
         for i in range(S // hop - 1):
             ring.push(pinned[i])
 
         def run_ring(first, count):
-            prev = None
+            inflight = []
             for t in range(first, first + count):
                 ring.push(pinned[S // hop - 1 + t])
-                tk = pipe.launch(ring)
-                if prev is not None:
-                    pipe.finish(prev, want_scores=True)
-                prev = tk
-            pipe.finish(prev, want_scores=True)
+                inflight.append(pipe.launch(ring))
+                if len(inflight) > pipe.depth:
+                    pipe.finish(inflight.pop(0), want_scores=True)
+            while inflight:
+                pipe.finish(inflight.pop(0), want_scores=True)
 
         run_ring(0, args.warmup)
         torch.cuda.synchronize()
@@ -387,67 +425,76 @@ def main():
     if rank == 0:
         chunks = world * n * args.steps
         cps = chunks / elapsed
+        # ---- per DEVICE kernel: achieved vs the CHIP peak of its binding resource -------------
         groups = {}
         for r in table:
-            if "tflops" not in r:
+            if r["kernel"] not in KERNELS:
                 continue
-            g = groups.setdefault(symbol.get(r["kernel"], r["kernel"]),
-                                  {"ms": 0.0, "launches": 0, "gflop": 0.0, "tags": []})
+            sym, bound, peak, unit = device_kernel(r["kernel"], precision)
+            g = groups.setdefault(sym, {"ms": 0.0, "launches": 0, "gflop": 0.0, "bytes": 0.0, "chunks": 0.0,
+                                        "tags": [], "bound": bound, "peak": peak, "unit": unit})
             g["ms"] += r["total_ms"]
             g["launches"] += r["launches"]
             g["gflop"] += r["alg_gflop_per_launch"] * r["launches"]
+            g["bytes"] += float(r["alg_bytes_per_launch"]) * r["launches"]
+            g["chunks"] += r["chunks_per_launch"] * r["launches"]
             g["tags"].append(r["kernel"])
-        # the dominant kernel = the MFMA-bound device kernel with the largest total time; the
-        # recurrence (f32 VALU chains, one per CU, latency bound) is priced against the FMA rate
-        # of the CUs it occupies and listed with every other kernel in `roofline_kernels`
-        def peak_of(g):
-            if g == "lstm_rec_kernel":
-                cus = min(256, 2 * n)                    # one (chunk, direction) chain per workgroup / CU
-                return PEAK_F32_FMA_TFLOPS * cus / 256.0, "valu"
-            if g.startswith("gemm_split_kernel"):        # 3 f16 MFMAs per algorithmic product
-                return PEAK_F16_MATRIX_TFLOPS / SPLIT_PRODUCTS, "mfma"
-            return PEAK_F32_MATRIX_TFLOPS, "mfma"
-
-        mfma_groups = {k: v for k, v in groups.items() if k != "lstm_rec_kernel"}
-        sym, dom = max(mfma_groups.items(), key=lambda kv: kv[1]["ms"])
-        tflops = dom["gflop"] / dom["ms"]               # GFLOP / ms = TFLOP/s
         traffic_of, mfma_util_of = {}, {}
         tfile = ROOT / "profiles" / "traffic.json"      # rocprofv3 --pmc passes of this command
         if tfile.exists():
             for name, v in json.loads(tfile.read_text())["kernels"].items():
                 for g in groups:
-                    if g in name:
+                    if g.split(" (")[0] in name:
                         traffic_of[g] = v["hbm_bytes_per_launch"]
         mfile = ROOT / "profiles" / "mfma_util.json"
         if mfile.exists():
             for name, v in json.loads(mfile.read_text())["kernels"].items():
                 for g in groups:
-                    if g in name:
+                    if g.split(" (")[0] in name:
                         mfma_util_of[g] = v.get("mfma_util")
-        traffic = traffic_of.get(sym)
-        per_kernel = []
-        for g, v in sorted(groups.items(), key=lambda kv: -kv[1]["ms"]):
-            ach = v["gflop"] / v["ms"]
-            peak, bound = peak_of(g)
-            per_kernel.append({"kernel": g, "layers": v["tags"], "bound": bound, "achieved": round(ach, 2),
-                               "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(ach / peak, 4),
-                               "avg_launch_us": round(1e3 * v["ms"] / v["launches"], 2),
-                               "launches_per_step": round(v["launches"] / max(1, sampled[0]), 2),
-                               "traffic": traffic_of.get(g), "mfma_util_pmc": mfma_util_of.get(g)})
-        dom_peak = peak_of(sym)[0]
-        roof = {"bound": "mfma", "kernel": sym, "layers": dom["tags"], "achieved": round(tflops, 2),
-                "peak": round(dom_peak, 1), "unit": "TFLOP/s",
-                "peak_note": ("f16 matrix peak 2500 TFLOP/s / 3: the split-f16 path spends three f16 MFMAs "
-                              "per algorithmic product; `achieved` counts algorithmic FLOPs only"
-                              if sym.startswith("gemm_split_kernel") else "exact-f32 matrix peak"),
-                "frac": round(tflops / dom_peak, 4), "traffic": traffic,
-                "traffic_source": "profiles/traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes "
-                                  "of `bench.py --steps 3`, avg bytes per launch, FETCH doubled per the "
-                                  "gfx950 correction)" if traffic is not None else None,
-                "mfma_util_pmc": mfma_util_of.get(sym),
-                "alg_gflop_per_launch": round(dom["gflop"] / dom["launches"], 3),
-                "avg_launch_us": round(1e3 * dom["ms"] / dom["launches"], 2),
-                "whole_path_tflops": round(cps / world * ALG_GFLOP_PER_CHUNK / 1e3, 2)}
+        total_ms = sum(v["ms"] for v in groups.values()) or 1.0
+
+        def entry(g, v):
+            if v["bound"] == "hbm":
+                ach = v["bytes"] / v["ms"] / 1e6          # bytes / ms -> GB/s
+            else:
+                ach = v["gflop"] / v["ms"]                # GFLOP / ms = TFLOP/s
+            e = {"kernel": g, "layers": v["tags"], "bound": v["bound"], "achieved": round(ach, 2),
+                 "peak": round(v["peak"], 1), "unit": v["unit"], "frac": round(ach / v["peak"], 4),
+                 "avg_launch_us": round(1e3 * v["ms"] / v["launches"], 2),
+                 "chunks_per_launch": round(v["chunks"] / v["launches"], 2),
+                 "launches_per_step": round(v["launches"] / max(1, sampled[0]), 2),
+                 "share_of_kernel_time": round(v["ms"] / total_ms, 4),
+                 "alg_gflop_per_launch": round(v["gflop"] / v["launches"], 3),
+                 "alg_bytes_per_launch": int(v["bytes"] / v["launches"]),
+                 "traffic": traffic_of.get(g), "mfma_util_pmc": mfma_util_of.get(g)}
+            if e["traffic"]:
+                e["traffic_over_alg_bytes"] = round(e["traffic"] / max(1, e["alg_bytes_per_launch"]), 2)
+            if g.startswith("lstm_rec_kernel"):
+                cus = min(256.0, 2.0 * v["chunks"] / v["launches"])   # one (chunk, direction) chain per CU
+                e["cus_occupied"] = cus
+                e["frac_of_occupied_cus_plain_fma"] = round(ach / (PEAK_F32_VECTOR_TFLOPS / 2 * cus / 256.0), 4)
+            if g.startswith("lstm_mfma_kernel"):
+                e["cus_occupied"] = min(256.0, 2.0 * -(-v["chunks"] / v["launches"] // 16))  # 16 chains per workgroup
+                e["frac_of_occupied_cus"] = round(ach / (v["peak"] * e["cus_occupied"] / 256.0), 4)
+            return e
+
+        per_kernel = [entry(g, v) for g, v in sorted(groups.items(), key=lambda kv: -kv[1]["ms"])]
+        # the dominant kernel = the device kernel with the largest total time, whatever bounds it
+        roof = dict(per_kernel[0])
+        roof["peak_note"] = {
+            "mfma": ("f16 matrix peak 2500 TFLOP/s / 3: the split-f16 path spends three f16 MFMAs per algorithmic "
+                     "product; `achieved` counts algorithmic FLOPs only" if roof["peak"] > 200 else "exact-f32 matrix peak"),
+            "valu": "chip f32 vector peak (256 CUs); the kernel occupies `cus_occupied` CUs, one latency-bound chain each",
+            "hbm": "HBM3E peak"}[roof["bound"]]
+        roof["traffic_source"] = ("profiles/traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of `bench.py "
+                                  "--steps 3`, avg bytes per launch, FETCH doubled per the gfx950 correction)"
+                                  if roof["traffic"] is not None else None)
+        roof["whole_path_tflops"] = round(cps / world * ALG_GFLOP_PER_CHUNK / 1e3, 2)
+        roof["concurrency_note"] = ("per-kernel durations are measured while the kernels of %d HIP streams overlap on the "
+                                    "chip: their sum per step exceeds ms_per_step" % pipe.num_hip_streams)
+        roof["exact_f32_value"] = exact["value"] if exact else None
+        roof["host_fed_value"] = host_fed["value"] if host_fed else None
         out = {
             "metric": "real-time-factor xRT streams/GPU @500ms step", "value": round(cps / 2, 2),
             "unit": "xRT 16 kHz streams (chunks/s / 2)", "n_gpus": world, "steps": args.steps,
@@ -465,7 +512,11 @@ def main():
             "config": {"workload": "configs[1]: single MI355X, 5 s window / 500 ms step, "
                                    "pyannote/segmentation + pyannote/embedding architectures "
                                    "(random-init weights), %d concurrent synthetic 16 kHz streams per GPU" % n,
-                       "streams_per_gpu": n, "chunks_per_step": world * n, "parallelism": f"streams x{world}"},
+                       "streams_per_gpu": n, "chunks_per_step": world * n, "parallelism": f"streams x{world}",
+                       "steps_in_flight": pipe.depth, "seg_sub_batches": pipe.seg_split,
+                       "hip_streams": pipe.num_hip_streams,
+                       "exact_f32_value": exact["value"] if exact else None,
+                       "host_fed_value": host_fed["value"] if host_fed else None},
             "roofline": roof, "roofline_kernels": per_kernel,
             "roofline_sampling": f"{sampled[0]} of the {args.steps} timed steps (every {PROF_EVERY}th) carried the "
                                  "per-kernel event pairs; instrumenting every launch costs ~15 % of throughput",

@@ -30,7 +30,7 @@ class SegWeights(C.Structure):
                 ("lin0_w", vp), ("lin0_b", vp), ("lin1_w", vp), ("lin1_b", vp),
                 ("cls_w", vp), ("cls_b", vp),
                 ("num_classes", C.c_int), ("powerset", C.c_int), ("num_speakers", C.c_int),
-                ("wih_split", vp * 4), ("lin0_split", vp), ("lin1_split", vp)]
+                ("wih_split", vp * 4), ("lin0_split", vp), ("lin1_split", vp), ("whh_split", vp * 4), ("lstm_variant", C.c_int)]
 
 
 class EmbWeights(C.Structure):
@@ -80,7 +80,7 @@ SIGNATURES = {
     "dz_prof_pause": (C.c_int, [C.c_int]),
     "dz_prof_collect": (C.c_int, []),
     "dz_prof_get": (C.c_int, [C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_double),
-                              C.POINTER(C.c_longlong)]),
+                              C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]),
     "dz_osp": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_int,
                          C.c_int, vp, vp]),
     "dz_l2_normalize": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_float, vp]),
@@ -113,12 +113,15 @@ SIGNATURES = {
     # kernel-level entry points
     "dz_k_convgemm": (C.c_int, [vp, vp, vp]),
     "dz_k_gemm_split": (C.c_int, [vp, vp, vp]),
+    "dz_k_gemm_pre": (C.c_int, [vp, vp, vp]),
     "dz_k_convgemm_ntile": (C.c_int, [C.c_int]),
     "dz_k_wave_stats": (C.c_int, [vp, vp, C.c_longlong, C.c_int, C.c_int, vp, vp]),
     "dz_k_sinc_conv0": (C.c_int, [vp, vp, C.c_longlong, C.c_int, C.c_int, vp, C.c_float,
                                   C.c_float, vp, vp, vp, vp]),
     "dz_k_finalize_norm": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp]),
     "dz_k_lstm": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, vp]),
+    "dz_k_lstm_mfma": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
+    "dz_k_lstm_planes": (C.c_int, [vp, vp, vp, vp, C.c_int, vp, C.c_longlong, C.c_int, C.c_int, vp]),
     "dz_k_stats_pool": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, vp, C.c_int, C.c_int,
                                   C.c_int, vp, C.c_int, vp]),
     "dz_k_powerset": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, vp, vp]),
@@ -131,7 +134,8 @@ class ConvGemmDesc(C.Structure):
                                "Nstore", "ldx", "ldy", "nld", "Tstore")] + [
         ("xbs", C.c_longlong), ("ybs", C.c_longlong), ("norm_on_load", C.c_int), ("epi", C.c_int),
         ("ksplit", C.c_int), ("ysplit", C.c_longlong), ("agroup", C.c_int), ("pad", C.c_int),
-        ("X2", vp), ("rowbias", vp), ("Wsplit", vp)]
+        ("X2", vp), ("rowbias", vp), ("Wsplit", vp), ("Xsplit", vp), ("xplane", C.c_longlong),
+        ("Ysplit", vp), ("yplane", C.c_longlong)]
 
 
 (EPI_BIAS, EPI_BIAS_LEAKY, EPI_BIAS_SIGMOID, EPI_TDNN, EPI_POOL3, EPI_BIAS_RELU, EPI_RELU_BN,

@@ -4,7 +4,9 @@
 
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
+#include <mutex>
 #include <new>
 
 // ---------------------------------------------------------------------------
@@ -85,22 +87,33 @@ struct Prof {
     int used = 0;
     DzLaunchProf ev[PROF_POOL];
     int tag[PROF_POOL];
+    int units[PROF_POOL];        // chunks the bracketed launch works on
     bool made = false;
     double ms[PROF_TAGS];
     long long n[PROF_TAGS];
+    long long chunks[PROF_TAGS];
 };
+// One profiler per process, shared by every handle and host thread: slots are handed out under a
+// lock (the forward passes of different handles may be driven from different threads); the
+// "consumed by the next DZ_LAUNCH" hand-off itself is thread local.
 static Prof g_prof;
+static std::mutex g_prof_mu;
 struct ProfScope {
-    ProfScope(int tag, hipStream_t) {
+    // `chunks`: how many 5 s chunks this launch processes (the unit bench.py's roofline counts in)
+    ProfScope(int tag, int chunks) {
+        if (!g_prof.on) return;
+        std::lock_guard<std::mutex> lk(g_prof_mu);
         if (g_prof.on && g_prof.used < PROF_POOL) {
             const int slot = g_prof.used++;
             g_prof.tag[slot] = tag;
+            g_prof.units[slot] = chunks;
             dz_launch_prof = &g_prof.ev[slot];   // consumed by the next DZ_LAUNCH
         }
     }
     ~ProfScope() { dz_launch_prof = nullptr; }
 };
 extern "C" int dz_prof_enable(int on) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
     if (on && !g_prof.made) {
         for (int i = 0; i < PROF_POOL; ++i) {
             DZ_HIP(hipEventCreate(&g_prof.ev[i].start));
@@ -110,34 +123,40 @@ extern "C" int dz_prof_enable(int on) {
     }
     g_prof.on = on != 0;
     g_prof.used = 0;
-    for (int t = 0; t < PROF_TAGS; ++t) { g_prof.ms[t] = 0.0; g_prof.n[t] = 0; }
+    for (int t = 0; t < PROF_TAGS; ++t) { g_prof.ms[t] = 0.0; g_prof.n[t] = 0; g_prof.chunks[t] = 0; }
     return 0;
 }
 // suspend / resume the bracketing without touching what has been accumulated: bench.py instruments
 // every k-th step of its timed region only (a dispatch that carries profiling events costs the
 // runtime ~15 % of throughput when every launch has one)
 extern "C" int dz_prof_pause(int paused) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
     if (g_prof.made) g_prof.on = !paused;
     return 0;
 }
 // drains the event pool (device must be idle or will be synchronised); returns #tags
 extern "C" int dz_prof_collect(void) {
     DZ_HIP(hipDeviceSynchronize());
+    std::lock_guard<std::mutex> lk(g_prof_mu);
     for (int i = 0; i < g_prof.used; ++i) {
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, g_prof.ev[i].start, g_prof.ev[i].stop) == hipSuccess) {
             g_prof.ms[g_prof.tag[i]] += ms;
             g_prof.n[g_prof.tag[i]] += 1;
+            g_prof.chunks[g_prof.tag[i]] += g_prof.units[i];
         }
     }
     g_prof.used = 0;
     return PROF_TAGS;
 }
-extern "C" int dz_prof_get(int tag, const char** name, double* total_ms, long long* launches) {
+extern "C" int dz_prof_get(int tag, const char** name, double* total_ms, long long* launches,
+                           long long* chunks) {
     if (tag < 0 || tag >= PROF_TAGS) return 2;
+    std::lock_guard<std::mutex> lk(g_prof_mu);
     if (name) *name = kProfNames[tag];
     if (total_ms) *total_ms = g_prof.ms[tag];
     if (launches) *launches = g_prof.n[tag];
+    if (chunks) *chunks = g_prof.chunks[tag];
     return 0;
 }
 
@@ -170,6 +189,13 @@ extern "C" int dz_seg_frames_for(int num_samples) { return sinc_geom(num_samples
 extern "C" int dz_emb_frames_for(int num_samples) {
     const int f = sinc_geom(num_samples).P2 - 4 - 4 - 6;
     return f > 0 ? f : 0;
+}
+
+// DZ_GEMM_PRE=0 keeps the f32-activation split kernel for every layer (k_gemm_split.hip); the
+// default routes the wide layers through k_gemm_pre.hip (activations as f16 hi/lo planes)
+static bool pre_split_enabled() {
+    const char* v = getenv("DZ_GEMM_PRE");
+    return !(v && v[0] == '0');
 }
 
 // exact-f32 MFMA kernel, or the split-f16 kernel when the layer came with split planes
@@ -205,12 +231,12 @@ struct SincScratch {
 static int run_sincnet(const dz_sincnet_weights& w, const SincGeom& g, const SincScratch& s,
                        const float* wave, long long stride, int B, hipStream_t st) {
     int rc;
-    { ProfScope ps(T_WAVE, st); if ((rc = dz_launch_wave_stats(wave, stride, B, g.S, s.stats, st))) return rc; }
-    { ProfScope ps(T_CONV0, st);
+    { ProfScope ps(T_WAVE, B); if ((rc = dz_launch_wave_stats(wave, stride, B, g.S, s.stats, st))) return rc; }
+    { ProfScope ps(T_CONV0, B);
     if ((rc = dz_launch_sinc_conv0(wave, stride, B, g.S, s.stats, 1, w.wav_gamma, w.wav_beta, w.filt,
                                    s.y0, g.P0, s.part0, g.nt0, st)))
         return rc; }
-    { ProfScope ps(T_FIN, st);
+    { ProfScope ps(T_FIN, B);
     if ((rc = dz_launch_finalize_norm(s.part0, B, g.nt0, 80, g.P0, w.in0_g, w.in0_b, s.sc0, s.sh0,
                                       st)))
         return rc; }
@@ -223,8 +249,8 @@ static int run_sincnet(const dz_sincnet_weights& w, const SincGeom& g, const Sin
     p.Kpad = 416; p.Npad = 64; p.Nstore = 64; p.ldx = 80; p.ldy = 64; p.Tstore = g.P1;
     p.xbs = (long long)g.P0 * 80; p.ybs = (long long)g.P1 * 64;
     p.norm_on_load = 1; p.epi = DZ_EPI_POOL3;
-    { ProfScope ps(T_CONV1, st); if ((rc = run_gemm(p, w.w1_split, st))) return rc; }
-    { ProfScope ps(T_FIN, st);
+    { ProfScope ps(T_CONV1, B); if ((rc = run_gemm(p, w.w1_split, st))) return rc; }
+    { ProfScope ps(T_FIN, B);
     if ((rc = dz_launch_finalize_norm(s.part1, B, g.nt1, 64, g.P1, w.in1_g, w.in1_b, s.sc1, s.sh1,
                                       st)))
         return rc; }
@@ -233,8 +259,8 @@ static int run_sincnet(const dz_sincnet_weights& w, const SincGeom& g, const Sin
     p.Y = s.y2; p.partials = s.part2;
     p.Tin = g.P1; p.Tout = g.T2; p.Cin = 64; p.K = 320; p.Kpad = 320; p.ldx = 64;
     p.Tstore = g.P2; p.xbs = (long long)g.P1 * 64; p.ybs = (long long)g.P2 * 64;
-    { ProfScope ps(T_CONV2, st); if ((rc = run_gemm(p, w.w2_split, st))) return rc; }
-    ProfScope ps(T_FIN, st);
+    { ProfScope ps(T_CONV2, B); if ((rc = run_gemm(p, w.w2_split, st))) return rc; }
+    ProfScope ps(T_FIN, B);
     return dz_launch_finalize_norm(s.part2, B, g.nt2, 64, g.P2, w.in2_g, w.in2_b, s.sc2, s.sh2, st);
 }
 
@@ -256,6 +282,7 @@ struct dz_seg {
     dz_seg_weights w;
     SincGeom g;
     int Bm;
+    bool pre;    // wide layers on k_gemm_pre.hip (activations travel as f16 hi/lo planes)
     char* arena;
     SincScratch ss;
     float *gx, *h0, *h1, *m0, *m1, *logit;
@@ -288,6 +315,8 @@ extern "C" int dz_seg_create(dz_ctx* ctx, const dz_seg_weights* w, int max_batch
     dz_seg* s = new (std::nothrow) dz_seg;
     DZ_REQUIRE(s != nullptr, "dz_seg_create: out of memory");
     s->ctx = ctx; s->w = *w; s->g = g; s->Bm = max_batch; s->arena = nullptr;
+    s->pre = pre_split_enabled() && w->wih_split[1] && w->wih_split[2] && w->wih_split[3] &&
+             w->lin0_split && w->lin1_split;
     Arena measure;
     seg_carve(s, measure);
     hipError_t e = hipMalloc((void**)&s->arena, measure.used);
@@ -323,7 +352,10 @@ extern "C" int dz_seg_forward(dz_seg* s, const float* d_wave, long long wave_str
     const int F = s->g.P2;
     if ((rc = run_sincnet(s->w.sinc, s->g, s->ss, d_wave, wave_stride, B, st))) return rc;
 
-    // 4 x { x-projection of both directions as one GEMM (N = 1024); persistent recurrence }
+    // 4 x { x-projection of both directions as one GEMM (N = 1024); persistent recurrence }.
+    // With s->pre the hidden states travel as f16 (hi, lo) planes (same bytes as f32, same buffers)
+    // and the projections of layers 1..3 and the MLP run on k_gemm_pre.hip.
+    const long long rows = (long long)B * F;
     const float* lin = nullptr;
     for (int layer = 0; layer < 4; ++layer) {
         DzConvGemm p;
@@ -340,36 +372,62 @@ extern "C" int dz_seg_forward(dz_seg* s, const float* d_wave, long long wave_str
             p.B = 1; p.Tin = p.Tout = p.Tstore = B * F; p.Cin = 256; p.K = 256; p.Kpad = 256;
             p.ldx = 256;
         }
-        { ProfScope ps(layer == 0 ? T_PROJ0 : T_PROJ, st);
-          if ((rc = run_gemm(p, s->w.wih_split[layer], st))) return rc; }
+        { ProfScope ps(layer == 0 ? T_PROJ0 : T_PROJ, B);
+          if (layer > 0 && s->pre) {
+              p.X = nullptr; p.Xsplit = lin; p.xplane = rows * 256; p.Wsplit = s->w.wih_split[layer];
+              rc = dz_launch_gemm_pre(p, st);
+          } else {
+              rc = run_gemm(p, s->w.wih_split[layer], st);
+          }
+          if (rc) return rc; }
         float* hout = (layer & 1) ? s->h1 : s->h0;
-        { ProfScope ps(T_REC, st);
-          if ((rc = dz_launch_lstm(s->gx, s->w.whh[layer], hout, B, F, st))) return rc; }
+        { ProfScope ps(T_REC, B);
+          // gx columns are unit-major (weights.py permutes the rows of W_ih); 16 chains per
+          // workgroup on the matrix cores when the layer came with split planes of W_hh
+          float* hf = s->pre ? nullptr : hout;
+          void* hs = s->pre ? (void*)hout : nullptr;
+          rc = s->w.whh_split[layer]
+                   ? dz_launch_lstm_mfma(s->gx, s->w.whh_split[layer], hf, hs, rows * 256, B, F, 1,
+                                         s->w.lstm_variant, st)
+                   : dz_launch_lstm(s->gx, s->w.whh[layer], hf, hs, rows * 256, B, F, 1, st);
+          if (rc) return rc; }
         lin = hout;
     }
     // Linear(256,128)+leaky, Linear(128,128)+leaky, classifier
     DzConvGemm p;
     memset(&p, 0, sizeof(p));
     p.B = 1; p.Tin = p.Tout = p.Tstore = B * F; p.taps = 1; p.dil = 1;
-    p.X = lin; p.W = s->w.lin0_w; p.bias = s->w.lin0_b; p.Y = s->m0;
+    p.W = s->w.lin0_w; p.bias = s->w.lin0_b;
     p.Cin = 256; p.K = 256; p.Kpad = 256; p.ldx = 256; p.Npad = 128; p.Nstore = 128; p.ldy = 128;
     p.epi = DZ_EPI_BIAS_LEAKY;
-    { ProfScope ps(T_MLP, st); if ((rc = run_gemm(p, s->w.lin0_split, st))) return rc; }
-    p.X = s->m0; p.W = s->w.lin1_w; p.bias = s->w.lin1_b; p.Y = s->m1;
-    p.Cin = 128; p.K = 128; p.Kpad = 128; p.ldx = 128;
-    { ProfScope ps(T_MLP, st); if ((rc = run_gemm(p, s->w.lin1_split, st))) return rc; }
+    if (s->pre) {
+        p.Xsplit = lin; p.xplane = rows * 256; p.Wsplit = s->w.lin0_split;
+        p.Ysplit = s->m0; p.yplane = rows * 128;
+        { ProfScope ps(T_MLP, B); if ((rc = dz_launch_gemm_pre(p, st))) return rc; }
+        p.Xsplit = s->m0; p.xplane = rows * 128; p.Wsplit = s->w.lin1_split;
+        p.Ysplit = nullptr; p.Y = s->m1; p.W = s->w.lin1_w; p.bias = s->w.lin1_b;
+        p.Cin = 128; p.K = 128; p.Kpad = 128; p.ldx = 128;
+        { ProfScope ps(T_MLP, B); if ((rc = dz_launch_gemm_pre(p, st))) return rc; }
+        p.Xsplit = nullptr;
+    } else {
+        p.X = lin; p.Y = s->m0;
+        { ProfScope ps(T_MLP, B); if ((rc = run_gemm(p, s->w.lin0_split, st))) return rc; }
+        p.X = s->m0; p.W = s->w.lin1_w; p.bias = s->w.lin1_b; p.Y = s->m1;
+        p.Cin = 128; p.K = 128; p.Kpad = 128; p.ldx = 128;
+        { ProfScope ps(T_MLP, B); if ((rc = run_gemm(p, s->w.lin1_split, st))) return rc; }
+    }
     p.Wsplit = nullptr;
     p.X = s->m1; p.W = s->w.cls_w; p.bias = s->w.cls_b;
     p.Npad = 64; p.Nstore = s->w.num_classes; p.ldy = s->w.num_classes;
     if (s->w.powerset) {
         // log_softmax is monotone: argmax of the logits == argmax of the log-probabilities
         p.Y = s->logit; p.epi = DZ_EPI_BIAS;
-        { ProfScope ps(T_CLS, st); if ((rc = dz_launch_convgemm(p, st))) return rc; }
-        ProfScope ps(T_PSET, st);
+        { ProfScope ps(T_CLS, B); if ((rc = dz_launch_convgemm(p, st))) return rc; }
+        ProfScope ps(T_PSET, B);
         return dz_launch_powerset(s->logit, B * F, s->w.num_classes, s->w.num_speakers, d_out, st);
     }
     p.Y = d_out; p.epi = DZ_EPI_BIAS_SIGMOID;
-    ProfScope ps(T_CLS, st);
+    ProfScope ps(T_CLS, B);
     return dz_launch_convgemm(p, st);
 }
 
@@ -381,6 +439,7 @@ struct dz_emb {
     dz_emb_weights w;
     SincGeom g;
     int Bm, T[5];
+    bool pre;    // tdnn2..5 on k_gemm_pre.hip (tdnn1 writes f16 hi/lo planes)
     char* arena;
     SincScratch ss;
     float *a, *b, *x5, *pooled, *parts;
@@ -413,6 +472,8 @@ extern "C" int dz_emb_create(dz_ctx* ctx, const dz_emb_weights* w, int max_batch
     dz_emb* e = new (std::nothrow) dz_emb;
     DZ_REQUIRE(e != nullptr, "dz_emb_create: out of memory");
     e->ctx = ctx; e->w = *w; e->g = g; e->Bm = max_batch; e->arena = nullptr;
+    e->pre = pre_split_enabled() && w->tw_split[0] && w->tw_split[1] && w->tw_split[2] &&
+             w->tw_split[3] && w->tw_split[4];
     int t = g.P2;
     for (int i = 0; i < 5; ++i) {
         t -= (kTdnnTaps[i] - 1) * kTdnnDil[i];
@@ -455,6 +516,9 @@ static int emb_frames(dz_emb* e, const float* d_wave, long long stride, int B, h
     // exchange the M tiles are 95 % full instead of 73 % (279 rows in 3 x 128).
     const float* in = e->ss.y2;
     const int P = e->g.P2;
+    // e->pre: tdnn1 writes its output as f16 (hi, lo) planes (same bytes, same buffers), tdnn2..5 run
+    // on k_gemm_pre.hip, tdnn5 writes the f32 features the statistics pooling reads
+    const long long plane = (long long)B * P * 512;
     for (int i = 0; i < 5; ++i) {
         DzConvGemm p;
         memset(&p, 0, sizeof(p));
@@ -470,10 +534,19 @@ static int emb_frames(dz_emb* e, const float* d_wave, long long stride, int B, h
             p.B = B; p.Tin = P; p.Tout = p.Tstore = e->T[0];
             p.xbs = (long long)P * cin[i]; p.ybs = (long long)P * npad[i];
             p.nscale = e->ss.sc2; p.nshift = e->ss.sh2; p.nld = 64; p.norm_on_load = 1;
+            if (e->pre) { p.Y = nullptr; p.Ysplit = outp; p.yplane = plane; }
         } else {
             p.B = 1; p.Tin = B * P; p.Tout = p.Tstore = B * P - span;
         }
-        { ProfScope ps(T_TDNN1 + i, st); if ((rc = run_gemm(p, e->w.tw_split[i], st))) return rc; }
+        { ProfScope ps(T_TDNN1 + i, B);
+          if (i > 0 && e->pre) {
+              p.X = nullptr; p.Xsplit = in; p.xplane = plane; p.Wsplit = e->w.tw_split[i];
+              if (i < 4) { p.Y = nullptr; p.Ysplit = outp; p.yplane = plane; }
+              rc = dz_launch_gemm_pre(p, st);
+          } else {
+              rc = run_gemm(p, e->w.tw_split[i], st);
+          }
+          if (rc) return rc; }
         in = outp;
     }
     return 0;
@@ -482,7 +555,7 @@ static int emb_frames(dz_emb* e, const float* d_wave, long long stride, int B, h
 static int emb_head(dz_emb* e, const float* d_weights, int Fw, int rows, int rows_per_x,
                     int normalize, float* d_out, hipStream_t st) {
     int rc;
-    { ProfScope ps(T_POOL, st);
+    { ProfScope ps(T_POOL, rows / rows_per_x);
     if ((rc = dz_launch_stats_pool(e->x5, (long long)e->g.P2 * 1536, e->T[4], 1500, 1536, d_weights, Fw,
                                    rows, rows_per_x, e->pooled, kPoolLd, st)))
         return rc; }
@@ -494,8 +567,8 @@ static int emb_head(dz_emb* e, const float* d_weights, int Fw, int rows, int row
     p.B = 1; p.Tin = p.Tout = p.Tstore = rows; p.Cin = kPoolLd; p.taps = 1; p.dil = 1;
     p.K = kPoolLd; p.Kpad = kPoolLd; p.Npad = 512; p.Nstore = 512; p.ldx = kPoolLd; p.ldy = 512;
     p.epi = DZ_EPI_BIAS; p.ksplit = kEmbSplit; p.ysplit = (long long)rows * 512;
-    { ProfScope ps(T_EMBLIN, st); if ((rc = dz_launch_convgemm(p, st))) return rc; }
-    ProfScope ps(T_L2, st);
+    { ProfScope ps(T_EMBLIN, rows / rows_per_x); if ((rc = dz_launch_convgemm(p, st))) return rc; }
+    ProfScope ps(T_L2, rows / rows_per_x);
     return dz_launch_splitk_finish(e->parts, kEmbSplit, p.ysplit, rows, 512, normalize, d_out, st);
 }
 
@@ -565,7 +638,7 @@ extern "C" int dz_osp(dz_ctx* ctx, const float* d_seg, int batch, int frames, in
     DZ_REQUIRE(ctx && d_seg && d_out, "dz_osp: NULL argument");
     DZ_REQUIRE(batch >= 1 && frames >= 1, "dz_osp: empty input");
     DZ_HIP(hipSetDevice(ctx->device));
-    ProfScope ps(T_OSP, (hipStream_t)stream);
+    ProfScope ps(T_OSP, batch);
     return dz_launch_osp(d_seg, batch, frames, speakers, gamma, beta, normalize, speaker_major,
                          d_out, (hipStream_t)stream);
 }
@@ -601,6 +674,11 @@ extern "C" int dz_k_gemm_split(dz_ctx* ctx, const dz_convgemm_desc* d, void* str
     DZ_REQUIRE(ctx && d, "dz_k_gemm_split: NULL argument");
     DZ_HIP(hipSetDevice(ctx->device));
     return dz_launch_gemm_split(*d, (hipStream_t)stream);
+}
+extern "C" int dz_k_gemm_pre(dz_ctx* ctx, const dz_convgemm_desc* d, void* stream) {
+    DZ_REQUIRE(ctx && d, "dz_k_gemm_pre: NULL argument");
+    DZ_HIP(hipSetDevice(ctx->device));
+    return dz_launch_gemm_pre(*d, (hipStream_t)stream);
 }
 extern "C" int dz_k_convgemm_ntile(int t_out) { return dz_convgemm_ntile(t_out); }
 extern "C" int dz_k_wave_stats(dz_ctx* ctx, const float* d_wave, long long stride, int batch,
@@ -645,7 +723,26 @@ extern "C" int dz_k_lstm(dz_ctx* ctx, const float* d_gx, const float* d_whh, flo
     DZ_REQUIRE(ctx && d_gx && d_whh && d_hout, "dz_k_lstm: NULL argument");
     DZ_REQUIRE(batch >= 1 && frames >= 1, "dz_k_lstm: empty input");
     DZ_HIP(hipSetDevice(ctx->device));
-    return dz_launch_lstm(d_gx, d_whh, d_hout, batch, frames, (hipStream_t)stream);
+    return dz_launch_lstm(d_gx, d_whh, d_hout, nullptr, 0, batch, frames, 0, (hipStream_t)stream);
+}
+extern "C" int dz_k_lstm_planes(dz_ctx* ctx, const float* d_gx, const float* d_whh,
+                                const void* d_whh_split, int variant, void* d_hsplit, long long hplane,
+                                int batch, int frames, void* stream) {
+    DZ_REQUIRE(ctx && d_gx && d_hsplit && (d_whh || d_whh_split), "dz_k_lstm_planes: NULL argument");
+    DZ_REQUIRE(batch >= 1 && frames >= 1, "dz_k_lstm_planes: empty input");
+    DZ_HIP(hipSetDevice(ctx->device));
+    if (d_whh_split)
+        return dz_launch_lstm_mfma(d_gx, d_whh_split, nullptr, d_hsplit, hplane, batch, frames, 0,
+                                   variant, (hipStream_t)stream);
+    return dz_launch_lstm(d_gx, d_whh, nullptr, d_hsplit, hplane, batch, frames, 0, (hipStream_t)stream);
+}
+extern "C" int dz_k_lstm_mfma(dz_ctx* ctx, const float* d_gx, const void* d_whh_split, float* d_hout,
+                              int batch, int frames, int unit_major, int variant, void* stream) {
+    DZ_REQUIRE(ctx && d_gx && d_whh_split && d_hout, "dz_k_lstm_mfma: NULL argument");
+    DZ_REQUIRE(batch >= 1 && frames >= 1, "dz_k_lstm_mfma: empty input");
+    DZ_HIP(hipSetDevice(ctx->device));
+    return dz_launch_lstm_mfma(d_gx, d_whh_split, d_hout, nullptr, 0, batch, frames, unit_major,
+                               variant, (hipStream_t)stream);
 }
 extern "C" int dz_k_stats_pool(dz_ctx* ctx, const float* d_x, int frames, int channels, int ldx,
                                const float* d_weights, int weight_frames, int rows,

@@ -4,6 +4,7 @@
 #include <hip/hip_ext.h>
 #include <stdint.h>
 #include <stddef.h>
+#include <mutex>
 #include "../../include/diart_amd.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -16,17 +17,20 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 #define DZ_LEAKY_SLOPE 0.01f
 
 // hipFuncSetAttribute is a per-device setting and a process may drive several GPUs (one dz_ctx
-// each): remember per device whether a kernel's dynamic-LDS limit has been raised.  (Two host
-// threads racing here would both set the same value: harmless.)
+// each) from several host threads: raise a kernel's dynamic-LDS limit once per device, under a
+// lock that is held until the attribute is set (a second thread launching the same kernel for the
+// first time waits for it instead of launching with the old limit).
 struct DzAttrOnce {
+    std::mutex mu;
     bool done[64] = {};
-    bool need() {
+    hipError_t raise(const void* fn, int bytes) {
         int d = 0;
         (void)hipGetDevice(&d);
-        if (d < 0 || d >= 64) return true;
-        if (done[d]) return false;
-        done[d] = true;
-        return true;
+        std::lock_guard<std::mutex> lk(mu);
+        if (d >= 0 && d < 64 && done[d]) return hipSuccess;
+        const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+        if (e == hipSuccess && d >= 0 && d < 64) done[d] = true;
+        return e;
     }
 };
 
@@ -80,6 +84,31 @@ __device__ __forceinline__ void dz_tile_map(int agroup, int& bx, int& by, int& b
 }
 
 // ---------------------------------------------------------------------------
+// Epilogue helper of the split-f16 GEMMs: write an f32 result as the two f16 planes the next
+// layer's k_gemm_pre.hip reads (hi = f16(v), lo = f16((v - hi) * 2^11), lo plane `yplane` elements
+// after the hi plane).  Lanes 2i and 2i+1 of a quad hold columns n and n+1 of the same row (MFMA C/D
+// layout: column = lane & 31): they exchange their (hi, lo) pair through one DPP move, the even
+// lane stores (hi[n], hi[n+1]) to the hi plane and the odd lane (lo[n-1], lo[n]) to the lo plane —
+// one 4-byte store per lane, like an f32 store.  Every lane of the quad must call it; `ypl` is
+// dz_split_base(Yhi, yplane, odd); `idx` = row * ldy + column; inputs are clamped to +-65504.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ unsigned short* dz_split_base(void* ysplit, long long yplane, bool odd) {
+    unsigned short* y = reinterpret_cast<unsigned short*>(ysplit);
+    return odd ? y + (yplane - 1) : y;
+}
+__device__ __forceinline__ void dz_store_split(unsigned short* ypl, long long idx, float v, bool store,
+                                               bool odd) {
+    const float x = __builtin_amdgcn_fmed3f(v, -65504.f, 65504.f);
+    const _Float16 h = (_Float16)x;
+    const _Float16 lw = (_Float16)((x - (float)h) * 2048.f);
+    const unsigned P = (unsigned)__builtin_bit_cast(unsigned short, h) |
+                       ((unsigned)__builtin_bit_cast(unsigned short, lw) << 16);
+    const unsigned Q = (unsigned)__builtin_amdgcn_update_dpp(0, (int)P, 0xB1, 0xF, 0xF, true);
+    const unsigned word = odd ? ((Q >> 16) | (P & 0xffff0000u)) : ((P & 0xffffu) | (Q << 16));
+    if (store) *reinterpret_cast<unsigned*>(ypl + idx) = word;
+}
+
+// ---------------------------------------------------------------------------
 // error plumbing (api.hip)
 // ---------------------------------------------------------------------------
 void dz_set_error(const char* fmt, ...);
@@ -127,12 +156,21 @@ int dz_launch_convgemm(const DzConvGemm& p, hipStream_t st);
 // k_gemm_split.hip: the same contraction on the f16 matrix cores with both operands split into
 // (hi, lo) f16 pairs — 3 MFMAs per product, f32 accumulation
 int dz_launch_gemm_split(const DzConvGemm& p, hipStream_t st);
+// k_gemm_pre.hip: both operands pre-split into f16 planes, tiles loaded by LDS-DMA
+int dz_launch_gemm_pre(const DzConvGemm& p, hipStream_t st);
 int dz_convgemm_ntile(int Tout);
 
 // k_lstm.hip ----------------------------------------------------------------
-// gx [B*T][1024] (dir*512+gate*128+unit, biases included), whh [2][512][128]
-// -> hout [B][T][256] (fwd | bwd)
-int dz_launch_lstm(const float* gx, const float* whh, float* hout, int B, int T, hipStream_t st);
+// gx [B*T][1024] (biases included; columns dir*512+gate*128+unit, or dir*512+unit*4+gate when
+// unit_major), whh [2][512][128] -> hout [B][T][256] (fwd | bwd).  One chain per workgroup, f32 VALU.
+// Output: hout (f32) and / or hsplit = two f16 planes [B][T][256] (hi, lo * 2^11; lo plane hplane
+// elements after hi) for a k_gemm_pre.hip consumer; either may be NULL.
+int dz_launch_lstm(const float* gx, const float* whh, float* hout, void* hsplit, long long hplane,
+                   int B, int T, int unit_major, hipStream_t st);
+// k_lstm_mfma.hip: the same recurrence, 16 chains per workgroup on the f16 matrix cores with split
+// operands; whh_split = [2 dir][2 planes (hi, lo * 2^11)][512][128] f16 (weights.py split_f16 per direction)
+int dz_launch_lstm_mfma(const float* gx, const void* whh_split, float* hout, void* hsplit,
+                        long long hplane, int B, int T, int unit_major, int variant, hipStream_t st);
 
 // k_pool.hip ----------------------------------------------------------------
 // weighted statistics pooling; X: nx chunks `xstride` floats apart, each [T][ldx] (C valid

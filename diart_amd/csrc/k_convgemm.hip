@@ -238,10 +238,7 @@ template <int BN, bool PRO, int EPI>
 int launch(const DzConvGemm& p, hipStream_t st) {
     using C = Cfg<BN>;
     static DzAttrOnce attr_once;
-    if (attr_once.need()) {
-        DZ_HIP(hipFuncSetAttribute((const void*)convgemm_kernel<BN, PRO, EPI>,
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS));
-    }
+    DZ_HIP(attr_once.raise((const void*)convgemm_kernel<BN, PRO, EPI>, (int)C::LDS));
     dim3 grid((p.Tout + BM - 1) / BM, p.Npad / BN, p.B * (p.ksplit > 1 ? p.ksplit : 1));
     DZ_LAUNCH((convgemm_kernel<BN, PRO, EPI>), grid, dim3(256), C::LDS, st, p);
     DZ_HIP(hipGetLastError());

@@ -264,10 +264,7 @@ int dz_launch_sinc_conv0(const float* wave, long long stride, int B, int S, cons
     const size_t epi = (size_t)C0_FR * C0_OLD * sizeof(float);
     const size_t lds = k_loop > epi ? k_loop : epi;
     static DzAttrOnce attr_once;
-    if (attr_once.need()) {
-        DZ_HIP(hipFuncSetAttribute((const void*)sinc_conv0_kernel,
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    }
+    DZ_HIP(attr_once.raise((const void*)sinc_conv0_kernel, (int)lds));
     DZ_LAUNCH(sinc_conv0_kernel, dim3(ntile, B), dim3(256), lds, st, wave, stride, S,
                        stats, stats_are_moments, gamma, beta, filt, y0, P0, partials, ntile);
     DZ_HIP(hipGetLastError());

@@ -1,0 +1,201 @@
+// Implicit-GEMM 1-D convolution / linear layer on the f16 matrix cores, BOTH operands pre-split.
+//
+//   Y[t][n] = epi( sum_{tap,c} X[t + tap*dil][c] * W[n][tap*Cin + c] + bias[n] )
+//
+// Same contraction and arithmetic as k_gemm_split.hip (x = hi + lo * 2^-11 with hi, lo f16; three
+// v_mfma_f32_32x32x16_f16 per product into two f32 accumulators), for the wide layers in the
+// middle of the networks (x-vector tdnn2..5, the LSTM input projections of layers 1..3, the
+// segmentation MLP; third-party graphs called from /root/reference/src/diart/models.py:133, :262;
+// SURVEY.md Appendix A, kernels K5 / K6 / K8).  What changed is where the split happens:
+//
+//   * k_gemm_split.hip reads f32 activations and splits them on the way into LDS: ~4 VALU
+//     instructions per element, once per N-tile that re-reads the row (4..12 times), plus four
+//     ds_write_b128 per thread per k-tile — at 29 % matrix-core busy the loop was bound by exactly
+//     this traffic (profiles/r01_p_*).
+//   * here the PRODUCER's epilogue writes the two f16 planes (4 bytes per element, the same HBM
+//     bytes as the f32 it replaces; split once per element), so a k-tile of either operand is
+//     plain bytes: it goes global -> LDS by LDS-DMA (buffer_load_dwordx4 ... lds, 16 B per lane, no
+//     VGPR staging, no ds_write, no VALU; the k-tile / tap offset is the instruction's scalar
+//     offset, out-of-range rows read as zeros through the buffer bounds check).
+//
+// Tile 128 x 128 x 32, 4 waves (2 x 2), wave tile 64 x 64 = 2 x 2 fragments of 32 x 32: per 16-wide
+// k-step a wave issues 8 ds_read_b128 for 12 MFMAs (k_gemm_split: 6 for 6).  LDS stage = four
+// planes [128 rows][64 B] (A hi, A lo, B hi, B lo), 16-byte chunks XOR-swizzled with (row >> 2) & 3
+// (the LDS-DMA destination is lane-linear, so the swizzle is applied to the per-lane SOURCE chunk
+// and again on the fragment read: cdna_hip_programming.md rule 21); two stages = 64 KiB, two
+// workgroups per CU.  One barrier per k-tile: wait own DMA, barrier, issue the DMA of tile kt+1
+// into the stage everybody has just finished reading, compute tile kt.
+#include "dz_common.h"
+
+namespace {
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int BM = 128, BN = 128, KT = 32;
+constexpr int PLANE = 128 * 64;            // bytes of one f16 plane of a stage
+constexpr int STAGE = 4 * PLANE;           // A hi | A lo | B hi | B lo
+constexpr size_t LDS_BYTES = 2 * STAGE;
+constexpr float LO_UNSCALE = 1.f / 2048.f;
+
+__device__ __forceinline__ float leaky(float v) { return v > 0.f ? v : v * DZ_LEAKY_SLOPE; }
+
+template <int EPI>
+__global__ __launch_bounds__(256, 2) void gemm_pre_kernel(DzConvGemm p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6), l = tid & 63;
+    int bx, by, bz;
+    dz_tile_map(p.agroup, bx, by, bz);
+    const int t0 = bx * BM, n0 = by * BN;
+
+    // ---- staging role of this wave: plane w of every stage (0 A hi, 1 A lo, 2 B hi, 3 B lo) ----
+    const bool isB = w >= 2;
+    const int lo = w & 1;
+    const unsigned short* A = reinterpret_cast<const unsigned short*>(p.Xsplit);
+    const unsigned short* W = reinterpret_cast<const unsigned short*>(p.Wsplit);
+    const unsigned short* src = isB ? W + (long long)lo * p.Npad * p.Kpad : A + (long long)lo * p.xplane;
+    const int ld = isB ? p.Kpad : p.ldx;                          // f16 elements per row
+    const unsigned nbytes = (unsigned)((isB ? (long long)p.Npad : (long long)p.Tin) * ld * 2);
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)src, 0, nbytes, 0x00020000);
+    // lane -> (row l>>2 [+16 i], LDS slot l&3) of each 16-row piece; the slot holds source chunk
+    // slot ^ ((row >> 2) & 3), and (row >> 2) & 3 = (l >> 4) & 3 for every piece
+    const int row0 = (isB ? n0 : t0) + (l >> 2);
+    const int voff0 = row0 * ld * 2 + (((l & 3) ^ ((l >> 4) & 3)) << 4);
+    const int vstep = 16 * ld * 2;
+    auto issue = [&](int kt, int stage) {
+        int soff;
+        if (isB) {
+            soff = kt * (KT * 2);
+        } else {
+            const int k = kt * KT;
+            int tap = 0, c = k;
+            if (p.taps > 1) {
+                tap = k / p.Cin;
+                c = k - tap * p.Cin;
+            }
+            soff = (tap * p.dil * p.ldx + c) * 2;
+        }
+        char* dst = smem + stage * STAGE + w * PLANE;
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(
+                rsrc, (__attribute__((address_space(3))) void*)(dst + i * 1024), 16, voff0 + i * vstep, soff, 0, 0);
+    };
+
+    // ---- MFMA coordinates: 2 x 2 waves, wave tile 64 x 64 ---------------------------------------
+    const int li = l & 31, g = l >> 5;
+    const int wm = w >> 1, wn = w & 1;
+    const int sw = (li >> 2) & 3;
+    int foff[2];                               // fragment offset of this lane inside a 32-row block
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) foff[ks] = li * 64 + (((2 * ks + g) ^ sw) << 4);
+    f32x16 accm[2][2], accx[2][2];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) accm[mt][nt][r] = accx[mt][nt][r] = 0.f;
+
+    auto compute = [&](int stage) {
+        const char* st = smem + stage * STAGE;
+        const char* sa = st + (wm * 64) * 64;
+        const char* sb = st + 2 * PLANE + (wn * 64) * 64;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            f16x8 ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                ah[t] = *reinterpret_cast<const f16x8*>(sa + t * 2048 + foff[ks]);
+                al[t] = *reinterpret_cast<const f16x8*>(sa + PLANE + t * 2048 + foff[ks]);
+                bh[t] = *reinterpret_cast<const f16x8*>(sb + t * 2048 + foff[ks]);
+                bl[t] = *reinterpret_cast<const f16x8*>(sb + PLANE + t * 2048 + foff[ks]);
+            }
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) {
+                    accx[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[mt], bh[nt], accx[mt][nt], 0, 0, 0);
+                    accm[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mt], bh[nt], accm[mt][nt], 0, 0, 0);
+                    accx[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mt], bl[nt], accx[mt][nt], 0, 0, 0);
+                }
+        }
+    };
+
+    const int nk = p.Kpad / KT;
+    issue(0, 0);
+    for (int kt = 0; kt < nk; ++kt) {
+        // own DMA of tile kt has landed + every wave has finished the fragment reads of tile kt-1
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if (kt + 1 < nk) issue(kt + 1, (kt + 1) & 1);
+        compute(kt & 1);
+    }
+
+    // ---- epilogue: C/D map col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5) ---------
+    // (hi, lo) plane output: see dz_store_split; columns >= Nstore of a padded layer are written
+    // as zeros (they are K padding of the consumer)
+    unsigned short* Ypl = p.Ysplit ? dz_split_base(p.Ysplit, p.yplane, li & 1) : nullptr;
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+        const int n = n0 + wn * 64 + nt * 32 + li;
+        const float bv = p.bias[n];
+        float e0 = 1.f, e1 = 0.f;
+        if (EPI == DZ_EPI_TDNN || EPI == DZ_EPI_RELU_BN) {
+            e0 = p.e0[n];
+            e1 = p.e1[n];
+        }
+        const bool nok = n < p.Nstore;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int t = t0 + wm * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
+                float v = (accm[mt][nt][r] + accx[mt][nt][r] * LO_UNSCALE) + bv;
+                if (EPI == DZ_EPI_BIAS_LEAKY) v = leaky(v);
+                if (EPI == DZ_EPI_TDNN) v = leaky(v) * e0 + e1;
+                if (EPI == DZ_EPI_RELU_BN) v = fmaxf(v, 0.f) * e0 + e1;
+                const bool ok = t < p.Tout;
+                if (p.Y && ok && nok) p.Y[(long long)t * p.ldy + n] = v;
+                if (Ypl) dz_store_split(Ypl, (long long)t * p.ldy + n, nok ? v : 0.f, ok, li & 1);
+            }
+    }
+}
+
+template <int EPI>
+int launch(const DzConvGemm& p, hipStream_t st) {
+    static DzAttrOnce attr_once;
+    DZ_HIP(attr_once.raise((const void*)gemm_pre_kernel<EPI>, (int)LDS_BYTES));
+    dim3 grid((p.Tout + BM - 1) / BM, p.Npad / BN, 1);
+    DZ_LAUNCH((gemm_pre_kernel<EPI>), grid, dim3(256), LDS_BYTES, st, p);
+    DZ_HIP(hipGetLastError());
+    return 0;
+}
+
+}  // namespace
+
+int dz_launch_gemm_pre(const DzConvGemm& p, hipStream_t st) {
+    DZ_REQUIRE(p.Wsplit != nullptr && p.Xsplit != nullptr,
+               "gemm_pre: Wsplit / Xsplit (f16 hi/lo planes of W and of the input) are NULL");
+    DZ_REQUIRE(p.Y != nullptr || p.Ysplit != nullptr, "gemm_pre: no output");
+    DZ_REQUIRE(p.B == 1, "gemm_pre: flattened layers only (B = 1)");
+    DZ_REQUIRE(p.K == p.Kpad && p.K == p.taps * p.Cin && p.Cin % KT == 0 && p.ldx % 8 == 0,
+               "gemm_pre: K = taps * Cin without padding, Cin a multiple of 32, ldx of 8");
+    DZ_REQUIRE(p.Npad % BN == 0, "gemm_pre: Npad must be a multiple of 128");
+    DZ_REQUIRE(p.Tout > 0 && p.Tout == p.Tin - (p.taps - 1) * p.dil, "gemm_pre: Tout mismatch");
+    DZ_REQUIRE(p.pad == 0 && p.X2 == nullptr && p.rowbias == nullptr && p.ksplit <= 1 && !p.norm_on_load,
+               "gemm_pre: padding / second input / row bias / split-K / norm-on-load are not built here");
+    DZ_REQUIRE((long long)p.Tin * p.ldx * 2 < (1ll << 31) && (long long)p.Npad * p.Kpad * 2 < (1ll << 31),
+               "gemm_pre: operand plane exceeds the 2 GiB buffer-offset range");
+    DZ_REQUIRE(p.Ysplit == nullptr || (p.ldy % 2 == 0 && p.yplane % 2 == 0 && p.Npad <= p.ldy),
+               "gemm_pre: plane output needs even ldy / yplane and Npad <= ldy");
+    switch (p.epi) {
+        case DZ_EPI_BIAS: return launch<DZ_EPI_BIAS>(p, st);
+        case DZ_EPI_BIAS_LEAKY: return launch<DZ_EPI_BIAS_LEAKY>(p, st);
+        case DZ_EPI_TDNN: return launch<DZ_EPI_TDNN>(p, st);
+        case DZ_EPI_RELU_BN: return launch<DZ_EPI_RELU_BN>(p, st);
+    }
+    dz_set_error("gemm_pre: epilogue %d is not built on the pre-split path", p.epi);
+    return 2;
+}

@@ -249,7 +249,9 @@ __global__ __launch_bounds__(128 * WM) void gemm_split_kernel(DzConvGemm p) {
         }
         return;
     }
-    float* Yb = p.Y + (long long)b * p.ybs;
+    float* Yb = p.Y ? p.Y + (long long)b * p.ybs : nullptr;
+    // optional (hi, lo) f16 plane output for a k_gemm_pre.hip consumer (dz_store_split)
+    unsigned short* Ypl = p.Ysplit ? dz_split_base(p.Ysplit, p.yplane, li & 1) + (long long)b * p.ybs : nullptr;
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
         const int n = n0 + wn * 32 * NB + nb * 32 + li;
@@ -259,18 +261,17 @@ __global__ __launch_bounds__(128 * WM) void gemm_split_kernel(DzConvGemm p) {
             e0 = p.e0[n];
             e1 = p.e1[n];
         }
-        if (n < p.Nstore) {
+        const bool nok = n < p.Nstore;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int t = t0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
-                if (t < p.Tout) {
-                    float v = (accm[nb][r] + accx[nb][r] * LO_UNSCALE) + bv;
-                    if (EPI == DZ_EPI_BIAS_LEAKY) v = leaky(v);
-                    if (EPI == DZ_EPI_TDNN) v = leaky(v) * e0 + e1;
-                    if (EPI == DZ_EPI_RELU_BN) v = fmaxf(v, 0.f) * e0 + e1;
-                    Yb[(long long)t * p.ldy + n] = v;
-                }
-            }
+        for (int r = 0; r < 16; ++r) {
+            const int t = t0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
+            const bool ok = t < p.Tout;
+            float v = (accm[nb][r] + accx[nb][r] * LO_UNSCALE) + bv;
+            if (EPI == DZ_EPI_BIAS_LEAKY) v = leaky(v);
+            if (EPI == DZ_EPI_TDNN) v = leaky(v) * e0 + e1;
+            if (EPI == DZ_EPI_RELU_BN) v = fmaxf(v, 0.f) * e0 + e1;
+            if (Yb && ok && nok) Yb[(long long)t * p.ldy + n] = v;
+            if (Ypl) dz_store_split(Ypl, (long long)t * p.ldy + n, nok ? v : 0.f, ok, li & 1);
         }
     }
 }
@@ -279,10 +280,7 @@ template <int WM, int NB, bool PRO, int EPI>
 int launch(const DzConvGemm& p, hipStream_t st) {
     using C = Cfg<WM, NB>;
     static DzAttrOnce attr_once;
-    if (attr_once.need()) {
-        DZ_HIP(hipFuncSetAttribute((const void*)gemm_split_kernel<WM, NB, PRO, EPI>,
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS));
-    }
+    DZ_HIP(attr_once.raise((const void*)gemm_split_kernel<WM, NB, PRO, EPI>, (int)C::LDS));
     dim3 grid((p.Tout + C::BM - 1) / C::BM, p.Npad / C::BN, p.B);
     DZ_LAUNCH((gemm_split_kernel<WM, NB, PRO, EPI>), grid, dim3(C::T), C::LDS, st, p);
     DZ_HIP(hipGetLastError());
@@ -299,6 +297,10 @@ int dz_launch_gemm_split(const DzConvGemm& p, hipStream_t st) {
     DZ_REQUIRE(p.pad == 0 && p.X2 == nullptr && p.rowbias == nullptr && p.ksplit <= 1,
                "gemm_split: padding / second input / row bias / split-K are f32-path features");
     DZ_REQUIRE(p.Tout > 0 && p.Tout == p.Tin - (p.taps - 1) * p.dil, "gemm_split: Tout mismatch");
+    DZ_REQUIRE(p.Y != nullptr || p.Ysplit != nullptr, "gemm_split: no output");
+    DZ_REQUIRE(p.Ysplit == nullptr || (p.epi != DZ_EPI_POOL3 && p.ldy % 2 == 0 && p.yplane % 2 == 0 &&
+                                       p.ybs % 2 == 0 && p.Npad <= p.ldy),
+               "gemm_split: plane output needs even ldy / yplane / ybs, Npad <= ldy and no pooling");
     const bool pro = p.norm_on_load != 0;
 #define DZ_SP(WM, NB, PRO, EPI) return launch<WM, NB, PRO, EPI>(p, st)
     if (p.epi == DZ_EPI_POOL3) {

@@ -25,6 +25,7 @@
 namespace {
 
 // quad_perm DPP controls
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 constexpr int DPP_XOR1 = 0xB1;  // [1,0,3,2]
 constexpr int DPP_XOR2 = 0x4E;  // [2,3,0,1]
 template <int CTRL>
@@ -48,9 +49,15 @@ constexpr int RING = 16;   // h_t history kept in LDS (slot (t+1) & 15); flushed
 constexpr int BLK = 8;     // steps per flush
 constexpr int PF = 4;      // x-projection prefetch distance in steps
 
+// UM: gx columns are unit-major (dir*512 + unit*4 + gate: what dz_seg_forward's projection GEMM
+// writes, one fully contiguous 2 KiB row read per step) instead of PyTorch's gate-major
+// (dir*512 + gate*128 + unit)
+template <bool UM>
 __global__ __launch_bounds__(512) void lstm_rec_kernel(const float* __restrict__ gx,
                                                        const float* __restrict__ whh,
-                                                       float* __restrict__ hout, int B, int T) {
+                                                       float* __restrict__ hout,
+                                                       unsigned short* __restrict__ hsp,
+                                                       long long hplane, int B, int T) {
     __shared__ __attribute__((aligned(16))) float hs[RING][128];
     const int b = blockIdx.x, dir = blockIdx.y;
     const int tid = threadIdx.x, p = tid & 3, u = tid >> 2;
@@ -80,8 +87,10 @@ __global__ __launch_bounds__(512) void lstm_rec_kernel(const float* __restrict__
     const float act_shift = (p == 2) ? -1.f : 0.f;
     // step s works on frame tt(s) = s (forward) or T-1-s (backward)
     const long long tstep = dir ? -1024 : 1024;
-    const float* gptr = gx + ((long long)b * T + (dir ? T - 1 : 0)) * 1024 + dir * 512 + p * 128 + u;
-    float* hrow = hout + (long long)b * T * 256 + dir * 128;
+    const float* gptr = gx + ((long long)b * T + (dir ? T - 1 : 0)) * 1024 + dir * 512 + (UM ? u * 4 + p : p * 128 + u);
+    // h_t goes out as f32 (hout) and / or as the two f16 planes a k_gemm_pre.hip consumer reads
+    // (hsp: hi = f16(h), lo = f16((h - hi) * 2^11) hplane elements further)
+    const long long hbase = (long long)b * T * 256 + dir * 128;
     // flush role of this thread: step i = tid / 64 of the block, units 2*(tid % 64), +1
     const int fl_i = tid >> 6, fl_u = (tid & 63) * 2;
 
@@ -123,7 +132,15 @@ __global__ __launch_bounds__(512) void lstm_rec_kernel(const float* __restrict__
         if (fl_i < n) {
             const int tt = dir ? T - 1 - s : s;
             const float2 v = *reinterpret_cast<const float2*>(&hs[(s + 1) & (RING - 1)][fl_u]);
-            *reinterpret_cast<float2*>(hrow + (long long)tt * 256 + fl_u) = v;
+            const long long o = hbase + (long long)tt * 256 + fl_u;
+            if (hout) *reinterpret_cast<float2*>(hout + o) = v;
+            if (hsp) {
+                const f32x2 x = {v.x, v.y};
+                const f16x2 hi = __builtin_convertvector(x, f16x2);
+                const f16x2 lo = __builtin_convertvector((x - __builtin_convertvector(hi, f32x2)) * 2048.f, f16x2);
+                *reinterpret_cast<f16x2*>(hsp + o) = hi;
+                *reinterpret_cast<f16x2*>(hsp + hplane + o) = lo;
+            }
         }
     };
 
@@ -154,9 +171,16 @@ __global__ __launch_bounds__(512) void lstm_rec_kernel(const float* __restrict__
 
 }  // namespace
 
-int dz_launch_lstm(const float* gx, const float* whh, float* hout, int B, int T, hipStream_t st) {
+int dz_launch_lstm(const float* gx, const float* whh, float* hout, void* hsplit, long long hplane,
+                   int B, int T, int unit_major, hipStream_t st) {
     dim3 grid(B, 2);
-    DZ_LAUNCH(lstm_rec_kernel, grid, dim3(512), 0, st, gx, whh, hout, B, T);
+    unsigned short* hsp = reinterpret_cast<unsigned short*>(hsplit);
+    DZ_REQUIRE(hout || hsp, "lstm: no output");
+    DZ_REQUIRE(hplane % 2 == 0, "lstm: odd plane distance");
+    if (unit_major)
+        DZ_LAUNCH(lstm_rec_kernel<true>, grid, dim3(512), 0, st, gx, whh, hout, hsp, hplane, B, T);
+    else
+        DZ_LAUNCH(lstm_rec_kernel<false>, grid, dim3(512), 0, st, gx, whh, hout, hsp, hplane, B, T);
     DZ_HIP(hipGetLastError());
     return 0;
 }

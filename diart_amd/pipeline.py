@@ -10,7 +10,9 @@ producing for each stream exactly what its own ``SpeakerDiarization.__call__`` c
 max_speakers)`` scores and the speech turns of the region the step finalises.  ``AudioRing`` keeps
 the rolling windows of host-fed streams on the device (only new samples are uploaded).
 
-GPU schedule per step (``seg_split`` + ``emb_split`` HIP streams, default 2 + 1):
+GPU schedule per step (``seg_split`` + ``emb_split`` HIP streams per lane; ``depth`` lanes so that
+``depth`` consecutive steps can be in flight at once — the GPU halves of different steps are
+independent, only the host-side clustering is sequential per stream):
 
     stream A_i : sub-batch i: dz_seg_forward (SincNet -> 4 x {x-projection GEMM, persistent
                  LSTM} -> MLP) -> dz_osp  --event-->        (the GEMMs of one sub-batch run
@@ -112,7 +114,7 @@ class StreamBatch:
                  device: Optional[torch.device] = None, cluster_threads: int = 8,
                  seg_split: Optional[int] = None, emb_split: Optional[int] = None,
                  tail: bool = False, duration: float = 5.0, step: float = 0.5,
-                 latency: Optional[float] = None):
+                 latency: Optional[float] = None, depth: Optional[int] = None):
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else device
         self.seg, self.emb = segmentation.to(self.device), embedding.to(self.device)
         self.device = self.seg.device
@@ -127,7 +129,8 @@ class StreamBatch:
         self.latency = self.step if latency is None else float(latency)
         self.tau_active, self.cluster_threads = tau_active, cluster_threads
         self.tail: Optional[BatchedOutputTail] = None
-        self._t = 0
+        self._t = 0                                        # launches so far (lane selection)
+        self._steps = np.zeros(num_streams, dtype=np.int64)   # windows seen by each stream slot
         # sub-batches per network, each on its own HIP stream with its own scratch arena: the
         # x-projection GEMM of one sub-batch runs under the latency-bound recurrence of another
         self.seg_split = max(1, min(int(os.environ.get("DZ_SEG_SPLIT", "2" if num_streams >= 16 else "1") if seg_split is None else seg_split), num_streams))
@@ -136,9 +139,17 @@ class StreamBatch:
         # changes the step time by < 3 % (noise level) while it stretches the embedding kernels'
         # wall durations 2x, so both stay at the default; the knobs remain for experiments
         pa, pb = int(os.environ.get("DZ_PRIO_A", "0")), int(os.environ.get("DZ_PRIO_B", "0"))
-        self.streams_a = [torch.cuda.Stream(self.device, priority=pa) for _ in range(self.seg_split)]
-        self.streams_b = [torch.cuda.Stream(self.device, priority=pb) for _ in range(self.emb_split)]
+        # `depth` lanes, each with its own HIP streams and scratch arenas: step t runs on lane
+        # t % depth, so a caller that keeps `depth` tickets between launch() and finish() has that
+        # many steps on the GPU at once (the latency-bound recurrence of one step under the GEMMs
+        # of the others).  A lane is reused in stream order, which also orders its arenas.
+        self.depth = max(1, int(os.environ.get("DZ_DEPTH", "2") if depth is None else depth))
+        self.lanes = [dict(a=[torch.cuda.Stream(self.device, priority=pa) for _ in range(self.seg_split)],
+                           b=[torch.cuda.Stream(self.device, priority=pb) for _ in range(self.emb_split)])
+                      for _ in range(self.depth)]
+        self.streams_a, self.streams_b = self.lanes[0]["a"], self.lanes[0]["b"]
         self.stream_a, self.stream_b = self.streams_a[0], self.streams_b[0]
+        self.num_hip_streams = self.depth * (self.seg_split + self.emb_split)
         self._sub: dict = {}
         self._slots: List[dict] = []
         self._lib = _lib.load()
@@ -150,7 +161,9 @@ class StreamBatch:
         if self.tail is not None:
             self.tail.reset(slot)
         if slot is None:
-            self._t = 0
+            self._steps[:] = 0
+        else:
+            self._steps[slot] = 0
 
     # ------------------------------------------------------------------ GPU half
     def _slot(self, F: int, K: int, D: int) -> dict:
@@ -177,31 +190,24 @@ class StreamBatch:
     def _ranges(n: int, parts: int) -> List[Tuple[int, int]]:
         return [(n * i // parts, n * (i + 1) // parts) for i in range(parts)]
 
-    def _handles(self, S: int):
-        """C handles (one scratch arena each) of the sub-batches for windows of S samples."""
-        got = self._sub.get(S)
+    def _handles(self, S: int, lane: int):
+        """C handles (one scratch arena each, owned by this object) of the sub-batches of one lane
+        for windows of S samples."""
+        got = self._sub.get((S, lane))
         if got is None:
             sa, sb = self._ranges(self.n, self.seg_split), self._ranges(self.n, self.emb_split)
-            if self.seg_split == 1:
-                hs = [self.seg._need(S, self.n)]
-            else:
-                hs = [self.seg._create(S, -(-self.n // self.seg_split)) for _ in sa]
-            if self.emb_split == 1:
-                he = [self.emb._need(S, self.n)]
-            else:
-                he = [self.emb._create(S, -(-self.n // self.emb_split)) for _ in sb]
-            got = self._sub[S] = (hs, he, sa, sb)
+            hs = [self.seg._create(S, max(1, -(-self.n // self.seg_split))) for _ in sa]
+            he = [self.emb._create(S, max(1, -(-self.n // self.emb_split))) for _ in sb]
+            got = self._sub[(S, lane)] = (hs, he, sa, sb)
         return got
 
     def __del__(self):
         try:
             for hs, he, _, _ in self._sub.values():
-                if self.seg_split > 1:
-                    for h in hs:
-                        self.seg._destroy(h)
-                if self.emb_split > 1:
-                    for h in he:
-                        self.emb._destroy(h)
+                for h in hs:
+                    self.seg._destroy(h)
+                for h in he:
+                    self.emb._destroy(h)
         except Exception:
             pass
 
@@ -209,7 +215,8 @@ class StreamBatch:
         """Enqueue the GPU work for one step.  ``waves``: (N, S) or (N, 1, S) float32 on the GPU
         (a strided rolling-window view is used in place) or an ``AudioRing`` holding a complete
         window.  ``starts``: start time in seconds of each
-        stream's window (default: step index x ``step``), used by the output tail only.
+        stream's window (default: the number of windows that stream slot has seen since its last
+        ``reset`` x ``step``), used by the output tail only.
         ``slots``: which of the ``num_streams`` clustering / tail states the rows belong to, for a
         step in which only some streams have a new window (``len(slots)`` rows; default: all, in
         order).  Returns a ticket for ``finish``."""
@@ -229,22 +236,23 @@ class StreamBatch:
             assert N == len(slots) and 1 <= N <= self.n and len(set(slots)) == N, "bad slots"
             assert all(0 <= i < self.n for i in slots), "slot out of range"
         F, K, D = self.seg.num_frames(S), None, self.emb.dimension
-        hsegs, hembs, _, _ = self._handles(S)
+        lane = self.lanes[self._t % self.depth]
+        hsegs, hembs, _, _ = self._handles(S, self._t % self.depth)
         # sub-batch ranges of THIS step's rows (each at most the capacity its handle was built for)
         sa, sb = self._ranges(N, self.seg_split), self._ranges(N, self.emb_split)
         K = self.seg.num_speakers
         if not any(s["shape"] == (F, K, D) for s in self._slots):
-            # both in-flight slots up front: a pinned-memory allocation made while kernels are
+            # every in-flight slot up front: a pinned-memory allocation made while kernels are
             # running stalls the queues for tens of milliseconds (seen as one 40 ms "kernel" in the
             # rocprofv3 trace of the second step)
-            self._new_slot(F, K, D)
-            self._new_slot(F, K, D)
+            for _ in range(self.depth + 1):
+                self._new_slot(F, K, D)
         slot = self._slot(F, K, D)
         slot["busy"] = True
         lib, esz = self._lib, 4
         cur = torch.cuda.current_stream(self.device)
         slot["ev_in"].record(cur)                       # inputs produced on the caller's stream
-        for (i0, i1), h, a, ev in zip(sa, hsegs, self.streams_a, slot["ev_seg"]):
+        for (i0, i1), h, a, ev in zip(sa, hsegs, lane["a"], slot["ev_seg"]):
             a.wait_event(slot["ev_in"])
             if i1 == i0:                                 # fewer rows than sub-batches
                 ev.record(a)
@@ -255,7 +263,7 @@ class StreamBatch:
                                   self.beta, int(self.norm_w), 1, slot["w"][i0:i1].data_ptr(),
                                   a.cuda_stream), "dz_osp")
             ev.record(a)
-        for (i0, i1), h, b in zip(sb, hembs, self.streams_b):
+        for (i0, i1), h, b in zip(sb, hembs, lane["b"]):
             b.wait_event(slot["ev_in"])
             if i1 == i0:
                 continue
@@ -266,8 +274,8 @@ class StreamBatch:
                     b.wait_event(ev)
             _lib.check(lib.dz_emb_pool(h, slot["w"][i0:i1].data_ptr(), i1 - i0, K, F, 1,
                                        slot["emb"][i0:i1].data_ptr(), b.cuda_stream), "dz_emb_pool")
-        b0 = self.streams_b[0]
-        for b, ev in zip(self.streams_b[1:], slot["ev_emb"]):
+        b0 = lane["b"][0]
+        for b, ev in zip(lane["b"][1:], slot["ev_emb"]):
             ev.record(b)
             b0.wait_event(ev)
         with torch.cuda.stream(b0):
@@ -278,14 +286,18 @@ class StreamBatch:
         slot["keep"] = rows                              # keep the view alive until the GPU is done
         if ring is not None:
             ring._read_by(slot["done"])                  # pushes `slack` steps from now wait for this
-        slot["starts"] = self._t * self.step if starts is None else starts
+        idx = np.arange(self.n) if slots is None else np.asarray(slots, dtype=np.int64)
+        slot["starts"] = self._steps[idx] * self.step if starts is None else starts
+        self._steps[idx] += 1
         self._t += 1
         return slot
 
     # ------------------------------------------------------------------ host half
     def finish(self, ticket: dict, want_scores: bool = True) -> Tuple[np.ndarray, np.ndarray, np.ndarray, np.ndarray]:
         """Wait for the step's GPU work, run the N clustering updates.
-        -> (segmentation (N,F,K) f32, embeddings (N,K,D) f32, scores (N,F,G) f64 | None, assign (N,K))."""
+        -> (segmentation (N,F,K) f32, embeddings (N,K,D) f32, scores (N,F,G) f64 | None, assign (N,K)).
+        The arrays (and ``ticket["tail"]``) are views of buffers that a later ``launch`` / ``finish``
+        reuses: copy what has to outlive the next step."""
         ticket["done"].synchronize()
         N, slots = ticket["rows"], ticket["slots"]
         seg = ticket["seg_h"].numpy()[:N]

@@ -53,9 +53,12 @@ class StreamServer:
         self.chunk_samples = int(round(sample_rate * duration))
         self.step_samples = int(round(sample_rate * step))
         self.max_streams, self.patch_collar = int(max_streams), patch_collar
-        self._lock = threading.Lock()
+        self._lock = threading.Lock()          # stream table, buffers, slot lists
+        self._step_lock = threading.Lock()     # serialises step(): one engine
         self._streams: Dict[Hashable, _Stream] = {}
         self._free = list(range(self.max_streams - 1, -1, -1))
+        self._inflight: set = set()            # slots whose window the worker is processing now
+        self._deferred: List[int] = []         # slots closed while in flight: freed after the step
         self._stop = False
         # `engine(windows (k, S) float32, starts (k,), slots [k]) -> list of k (turns (m, 3) array)`;
         # the default engine is a StreamBatch with the C++ output tail
@@ -78,6 +81,8 @@ class StreamServer:
                 raise ValueError(f"stream {stream_id!r} is already open")
             if not self._free:
                 raise RuntimeError(f"all {self.max_streams} stream slots are in use")
+            # a free slot is never in flight (close() defers the release of a slot the worker is
+            # still stepping), so resetting its clustering / aggregation state here is safe
             slot = self._free.pop()
             self._reset_slot(slot)
             self._streams[stream_id] = _Stream(slot)
@@ -88,7 +93,14 @@ class StreamServer:
         (``sinks.py:59-88``)."""
         with self._lock:
             st = self._streams.pop(stream_id)
-            self._free.append(st.slot)
+            if st.slot in self._inflight:
+                # the worker is inside step() with a window of this stream: its clustering / tail
+                # state is being read on host threads right now.  The slot is handed back (and may
+                # then be reset by the next open()) only when that step has finished; the step's
+                # result for this stream is discarded.
+                self._deferred.append(st.slot)
+            else:
+                self._free.append(st.slot)
         pred = st.prediction if st.prediction is not None else Annotation(str(stream_id), "speech")
         pred.uri = str(stream_id)
         return pred.support(self.patch_collar)
@@ -121,26 +133,37 @@ class StreamServer:
         """Process at most one pending window of every open stream, as ONE batch.  Returns the
         speech turns each of those streams gained (the per-chunk ``Annotation`` of the reference's
         pipeline); the running total is kept per stream until ``close``."""
-        with self._lock:
-            ready = [(sid, st) for sid, st in self._streams.items() if st.pending]
-            if not ready:
-                return {}
-            work = [(sid, st, *st.pending.pop(0)) for sid, st in ready]
-        windows = np.stack([w for _, _, w, _ in work])
-        starts = np.array([t for _, _, _, t in work], dtype=np.float64)
-        slots = [st.slot for _, st, _, _ in work]
-        turns = self._engine(windows, starts, slots)
-        out = {}
-        for (sid, st, _, _), tr in zip(work, turns):
-            ann = BatchedOutputTail.annotation(np.asarray(tr, dtype=np.float64).reshape(-1, 3), len(tr),
-                                               uri=str(sid))
-            st.emitted += 1
-            if st.prediction is None:
-                st.prediction = ann
-            else:
-                st.prediction.update(ann)
-            out[sid] = ann
-        return out
+        with self._step_lock:                       # one engine, one step at a time
+            with self._lock:
+                ready = [(sid, st) for sid, st in self._streams.items() if st.pending]
+                if not ready:
+                    return {}
+                work = [(sid, st, *st.pending.pop(0)) for sid, st in ready]
+                self._inflight = {st.slot for _, st, _, _ in work}
+            try:
+                windows = np.stack([w for _, _, w, _ in work])
+                starts = np.array([t for _, _, _, t in work], dtype=np.float64)
+                slots = [st.slot for _, st, _, _ in work]
+                turns = self._engine(windows, starts, slots)
+            finally:
+                with self._lock:
+                    self._inflight = set()
+                    self._free.extend(self._deferred)     # slots closed while they were in flight
+                    self._deferred = []
+            out = {}
+            with self._lock:
+                for (sid, st, _, _), tr in zip(work, turns):
+                    if self._streams.get(sid) is not st:      # closed (or re-opened) mid-step: drop
+                        continue
+                    ann = BatchedOutputTail.annotation(np.asarray(tr, dtype=np.float64).reshape(-1, 3),
+                                                       len(tr), uri=str(sid))
+                    st.emitted += 1
+                    if st.prediction is None:
+                        st.prediction = ann
+                    else:
+                        st.prediction.update(ann)
+                    out[sid] = ann
+            return out
 
     def drain(self) -> int:
         """``step`` until no window is pending; returns the number of steps."""

@@ -160,6 +160,51 @@ def synth_embedding_state(seed: int = 4321, dimension: int = 512) -> Dict[str, t
     return sd
 
 
+def _sincnet_spec(prefix: str = "sincnet."):
+    f32 = torch.float32
+    spec = [(prefix + "wav_norm1d.weight", (1,), f32), (prefix + "wav_norm1d.bias", (1,), f32),
+            (prefix + "conv1d.0.filterbank.low_hz_", (40, 1), f32),
+            (prefix + "conv1d.0.filterbank.band_hz_", (40, 1), f32),
+            (prefix + "conv1d.0.filterbank.window_", (125,), f32),
+            (prefix + "conv1d.0.filterbank.n_", (1, 125), f32)]
+    for i, (cin, cout) in ((1, (80, 60)), (2, (60, 60))):
+        spec += [(prefix + f"conv1d.{i}.weight", (cout, cin, 5), f32), (prefix + f"conv1d.{i}.bias", (cout,), f32)]
+    for i, c in enumerate((80, 60, 60)):
+        spec += [(prefix + f"norm1d.{i}.weight", (c,), f32), (prefix + f"norm1d.{i}.bias", (c,), f32)]
+    return spec
+
+
+def segmentation_spec(num_speakers: int = 3, powerset: bool = False):
+    """[(key, shape, dtype)] of a pyannote/segmentation state dict, from the architecture alone
+     — what every rank needs to know to receive the broadcast of the
+    weights (``distributed.broadcast_state``) without loading or synthesising them itself."""
+    f32, H = torch.float32, 128
+    spec = _sincnet_spec()
+    for layer in range(4):
+        cin = 60 if layer == 0 else 2 * H
+        for suf in ("", "_reverse"):
+            spec += [(f"lstm.weight_ih_l{layer}{suf}", (4 * H, cin), f32), (f"lstm.weight_hh_l{layer}{suf}", (4 * H, H), f32),
+                     (f"lstm.bias_ih_l{layer}{suf}", (4 * H,), f32), (f"lstm.bias_hh_l{layer}{suf}", (4 * H,), f32)]
+    out = 7 if powerset else num_speakers
+    spec += [("linear.0.weight", (128, 256), f32), ("linear.0.bias", (128,), f32),
+             ("linear.1.weight", (128, 128), f32), ("linear.1.bias", (128,), f32),
+             ("classifier.weight", (out, 128), f32), ("classifier.bias", (out,), f32)]
+    return spec
+
+
+def embedding_spec(dimension: int = 512):
+    """[(key, shape, dtype)] of a pyannote/embedding (XVectorSincNet) state dict (Appendix A.2)."""
+    f32 = torch.float32
+    spec = _sincnet_spec()
+    for i, (cin, cout, k) in enumerate([(60, 512, 5), (512, 512, 3), (512, 512, 3), (512, 512, 1), (512, 1500, 1)]):
+        spec += [(f"tdnns.{3 * i}.weight", (cout, cin, k), f32), (f"tdnns.{3 * i}.bias", (cout,), f32),
+                 (f"tdnns.{3 * i + 2}.weight", (cout,), f32), (f"tdnns.{3 * i + 2}.bias", (cout,), f32),
+                 (f"tdnns.{3 * i + 2}.running_mean", (cout,), f32), (f"tdnns.{3 * i + 2}.running_var", (cout,), f32),
+                 (f"tdnns.{3 * i + 2}.num_batches_tracked", (), torch.int64)]
+    spec += [("embedding.weight", (dimension, 3000), f32), ("embedding.bias", (dimension,), f32)]
+    return spec
+
+
 def synth_ecapa_state(seed: int = 777, channels: int = 1024, lin_neurons: int = 192) -> Dict[str, torch.Tensor]:
     """Random-init weights of speechbrain's ECAPA-TDNN (spkrec-ecapa-voxceleb geometry), keyed like
     its checkpoint (``blocks.0.conv.conv.weight``, ``blocks.1.res2net_block.blocks.0.norm.norm.

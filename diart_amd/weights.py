@@ -86,6 +86,36 @@ def split_f16(w: torch.Tensor) -> torch.Tensor:
     return torch.stack([hi, lo]).view(torch.int16).contiguous()
 
 
+def lstm_whh_planes(whh: torch.Tensor, variant: int) -> torch.Tensor:
+    """W_hh ``[2 dir][512][128]`` (PyTorch row order gate*128 + unit) -> int16 ``[2 dir][2 planes][512][128]``
+    of f16 bit patterns for the matrix-core recurrence (``k_lstm_mfma.hip``).
+
+    variant 0: ``split_f16`` per direction (lo scaled by 2^11, two accumulators in the kernel).
+    variant 1 / 2: the activation scale of each gate row is folded in, ``W' = W * s * 2^SH`` with
+    ``s = -log2(e)`` (i, f, o) or ``-2 log2(e)`` (g) and ``SH = 0 / 8``; ``hi = f16(W')``,
+    ``lo = f16(W' - hi)`` UNSCALED, so that one accumulator holds ``hi.hi + hi.lo + lo.hi``."""
+    whh = whh.detach().float().cpu()
+    assert whh.shape == (2, 512, 128), whh.shape
+    if variant == 0:
+        return torch.stack([split_f16(whh[0]), split_f16(whh[1])]).contiguous()
+    sh = {1: 0, 2: 8}[variant]
+    log2e = 1.44269504088896341
+    scale = torch.full((4, 1, 1), -log2e, dtype=torch.float64)
+    scale[2] = -2.0 * log2e                                   # PyTorch gate order i, f, g, o
+    w = (whh.double().view(2, 4, 128, 128) * scale[None] * float(2 ** sh)).float().view(2, 512, 128)
+    hi = w.to(torch.float16)
+    lo = (w - hi.float()).to(torch.float16)
+    return torch.stack([hi, lo], dim=1).view(torch.int16).contiguous()
+
+
+def default_lstm_variant() -> int:
+    """``DZ_LSTM``: ``valu`` (-1: one chain per CU on the f32 vector units even in the f16x3
+    precision) or the matrix-core variant 0 / 1 / 2 (``lstm_whh_planes``)."""
+    import os
+    v = os.environ.get("DZ_LSTM", "0")
+    return -1 if v == "valu" else int(v)
+
+
 def _pad2(w: torch.Tensor, rows: int, cols: int) -> torch.Tensor:
     out = torch.zeros(rows, cols, dtype=torch.float32)
     out[: w.shape[0], : w.shape[1]] = w
@@ -162,18 +192,28 @@ class PackedSegmentation:
         g = lambda k: sd[k].detach().cpu().float()
         w = _lib.SegWeights()
         w.sinc = _pack_sincnet(sd, pk, split=split)
+        lstm_variant = default_lstm_variant()
         for layer in range(4):
-            wih = torch.cat([g(f"lstm.weight_ih_l{layer}"), g(f"lstm.weight_ih_l{layer}_reverse")], 0)
+            # rows of the stacked W_ih (and the bias) go unit-major, dir*512 + unit*4 + gate, so the
+            # x-projection GEMM writes the four gates of a unit next to each other and the recurrence
+            # reads them as one 16-byte word (PyTorch's order is dir*512 + gate*128 + unit)
+            um = lambda t: t.reshape(2, 4, 128, *t.shape[1:]).transpose(1, 2).reshape(t.shape).contiguous()
+            wih = um(torch.cat([g(f"lstm.weight_ih_l{layer}"), g(f"lstm.weight_ih_l{layer}_reverse")], 0))
             kpad = 64 if layer == 0 else 256
             w.wih[layer] = pk.put(_pad2(wih, 1024, kpad))
             if split:
                 w.wih_split[layer] = pk.put_split(_pad2(wih, 1024, kpad))
             bias = torch.cat([g(f"lstm.bias_ih_l{layer}") + g(f"lstm.bias_hh_l{layer}"),
                               g(f"lstm.bias_ih_l{layer}_reverse") + g(f"lstm.bias_hh_l{layer}_reverse")], 0)
-            w.bih[layer] = pk.put(bias)
+            w.bih[layer] = pk.put(um(bias))
             whh = torch.stack([g(f"lstm.weight_hh_l{layer}"), g(f"lstm.weight_hh_l{layer}_reverse")], 0)
             assert whh.shape == (2, 512, 128)
             w.whh[layer] = pk.put(whh)
+            if split and lstm_variant >= 0:   # [dir][plane][512][128] f16 for the matrix-core recurrence
+                d = lstm_whh_planes(whh, lstm_variant).to(pk.device)
+                pk.tensors.append(d)
+                w.whh_split[layer] = d.data_ptr()
+                w.lstm_variant = lstm_variant
         w.lin0_w, w.lin0_b = pk.put(g("linear.0.weight")), pk.put(g("linear.0.bias"))
         w.lin1_w, w.lin1_b = pk.put(g("linear.1.weight")), pk.put(g("linear.1.bias"))
         if split:

@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define DZ_VERSION 100
+#define DZ_VERSION 200
 
 typedef struct dz_ctx dz_ctx;
 typedef struct dz_seg dz_seg;
@@ -63,9 +63,10 @@ typedef struct {
 
 typedef struct {
     dz_sincnet_weights sinc;
-    const float* wih[4];         /* [1024][Kpad] rows = dir*512 + gate*128 + unit    */
-    const float* bih[4];         /* [1024]  b_ih + b_hh                              */
-    const float* whh[4];         /* [2][512][128]                                    */
+    const float* wih[4];         /* [1024][Kpad] rows = dir*512 + unit*4 + gate (unit-major: the
+                                    recurrence reads the four gates of a unit as one 16-byte word) */
+    const float* bih[4];         /* [1024]  b_ih + b_hh, same row order                */
+    const float* whh[4];         /* [2][512][128]  PyTorch row order (gate*128 + unit) */
     const float* lin0_w;         /* [128][256] */
     const float* lin0_b;         /* [128]      */
     const float* lin1_w;         /* [128][128] */
@@ -80,6 +81,12 @@ typedef struct {
     const void* wih_split[4];
     const void* lin0_split;
     const void* lin1_split;
+    /* W_hh as f16 planes [2 dir][2 (hi, lo*2^11)][512][128], PyTorch row order: the recurrence then
+     * runs 16 chains per workgroup on the matrix cores (k_lstm_mfma.hip); NULL = one chain per CU on
+     * the f32 vector units (k_lstm.hip, exact f32)                                               */
+    const void* whh_split[4];
+    int lstm_variant;            /* how whh_split was prepared (weights.py lstm_whh_planes): 0 = split_f16 of
+                                    W_hh; 1 / 2 = activation scales folded in, H scaled by 2^0 / 2^8 */
 } dz_seg_weights;
 
 typedef struct {
@@ -220,10 +227,21 @@ typedef struct {
     const float* rowbias; /* optional [B][Npad] per-batch-item bias added to `bias`   */
     const void* Wsplit;   /* split-f16 path: W as two f16 planes [2][Npad][Kpad], hi = f16(W),
                              lo = f16((W - hi) * 2^11) (weights.py split_f16); NULL on the f32 path   */
+    /* pre-split activations (k_gemm_pre.hip): the input as two f16 planes [Tin][ldx], hi at Xsplit,
+     * lo (scaled by 2^11) xplane ELEMENTS further; the output, when Ysplit is set, in the same form
+     * ([Tstore][ldy] f16, lo plane yplane elements further) so that the next layer reads plain
+     * bytes.  Y (f32) and Ysplit may both be set.                                               */
+    const void* Xsplit;
+    long long xplane;
+    void* Ysplit;
+    long long yplane;
 } dz_convgemm_desc;
 int dz_k_convgemm(dz_ctx* ctx, const dz_convgemm_desc* desc, void* stream);
 /* the same layer on the split-f16 matrix-core path (desc->Wsplit must be set)       */
 int dz_k_gemm_split(dz_ctx* ctx, const dz_convgemm_desc* desc, void* stream);
+/* ... with the activations pre-split as well (desc->Wsplit and desc->Xsplit set; B = 1, K = taps*Cin
+ * unpadded, Cin % 32 == 0): operand tiles go global -> LDS by LDS-DMA                            */
+int dz_k_gemm_pre(dz_ctx* ctx, const dz_convgemm_desc* desc, void* stream);
 int dz_k_convgemm_ntile(int t_out);
 /* d_stats (B, 2) = (mean, 1/sqrt(biased var + 1e-5)) of each window: InstanceNorm1d(1).  Inside
  * the forward passes the 8 slice moments stay separate and the consumer merges them; this entry
@@ -238,9 +256,19 @@ int dz_k_sinc_conv0(dz_ctx* ctx, const float* d_wave, long long stride, int batc
 int dz_k_finalize_norm(dz_ctx* ctx, const float* d_partials, int batch, int ntile, int channels,
                        int frames, const float* d_gamma, const float* d_beta, float* d_scale,
                        float* d_shift, void* stream);
-/* gx (B*T, 1024) = x-projection incl. biases, whh (2,512,128) -> hout (B,T,256)      */
+/* gx (B*T, 1024) = x-projection incl. biases (PyTorch column order dir*512 + gate*128 + unit),
+ * whh (2,512,128) -> hout (B,T,256)                                                  */
 int dz_k_lstm(dz_ctx* ctx, const float* d_gx, const float* d_whh, float* d_hout, int batch,
               int frames, void* stream);
+/* the same recurrence on the f16 matrix cores, 16 chains per workgroup; d_whh_split / variant as
+ * dz_seg_weights.whh_split / lstm_variant; unit_major != 0: gx columns are dir*512 + unit*4 + gate */
+int dz_k_lstm_mfma(dz_ctx* ctx, const float* d_gx, const void* d_whh_split, float* d_hout,
+                   int batch, int frames, int unit_major, int variant, void* stream);
+/* either recurrence kernel (d_whh_split NULL: the f32 vector kernel on d_whh) writing h as the two
+ * f16 planes (B,T,256) a dz_k_gemm_pre consumer reads: hi = f16(h) at d_hsplit, lo = f16((h - hi) *
+ * 2^11) hplane elements further; gx in PyTorch column order                                      */
+int dz_k_lstm_planes(dz_ctx* ctx, const float* d_gx, const float* d_whh, const void* d_whh_split,
+                     int variant, void* d_hsplit, long long hplane, int batch, int frames, void* stream);
 int dz_k_stats_pool(dz_ctx* ctx, const float* d_x, int frames, int channels, int ldx,
                     const float* d_weights, int weight_frames, int rows, int rows_per_x,
                     float* d_out, int ldo, void* stream);
@@ -277,7 +305,10 @@ int dz_clu_destroy(dz_clu* clu);
 int dz_prof_enable(int on);
 int dz_prof_pause(int paused);   /* suspend / resume bracketing, accumulators untouched */
 int dz_prof_collect(void);
-int dz_prof_get(int tag, const char** name, double* total_ms, long long* launches);
+/* chunks: total number of 5 s chunks the tag's bracketed launches processed (a launch of a
+ * 32-chunk sub-batch counts 32): the unit the per-launch algorithmic work is priced in */
+int dz_prof_get(int tag, const char** name, double* total_ms, long long* launches,
+                long long* chunks);
 
 /* ---- device-resident rolling window of N streams ------------------------------------------
  * Replaces rearrange_audio_stream (/root/reference/src/diart/operators.py:44-100) plus the

@@ -242,8 +242,13 @@ def test_convgemm_pool3(gpu, Cin, Tin, split):
 
 
 # --------------------------------------------------------------------------- #
-@pytest.mark.parametrize("B,T", [(1, 293), (3, 40), (17, 64)])
-def test_lstm_recurrence(gpu, B, T):
+@pytest.mark.parametrize("kernel", ["valu", "mfma0", "mfma0_um", "mfma1", "mfma1_um", "mfma2", "mfma2_um"])
+@pytest.mark.parametrize("B,T", [(1, 293), (3, 40), (17, 64), (32, 293)])
+def test_lstm_recurrence(gpu, B, T, kernel):
+    """k_lstm.hip (one chain per CU, exact f32) and k_lstm_mfma.hip (16 chains per workgroup on the
+    f16 matrix cores, split operands; both gx column orders) against torch.nn.LSTM on the CPU —
+    the SAME tolerance for both."""
+    from diart_amd.weights import lstm_whh_planes
     g = torch.Generator().manual_seed(B * 100 + T)
     H, I = 128, 32
     lstm = torch.nn.LSTM(I, H, 1, bidirectional=True, batch_first=True)
@@ -255,11 +260,21 @@ def test_lstm_recurrence(gpu, B, T):
         ref, _ = lstm(x)
         gx = torch.cat([x @ lstm.weight_ih_l0.t() + lstm.bias_ih_l0 + lstm.bias_hh_l0,
                         x @ lstm.weight_ih_l0_reverse.t() + lstm.bias_ih_l0_reverse + lstm.bias_hh_l0_reverse],
-                       dim=-1)  # (B,T,1024)
+                       dim=-1)  # (B,T,1024), PyTorch column order dir*512 + gate*128 + unit
         whh = torch.stack([lstm.weight_hh_l0, lstm.weight_hh_l0_reverse]).contiguous()
-    dgx, dw = gx.contiguous().to(gpu), whh.to(gpu)
     hout = torch.full((B, T, 256), float("nan"), device=gpu)
-    _lib.check(_lib.load().dz_k_lstm(_ctx(gpu), dgx.data_ptr(), dw.data_ptr(), hout.data_ptr(), B, T, None))
+    lib = _lib.load()
+    if kernel == "valu":
+        dgx, dw = gx.contiguous().to(gpu), whh.to(gpu)
+        _lib.check(lib.dz_k_lstm(_ctx(gpu), dgx.data_ptr(), dw.data_ptr(), hout.data_ptr(), B, T, None))
+    else:
+        um, variant = kernel.endswith("_um"), int(kernel[4])
+        if um:   # dir*512 + unit*4 + gate
+            gx = gx.view(B, T, 2, 4, 128).transpose(3, 4).reshape(B, T, 1024)
+        dgx = gx.contiguous().to(gpu)
+        dw = lstm_whh_planes(whh, variant).to(gpu)
+        _lib.check(lib.dz_k_lstm_mfma(_ctx(gpu), dgx.data_ptr(), dw.data_ptr(), hout.data_ptr(), B, T,
+                                      int(um), variant, None))
     _sync()
     got = hout.cpu()
     assert not torch.isnan(got).any()
@@ -347,3 +362,173 @@ def test_powerset(gpu):
     _lib.check(_lib.load().dz_k_powerset(_ctx(gpu), d.data_ptr(), 1000, 7, 3, out.data_ptr(), None))
     _sync()
     assert torch.equal(out.cpu(), powerset_to_multilabel(lp))
+
+
+# --------------------------------------------------------------------------- #
+# pre-split path: activations travel as two f16 planes (hi, lo * 2^11)
+# --------------------------------------------------------------------------- #
+def _planes(x):
+    """f32 (rows, cols) -> int16 (2, rows, cols) of f16 bit patterns, like weights.split_f16."""
+    from diart_amd.weights import split_f16
+    return split_f16(x)
+
+
+def _unplanes(p):
+    h = p.view(torch.float16).double()
+    return h[0] + h[1] / 2048.0
+
+
+@pytest.mark.parametrize("M,Cin,taps,dil,N,Nstore,epi,outs", [
+    (300, 512, 3, 2, 512, 512, "tdnn", "planes"),
+    (1000, 256, 1, 1, 1024, 1024, "bias", "f32"),
+    (130, 128, 1, 1, 128, 128, "leaky", "both"),
+    (700, 512, 3, 3, 1536, 1500, "tdnn", "both"),
+    (64 * 293, 512, 1, 1, 512, 512, "tdnn", "planes"),
+    (5, 256, 1, 1, 128, 128, "leaky", "f32"),
+])
+def test_gemm_pre(gpu, M, Cin, taps, dil, N, Nstore, epi, outs):
+    """k_gemm_pre.hip (both operands as f16 hi/lo planes, tiles by LDS-DMA) against an f64 torch
+    restatement: implicit-GEMM convolution over the flattened rows, every epilogue, f32 and / or
+    plane output (whose hi + lo * 2^-11 must reproduce the f32 result to 2^-21), zeroed padding
+    columns, ragged last tile."""
+    g = torch.Generator().manual_seed(M + Cin + N)
+    K = taps * Cin
+    Tout = M - (taps - 1) * dil
+    X = torch.randn(M, Cin, generator=g) * 1.5
+    W = torch.zeros(N, K)
+    W[:Nstore] = torch.randn(Nstore, K, generator=g) / math.sqrt(K)
+    bias = torch.zeros(N)
+    bias[:Nstore] = torch.randn(Nstore, generator=g) * 0.2
+    e0, e1 = torch.rand(N, generator=g) + 0.5, torch.randn(N, generator=g) * 0.1
+    code = {"bias": _lib.EPI_BIAS, "leaky": _lib.EPI_BIAS_LEAKY, "tdnn": _lib.EPI_TDNN}[epi]
+    dX, dW = _planes(X).to(gpu), _planes(W).to(gpu)
+    db, de0, de1 = bias.to(gpu), e0.to(gpu), e1.to(gpu)
+    Y = torch.full((M, N), float("nan"), device=gpu) if outs in ("f32", "both") else None
+    Yp = torch.full((2, M, N), 0x7e00, dtype=torch.int16, device=gpu) if outs in ("planes", "both") else None
+    d = _lib.ConvGemmDesc()
+    d.Xsplit, d.xplane, d.Wsplit = dX.data_ptr(), M * Cin, dW.data_ptr()
+    d.bias, d.e0, d.e1 = db.data_ptr(), de0.data_ptr(), de1.data_ptr()
+    if Y is not None:
+        d.Y = Y.data_ptr()
+    if Yp is not None:
+        d.Ysplit, d.yplane = Yp.data_ptr(), M * N
+    d.B, d.Tin, d.Tout, d.Tstore, d.Cin, d.taps, d.dil = 1, M, Tout, Tout, Cin, taps, dil
+    d.K, d.Kpad, d.Npad, d.Nstore, d.ldx, d.ldy, d.epi = K, K, N, Nstore, Cin, N, code
+    _lib.check(_lib.load().dz_k_gemm_pre(_ctx(gpu), C.byref(d), None), "dz_k_gemm_pre")
+    _sync()
+    # reference on the operands the kernel saw (22-bit planes), f64
+    Xq, Wq = _unplanes(_planes(X)), _unplanes(_planes(W))
+    cols = torch.cat([Xq[j * dil: j * dil + Tout] for j in range(taps)], dim=1)   # (Tout, taps*Cin)
+    ref = cols @ Wq.t() + bias.double()
+    if epi == "leaky":
+        ref = F.leaky_relu(ref, 0.01)
+    if epi == "tdnn":
+        ref = F.leaky_relu(ref, 0.01) * e0.double() + e1.double()
+    scale = max(1.0, ref.abs().max().item())
+    if Y is not None:
+        got = Y.cpu()[:Tout, :Nstore].double()
+        assert not torch.isnan(got).any()
+        assert (got - ref[:, :Nstore]).abs().max().item() < 4e-6 * scale
+    if Yp is not None:
+        P = Yp.cpu()
+        got = _unplanes(P)[:Tout]
+        assert (got[:, :Nstore] - ref[:, :Nstore]).abs().max().item() < 4e-6 * scale
+        assert (P[:, :Tout, Nstore:] == 0).all()                          # padding columns are zeros
+        if Tout < M:
+            assert (P[:, Tout:] == 0x7e00).all()                          # rows >= Tout untouched
+        if Y is not None:   # the planes are the split of exactly the f32 output
+            assert (got[:, :Nstore] - Y.cpu()[:Tout, :Nstore].double()).abs().max().item() < 2.0 ** -21 * scale
+
+
+def test_gemm_split_plane_output(gpu):
+    """k_gemm_split.hip (f32 input, norm-on-load, per-chunk batches: the tdnn1 call) writing its
+    output as f16 planes for a k_gemm_pre.hip consumer."""
+    g = torch.Generator().manual_seed(3)
+    B, T, Cin, N, taps = 3, 293, 64, 512, 5
+    Tout = T - 4
+    X = torch.randn(B, T, Cin, generator=g)
+    W = torch.randn(N, taps * Cin, generator=g) / math.sqrt(taps * Cin)
+    bias, e0, e1 = torch.randn(N, generator=g) * 0.1, torch.rand(N, generator=g) + 0.5, torch.randn(N, generator=g) * 0.1
+    sc, sh = torch.rand(B, Cin, generator=g) + 0.5, torch.randn(B, Cin, generator=g) * 0.2
+    keep = [t.to(gpu) for t in (X, W, _planes(W), bias, e0, e1, sc, sh)]
+    Yp = torch.zeros((2, B, T, N), dtype=torch.int16, device=gpu)
+    Yf = torch.zeros((B, T, N), device=gpu)
+    lib = _lib.load()
+    for planes in (False, True):
+        d = _lib.ConvGemmDesc()
+        d.X, d.W, d.Wsplit, d.bias, d.e0, d.e1, d.nscale, d.nshift = [t.data_ptr() for t in keep]
+        if planes:
+            d.Ysplit, d.yplane = Yp.data_ptr(), B * T * N
+        else:
+            d.Y = Yf.data_ptr()
+        d.B, d.Tin, d.Tout, d.Tstore, d.Cin, d.taps, d.dil = B, T, Tout, Tout, Cin, taps, 1
+        d.K, d.Kpad, d.Npad, d.Nstore, d.ldx, d.ldy, d.nld = taps * Cin, taps * Cin, N, N, Cin, N, Cin
+        d.xbs, d.ybs, d.norm_on_load, d.epi = T * Cin, T * N, 1, _lib.EPI_TDNN
+        _lib.check(lib.dz_k_gemm_split(_ctx(gpu), C.byref(d), None), "dz_k_gemm_split")
+    _sync()
+    want = Yf.cpu()[:, :Tout].double()
+    got = _unplanes(Yp.cpu().view(2, B * T, N)).view(B, T, N)[:, :Tout]
+    assert want.abs().max() > 0.5
+    assert (got - want).abs().max().item() < 2.0 ** -21 * want.abs().max().item()
+
+
+@pytest.mark.parametrize("kernel", ["valu", "mfma0", "mfma1"])
+def test_lstm_plane_output(gpu, kernel):
+    """Both recurrence kernels writing h as f16 (hi, lo) planes == their f32 output split."""
+    from diart_amd.weights import lstm_whh_planes
+    g = torch.Generator().manual_seed(11)
+    B, T = 19, 50
+    gx = (torch.randn(B, T, 1024, generator=g) * 0.8).to(gpu)
+    whh = (torch.rand(2, 512, 128, generator=g) * 2 - 1) * 0.2
+    lib = _lib.load()
+    hf = torch.zeros(B, T, 256, device=gpu)
+    hp = torch.zeros((2, B, T, 256), dtype=torch.int16, device=gpu)
+    if kernel == "valu":
+        dw = whh.to(gpu)
+        _lib.check(lib.dz_k_lstm(_ctx(gpu), gx.data_ptr(), dw.data_ptr(), hf.data_ptr(), B, T, None))
+        _lib.check(lib.dz_k_lstm_planes(_ctx(gpu), gx.data_ptr(), dw.data_ptr(), None, 0, hp.data_ptr(),
+                                        B * T * 256, B, T, None))
+    else:
+        v = int(kernel[4])
+        dw = lstm_whh_planes(whh, v).to(gpu)
+        _lib.check(lib.dz_k_lstm_mfma(_ctx(gpu), gx.data_ptr(), dw.data_ptr(), hf.data_ptr(), B, T, 0, v, None))
+        _lib.check(lib.dz_k_lstm_planes(_ctx(gpu), gx.data_ptr(), None, dw.data_ptr(), v, hp.data_ptr(),
+                                        B * T * 256, B, T, None))
+    _sync()
+    want = hf.cpu().double()
+    got = _unplanes(hp.cpu().view(2, B * T, 256)).view(B, T, 256)
+    assert want.abs().max() > 0.3
+    assert (got - want).abs().max().item() < 2.0 ** -21
+
+
+@pytest.mark.parametrize("kernel", ["split", "pre"])
+def test_split_gemm_dynamic_range(gpu, kernel):
+    """The split-f16 arithmetic on inputs an f32 reference handles without thinking: magnitudes from
+    1e-7 to 1e4 mixed inside one K row (both kernels keep f32-grade accuracy relative to
+    sum |x w|: the scaled low part stays a normal f16 down to |x| = 2^-14 and below that the
+    absolute error is < 2^-36)."""
+    g = torch.Generator().manual_seed(5)
+    M, K, N = 256, 256, 128
+    mags = torch.tensor([1e-7, 1e-5, 1e-3, 1.0, 30.0, 1e4])
+    X = torch.randn(M, K, generator=g) * mags[torch.randint(0, len(mags), (M, K), generator=g)]
+    W = torch.randn(N, K, generator=g) / math.sqrt(K)
+    bias = torch.zeros(N)
+    Y = torch.full((M, N), float("nan"), device=gpu)
+    dW, db = _planes(W).to(gpu), bias.to(gpu)
+    d = _lib.ConvGemmDesc()
+    d.Wsplit, d.bias, d.Y = dW.data_ptr(), db.data_ptr(), Y.data_ptr()
+    d.B, d.Tin, d.Tout, d.Tstore, d.Cin, d.taps, d.dil = 1, M, M, M, K, 1, 1
+    d.K, d.Kpad, d.Npad, d.Nstore, d.ldx, d.ldy, d.epi = K, K, N, N, K, N, _lib.EPI_BIAS
+    if kernel == "pre":
+        dX = _planes(X).to(gpu)
+        d.Xsplit, d.xplane = dX.data_ptr(), M * K
+        _lib.check(_lib.load().dz_k_gemm_pre(_ctx(gpu), C.byref(d), None))
+    else:
+        dX, dWf = X.to(gpu), W.to(gpu)
+        d.X, d.W = dX.data_ptr(), dWf.data_ptr()
+        _lib.check(_lib.load().dz_k_gemm_split(_ctx(gpu), C.byref(d), None))
+    _sync()
+    ref = X.double() @ W.double().t()
+    denom = (X.double().abs() @ W.double().abs().t())
+    err = ((Y.cpu().double() - ref).abs() / denom).max().item()
+    assert err < 1e-6, err        # an f32 GEMM of this depth lands at 1e-7 .. 3e-7 by the same measure

@@ -118,3 +118,36 @@ def test_push_is_thread_safe():
         assert [t for t, _ in seq] == [0.5 * i for i in range(7)]     # every window, in order
         first = [v for _, v in seq]
         assert np.allclose(np.diff(first), 8000 / 1e6, atol=1e-9)     # each window starts 8000 samples later
+
+
+def test_close_during_a_step_defers_the_slot_and_drops_the_result():
+    """close() while the worker is inside step() must not hand the slot to the next
+    open() (whose reset would clear clustering / tail state that host threads are still reading);
+    the in-flight result of the closed stream is discarded."""
+    gate_in, gate_out = threading.Event(), threading.Event()
+
+    class Slow(Recorder):
+        def __call__(self, windows, starts, slots):
+            gate_in.set()
+            assert gate_out.wait(10)
+            return super().__call__(windows, starts, slots)
+
+    rec = Slow()
+    srv = StreamServer(None, None, max_streams=2, engine=rec)
+    srv.open("a")
+    srv.open("b")
+    srv.push("a", ramp(80000))
+    srv.push("b", ramp(80000))
+    result = {}
+    worker = threading.Thread(target=lambda: result.update(srv.step()))
+    worker.start()
+    assert gate_in.wait(10)                     # the engine is now working on slots 0 and 1
+    srv.close("a")                              # slot 0 is in flight: must not become free yet
+    with pytest.raises(RuntimeError):
+        srv.open("c")                           # ... so there is no slot for a newcomer
+    assert rec.resets == [0, 1]                 # and nothing was reset under the worker
+    gate_out.set()
+    worker.join(timeout=10)
+    assert set(result) == {"b"}                 # a's window was processed but its result dropped
+    srv.open("c")                               # the deferred slot is free now
+    assert rec.resets == [0, 1, 0]

@@ -96,6 +96,34 @@ def convgemm(name, Bn, Tin, Cin, N, taps, dil, epi, Npad=None, pro=False, pool=F
         mx = ((Y - y32).abs().max() / y32.abs().max()).item()
         results[name + "_split"]["rel_l2_vs_f32"] = err
         print(f"    {name}_split vs f32 kernel: rel L2 {err:.2e}, max|d|/max|y| {mx:.2e}", flush=True)
+    if not ksplit and not pro and not pool and Cin % 32 == 0 and Npad % 128 == 0 and (not only or name + "_pre" in only or name in only):
+        # k_gemm_pre.hip: flattened rows, both operands as f16 planes, f32 and plane output
+        from diart_amd.weights import split_f16
+        M = Bn * Tin
+        xs = split_f16(X.reshape(M, Cin).cpu()).to(dev)
+        ws = split_f16(W.cpu()).to(dev)
+        Yf = torch.zeros(M, Npad, device=dev)
+        Yp = torch.zeros(2, M, Npad, dtype=torch.int16, device=dev)
+        d2 = _lib.ConvGemmDesc()
+        d2.Xsplit, d2.xplane, d2.Wsplit, d2.bias, d2.e0, d2.e1 = xs.data_ptr(), M * Cin, ws.data_ptr(), bias.data_ptr(), e0.data_ptr(), bias.data_ptr()
+        d2.B, d2.Tin, d2.Tout, d2.Tstore, d2.Cin, d2.taps, d2.dil = 1, M, M - (taps - 1) * dil, M - (taps - 1) * dil, Cin, taps, dil
+        d2.K, d2.Kpad, d2.Npad, d2.Nstore, d2.ldx, d2.ldy, d2.epi = K, K, Npad, Npad, Cin, Npad, epi
+        d2.agroup = args.agroup
+        only_saved = set(only)
+        only.clear()
+        d2.Y = Yf.data_ptr()
+        timeit(name + "_pre_f32out", lambda: _lib.check(lib.dz_k_gemm_pre(ctx, C.byref(d2), st), name), flop=flop)
+        d2.Y, d2.Ysplit, d2.yplane = None, Yp.data_ptr(), M * Npad
+        timeit(name + "_pre", lambda: _lib.check(lib.dz_k_gemm_pre(ctx, C.byref(d2), st), name), flop=flop)
+        only.update(only_saved)
+        torch.cuda.synchronize()
+        # compare the rows every chunk computes validly with the f32 kernel's result
+        y32 = Y.reshape(Bn, Tstore, Npad)
+        got = Yf.reshape(Bn, Tin, Npad)[:, :Tstore]
+        err = ((got - y32).norm() / y32.norm()).item()
+        results[name + "_pre"]["rel_l2_vs_f32"] = err
+        print(f"    {name}_pre vs f32 kernel: rel L2 {err:.2e}", flush=True)
+        keep += [xs, ws, Yf, Yp]
     return keep
 
 
@@ -106,6 +134,18 @@ whh = torch.randn(2, 512, 128, device=dev) * 0.1
 hout = torch.empty(B, F, 256, device=dev)
 timeit("lstm", lambda: _lib.check(lib.dz_k_lstm(ctx, gx.data_ptr(), whh.data_ptr(), hout.data_ptr(), B, F, st)),
        flop=2.0 * B * F * 2 * 512 * 128)
+from diart_amd.weights import lstm_whh_planes  # noqa: E402
+hout2 = torch.empty(B, F, 256, device=dev)
+for variant in (0, 1, 2):
+    whs = lstm_whh_planes(whh.cpu(), variant).to(dev)
+    nm = f"lstm_mfma{variant}"
+    timeit(nm, lambda: _lib.check(lib.dz_k_lstm_mfma(ctx, gx.data_ptr(), whs.data_ptr(), hout2.data_ptr(), B, F, 0, variant, st)),
+           flop=2.0 * B * F * 2 * 512 * 128)
+    if "lstm" in results and nm in results:
+        torch.cuda.synchronize()
+        d = (hout2 - hout).abs().max().item()
+        results[nm]["max_abs_vs_valu"] = d
+        print(f"    {nm} vs lstm (f32 VALU): max|d| {d:.2e}", flush=True)
 # ---- sinc conv0 -----------------------------------------------------------------------------
 wave = torch.randn(B, 80000, device=dev) * 0.1
 stats = torch.zeros(B, 2, device=dev)
