@@ -32,6 +32,8 @@ import json
 import os
 import sys
 import time
+
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")   # before the HIP runtime starts (diart_amd/__init__.py)
 from pathlib import Path
 
 import numpy as np
@@ -80,7 +82,7 @@ def device_kernel(tag, precision):
     DEVICE kernel, so the layers that share one instantiation are one entry."""
     split = precision == "f16x3"
     pre = split and os.environ.get("DZ_GEMM_PRE", "1") != "0"     # wide layers on k_gemm_pre.hip
-    lstm = os.environ.get("DZ_LSTM", "0")                          # weights.default_lstm_variant
+    lstm = os.environ.get("DZ_LSTM", "valu")                          # weights.default_lstm_variant
     k = KERNELS[tag]
     if k["bound"] == "hbm":
         return {"wave_stats": "wave_stats_kernel", "stats_pool": "stats_pool_kernel<3>"}[tag], "hbm", PEAK_HBM_GBPS, "GB/s"
@@ -89,6 +91,8 @@ def device_kernel(tag, precision):
             sym = "lstm_mfma_kernel<true>" if lstm == "0" else "lstm_mfma1_kernel<true, %d>" % (0 if lstm == "1" else 8)
             return sym, "mfma", PEAK_F16_MATRIX_TFLOPS / SPLIT_PRODUCTS, "TFLOP/s"
         return "lstm_rec_kernel<true>", "valu", PEAK_F32_VECTOR_TFLOPS, "TFLOP/s"
+    if tag == "sinc_conv0" and split and os.environ.get("DZ_CONV0_SPLIT", "1") != "0":
+        return "sinc_conv0_h_kernel", "mfma", PEAK_F16_MATRIX_TFLOPS / SPLIT_PRODUCTS, "TFLOP/s"
     if k["bound"] == "mfma_f32" or not split:
         sym = {"sinc_conv0": "sinc_conv0_kernel", "conv1_pool": "convgemm_kernel<64, true, 4>",
                "conv2_pool": "convgemm_kernel<64, true, 4>", "lstm_proj": "convgemm_kernel<128, false, 0>",
@@ -393,11 +397,14 @@ def main():
         for i in range(S // hop - 1):
             ring.push(pinned[i])
 
+        feed = torch.cuda.Stream(device)     # uploads + the launch's input event: off the default stream
+
         def run_ring(first, count):
             inflight = []
             for t in range(first, first + count):
-                ring.push(pinned[S // hop - 1 + t])
-                inflight.append(pipe.launch(ring))
+                with torch.cuda.stream(feed):
+                    ring.push(pinned[S // hop - 1 + t])
+                    inflight.append(pipe.launch(ring))
                 if len(inflight) > pipe.depth:
                     pipe.finish(inflight.pop(0), want_scores=True)
             while inflight:

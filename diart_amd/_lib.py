@@ -22,7 +22,7 @@ vp = C.c_void_p
 class SincNetWeights(C.Structure):
     _fields_ = [("wav_gamma", C.c_float), ("wav_beta", C.c_float)] + [
         (n, vp) for n in ("filt", "in0_g", "in0_b", "w1", "b1", "in1_g", "in1_b",
-                          "w2", "b2", "in2_g", "in2_b", "w1_split", "w2_split")]
+                          "w2", "b2", "in2_g", "in2_b", "w1_split", "w2_split", "filt_split")]
 
 
 class SegWeights(C.Structure):
@@ -118,6 +118,9 @@ SIGNATURES = {
     "dz_k_wave_stats": (C.c_int, [vp, vp, C.c_longlong, C.c_int, C.c_int, vp, vp]),
     "dz_k_sinc_conv0": (C.c_int, [vp, vp, C.c_longlong, C.c_int, C.c_int, vp, C.c_float,
                                   C.c_float, vp, vp, vp, vp]),
+    "dz_k_sinc_conv0_split": (C.c_int, [vp, vp, C.c_longlong, C.c_int, C.c_int, vp, C.c_float,
+                                        C.c_float, vp, vp, vp, vp]),
+    "dz_k_conv0_split_ntile": (C.c_int, [C.c_int]),
     "dz_k_finalize_norm": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp]),
     "dz_k_lstm": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, vp]),
     "dz_k_lstm_mfma": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp]),

@@ -168,7 +168,7 @@ struct SincGeom {
     int nt0, nt1, nt2;              // tiles carrying instance-norm partials
     bool ok;
 };
-static SincGeom sinc_geom(int S) {
+static SincGeom sinc_geom(int S, bool conv0_split = false) {
     SincGeom g;
     memset(&g, 0, sizeof(g));
     g.S = S;
@@ -179,7 +179,7 @@ static SincGeom sinc_geom(int S) {
     g.P1 = g.T1 > 0 ? g.T1 / 3 : 0;
     g.T2 = g.P1 - 4;
     g.P2 = g.T2 > 0 ? g.T2 / 3 : 0;
-    g.nt0 = (g.F0 + 191) / 192;
+    g.nt0 = conv0_split ? dz_conv0_split_ntile(g.F0) : (g.F0 + 191) / 192;
     g.nt1 = g.T1 > 0 ? dz_convgemm_ntile(g.T1) : 0;
     g.nt2 = g.T2 > 0 ? dz_convgemm_ntile(g.T2) : 0;
     g.ok = g.P2 > 0;
@@ -233,9 +233,12 @@ static int run_sincnet(const dz_sincnet_weights& w, const SincGeom& g, const Sin
     int rc;
     { ProfScope ps(T_WAVE, B); if ((rc = dz_launch_wave_stats(wave, stride, B, g.S, s.stats, st))) return rc; }
     { ProfScope ps(T_CONV0, B);
-    if ((rc = dz_launch_sinc_conv0(wave, stride, B, g.S, s.stats, 1, w.wav_gamma, w.wav_beta, w.filt,
-                                   s.y0, g.P0, s.part0, g.nt0, st)))
-        return rc; }
+    rc = w.filt_split
+             ? dz_launch_sinc_conv0_split(wave, stride, B, g.S, s.stats, 1, w.wav_gamma, w.wav_beta,
+                                          w.filt_split, s.y0, g.P0, s.part0, g.nt0, st)
+             : dz_launch_sinc_conv0(wave, stride, B, g.S, s.stats, 1, w.wav_gamma, w.wav_beta, w.filt,
+                                    s.y0, g.P0, s.part0, g.nt0, st);
+    if (rc) return rc; }
     { ProfScope ps(T_FIN, B);
     if ((rc = dz_launch_finalize_norm(s.part0, B, g.nt0, 80, g.P0, w.in0_g, w.in0_b, s.sc0, s.sh0,
                                       st)))
@@ -303,7 +306,7 @@ extern "C" int dz_seg_create(dz_ctx* ctx, const dz_seg_weights* w, int max_batch
                              dz_seg** out) {
     DZ_REQUIRE(ctx && w && out, "dz_seg_create: NULL argument");
     DZ_REQUIRE(max_batch >= 1, "dz_seg_create: max_batch %d", max_batch);
-    const SincGeom g = sinc_geom(num_samples);
+    const SincGeom g = sinc_geom(num_samples, w->sinc.filt_split != nullptr);
     DZ_REQUIRE(g.ok, "dz_seg_create: %d samples is too short for SincNet", num_samples);
     DZ_REQUIRE(w->num_classes >= 1 && w->num_classes <= 8, "dz_seg_create: num_classes %d",
                w->num_classes);
@@ -466,7 +469,7 @@ extern "C" int dz_emb_create(dz_ctx* ctx, const dz_emb_weights* w, int max_batch
     DZ_REQUIRE(ctx && w && out, "dz_emb_create: NULL argument");
     DZ_REQUIRE(max_batch >= 1, "dz_emb_create: max_batch %d", max_batch);
     DZ_REQUIRE(w->dimension == 512, "dz_emb_create: dimension %d (only 512 is built)", w->dimension);
-    const SincGeom g = sinc_geom(num_samples);
+    const SincGeom g = sinc_geom(num_samples, w->sinc.filt_split != nullptr);
     DZ_REQUIRE(g.ok && g.P2 > 14, "dz_emb_create: %d samples is too short", num_samples);
     DZ_HIP(hipSetDevice(ctx->device));
     dz_emb* e = new (std::nothrow) dz_emb;
@@ -708,6 +711,20 @@ extern "C" int dz_k_sinc_conv0(dz_ctx* ctx, const float* d_wave, long long strid
     return dz_launch_sinc_conv0(d_wave, stride, batch, samples, d_stats, 0, gamma, beta, d_filt, d_y0,
                                 g.P0, d_partials, g.nt0, (hipStream_t)stream);
 }
+extern "C" int dz_k_sinc_conv0_split(dz_ctx* ctx, const float* d_wave, long long stride, int batch,
+                                     int samples, const float* d_stats, float gamma, float beta,
+                                     const void* d_filt_split, float* d_y0, float* d_partials,
+                                     void* stream) {
+    DZ_REQUIRE(ctx && d_stats && d_filt_split && d_y0 && d_partials, "dz_k_sinc_conv0_split: NULL argument");
+    int rc;
+    if ((rc = check_wave("dz_k_sinc_conv0_split", d_wave, stride, samples))) return rc;
+    const SincGeom g = sinc_geom(samples, true);
+    DZ_REQUIRE(g.P0 > 0, "dz_k_sinc_conv0_split: %d samples is too short", samples);
+    DZ_HIP(hipSetDevice(ctx->device));
+    return dz_launch_sinc_conv0_split(d_wave, stride, batch, samples, d_stats, 0, gamma, beta,
+                                      d_filt_split, d_y0, g.P0, d_partials, g.nt0, (hipStream_t)stream);
+}
+extern "C" int dz_k_conv0_split_ntile(int samples) { return sinc_geom(samples, true).nt0; }
 extern "C" int dz_k_finalize_norm(dz_ctx* ctx, const float* d_partials, int batch, int ntile,
                                   int channels, int frames, const float* d_gamma,
                                   const float* d_beta, float* d_scale, float* d_shift,

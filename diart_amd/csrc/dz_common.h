@@ -145,6 +145,12 @@ int dz_launch_wave_stats_combine(const float* mom, int B, int S, float* stats, h
 int dz_launch_sinc_conv0(const float* wave, long long stride, int B, int S, const float* stats,
                          int stats_are_moments, float gamma, float beta, const float* filt,
                          float* y0, int P0, float* partials, int ntile, hipStream_t st);
+// the same on the f16 matrix cores with split operands; filt_split = f16 planes [2][96][256] of the
+// unfolded bank; partials tiles are 96 frames: ntile = dz_conv0_split_ntile(F0)
+int dz_launch_sinc_conv0_split(const float* wave, long long stride, int B, int S, const float* stats,
+                               int stats_are_moments, float gamma, float beta, const void* filt_split,
+                               float* y0, int P0, float* partials, int ntile, hipStream_t st);
+int dz_conv0_split_ntile(int F0);
 // partial (sum,sumsq) -> per (b,c) scale/shift of InstanceNorm1d(C, affine)
 int dz_launch_finalize_norm(const float* partials, int B, int ntile, int C, int T,
                             const float* gamma, const float* beta, float* scale, float* shift,

@@ -272,6 +272,165 @@ int dz_launch_sinc_conv0(const float* wave, long long stride, int B, int S, cons
 }
 
 // ---------------------------------------------------------------------------
+// sinc_conv0 on the f16 matrix cores (default precision).  The same contraction, unfolded:
+//     out[t][c] = sum_{k < 251} xn[10 t + k] * filt[c][k]          M = frames, N = 80 -> 96, K -> 256
+// with both operands split into (hi, lo * 2^11) f16 pairs, three v_mfma_f32_32x32x16_f16 per
+// product into two f32 accumulators — the arithmetic of k_gemm_split.hip.  The exact-f32 kernel
+// above needs half the multiply-adds (symmetric fold) but runs them on the f32 matrix pipe,
+// 16x slower per multiply-add than the f16 pipe; and the fold costs an add + a sub per A element
+// that an f16 version would have to split again.  Here the A operand needs NO arithmetic at all:
+//   * A is a Toeplitz view of the tile's samples.  Row t, k-chunk (8 consecutive k) = 8
+//     consecutive samples starting at 10 t + k0: a 16-byte LDS read if the f16 sample array is
+//     16-byte aligned there.  10 t is only even, so the tile keeps FOUR copies of its samples,
+//     copy c shifted by 2c samples (copy_c[i] = x[i + 2c]); frame t reads copy t & 3, where
+//     10 t - 2 (t & 3) is a multiple of 8.  4 copies x 2 planes x 1216 samples = 20 KiB.
+//   * B (the filter bank, 96 x 256 x 2 planes) lives in REGISTERS for the whole kernel: wave w of a
+//     workgroup owns filters 32w .. 32w+31 = 16 k-steps x (hi, lo) fragments = 128 VGPRs.
+//   * MaxPool1d(3) needs no exchange either: the workgroup's 96 frames are processed as three
+//     32-row MFMA blocks, block b = frames {3 m + b}; pooled row m is then the element-wise
+//     maximum of the three blocks' |accumulators| in the SAME lane and register.
+// Workgroup = 3 waves (one per 32-filter column block), tile = 96 frames = 32 pooled rows, two
+// workgroups per CU; per k-step a wave reads 2 fragments (2 KiB) for 3 MFMAs.  MFMA row i of a
+// block carries pooled row pi(i) = bits (1,0) and (3,2) of i swapped, and copy c starts 16 * E[c]
+// bytes into its slot: with that the 16 lanes of every ds_read_b128 group hit at most 2-way bank
+// conflicts (brute-forced; the straight order is 4-way).
+// ---------------------------------------------------------------------------
+#define CH_FR 96                       /* frames per tile                                        */
+#define CH_NS 1216                     /* f16 samples per copy plane: >= 10*95 + 255 + 1         */
+#define CH_PL 2560                     /* bytes per copy plane, padded to a multiple of 256      */
+#define CH_CP (2 * CH_PL + 256)        /* bytes per copy (hi | lo) + room for the start offset   */
+#define CH_LDS (4 * CH_CP)
+
+typedef _Float16 ch_f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 ch_f16x2 __attribute__((ext_vector_type(2)));
+typedef float ch_f32x16 __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ int ch_copy_base(int c) {
+    // 16-byte start offsets (0, 12, 8, 5) of the four copies inside their slots
+    return c * CH_CP + 16 * ((0x58c0 >> (4 * c)) & 15);
+}
+__device__ __forceinline__ int ch_pi(int i) { return ((i & 3) << 2) | ((i >> 2) & 3) | (i & 16); }
+
+__global__ __launch_bounds__(192, 2) void sinc_conv0_h_kernel(
+    const float* __restrict__ wave, long long stride, int S, const float* __restrict__ stats,
+    int stats_are_moments, float gamma, float beta, const unsigned short* __restrict__ fsp,
+    float* __restrict__ y0, int P0, float* __restrict__ partials, int ntile) {
+    __shared__ __attribute__((aligned(256))) char xs[CH_LDS];
+    const int b = blockIdx.y, tile = blockIdx.x, tid = threadIdx.x;
+    const int w = tid >> 6, l = tid & 63, li = l & 31, g = l >> 5;
+
+    // ---- B fragments: filters 32w + li, k = 16 ks + 8 g .. +7, hi and lo planes ------------------
+    ch_f16x8 bh[16], bl[16];
+    {
+        const unsigned short* row = fsp + (long long)(32 * w + li) * 256 + 8 * g;
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks) {
+            bh[ks] = *reinterpret_cast<const ch_f16x8*>(row + 16 * ks);
+            bl[ks] = *reinterpret_cast<const ch_f16x8*>(row + 96 * 256 + 16 * ks);
+        }
+    }
+    // ---- samples of the tile: normalise (InstanceNorm1d(1)), split, four shifted copies -----------
+    {
+        float mean, rstd;
+        if (stats_are_moments)
+            dz_ws_combine(stats, b, S, &mean, &rstd);
+        else
+            mean = stats[2 * b], rstd = stats[2 * b + 1];
+        const float* wb = wave + (long long)b * stride;
+        const int s0 = tile * (CH_FR * 10);
+        for (int i = tid; i < (CH_NS + 6) / 2; i += 192) {
+            const int j = 2 * i, sidx = s0 + j;
+            float x0 = 0.f, x1 = 0.f;
+            if (sidx + 1 < S) {
+                const float2 v = *reinterpret_cast<const float2*>(wb + sidx);
+                x0 = v.x; x1 = v.y;
+            } else if (sidx < S) {
+                x0 = wb[sidx];
+            }
+            f32x2 x = {sidx < S ? ((x0 - mean) * rstd) * gamma + beta : 0.f,
+                       sidx + 1 < S ? ((x1 - mean) * rstd) * gamma + beta : 0.f};
+            x[0] = __builtin_amdgcn_fmed3f(x[0], -65504.f, 65504.f);
+            x[1] = __builtin_amdgcn_fmed3f(x[1], -65504.f, 65504.f);
+            const ch_f16x2 hi = __builtin_convertvector(x, ch_f16x2);
+            const ch_f16x2 lo = __builtin_convertvector((x - __builtin_convertvector(hi, f32x2)) * 2048.f, ch_f16x2);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int idx = j - 2 * c;            // copy_c[idx] = x[idx + 2c]
+                if (idx >= 0 && idx < CH_NS) {
+                    char* d = xs + ch_copy_base(c) + 2 * idx;
+                    *reinterpret_cast<ch_f16x2*>(d) = hi;
+                    *reinterpret_cast<ch_f16x2*>(d + CH_PL) = lo;
+                }
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- three 32-row blocks: block bk = frames 3 m + bk, MFMA row li <-> pooled row m = pi(li) --
+    const int m_a = ch_pi(li);
+    ch_f32x16 pmax;
+#pragma unroll
+    for (int bk = 0; bk < 3; ++bk) {
+        const int f = 3 * m_a + bk, c = f & 3;
+        const char* ap = xs + ch_copy_base(c) + 2 * (10 * f - 2 * c + 8 * g);
+        ch_f32x16 accm, accx;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) accm[r] = accx[r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks) {
+            const ch_f16x8 ah = *reinterpret_cast<const ch_f16x8*>(ap + 32 * ks);
+            const ch_f16x8 al = *reinterpret_cast<const ch_f16x8*>(ap + CH_PL + 32 * ks);
+            accx = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[ks], accx, 0, 0, 0);
+            accm = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[ks], accm, 0, 0, 0);
+            accx = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[ks], accx, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float v = fabsf(accm[r] + accx[r] * (1.f / 2048.f));
+            pmax[r] = bk == 0 ? v : fmaxf(pmax[r], v);
+        }
+    }
+
+    // ---- pooled rows + InstanceNorm partials: C/D column = lane & 31 = filter, row rho <-> m = pi(rho)
+    const int ch = 32 * w + li;
+    float sum = 0.f, ssq = 0.f;
+    if (ch < 80) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int rho = (r & 3) + 8 * (r >> 2) + 4 * g;
+            const int p = tile * 32 + ch_pi(rho);
+            if (p < P0) {
+                const float v = pmax[r];
+                y0[((long long)b * P0 + p) * 80 + ch] = v;
+                sum += v;
+                ssq += v * v;
+            }
+        }
+    }
+    sum += __shfl_xor(sum, 32, 64);
+    ssq += __shfl_xor(ssq, 32, 64);
+    if (ch < 80 && g == 0) {
+        float* pp = partials + (((long long)b * ntile + tile) * 80 + ch) * 2;
+        pp[0] = sum;
+        pp[1] = ssq;
+    }
+}
+
+int dz_conv0_split_ntile(int F0) { return (F0 + CH_FR - 1) / CH_FR; }
+
+// fsp: the UNFOLDED bank as f16 planes [2][96][256] (weights.py split_f16 of the zero-padded
+// [96][256] filter matrix); partials [B][ntile][80][2] with ntile = dz_conv0_split_ntile(F0)
+int dz_launch_sinc_conv0_split(const float* wave, long long stride, int B, int S, const float* stats,
+                               int stats_are_moments, float gamma, float beta, const void* fsp,
+                               float* y0, int P0, float* partials, int ntile, hipStream_t st) {
+    DZ_LAUNCH(sinc_conv0_h_kernel, dim3(ntile, B), dim3(192), 0, st, wave, stride, S, stats,
+              stats_are_moments, gamma, beta, reinterpret_cast<const unsigned short*>(fsp), y0, P0,
+              partials, ntile);
+    DZ_HIP(hipGetLastError());
+    return 0;
+}
+
+// ---------------------------------------------------------------------------
 // finalize_norm: fixed-order (deterministic) reduction of the tile partials in fp64.
 // scale = gamma * rstd, shift = beta - mean * scale  (InstanceNorm1d, eps 1e-5, biased var)
 // ---------------------------------------------------------------------------

@@ -11,8 +11,9 @@
 // W samples are ALWAYS one contiguous span [q, q + W) of the row, q = (p + slack*hop) mod P: the
 // segmentation / embedding kernels read the rolling window in place through (base pointer +
 // offset, row stride 2*P) with their usual coalesced 16-byte loads — no wrap-around logic in any
-// kernel, nothing is copied or repeated.  Only the new samples cross PCIe (one strided H2D copy)
-// plus one device-side mirror copy.  The slack keeps a push from overwriting samples a forward
+// kernel, nothing is copied or repeated.  Only the new samples cross PCIe: ONE contiguous
+// asynchronous H2D copy into a staging block, then one small kernel writes the block to both
+// positions (the 2-D runtime copies this replaced cost the step ~0.3 ms of host and queue time).  The slack keeps a push from overwriting samples a forward
 // pass of the previous `slack` windows may still be reading: block t+1 lands on the slot of
 // block t+1-W/hop-slack, which belongs to windows <= t-slack only.
 #include "dz_common.h"
@@ -23,6 +24,7 @@ struct dz_ring {
     dz_ctx* ctx;
     int n, W, hop, P;
     float* buf;        // [n][2P]
+    float* stage[2];   // [n][hop] landing blocks of the H2D copies, used alternately
     long long pushed;  // blocks pushed so far
     int pos;           // write position of the NEXT block, in [0, P)
 };
@@ -49,13 +51,36 @@ extern "C" int dz_ring_create(dz_ctx* ctx, int n_streams, int window, int hop, i
         return 1;
     }
     DZ_HIP(hipMemset(r->buf, 0, bytes));
+    r->stage[0] = r->stage[1] = nullptr;
+    e = hipMalloc((void**)&r->stage[0], (size_t)2 * n_streams * hop * sizeof(float));
+    if (e != hipSuccess) {
+        dz_set_error("dz_ring_create: hipMalloc(stage) failed: %s", hipGetErrorString(e));
+        (void)hipFree(r->buf);
+        delete r;
+        return 1;
+    }
+    r->stage[1] = r->stage[0] + (size_t)n_streams * hop;
     *out = r;
     return 0;
+}
+
+// block [n][hop] (rows `bstride` floats apart) -> ring rows at `pos` and `pos + P`; 16 bytes per lane
+__global__ __launch_bounds__(256) void ring_scatter_kernel(const float* __restrict__ block, long long bstride,
+                                                           float* __restrict__ buf, int n, int hop4, int P,
+                                                           int pos) {
+    const int i = blockIdx.y;
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= hop4) return;
+    const f32x4 v = *reinterpret_cast<const f32x4*>(block + (long long)i * bstride + 4 * j);
+    float* row = buf + (long long)i * 2 * P + pos + 4 * j;
+    *reinterpret_cast<f32x4*>(row) = v;
+    *reinterpret_cast<f32x4*>(row + P) = v;
 }
 
 extern "C" int dz_ring_destroy(dz_ring* r) {
     if (r) {
         if (r->buf) (void)hipFree(r->buf);
+        if (r->stage[0]) (void)hipFree(r->stage[0]);
         delete r;
     }
     return 0;
@@ -77,11 +102,29 @@ extern "C" int dz_ring_push(dz_ring* r, const float* block, long long block_stri
                r->hop);
     DZ_HIP(hipSetDevice(r->ctx->device));
     hipStream_t st = (hipStream_t)stream;
-    const size_t pitch = (size_t)2 * r->P * sizeof(float), width = (size_t)r->hop * sizeof(float);
-    float* lo = r->buf + r->pos;
-    DZ_HIP(hipMemcpy2DAsync(lo, pitch, block, (size_t)block_stride * sizeof(float), width, r->n,
-                            on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st));
-    DZ_HIP(hipMemcpy2DAsync(lo + r->P, pitch, lo, pitch, width, r->n, hipMemcpyDeviceToDevice, st));
+    DZ_REQUIRE(((uintptr_t)block & 15) == 0 && (block_stride & 3) == 0,
+               "dz_ring_push: block rows must be 16-byte aligned");
+    const float* src = block;
+    long long sstride = block_stride;
+    if (!on_device) {
+        // pushes of one ring are issued in stream order, so two landing blocks used alternately
+        // are never overwritten before the scatter that reads them has run
+        float* land = r->stage[r->pushed & 1];
+        if (block_stride == r->hop) {
+            DZ_HIP(hipMemcpyAsync(land, block, (size_t)r->n * r->hop * sizeof(float),
+                                  hipMemcpyHostToDevice, st));
+        } else {
+            DZ_HIP(hipMemcpy2DAsync(land, (size_t)r->hop * sizeof(float), block,
+                                    (size_t)block_stride * sizeof(float), (size_t)r->hop * sizeof(float),
+                                    r->n, hipMemcpyHostToDevice, st));
+        }
+        src = land;
+        sstride = r->hop;
+    }
+    const int hop4 = r->hop / 4;
+    hipLaunchKernelGGL(ring_scatter_kernel, dim3((hop4 + 255) / 256, r->n), dim3(256), 0, st, src, sstride,
+                       r->buf, r->n, hop4, r->P, r->pos);
+    DZ_HIP(hipGetLastError());
     r->pos = (r->pos + r->hop) % r->P;
     r->pushed += 1;
     return 0;

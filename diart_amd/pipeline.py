@@ -51,7 +51,7 @@ class AudioRing:
         _lib.check(self._lib.dz_ring_create(_lib.context(self.device.index), num_streams, window, hop,
                                             slack_blocks, C.byref(self._h)), "dz_ring_create")
         self._keep: List[torch.Tensor] = []          # pinned blocks of in-flight copies
-        self._readers: List[torch.cuda.Event] = []   # `done` events of the steps reading the ring
+        self._readers: List[List[torch.cuda.Event]] = []   # per step: events after its forward passes
 
     def __del__(self):
         try:
@@ -76,15 +76,16 @@ class AudioRing:
         while len(self._readers) > self.slack + 1:
             self._readers.pop(0)
         if len(self._readers) == self.slack + 1:
-            cur.wait_event(self._readers[0])
+            for ev in self._readers[0]:
+                cur.wait_event(ev)
         on_dev = block.is_cuda
         _lib.check(self._lib.dz_ring_push(self._h, block.data_ptr(), block.stride(0), int(on_dev),
                                           cur.cuda_stream), "dz_ring_push")
         self._keep = (self._keep + [block])[-4:]
         return self.filled == self.window
 
-    def _read_by(self, done: torch.cuda.Event):
-        self._readers.append(done)
+    def _read_by(self, events: List[torch.cuda.Event]):
+        self._readers.append(list(events))
 
     def raw(self) -> Tuple[int, int]:
         ptr, stride = _lib.vp(), C.c_longlong()
@@ -133,7 +134,7 @@ class StreamBatch:
         self._steps = np.zeros(num_streams, dtype=np.int64)   # windows seen by each stream slot
         # sub-batches per network, each on its own HIP stream with its own scratch arena: the
         # x-projection GEMM of one sub-batch runs under the latency-bound recurrence of another
-        self.seg_split = max(1, min(int(os.environ.get("DZ_SEG_SPLIT", "2" if num_streams >= 16 else "1") if seg_split is None else seg_split), num_streams))
+        self.seg_split = max(1, min(int(os.environ.get("DZ_SEG_SPLIT", "1") if seg_split is None else seg_split), num_streams))
         self.emb_split = max(1, min(int(os.environ.get("DZ_EMB_SPLIT", "1") if emb_split is None else emb_split), num_streams))
         # HIP stream priorities (0 normal, -1 high) were measured: raising the segmentation chain
         # changes the step time by < 3 % (noise level) while it stretches the embedding kernels'
@@ -144,12 +145,23 @@ class StreamBatch:
         # many steps on the GPU at once (the latency-bound recurrence of one step under the GEMMs
         # of the others).  A lane is reused in stream order, which also orders its arenas.
         self.depth = max(1, int(os.environ.get("DZ_DEPTH", "2") if depth is None else depth))
-        self.lanes = [dict(a=[torch.cuda.Stream(self.device, priority=pa) for _ in range(self.seg_split)],
-                           b=[torch.cuda.Stream(self.device, priority=pb) for _ in range(self.emb_split)])
+        # The embedding network does not need a lane of its own: only its last two kernels (pooling,
+        # Linear) wait for the segmentation.  With DZ_SHARED_EMB (default) ONE set of embedding
+        # streams serves every lane in step order and the pooling of step t is enqueued `lag` =
+        # depth - 1 launches later, behind the frame features of the following steps — by then the
+        # segmentation of step t has finished, so the stream never blocks on it.  Fewer HIP streams
+        # also means fewer hardware queues (the runtime multiplexes streams onto
+        # GPU_MAX_HW_QUEUES queues; streams that share one serialise).
+        self.shared_emb = os.environ.get("DZ_SHARED_EMB", "1") != "0"
+        self.lag = self.depth - 1 if self.shared_emb else 0
+        mk = lambda prio, k: [torch.cuda.Stream(self.device, priority=prio) for _ in range(k)]
+        shared_b = mk(pb, self.emb_split) if self.shared_emb else None
+        self.lanes = [dict(a=mk(pa, self.seg_split), b=shared_b or mk(pb, self.emb_split))
                       for _ in range(self.depth)]
         self.streams_a, self.streams_b = self.lanes[0]["a"], self.lanes[0]["b"]
         self.stream_a, self.stream_b = self.streams_a[0], self.streams_b[0]
-        self.num_hip_streams = self.depth * (self.seg_split + self.emb_split)
+        self.num_hip_streams = self.depth * self.seg_split + self.emb_split * (1 if self.shared_emb else self.depth)
+        self._pending: List[dict] = []                     # launched, pooling not enqueued yet
         self._sub: dict = {}
         self._slots: List[dict] = []
         self._lib = _lib.load()
@@ -182,6 +194,7 @@ class StreamBatch:
                  emb_h=torch.empty((n, K, D), dtype=torch.float32).pin_memory(),
                  ev_seg=[torch.cuda.Event() for _ in range(self.seg_split)],
                  ev_emb=[torch.cuda.Event() for _ in range(self.emb_split - 1)],
+                 ev_frames=[torch.cuda.Event() for _ in range(self.emb_split)],
                  ev_in=torch.cuda.Event(), done=torch.cuda.Event())
         self._slots.append(s)
         return s
@@ -245,7 +258,7 @@ class StreamBatch:
             # every in-flight slot up front: a pinned-memory allocation made while kernels are
             # running stalls the queues for tens of milliseconds (seen as one 40 ms "kernel" in the
             # rocprofv3 trace of the second step)
-            for _ in range(self.depth + 1):
+            for _ in range(self.depth + self.lag + 1):
                 self._new_slot(F, K, D)
         slot = self._slot(F, K, D)
         slot["busy"] = True
@@ -263,12 +276,35 @@ class StreamBatch:
                                   self.beta, int(self.norm_w), 1, slot["w"][i0:i1].data_ptr(),
                                   a.cuda_stream), "dz_osp")
             ev.record(a)
-        for (i0, i1), h, b in zip(sb, hembs, lane["b"]):
+        for (i0, i1), h, b, ev in zip(sb, hembs, lane["b"], slot["ev_frames"]):
             b.wait_event(slot["ev_in"])
+            if i1 > i0:
+                _lib.check(lib.dz_emb_frames(h, base + i0 * stride * esz, stride, i1 - i0, b.cuda_stream),
+                           "dz_emb_frames")
+            ev.record(b)
+        slot["rows"], slot["slots"] = N, slots
+        slot["keep"] = rows                              # keep the view alive until the GPU is done
+        slot["pool"] = (lane, hembs, sa, sb, N, K, F)     # what _enqueue_pool needs
+        if ring is not None:                             # pushes `slack` steps from now wait for these
+            ring._read_by(slot["ev_seg"] + slot["ev_frames"])
+        self._pending.append(slot)
+        while len(self._pending) > self.lag:
+            self._enqueue_pool(self._pending.pop(0))
+        idx = np.arange(self.n) if slots is None else np.asarray(slots, dtype=np.int64)
+        slot["starts"] = self._steps[idx] * self.step if starts is None else starts
+        self._steps[idx] += 1
+        self._t += 1
+        return slot
+
+    def _enqueue_pool(self, slot: dict):
+        """Statistics pooling + Linear + normalisation of a launched step (they consume the OSP
+        weights, i.e. wait for its segmentation), the copy of its results to pinned memory and its
+        `done` event, on the embedding stream(s)."""
+        lane, hembs, sa, sb, N, K, F = slot["pool"]
+        lib = self._lib
+        for (i0, i1), h, b in zip(sb, hembs, lane["b"]):
             if i1 == i0:
                 continue
-            _lib.check(lib.dz_emb_frames(h, base + i0 * stride * esz, stride, i1 - i0, b.cuda_stream),
-                       "dz_emb_frames")
             for (j0, j1), ev in zip(sa, slot["ev_seg"]):
                 if j0 < i1 and i0 < j1:
                     b.wait_event(ev)
@@ -282,15 +318,7 @@ class StreamBatch:
             slot["seg_h"][:N].copy_(slot["seg"][:N], non_blocking=True)
             slot["emb_h"][:N].copy_(slot["emb"][:N], non_blocking=True)
         slot["done"].record(b0)
-        slot["rows"], slot["slots"] = N, slots
-        slot["keep"] = rows                              # keep the view alive until the GPU is done
-        if ring is not None:
-            ring._read_by(slot["done"])                  # pushes `slack` steps from now wait for this
-        idx = np.arange(self.n) if slots is None else np.asarray(slots, dtype=np.int64)
-        slot["starts"] = self._steps[idx] * self.step if starts is None else starts
-        self._steps[idx] += 1
-        self._t += 1
-        return slot
+        slot["pool"] = None
 
     # ------------------------------------------------------------------ host half
     def finish(self, ticket: dict, want_scores: bool = True) -> Tuple[np.ndarray, np.ndarray, np.ndarray, np.ndarray]:
@@ -298,6 +326,8 @@ class StreamBatch:
         -> (segmentation (N,F,K) f32, embeddings (N,K,D) f32, scores (N,F,G) f64 | None, assign (N,K)).
         The arrays (and ``ticket["tail"]``) are views of buffers that a later ``launch`` / ``finish``
         reuses: copy what has to outlive the next step."""
+        while ticket["pool"] is not None:               # its pooling is still held back: flush in order
+            self._enqueue_pool(self._pending.pop(0))
         ticket["done"].synchronize()
         N, slots = ticket["rows"], ticket["slots"]
         seg = ticket["seg_h"].numpy()[:N]

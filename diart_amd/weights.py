@@ -112,7 +112,7 @@ def default_lstm_variant() -> int:
     """``DZ_LSTM``: ``valu`` (-1: one chain per CU on the f32 vector units even in the f16x3
     precision) or the matrix-core variant 0 / 1 / 2 (``lstm_whh_planes``)."""
     import os
-    v = os.environ.get("DZ_LSTM", "0")
+    v = os.environ.get("DZ_LSTM", "valu")
     return -1 if v == "valu" else int(v)
 
 
@@ -168,6 +168,10 @@ def _pack_sincnet(sd: Dict[str, torch.Tensor], pk: _Packed, prefix: str = "sincn
     w.wav_gamma = float(g("wav_norm1d.weight").reshape(-1)[0])
     w.wav_beta = float(g("wav_norm1d.bias").reshape(-1)[0])
     w.filt = pk.put(fold_sinc_filters(filt))
+    import os
+    if split and os.environ.get("DZ_CONV0_SPLIT", "1") != "0":
+        # the unfolded bank, zero padded to [96][256], as f16 planes for the matrix-core kernel
+        w.filt_split = pk.put_split(_pad2(filt, 96, 256))
     w.in0_g, w.in0_b = pk.put(g("norm1d.0.weight")), pk.put(g("norm1d.0.bias"))
     w.w1 = pk.put(_conv_pack(g("conv1d.1.weight"), 80, 64, 416))
     if split:

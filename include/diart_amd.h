@@ -59,6 +59,8 @@ typedef struct {
     const float* in2_b;          /* [64]                                             */
     const void* w1_split;        /* split-f16 planes of w1 / w2 (optional, NULL = exact f32)  */
     const void* w2_split;
+    const void* filt_split;      /* [2][96][256] f16 planes of the UNFOLDED sinc bank, rows >= 80 and
+                                    taps >= 251 zero (optional; NULL = the exact-f32 folded kernel) */
 } dz_sincnet_weights;
 
 typedef struct {
@@ -253,6 +255,12 @@ int dz_k_wave_stats(dz_ctx* ctx, const float* d_wave, long long stride, int batc
 int dz_k_sinc_conv0(dz_ctx* ctx, const float* d_wave, long long stride, int batch, int samples,
                     const float* d_stats, float gamma, float beta, const float* d_filt,
                     float* d_y0, float* d_partials, void* stream);
+/* the same layer on the f16 matrix cores (split operands); d_filt_split as dz_sincnet_weights.filt_split;
+ * partials (B, ntile, 80, 2) with ntile = dz_k_conv0_split_ntile(samples) (96-frame tiles) */
+int dz_k_sinc_conv0_split(dz_ctx* ctx, const float* d_wave, long long stride, int batch, int samples,
+                          const float* d_stats, float gamma, float beta, const void* d_filt_split,
+                          float* d_y0, float* d_partials, void* stream);
+int dz_k_conv0_split_ntile(int samples);
 int dz_k_finalize_norm(dz_ctx* ctx, const float* d_partials, int batch, int ntile, int channels,
                        int frames, const float* d_gamma, const float* d_beta, float* d_scale,
                        float* d_shift, void* stream);

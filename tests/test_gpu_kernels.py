@@ -88,6 +88,48 @@ def test_sinc_conv0(gpu):
     assert (normed - refn).abs().max().item() < 2e-4
 
 
+@pytest.mark.parametrize("S", [80000, 40000, 2661])
+def test_sinc_conv0_split(gpu, S):
+    """The f16 matrix-core form of sinc_conv0 (unfolded bank, split operands, four shifted sample
+    copies, pooling by in-register maximum over three interleaved frame blocks) against the same
+    torch restatement and the same tolerances as the exact-f32 kernel; several window lengths
+    exercise the ragged last tile."""
+    from diart_amd.synth import synth_segmentation_state, synth_stream
+    from diart_amd.weights import sinc_filters, split_f16, _pad2
+    sd = synth_segmentation_state()
+    p = "sincnet.conv1d.0.filterbank."
+    filt = sinc_filters(sd[p + "low_hz_"], sd[p + "band_hz_"], sd[p + "window_"], sd[p + "n_"])
+    B = 3
+    wave = synth_stream(5, 8.0)
+    x = torch.stack([torch.from_numpy(wave[i * 8000: i * 8000 + S].copy()) for i in range(B)])
+    x[1] *= 25.0                                       # a loud chunk: the normalisation removes it
+    gamma, beta = 1.3, -0.05
+    xn = F.instance_norm(x[:, None, :]) * gamma + beta
+    ref = F.max_pool1d(F.conv1d(xn, filt[:, None, :], stride=10).abs(), 3, 3)
+    P0 = ref.shape[2]
+    lib = _lib.load()
+    pad = torch.zeros(B, (S + 3) // 4 * 4 + 64)
+    pad[:, :S] = x
+    d = pad.to(gpu)
+    st = torch.empty(B, 2, device=gpu)
+    _lib.check(lib.dz_k_wave_stats(_ctx(gpu), d.data_ptr(), d.stride(0), B, S, st.data_ptr(), None))
+    fs = split_f16(_pad2(filt, 96, 256)).to(gpu)
+    nt = lib.dz_k_conv0_split_ntile(S)
+    assert nt == -(-((S - 251) // 10 + 1) // 96)
+    y0 = torch.full((B, P0, 80), float("nan"), device=gpu)
+    part = torch.full((B, nt, 80, 2), float("nan"), device=gpu)
+    _lib.check(lib.dz_k_sinc_conv0_split(_ctx(gpu), d.data_ptr(), d.stride(0), B, S, st.data_ptr(), gamma,
+                                         beta, fs.data_ptr(), y0.data_ptr(), part.data_ptr(), None))
+    _sync()
+    got = y0.cpu().permute(0, 2, 1)
+    assert not torch.isnan(got).any()
+    assert _rel(got, ref) < 2e-5
+    ps = part.cpu().double().sum(1)
+    assert not torch.isnan(ps).any()
+    assert torch.allclose(ps[..., 0], ref.double().sum(2), rtol=1e-5)
+    assert torch.allclose(ps[..., 1], (ref.double() ** 2).sum(2), rtol=1e-5)
+
+
 # --------------------------------------------------------------------------- #
 def _run_convgemm(gpu, X, W, bias, *, taps, dil, epi, Npad, Nstore, Kpad, e0=None, e1=None,
                   nscale=None, nshift=None, Tstore=None, ldy=None, ksplit=0, split=False):

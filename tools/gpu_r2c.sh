@@ -6,6 +6,7 @@ mkdir -p gpurun_out
 export PYTHONDONTWRITEBYTECODE=1 TMPDIR=/tmp
 OUT=gpurun_out/sweep_$TAG.log
 : > $OUT
+if [ -z "$SKIP_TESTS" ]; then
 echo "=== kernel tests" >> $OUT
 timeout 600 python -m pytest tests/test_gpu_kernels.py -m gpu -q --timeout 500 -p no:cacheprovider 2>&1 | tail -30 >> $OUT
 echo "=== model / pipeline tests" >> $OUT
@@ -13,7 +14,9 @@ timeout 900 python -m pytest tests/test_gpu_models.py tests/test_gpu_pipeline.py
 echo "=== kbench" >> $OUT
 timeout 300 python tools/kbench.py --only lstm_proj,seg_mlp0,tdnn2,tdnn3,tdnn4,tdnn5 2>&1 | grep -v amdgpu.ids | tail -40 >> $OUT
 cp gpurun_out/kbench.json gpurun_out/kbench_$TAG.json 2>/dev/null
-for cfg in ${2:-"valu,2,1,0 valu,2,1,1 valu,1,2,1 0,1,3,1 0,1,4,1"}; do
+fi
+GRID=${2:-"valu,2,1,0 valu,2,1,1 valu,1,2,1 0,1,3,1 0,1,4,1"}
+for cfg in $GRID; do
   IFS=, read l s d pre <<< "$cfg"
   echo "=== bench lstm=$l seg_split=$s depth=$d pre=$pre" >> $OUT
   DZ_GEMM_PRE=$pre DZ_LSTM=$l DZ_SEG_SPLIT=$s DZ_DEPTH=$d timeout 300 python bench.py --steps 40 --warmup 5 --no-cpu-baseline --no-exact-f32 \

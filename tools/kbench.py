@@ -158,6 +158,14 @@ timeit("wave_stats", lambda: _lib.check(lib.dz_k_wave_stats(ctx, wave.data_ptr()
 timeit("sinc_conv0", lambda: _lib.check(lib.dz_k_sinc_conv0(ctx, wave.data_ptr(), 80000, B, 80000, stats.data_ptr(), 1.0, 0.0,
                                                            filt.data_ptr(), y0.data_ptr(), part0.data_ptr(), st)),
        flop=2.0 * B * 7975 * 251 * 80)
+from diart_amd.weights import split_f16 as _sp16  # noqa: E402
+fsplit = _sp16(torch.randn(96, 256) * 0.05).to(dev)
+nt_s = lib.dz_k_conv0_split_ntile(80000)
+part0s = torch.empty(B, nt_s, 80, 2, device=dev)
+y0s = torch.empty(B, 2658, 80, device=dev)
+timeit("sinc_conv0_split", lambda: _lib.check(lib.dz_k_sinc_conv0_split(ctx, wave.data_ptr(), 80000, B, 80000, stats.data_ptr(), 1.0, 0.0,
+                                                                       fsplit.data_ptr(), y0s.data_ptr(), part0s.data_ptr(), st)),
+       flop=2.0 * B * 7975 * 251 * 80)
 # ---- implicit-GEMM layers ------------------------------------------------------------------
 convgemm("conv1_pool", B, 2658, 80, 60, 5, 1, _lib.EPI_POOL3, Npad=64, pro=True, pool=True)
 convgemm("conv2_pool", B, 884, 64, 60, 5, 1, _lib.EPI_POOL3, Npad=64, pro=True, pool=True)
