@@ -351,13 +351,9 @@ def main():
     log("warm-up done")
     lib.dz_prof_enable(0 if os.environ.get("DZ_NO_PROF") else 1)
     host["launch"] = host["finish"] = 0.0
-    barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    run(args.warmup, args.steps, profiled=not os.environ.get("DZ_NO_PROF"))
-    torch.cuda.synchronize()
-    barrier()
-    elapsed = time.perf_counter() - t0
+    # barrier + synchronize on both sides, max over ranks (diart_amd.distributed.timed_max_over_ranks)
+    elapsed = D.timed_max_over_ranks(
+        lambda: run(args.warmup, args.steps, profiled=not os.environ.get("DZ_NO_PROF")), device)
     log(f"timed region done: {elapsed:.3f}s for {args.steps} steps; host time per step: launch "
         f"{1e3 * host['launch'] / args.steps:.3f} ms, finish (wait + clustering + tail) "
         f"{1e3 * host['finish'] / args.steps:.3f} ms")
@@ -370,18 +366,8 @@ def main():
     if precision != "f32" and not args.no_exact_f32:
         p32 = make_pipe("f32")
         run(0, args.warmup, p32)
-        torch.cuda.synchronize()
-        barrier()
-        t1 = time.perf_counter()
-        run(args.warmup, args.steps, p32)
-        torch.cuda.synchronize()
-        barrier()
-        e32 = time.perf_counter() - t1
-        if world > 1:
-            t32 = torch.tensor([e32], dtype=torch.float64, device=device)
-            torch.distributed.all_reduce(t32, op=torch.distributed.ReduceOp.MAX)
-            e32 = float(t32.item())
-        exact = {"value": round(world * n * args.steps / e32 / 2, 2), "ms_per_step": round(1e3 * e32 / args.steps, 3),
+        e32 = D.timed_max_over_ranks(lambda: run(args.warmup, args.steps, p32), device)
+        exact = {"value": round(D.whole_job_rate(n, args.steps, e32, world) / 2, 2), "ms_per_step": round(1e3 * e32 / args.steps, 3),
                  "note": "same job with precision='f32' (v_mfma_f32_16x16x4_f32 everywhere), no per-kernel "
                          "event brackets in this pass"}
         log(f"exact-f32 pass: {e32:.3f}s")
@@ -411,27 +397,15 @@ def main():
                 pipe.finish(inflight.pop(0), want_scores=True)
 
         run_ring(0, args.warmup)
-        torch.cuda.synchronize()
-        barrier()
-        t2 = time.perf_counter()
-        run_ring(args.warmup, args.steps)
-        torch.cuda.synchronize()
-        barrier()
-        eh = time.perf_counter() - t2
-        host_fed = {"value": round(world * n * args.steps / eh / 2, 2), "ms_per_step": round(1e3 * eh / args.steps, 3),
+        eh = D.timed_max_over_ranks(lambda: run_ring(args.warmup, args.steps), device)
+        host_fed = {"value": round(D.whole_job_rate(n, args.steps, eh, world) / 2, 2), "ms_per_step": round(1e3 * eh / args.steps, 3),
                     "h2d_bytes_per_step": n * hop * 4,
                     "note": "PCIe-inclusive: per step the 8000 new samples of every stream go pinned host -> "
                             "device ring (dz_ring_push), the window is read in place; not `value`"}
         log(f"host-fed pass: {eh:.3f}s")
 
-    if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
-        elapsed = float(tmax.item())
-
     if rank == 0:
-        chunks = world * n * args.steps
-        cps = chunks / elapsed
+        cps = D.whole_job_rate(n, args.steps, elapsed, world)
         # ---- per DEVICE kernel: achieved vs the CHIP peak of its binding resource -------------
         groups = {}
         for r in table:

@@ -59,6 +59,7 @@ SIGNATURES = {
     "dz_abi_struct_sizes": (C.c_int, [C.POINTER(C.c_int * 5)]),
     "dz_ctx_create": (C.c_int, [C.c_int, C.POINTER(vp)]),
     "dz_ctx_destroy": (C.c_int, [vp]),
+    "dz_range_check": (C.c_int, [vp, C.c_int]),
     "dz_seg_frames_for": (C.c_int, [C.c_int]),
     "dz_emb_frames_for": (C.c_int, [C.c_int]),
     "dz_seg_create": (C.c_int, [vp, C.POINTER(SegWeights), C.c_int, C.c_int, C.POINTER(vp)]),
@@ -138,7 +139,7 @@ class ConvGemmDesc(C.Structure):
         ("xbs", C.c_longlong), ("ybs", C.c_longlong), ("norm_on_load", C.c_int), ("epi", C.c_int),
         ("ksplit", C.c_int), ("ysplit", C.c_longlong), ("agroup", C.c_int), ("pad", C.c_int),
         ("X2", vp), ("rowbias", vp), ("Wsplit", vp), ("Xsplit", vp), ("xplane", C.c_longlong),
-        ("Ysplit", vp), ("yplane", C.c_longlong)]
+        ("Ysplit", vp), ("yplane", C.c_longlong), ("oflag", vp)]
 
 
 (EPI_BIAS, EPI_BIAS_LEAKY, EPI_BIAS_SIGMOID, EPI_TDNN, EPI_POOL3, EPI_BIAS_RELU, EPI_RELU_BN,
@@ -183,6 +184,14 @@ def check(rc: int, what: str = "") -> None:
 
 
 _contexts = {}
+
+
+def range_check(device_index: int, reset: bool = True) -> None:
+    """Raise if a split-f16 kernel of this GPU's context met an operand outside +-65504 (it was
+    clamped) since the last check.  The caller has synchronised the stream(s) that did the work."""
+    ctx = _contexts.get(device_index)
+    if ctx is not None:
+        check(load().dz_range_check(ctx, int(reset)), "f16x3 operand range")
 
 
 def context(device_index: int) -> vp:

@@ -54,6 +54,12 @@ class PipelineConfig(ABC):
         left = self.duration - total if total < self.duration else 0
         return left, right
 
+    def get_file_padding(self, filepath) -> Tuple[float, float]:
+        """The reference's entry point (``blocks/base.py:81-85`` -> ``utils.get_padding_left/right``):
+        padding for an audio FILE; the duration comes from the WAV header."""
+        from ..inference import wav_duration
+        return self.get_padding(wav_duration(filepath))
+
 
 class Pipeline(ABC):
     @staticmethod

@@ -21,6 +21,7 @@ import torch
 from .. import functional as F
 from ..features import TemporalFeatureFormatter, TemporalFeatures
 from ..models import EmbeddingModel
+from .segmentation import _range_check
 
 
 def _default_device(device):
@@ -65,8 +66,9 @@ class SpeakerEmbedding:
         with torch.no_grad():
             wave = self.waveform_formatter.cast(waveform)
             w = self.weights_formatter.cast(weights) if weights is not None else None
-            out = self._embed(wave, w)
-            return out.squeeze().cpu()                              # embedding.py:68
+            out = self._embed(wave, w).squeeze().cpu()              # embedding.py:68
+            _range_check(self.device)
+            return out
 
 
 class OverlappedSpeechPenalty:
@@ -122,4 +124,6 @@ class OverlapAwareSpeakerEmbedding:
             out = out.squeeze()                                     # embedding.py:68
             if out.ndim == 2:                                       # functional.py:20-21
                 out = out.unsqueeze(0)
-            return out.cpu()
+            out = out.cpu()
+            _range_check(emb.device)
+            return out

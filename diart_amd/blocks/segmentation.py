@@ -14,6 +14,13 @@ from ..features import TemporalFeatureFormatter, TemporalFeatures
 from ..models import SegmentationModel
 
 
+def _range_check(device) -> None:
+    """After the synchronising ``.cpu()``: an f16x3 operand beyond +-65504 raises (it was clamped)."""
+    if getattr(device, "type", None) == "cuda":
+        from .. import _lib
+        _lib.range_check(device.index if device.index is not None else torch.cuda.current_device())
+
+
 class SpeakerSegmentation:
     def __init__(self, model: SegmentationModel, device: Optional[torch.device] = None):
         self.model = model
@@ -35,4 +42,5 @@ class SpeakerSegmentation:
         rows = wave.transpose(1, 2)
         with torch.no_grad():
             out = self.model(rows.to(self.device)).cpu()
+        _range_check(self.device)
         return self.formatter.restore_type(out)

@@ -59,11 +59,28 @@ extern "C" int dz_ctx_create(int hip_device, dz_ctx** out) {
     dz_ctx* c = new (std::nothrow) dz_ctx;
     DZ_REQUIRE(c != nullptr, "dz_ctx_create: out of memory");
     c->device = hip_device;
+    c->oflag_host = c->oflag_dev = nullptr;
+    DZ_HIP(hipSetDevice(hip_device));
+    DZ_HIP(hipHostMalloc((void**)&c->oflag_host, sizeof(int), hipHostMallocMapped));
+    *c->oflag_host = 0;
+    DZ_HIP(hipHostGetDevicePointer((void**)&c->oflag_dev, c->oflag_host, 0));
     *out = c;
     return 0;
 }
 extern "C" int dz_ctx_destroy(dz_ctx* ctx) {
+    if (ctx && ctx->oflag_host) (void)hipHostFree(ctx->oflag_host);
     delete ctx;
+    return 0;
+}
+extern "C" int dz_range_check(dz_ctx* ctx, int reset) {
+    DZ_REQUIRE(ctx != nullptr, "dz_range_check: NULL context");
+    const int seen = *(volatile int*)ctx->oflag_host;
+    if (reset) *(volatile int*)ctx->oflag_host = 0;
+    if (seen) {
+        dz_set_error("an operand of a split-f16 (\"f16x3\") kernel was outside +-65504 and has been clamped: "
+                     "the result differs from an f32 reference; use precision=\"f32\" for such inputs");
+        return 6;
+    }
     return 0;
 }
 
@@ -82,6 +99,7 @@ static const char* kProfNames[PROF_TAGS] = {
 enum { T_WAVE = 0, T_CONV0, T_FIN, T_CONV1, T_CONV2, T_PROJ, T_REC, T_MLP, T_CLS, T_TDNN1, T_TDNN2,
        T_TDNN3, T_TDNN4, T_TDNN5, T_POOL, T_EMBLIN, T_L2, T_OSP, T_PSET, T_CDIST, T_PROJ0 };
 thread_local DzLaunchProf* dz_launch_prof = nullptr;
+thread_local int* dz_cur_oflag = nullptr;
 struct Prof {
     bool on = false;
     int used = 0;
@@ -351,6 +369,7 @@ extern "C" int dz_seg_forward(dz_seg* s, const float* d_wave, long long wave_str
     int rc;
     if ((rc = check_wave("dz_seg_forward", d_wave, wave_stride, s->g.S))) return rc;
     DZ_HIP(hipSetDevice(s->ctx->device));
+    DzRangeScope range_scope(s->ctx->oflag_dev);
     hipStream_t st = (hipStream_t)stream;
     const int F = s->g.P2;
     if ((rc = run_sincnet(s->w.sinc, s->g, s->ss, d_wave, wave_stride, B, st))) return rc;
@@ -586,6 +605,7 @@ extern "C" int dz_emb_forward(dz_emb* e, const float* d_wave, long long wave_str
     int rc;
     if ((rc = check_wave("dz_emb_forward", d_wave, wave_stride, e->g.S))) return rc;
     DZ_HIP(hipSetDevice(e->ctx->device));
+    DzRangeScope range_scope(e->ctx->oflag_dev);
     hipStream_t st = (hipStream_t)stream;
     if ((rc = emb_frames(e, d_wave, wave_stride, n_rows, st))) return rc;
     return emb_head(e, d_weights, d_weights ? weight_frames : e->T[4], n_rows, 1, 0, d_out, st);
@@ -603,6 +623,7 @@ extern "C" int dz_emb_forward_multi(dz_emb* e, const float* d_wave, long long wa
     int rc;
     if ((rc = check_wave("dz_emb_forward_multi", d_wave, wave_stride, e->g.S))) return rc;
     DZ_HIP(hipSetDevice(e->ctx->device));
+    DzRangeScope range_scope(e->ctx->oflag_dev);
     hipStream_t st = (hipStream_t)stream;
     if ((rc = emb_frames(e, d_wave, wave_stride, batch, st))) return rc;
     return emb_head(e, d_weights, weight_frames, batch * num_speakers, num_speakers, normalize,
@@ -618,6 +639,7 @@ extern "C" int dz_emb_frames(dz_emb* e, const float* d_wave, long long wave_stri
     int rc;
     if ((rc = check_wave("dz_emb_frames", d_wave, wave_stride, e->g.S))) return rc;
     DZ_HIP(hipSetDevice(e->ctx->device));
+    DzRangeScope range_scope(e->ctx->oflag_dev);
     return emb_frames(e, d_wave, wave_stride, batch, (hipStream_t)stream);
 }
 // pooling + Linear (+ normalisation) of the frame features left by the last dz_emb_frames
@@ -628,6 +650,7 @@ extern "C" int dz_emb_pool(dz_emb* e, const float* d_weights, int batch, int num
     DZ_REQUIRE(num_speakers >= 1 && num_speakers <= kMaxSpk, "dz_emb_pool: %d speakers", num_speakers);
     DZ_REQUIRE(weight_frames >= 2, "dz_emb_pool: weight_frames %d", weight_frames);
     DZ_HIP(hipSetDevice(e->ctx->device));
+    DzRangeScope range_scope(e->ctx->oflag_dev);
     return emb_head(e, d_weights, weight_frames, batch * num_speakers, num_speakers, normalize,
                     d_out, (hipStream_t)stream);
 }
@@ -671,16 +694,19 @@ extern "C" int dz_cdist_cosine(dz_ctx* ctx, const float* d_emb, const double* d_
 extern "C" int dz_k_convgemm(dz_ctx* ctx, const dz_convgemm_desc* d, void* stream) {
     DZ_REQUIRE(ctx && d, "dz_k_convgemm: NULL argument");
     DZ_HIP(hipSetDevice(ctx->device));
+    DzRangeScope range_scope(ctx->oflag_dev);
     return dz_launch_convgemm(*d, (hipStream_t)stream);
 }
 extern "C" int dz_k_gemm_split(dz_ctx* ctx, const dz_convgemm_desc* d, void* stream) {
     DZ_REQUIRE(ctx && d, "dz_k_gemm_split: NULL argument");
     DZ_HIP(hipSetDevice(ctx->device));
+    DzRangeScope range_scope(ctx->oflag_dev);
     return dz_launch_gemm_split(*d, (hipStream_t)stream);
 }
 extern "C" int dz_k_gemm_pre(dz_ctx* ctx, const dz_convgemm_desc* d, void* stream) {
     DZ_REQUIRE(ctx && d, "dz_k_gemm_pre: NULL argument");
     DZ_HIP(hipSetDevice(ctx->device));
+    DzRangeScope range_scope(ctx->oflag_dev);
     return dz_launch_gemm_pre(*d, (hipStream_t)stream);
 }
 extern "C" int dz_k_convgemm_ntile(int t_out) { return dz_convgemm_ntile(t_out); }
@@ -721,6 +747,7 @@ extern "C" int dz_k_sinc_conv0_split(dz_ctx* ctx, const float* d_wave, long long
     const SincGeom g = sinc_geom(samples, true);
     DZ_REQUIRE(g.P0 > 0, "dz_k_sinc_conv0_split: %d samples is too short", samples);
     DZ_HIP(hipSetDevice(ctx->device));
+    DzRangeScope range_scope(ctx->oflag_dev);
     return dz_launch_sinc_conv0_split(d_wave, stride, batch, samples, d_stats, 0, gamma, beta,
                                       d_filt_split, d_y0, g.P0, d_partials, g.nt0, (hipStream_t)stream);
 }

@@ -16,11 +16,13 @@
 #include <cstring>
 #include <limits>
 #include <new>
+#include <string>
 #include <thread>
 #include <utility>
 #include <vector>
 
 void dz_set_error(const char* fmt, ...);
+extern "C" const char* dz_last_error(void);
 
 namespace {
 
@@ -269,11 +271,14 @@ int identify(dz_clu* c, const float* seg, int F, int K, const float* emb32, int 
         c->has_centers = true;
         for (int k = 0; k < K; ++k)
             if (is_active[k]) {
+                // More active local speakers than max_speakers on the very first chunk (only
+                // possible with max_speakers < K): the reference does not raise — its
+                // get_next_center_position() returns None and `centers[None] = emb` then overwrites
+                // EVERY centroid (clustering.py:101-117), i.e. undefined results.  Here the speakers
+                // that found no slot stay unmapped for this chunk (their score columns are zero),
+                // like any speaker that cannot be assigned later on.
                 const int g = c->add_center(&emb[(size_t)k * D]);
-                if (g < 0) {
-                    dz_set_error("clustering: no free center on the first call (max_speakers=%d)", c->G);
-                    return 3;
-                }
+                if (g < 0) continue;
                 out.set_source(k, g);
             }
         return 0;
@@ -462,21 +467,34 @@ extern "C" int dz_clu_step_batch(dz_clu** clus, int n, const float* seg, int fra
         }
         return 0;
     }
-    std::vector<int> rcs(nt, 0);
+    // the error text is thread local: a failing worker copies its own message (and which stream
+    // it was) before it is lost with the thread.  Streams are independent, so the ones that
+    // succeeded HAVE been stepped; the caller decides what to do with the failed ones.
+    std::vector<int> rcs(nt, 0), who(nt, -1);
+    std::vector<std::string> msgs(nt);
     std::vector<std::thread> th;
     for (int t = 0; t < nt; ++t)
         th.emplace_back([&, t]() {
             for (int i = t; i < n; i += nt) {
                 const int rc = run(i);
-                if (rc && !rcs[t]) rcs[t] = rc;
+                if (rc && !rcs[t]) {
+                    rcs[t] = rc;
+                    who[t] = i;
+                    msgs[t] = dz_last_error();
+                }
             }
         });
     for (auto& x : th) x.join();
-    for (int rc : rcs)
-        if (rc) {
-            dz_set_error("dz_clu_step_batch: a stream failed (code %d)", rc);
-            return rc;
-        }
+    int first = -1;
+    for (int t = 0; t < nt; ++t)
+        if (rcs[t] && (first < 0 || who[t] < who[first])) first = t;
+    if (first >= 0) {
+        int failed = 0;
+        for (int rc : rcs) failed += rc != 0;
+        dz_set_error("dz_clu_step_batch: stream %d of %d failed (code %d): %s%s", who[first], n, rcs[first],
+                     msgs[first].c_str(), failed > 1 ? " (other streams failed too)" : "");
+        return rcs[first];
+    }
     return 0;
 }
 extern "C" int dz_clu_get_centers(dz_clu* c, double* out, int dim) {

@@ -41,6 +41,14 @@ struct DzAttrOnce {
 struct DzLaunchProf {
     hipEvent_t start, stop;
 };
+// range flag (dz_ctx::oflag_dev) of the context whose forward pass is being enqueued on this host
+// thread: picked up by the split-f16 launchers when the descriptor does not name one
+extern thread_local int* dz_cur_oflag;
+struct DzRangeScope {
+    int* prev;
+    explicit DzRangeScope(int* f) : prev(dz_cur_oflag) { dz_cur_oflag = f; }
+    ~DzRangeScope() { dz_cur_oflag = prev; }
+};
 extern thread_local DzLaunchProf* dz_launch_prof;
 #define DZ_LAUNCH(kernel, grid, block, lds, st, ...)                                          \
     do {                                                                                      \
@@ -96,8 +104,10 @@ __device__ __forceinline__ unsigned short* dz_split_base(void* ysplit, long long
     unsigned short* y = reinterpret_cast<unsigned short*>(ysplit);
     return odd ? y + (yplane - 1) : y;
 }
+// `amax` accumulates max |v| of what this lane wrote (dz_flag_range reports values beyond +-65504).
 __device__ __forceinline__ void dz_store_split(unsigned short* ypl, long long idx, float v, bool store,
-                                               bool odd) {
+                                               bool odd, float& amax) {
+    amax = fmaxf(amax, fabsf(v));
     const float x = __builtin_amdgcn_fmed3f(v, -65504.f, 65504.f);
     const _Float16 h = (_Float16)x;
     const _Float16 lw = (_Float16)((x - (float)h) * 2048.f);
@@ -106,6 +116,12 @@ __device__ __forceinline__ void dz_store_split(unsigned short* ypl, long long id
     const unsigned Q = (unsigned)__builtin_amdgcn_update_dpp(0, (int)P, 0xB1, 0xF, 0xF, true);
     const unsigned word = odd ? ((Q >> 16) | (P & 0xffff0000u)) : ((P & 0xffffu) | (Q << 16));
     if (store) *reinterpret_cast<unsigned*>(ypl + idx) = word;
+}
+
+// The split-f16 representation holds |x| <= 65504; larger operands are clamped — and REPORTED: a lane
+// that saw one stores 1 into the context's flag (rare store; dz_range_check turns it into an error).
+__device__ __forceinline__ void dz_flag_range(int* oflag, float amax) {
+    if (oflag && amax > 65504.f) *oflag = 1;
 }
 
 // ---------------------------------------------------------------------------
@@ -213,4 +229,8 @@ int dz_launch_nan_rows(float* out, int rows, int dim, const int* flags, hipStrea
 
 struct dz_ctx {
     int device;
+    // "an operand left the f16 range" flag of the split-f16 kernels: one int in pinned, device-mapped
+    // host memory (kernels store 1 into it; the host reads it without a copy: dz_range_check)
+    int* oflag_host;
+    int* oflag_dev;
 };

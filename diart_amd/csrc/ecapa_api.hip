@@ -140,6 +140,7 @@ extern "C" int dz_ecapa_forward(dz_ecapa* e, const float* d_wave, long long wave
     DZ_REQUIRE(d_masks == nullptr || mask_frames >= 1, "dz_ecapa_forward: mask_frames %d", mask_frames);
     DZ_REQUIRE(wave_stride >= 0, "dz_ecapa_forward: negative stride");
     DZ_HIP(hipSetDevice(e->ctx->device));
+    DzRangeScope range_scope(e->ctx->oflag_dev);
     hipStream_t st = (hipStream_t)stream;
     int rc;
     const dz_ecapa_weights& w = e->w;

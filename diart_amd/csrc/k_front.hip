@@ -311,14 +311,40 @@ __device__ __forceinline__ int ch_copy_base(int c) {
 }
 __device__ __forceinline__ int ch_pi(int i) { return ((i & 3) << 2) | ((i >> 2) & 3) | (i & 16); }
 
+// Persistent: the grid is at most two workgroups per CU, each walks a contiguous range of (chunk,
+// tile) pairs with its B fragments resident; the samples of tile t+1 are fetched into registers
+// before the MFMA loop of tile t and parked in the other LDS buffer after it (one barrier per tile).
 __global__ __launch_bounds__(192, 2) void sinc_conv0_h_kernel(
     const float* __restrict__ wave, long long stride, int S, const float* __restrict__ stats,
     int stats_are_moments, float gamma, float beta, const unsigned short* __restrict__ fsp,
-    float* __restrict__ y0, int P0, float* __restrict__ partials, int ntile) {
-    __shared__ __attribute__((aligned(256))) char xs[CH_LDS];
-    const int b = blockIdx.y, tile = blockIdx.x, tid = threadIdx.x;
+    float* __restrict__ y0, int P0, float* __restrict__ partials, int ntile, int total,
+    int* __restrict__ oflag) {
+    // one LDS object (a second one makes hipcc drain vmcnt before every ds_read while an LDS-DMA is
+    // in flight): [2][CH_LDS] sample copies | raw[1536] f32 landing zone | (mean, rstd) of 2 chunks
+    __shared__ __attribute__((aligned(256))) char lds_all[2 * CH_LDS + 1536 * 4 + 16];
+    char (*xs2)[CH_LDS] = reinterpret_cast<char (*)[CH_LDS]>(lds_all);
+    float* raw = reinterpret_cast<float*>(lds_all + 2 * CH_LDS);
+    float (*stat_s)[2] = reinterpret_cast<float (*)[2]>(lds_all + 2 * CH_LDS + 1536 * 4);
+    const int tid = threadIdx.x;
     const int w = tid >> 6, l = tid & 63, li = l & 31, g = l >> 5;
+    const int t_begin = (int)((long long)blockIdx.x * total / gridDim.x);
+    const int t_end = (int)((long long)(blockIdx.x + 1) * total / gridDim.x);
+    if (t_begin >= t_end) return;
+    const int b_first = t_begin / ntile;
 
+    // (mean, rstd) of the (at most two) chunks this range touches
+    if (tid < 2) {
+        const int bb = b_first + tid;
+        float mean = 0.f, rstd = 1.f;
+        if (bb * ntile < t_end) {
+            if (stats_are_moments)
+                dz_ws_combine(stats, bb, S, &mean, &rstd);
+            else
+                mean = stats[2 * bb], rstd = stats[2 * bb + 1];
+        }
+        stat_s[tid][0] = mean;
+        stat_s[tid][1] = rstd;
+    }
     // ---- B fragments: filters 32w + li, k = 16 ks + 8 g .. +7, hi and lo planes ------------------
     ch_f16x8 bh[16], bl[16];
     {
@@ -329,91 +355,126 @@ __global__ __launch_bounds__(192, 2) void sinc_conv0_h_kernel(
             bl[ks] = *reinterpret_cast<const ch_f16x8*>(row + 96 * 256 + 16 * ks);
         }
     }
-    // ---- samples of the tile: normalise (InstanceNorm1d(1)), split, four shifted copies -----------
-    {
-        float mean, rstd;
-        if (stats_are_moments)
-            dz_ws_combine(stats, b, S, &mean, &rstd);
-        else
-            mean = stats[2 * b], rstd = stats[2 * b + 1];
-        const float* wb = wave + (long long)b * stride;
-        const int s0 = tile * (CH_FR * 10);
-        for (int i = tid; i < (CH_NS + 6) / 2; i += 192) {
-            const int j = 2 * i, sidx = s0 + j;
-            float x0 = 0.f, x1 = 0.f;
-            if (sidx + 1 < S) {
-                const float2 v = *reinterpret_cast<const float2*>(wb + sidx);
-                x0 = v.x; x1 = v.y;
-            } else if (sidx < S) {
-                x0 = wb[sidx];
-            }
-            f32x2 x = {sidx < S ? ((x0 - mean) * rstd) * gamma + beta : 0.f,
-                       sidx + 1 < S ? ((x1 - mean) * rstd) * gamma + beta : 0.f};
-            x[0] = __builtin_amdgcn_fmed3f(x[0], -65504.f, 65504.f);
-            x[1] = __builtin_amdgcn_fmed3f(x[1], -65504.f, 65504.f);
-            const ch_f16x2 hi = __builtin_convertvector(x, ch_f16x2);
-            const ch_f16x2 lo = __builtin_convertvector((x - __builtin_convertvector(hi, f32x2)) * 2048.f, ch_f16x2);
+    __syncthreads();
+
+    // Raw samples of the NEXT tile travel global -> LDS by LDS-DMA (no registers: the resident
+    // filter fragments leave none): wave w fetches floats [512 w, 512 w + 512) of the tile's 1536-float
+    // window as two 1 KiB pieces and later parks exactly those (wave-local dependency: its own vmcnt).
+    // Samples past the end of the chunk read as zeros through the buffer bounds check.
+    auto fetch = [&](int t) {
+        const int bb = t / ntile, tile = t - bb * ntile;
+        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)(wave + (long long)bb * stride), 0, (unsigned)S * 4u, 0x00020000);
+        const int voff = (tile * (CH_FR * 10) + 512 * w + 4 * l) * 4;
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const int idx = j - 2 * c;            // copy_c[idx] = x[idx + 2c]
-                if (idx >= 0 && idx < CH_NS) {
-                    char* d = xs + ch_copy_base(c) + 2 * idx;
-                    *reinterpret_cast<ch_f16x2*>(d) = hi;
-                    *reinterpret_cast<ch_f16x2*>(d + CH_PL) = lo;
+        for (int i = 0; i < 2; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(
+                rsrc, (__attribute__((address_space(3))) void*)(raw + 512 * w + 256 * i), 16, voff + 1024 * i,
+                0, 0, 0);
+    };
+    float amax = 0.f;
+    // normalise (InstanceNorm1d(1)), split, write the four shifted copies
+    auto park = [&](int t, char* xs) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's two pieces have landed
+        const int bb = t / ntile, tile = t - bb * ntile;
+        const float mean = stat_s[bb - b_first][0], rstd = stat_s[bb - b_first][1];
+        const int s0 = tile * (CH_FR * 10);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int j = 512 * w + 2 * (l + 64 * q), sidx = s0 + j;
+            if (j < CH_NS + 6) {
+                const float2 pvq = *reinterpret_cast<const float2*>(raw + j);
+                f32x2 x = {sidx < S ? ((pvq.x - mean) * rstd) * gamma + beta : 0.f,
+                           sidx + 1 < S ? ((pvq.y - mean) * rstd) * gamma + beta : 0.f};
+                amax = fmaxf(amax, fmaxf(fabsf(x[0]), fabsf(x[1])));
+                x[0] = __builtin_amdgcn_fmed3f(x[0], -65504.f, 65504.f);
+                x[1] = __builtin_amdgcn_fmed3f(x[1], -65504.f, 65504.f);
+                const ch_f16x2 hi = __builtin_convertvector(x, ch_f16x2);
+                const ch_f16x2 lo =
+                    __builtin_convertvector((x - __builtin_convertvector(hi, f32x2)) * 2048.f, ch_f16x2);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const int idx = j - 2 * c;            // copy_c[idx] = x[idx + 2c]
+                    if (idx >= 0 && idx < CH_NS) {
+                        char* d = xs + ch_copy_base(c) + 2 * idx;
+                        *reinterpret_cast<ch_f16x2*>(d) = hi;
+                        *reinterpret_cast<ch_f16x2*>(d + CH_PL) = lo;
+                    }
                 }
             }
         }
-    }
-    __syncthreads();
+    };
 
-    // ---- three 32-row blocks: block bk = frames 3 m + bk, MFMA row li <-> pooled row m = pi(li) --
+    // MFMA row li <-> pooled row m = pi(li); block bk = frames 3 m + bk
     const int m_a = ch_pi(li);
-    ch_f32x16 pmax;
+    int aoff[3];
 #pragma unroll
     for (int bk = 0; bk < 3; ++bk) {
         const int f = 3 * m_a + bk, c = f & 3;
-        const char* ap = xs + ch_copy_base(c) + 2 * (10 * f - 2 * c + 8 * g);
-        ch_f32x16 accm, accx;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) accm[r] = accx[r] = 0.f;
-#pragma unroll
-        for (int ks = 0; ks < 16; ++ks) {
-            const ch_f16x8 ah = *reinterpret_cast<const ch_f16x8*>(ap + 32 * ks);
-            const ch_f16x8 al = *reinterpret_cast<const ch_f16x8*>(ap + CH_PL + 32 * ks);
-            accx = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[ks], accx, 0, 0, 0);
-            accm = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[ks], accm, 0, 0, 0);
-            accx = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[ks], accx, 0, 0, 0);
-        }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const float v = fabsf(accm[r] + accx[r] * (1.f / 2048.f));
-            pmax[r] = bk == 0 ? v : fmaxf(pmax[r], v);
-        }
+        aoff[bk] = ch_copy_base(c) + 2 * (10 * f - 2 * c + 8 * g);
     }
-
-    // ---- pooled rows + InstanceNorm partials: C/D column = lane & 31 = filter, row rho <-> m = pi(rho)
     const int ch = 32 * w + li;
-    float sum = 0.f, ssq = 0.f;
-    if (ch < 80) {
+
+    fetch(t_begin);
+    park(t_begin, xs2[0]);
+    __syncthreads();
+    for (int t = t_begin; t < t_end; ++t) {
+        const char* xs = xs2[(t - t_begin) & 1];
+        if (t + 1 < t_end) fetch(t + 1);
+        ch_f32x16 pmax;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int rho = (r & 3) + 8 * (r >> 2) + 4 * g;
-            const int p = tile * 32 + ch_pi(rho);
-            if (p < P0) {
-                const float v = pmax[r];
-                y0[((long long)b * P0 + p) * 80 + ch] = v;
-                sum += v;
-                ssq += v * v;
+        for (int bk = 0; bk < 3; ++bk) {
+            const char* ap = xs + aoff[bk];
+            ch_f32x16 accm, accx;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) accm[r] = accx[r] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < 16; ++ks) {
+                const ch_f16x8 ah = *reinterpret_cast<const ch_f16x8*>(ap + 32 * ks);
+                const ch_f16x8 al = *reinterpret_cast<const ch_f16x8*>(ap + CH_PL + 32 * ks);
+                accx = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[ks], accx, 0, 0, 0);
+                accm = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[ks], accm, 0, 0, 0);
+                accx = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[ks], accx, 0, 0, 0);
+                // keep the fragment reads at most four k-steps ahead of their MFMAs: hoisting all 32
+                // reads of a block (128 registers) spills the resident filter fragments
+                if ((ks & 3) == 3) asm volatile("" ::: "memory");
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float v = fabsf(accm[r] + accx[r] * (1.f / 2048.f));
+                pmax[r] = bk == 0 ? v : fmaxf(pmax[r], v);
             }
         }
+        // the next tile's samples first: parking waits for this wave's LDS-DMA (vmcnt), which must
+        // not also wait for the result stores below
+        if (t + 1 < t_end) park(t + 1, xs2[(t + 1 - t_begin) & 1]);
+        // pooled rows + InstanceNorm partials: C/D column = lane & 31 = filter, row rho <-> m = pi(rho)
+        const int bb = t / ntile, tile = t - bb * ntile;
+        float sum = 0.f, ssq = 0.f;
+        if (ch < 80) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int rho = (r & 3) + 8 * (r >> 2) + 4 * g;
+                const int p = tile * 32 + ch_pi(rho);
+                if (p < P0) {
+                    const float v = pmax[r];
+                    y0[((long long)bb * P0 + p) * 80 + ch] = v;
+                    sum += v;
+                    ssq += v * v;
+                }
+            }
+        }
+        sum += __shfl_xor(sum, 32, 64);
+        ssq += __shfl_xor(ssq, 32, 64);
+        if (ch < 80 && g == 0) {
+            float* pp = partials + (((long long)bb * ntile + tile) * 80 + ch) * 2;
+            pp[0] = sum;
+            pp[1] = ssq;
+        }
+        // LDS-only barrier (the parked copies become visible; the stores above drain on their own)
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     }
-    sum += __shfl_xor(sum, 32, 64);
-    ssq += __shfl_xor(ssq, 32, 64);
-    if (ch < 80 && g == 0) {
-        float* pp = partials + (((long long)b * ntile + tile) * 80 + ch) * 2;
-        pp[0] = sum;
-        pp[1] = ssq;
-    }
+    dz_flag_range(oflag, amax);
 }
 
 int dz_conv0_split_ntile(int F0) { return (F0 + CH_FR - 1) / CH_FR; }
@@ -423,9 +484,11 @@ int dz_conv0_split_ntile(int F0) { return (F0 + CH_FR - 1) / CH_FR; }
 int dz_launch_sinc_conv0_split(const float* wave, long long stride, int B, int S, const float* stats,
                                int stats_are_moments, float gamma, float beta, const void* fsp,
                                float* y0, int P0, float* partials, int ntile, hipStream_t st) {
-    DZ_LAUNCH(sinc_conv0_h_kernel, dim3(ntile, B), dim3(192), 0, st, wave, stride, S, stats,
+    const int total = ntile * B;
+    const int grid = total < 512 ? total : 512;    // two resident workgroups per CU
+    DZ_LAUNCH(sinc_conv0_h_kernel, dim3(grid), dim3(192), 0, st, wave, stride, S, stats,
               stats_are_moments, gamma, beta, reinterpret_cast<const unsigned short*>(fsp), y0, P0,
-              partials, ntile);
+              partials, ntile, total, dz_cur_oflag);
     DZ_HIP(hipGetLastError());
     return 0;
 }

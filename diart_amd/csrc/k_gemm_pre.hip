@@ -137,6 +137,7 @@ __global__ __launch_bounds__(256, 2) void gemm_pre_kernel(DzConvGemm p) {
     // (hi, lo) plane output: see dz_store_split; columns >= Nstore of a padded layer are written
     // as zeros (they are K padding of the consumer)
     unsigned short* Ypl = p.Ysplit ? dz_split_base(p.Ysplit, p.yplane, li & 1) : nullptr;
+    float amax = 0.f;
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) {
         const int n = n0 + wn * 64 + nt * 32 + li;
@@ -158,9 +159,10 @@ __global__ __launch_bounds__(256, 2) void gemm_pre_kernel(DzConvGemm p) {
                 if (EPI == DZ_EPI_RELU_BN) v = fmaxf(v, 0.f) * e0 + e1;
                 const bool ok = t < p.Tout;
                 if (p.Y && ok && nok) p.Y[(long long)t * p.ldy + n] = v;
-                if (Ypl) dz_store_split(Ypl, (long long)t * p.ldy + n, nok ? v : 0.f, ok, li & 1);
+                if (Ypl) dz_store_split(Ypl, (long long)t * p.ldy + n, nok ? v : 0.f, ok, li & 1, amax);
             }
     }
+    dz_flag_range(p.oflag, amax);
 }
 
 template <int EPI>
@@ -175,7 +177,9 @@ int launch(const DzConvGemm& p, hipStream_t st) {
 
 }  // namespace
 
-int dz_launch_gemm_pre(const DzConvGemm& p, hipStream_t st) {
+int dz_launch_gemm_pre(const DzConvGemm& p_in, hipStream_t st) {
+    DzConvGemm p = p_in;
+    if (!p.oflag) p.oflag = dz_cur_oflag;
     DZ_REQUIRE(p.Wsplit != nullptr && p.Xsplit != nullptr,
                "gemm_pre: Wsplit / Xsplit (f16 hi/lo planes of W and of the input) are NULL");
     DZ_REQUIRE(p.Y != nullptr || p.Ysplit != nullptr, "gemm_pre: no output");

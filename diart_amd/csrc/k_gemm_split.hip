@@ -52,9 +52,10 @@ __device__ __forceinline__ int chunk_off(int row, int cidx) {
 constexpr float LO_SCALE = 2048.f, LO_UNSCALE = 1.f / 2048.f;
 constexpr float F16_MAX = 65504.f;
 // 8 floats -> 8 f16 hi + 8 f16 lo (lo scaled by 2^11)
-__device__ __forceinline__ void split8(const float* v, u32x4& hi, u32x4& lo) {
+__device__ __forceinline__ void split8(const float* v, u32x4& hi, u32x4& lo, float& amax) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
+        amax = fmaxf(amax, fmaxf(fabsf(v[2 * e]), fabsf(v[2 * e + 1])));
         const f32x2 x = {__builtin_amdgcn_fmed3f(v[2 * e], -F16_MAX, F16_MAX),
                          __builtin_amdgcn_fmed3f(v[2 * e + 1], -F16_MAX, F16_MAX)};
         const f16x2 h = __builtin_convertvector(x, f16x2);
@@ -96,6 +97,7 @@ __global__ __launch_bounds__(128 * WM) void gemm_split_kernel(DzConvGemm p) {
     const unsigned short* Wlo = Whi + (long long)p.Npad * p.Kpad;
     const long long wofs = (long long)(n0 + (has_b ? crow : 0)) * p.Kpad + cidx * 8;
 
+    float amax = 0.f;          // largest |operand| this thread split (reported beyond +-65504)
     struct Regs {
         f32x4 ra[2];
         u32x4 rbh, rbl;
@@ -147,7 +149,7 @@ __global__ __launch_bounds__(128 * WM) void gemm_split_kernel(DzConvGemm p) {
             v[4 + e] = R.ra[1][e];
         }
         u32x4 hi, lo;
-        split8(v, hi, lo);
+        split8(v, hi, lo, amax);
         *reinterpret_cast<u32x4*>(st + off) = hi;
         *reinterpret_cast<u32x4*>(st + C::APLANE + off) = lo;
         if (has_b) {
@@ -210,6 +212,8 @@ __global__ __launch_bounds__(128 * WM) void gemm_split_kernel(DzConvGemm p) {
         lds_barrier();
     }
 
+    dz_flag_range(p.oflag, amax);
+    amax = 0.f;
     // ---- epilogue: C/D map col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5) -----
     if (EPI == DZ_EPI_POOL3) {
         // conv (+bias) -> LDS tile -> MaxPool1d(3,3) over time -> pooled rows + stats partials
@@ -271,9 +275,10 @@ __global__ __launch_bounds__(128 * WM) void gemm_split_kernel(DzConvGemm p) {
             if (EPI == DZ_EPI_TDNN) v = leaky(v) * e0 + e1;
             if (EPI == DZ_EPI_RELU_BN) v = fmaxf(v, 0.f) * e0 + e1;
             if (Yb && ok && nok) Yb[(long long)t * p.ldy + n] = v;
-            if (Ypl) dz_store_split(Ypl, (long long)t * p.ldy + n, nok ? v : 0.f, ok, li & 1);
+            if (Ypl) dz_store_split(Ypl, (long long)t * p.ldy + n, nok ? v : 0.f, ok, li & 1, amax);
         }
     }
+    dz_flag_range(p.oflag, amax);
 }
 
 template <int WM, int NB, bool PRO, int EPI>
@@ -289,7 +294,9 @@ int launch(const DzConvGemm& p, hipStream_t st) {
 
 }  // namespace
 
-int dz_launch_gemm_split(const DzConvGemm& p, hipStream_t st) {
+int dz_launch_gemm_split(const DzConvGemm& p_in, hipStream_t st) {
+    DzConvGemm p = p_in;
+    if (!p.oflag) p.oflag = dz_cur_oflag;
     DZ_REQUIRE(p.Wsplit != nullptr, "gemm_split: Wsplit (f16 hi/lo planes of W) is NULL");
     DZ_REQUIRE(p.Kpad % KT == 0 && p.Cin % 8 == 0 && p.ldx % 4 == 0 && p.K % 8 == 0,
                "gemm_split: bad K/Cin/ldx (Cin and K must be multiples of 8)");

@@ -89,3 +89,37 @@ def gather_counts(values: Sequence[float], device: torch.device) -> List[List[fl
     bufs = [torch.empty_like(t) for _ in range(dist.get_world_size())]
     dist.all_gather(bufs, t)
     return [b.tolist() for b in bufs]
+
+
+def timed_max_over_ranks(fn, device: Optional[torch.device] = None) -> float:
+    """The timing bracket of ``bench.py``: barrier + device synchronise on both sides of ``fn()``,
+    then the MAXIMUM elapsed time over the ranks (the job is as slow as its slowest rank).  Works
+    without a process group (world 1) and without a GPU (``device`` None / CPU: gloo tests)."""
+    import time
+    multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    on_gpu = device is not None and device.type == "cuda"
+
+    def fence():
+        if on_gpu:
+            torch.cuda.synchronize(device)
+        if multi:
+            dist.barrier()
+        if on_gpu:
+            torch.cuda.synchronize(device)
+
+    fence()
+    t0 = time.perf_counter()
+    fn()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if multi:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device if on_gpu else None)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    return elapsed
+
+
+def whole_job_rate(units_per_rank_per_step: int, steps: int, elapsed_max: float, world: int) -> float:
+    """Units per second of the WHOLE job under weak scaling: every rank processed
+    ``units_per_rank_per_step * steps`` units in (at most) ``elapsed_max`` seconds."""
+    return world * units_per_rank_per_step * steps / elapsed_max

@@ -191,7 +191,9 @@ except ImportError:
             return out
 
         def support(self, collar: float = 0.0) -> "Annotation":
-            """Merge same-label turns closer than ``collar``."""
+            """Merge same-label turns that touch / overlap or whose gap is SHORTER than ``collar``
+            (pyannote.core ``Timeline.support``: ``gap.duration < collar``, strict; a gap below the
+            1e-6 s segment precision counts as empty)."""
             out = Annotation(self.uri, self.modality)
             by_label = {}
             for (seg, _), label in self._tracks.items():
@@ -200,7 +202,8 @@ except ImportError:
                 segs.sort()
                 cur_s, cur_e, n = segs[0].start, segs[0].end, 0
                 for seg in segs[1:]:
-                    if seg.start <= cur_e + collar:
+                    gap = seg.start - cur_e
+                    if gap <= 1e-6 or gap < collar:
                         cur_e = max(cur_e, seg.end)
                     else:
                         out[Segment(cur_s, cur_e), f"{label}_{n}"] = label

@@ -329,6 +329,7 @@ class StreamBatch:
         while ticket["pool"] is not None:               # its pooling is still held back: flush in order
             self._enqueue_pool(self._pending.pop(0))
         ticket["done"].synchronize()
+        _lib.range_check(self.device.index)      # an f16x3 operand beyond +-65504 is an error, not a clamp
         N, slots = ticket["rows"], ticket["slots"]
         seg = ticket["seg_h"].numpy()[:N]
         emb = ticket["emb_h"].numpy()[:N]

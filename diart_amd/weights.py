@@ -80,7 +80,11 @@ def split_f16(w: torch.Tensor) -> torch.Tensor:
     """f32 matrix ``[N][K]`` -> int16 ``[2][N][K]`` of IEEE f16 bit patterns: plane 0 ``hi = f16(w)``,
     plane 1 ``lo = f16((w - hi) * 2^11)`` — the two-term split ``k_gemm_split.hip`` multiplies with
     (``w = hi + lo * 2^-11`` to 22 mantissa bits; the scale keeps ``lo`` a normal f16)."""
-    w = w.detach().float().cpu().contiguous().clamp(-65504.0, 65504.0)
+    w = w.detach().float().cpu().contiguous()
+    big = float(w.abs().max()) if w.numel() else 0.0
+    if big > 65504.0:
+        raise ValueError(f"split_f16: |value| up to {big:g} does not fit the f16 range (+-65504) of the "
+                         "\"f16x3\" arithmetic; load the model with precision=\"f32\"")
     hi = w.to(torch.float16)
     lo = ((w - hi.float()) * 2048.0).to(torch.float16)
     return torch.stack([hi, lo]).view(torch.int16).contiguous()

@@ -35,6 +35,11 @@ int dz_version(void);
 /* one context per (process, GPU) */
 int dz_ctx_create(int hip_device, dz_ctx** out);
 int dz_ctx_destroy(dz_ctx* ctx);
+/* The default arithmetic ("f16x3") represents every GEMM operand as two f16 numbers, i.e. |x| <=
+ * 65504; an f32 reference has no such limit.  Operands beyond it are clamped AND flagged: this
+ * returns 0 if no kernel of the context has seen one since the last reset, 6 (with a message)
+ * otherwise.  Call it after the stream(s) have been synchronised; reset != 0 clears the flag.   */
+int dz_range_check(dz_ctx* ctx, int reset);
 
 /* SincNet(stride 10) frame count for a chunk of `num_samples` (293 for 80000):
  * the F of SegmentationModel's (batch, frames, speakers) output,
@@ -237,6 +242,9 @@ typedef struct {
     long long xplane;
     void* Ysplit;
     long long yplane;
+    int* oflag;           /* device-visible int set to 1 when an operand of the split-f16 path lies
+                             outside +-65504 (it is then clamped); NULL = the context's flag, read
+                             with dz_range_check                                                 */
 } dz_convgemm_desc;
 int dz_k_convgemm(dz_ctx* ctx, const dz_convgemm_desc* desc, void* stream);
 /* the same layer on the split-f16 matrix-core path (desc->Wsplit must be set)       */

@@ -138,9 +138,27 @@ def tail(ref):
     print("tail:", len(out), "arrays")
 
 
+def rttm_slice():
+    """The first 40 lines of two meetings of the reference's expected_outputs/online/0.5s/AMI.rttm
+    (paper-implementation output): an RTTM I/O fixture for features.load_rttm / Annotation.to_rttm."""
+    src = Path("/root/reference/expected_outputs/online/0.5s/AMI.rttm")
+    per, keep = {}, []
+    for line in src.read_text().splitlines():
+        uri = line.split()[1]
+        if len(per) < 2 or uri in per:
+            per[uri] = per.get(uri, 0) + 1
+            if per[uri] <= 40:
+                keep.append(line)
+    (OUT / "ami_0.5s_slice.rttm").write_text("\n".join(keep) + "\n")
+    print("rttm slice:", {u: min(n, 40) for u, n in per.items()})
+
+
 if __name__ == "__main__":
-    if "--tail-only" in sys.argv:
+    if "--rttm-only" in sys.argv:
+        rttm_slice()
+    elif "--tail-only" in sys.argv:
         tail(load_reference())
     else:
         main()
         tail(load_reference())
+        rttm_slice()

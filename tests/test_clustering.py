@@ -138,3 +138,21 @@ def test_argument_errors():
     clu(_swf(np.ones((10, 3), np.float32)), torch.randn(3, 8))
     with pytest.raises(_lib.DiartAmdError):
         clu(_swf(np.ones((10, 3), np.float32)), torch.randn(3, 9))    # dimension changed
+
+
+def test_more_first_chunk_speakers_than_slots_stay_unmapped():
+    """max_speakers < K on the very first chunk: the reference's ``centers[None] = emb`` overwrites
+    every centroid (undefined results, clustering.py:101-117); here the speakers that found no slot
+    are left unmapped for this chunk and the stream carries on (cluster.cpp)."""
+    rng = np.random.default_rng(0)
+    clu = OnlineSpeakerClustering(0.5, 0.3, 1.0, "cosine", 2)
+    seg = np.full((20, 3), 0.9, dtype=np.float32)
+    emb = rng.standard_normal((3, 16)).astype(np.float32)
+    emb /= np.linalg.norm(emb, axis=1, keepdims=True)
+    out = clu(_swf(seg), torch.from_numpy(emb))
+    assert out.data.shape == (20, 2)
+    assert np.array_equal(out.data[:, 0], seg[:, 0].astype(np.float64))
+    assert np.array_equal(out.data[:, 1], seg[:, 1].astype(np.float64))      # third speaker: nowhere
+    assert clu.active_centers == {0, 1}
+    out2 = clu(_swf(seg), torch.from_numpy(emb))                             # and the stream continues
+    assert out2.data.shape == (20, 2) and np.isfinite(out2.data).all()

@@ -1,11 +1,9 @@
 """Whole-network parity on the GPU: the HIP path (through the C ABI and the operator API) vs the
 CPU oracle (oracle/models_ref.py) on the same seeded weights and synthetic audio.
 
-Tolerances (stated, north-star: "within a stated tolerance"): the oracle evaluated in fp32 differs
-from the same oracle in fp64 by up to 8e-5 on the segmentation activations with these weights
-(measured, recurrent fp32 round-off through 4 BiLSTM layers x 293 steps); the HIP path is another
-fp32 summation order, so the gate is 5e-4 max-abs / 3e-5 mean-abs for segmentation and
-cosine >= 0.99999 for embeddings.
+Tolerances (stated, north-star: "within a stated tolerance"; SURVEY.md 8c / BASELINE.md 4.6): segmentation
+max|d| <= 1e-4, mean|d| <= 3e-5 (observed ~9e-6 / ~9e-7: the HIP path is another fp32 summation
+order through 4 BiLSTM layers x 293 steps); embeddings cosine >= 0.99999 and relative L2 <= 1e-4.
 """
 import numpy as np
 import pytest
@@ -17,7 +15,7 @@ from diart_amd.synth import (sliding_chunks, synth_embedding_state, synth_segmen
 
 pytestmark = pytest.mark.gpu
 
-SEG_MAX, SEG_MEAN, EMB_COS = 5e-4, 3e-5, 0.99999
+SEG_MAX, SEG_MEAN, EMB_COS = 1e-4, 3e-5, 0.99999     # seg max|d| <= 1e-4
 
 
 @pytest.fixture(scope="module")

@@ -17,7 +17,7 @@ from diart_amd.synth import synth_embedding_state, synth_segmentation_state, syn
 
 pytestmark = pytest.mark.gpu
 
-SEG_MAX, EMB_COS = 5e-4, 0.99999
+SEG_MAX, EMB_COS = 1e-4, 0.99999
 
 
 @pytest.fixture(scope="module")

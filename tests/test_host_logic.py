@@ -134,6 +134,49 @@ def test_weight_broadcast_world_size_2_gloo(tmp_path):
         assert f"rank {rank} ok" in o
 
 
+BENCH_WORKER = r'''
+import sys, time, torch
+sys.path.insert(0, sys.argv[1])
+from diart_amd import distributed as D
+from diart_amd.synth import (embedding_spec, segmentation_spec, synth_embedding_state,
+                             synth_segmentation_state)
+rank, world, local = D.init_from_env("gloo")
+cpu = torch.device("cpu")
+# bench.py's weight path: ONLY rank 0 has (synthesises / loads) the weights; the other ranks know
+# the architecture and receive the values
+seg = D.broadcast_state(synth_segmentation_state() if rank == 0 else None, segmentation_spec(), cpu)
+emb = D.broadcast_state(synth_embedding_state() if rank == 0 else None, embedding_spec(), cpu)
+ref_s, ref_e = synth_segmentation_state(), synth_embedding_state()
+assert all(torch.equal(seg[k].float(), ref_s[k].float()) and seg[k].dtype == ref_s[k].dtype for k in ref_s)
+assert all(torch.equal(emb[k].float(), ref_e[k].float()) and emb[k].dtype == ref_e[k].dtype for k in ref_e)
+# bench.py's timing bracket with a stub "pipeline": rank 1 is the slow one
+steps, units = 5, 64
+calls = []
+def run():
+    for _ in range(steps):
+        calls.append(1)
+        time.sleep(0.02 if rank == 0 else 0.06)
+elapsed = D.timed_max_over_ranks(run, None)
+assert len(calls) == steps
+assert 0.29 <= elapsed < 1.0, elapsed              # both ranks report the SLOW rank's 5 x 60 ms
+rate = D.whole_job_rate(units, steps, elapsed, world)
+assert abs(rate - 2 * 64 * 5 / elapsed) < 1e-9
+allv = D.gather_counts([elapsed], cpu)
+assert abs(allv[0][0] - allv[1][0]) < 1e-12          # identical on every rank
+print("rank", rank, "bench-bracket ok", round(elapsed, 3))
+'''
+
+
+def test_bench_weight_path_and_timing_bracket_world_size_2_gloo(tmp_path):
+    """The multi-rank logic of bench.py on CPU: architecture-derived specs (no weights on the
+    receiving ranks), barrier-bracketed timing with the maximum over ranks, whole-job rate."""
+    script = tmp_path / "bench_worker.py"
+    script.write_text(BENCH_WORKER)
+    for rank, (p, o) in enumerate(_two_ranks(script, [ROOT])):
+        assert p.returncode == 0, o
+        assert f"rank {rank} bench-bracket ok" in o
+
+
 def test_sinc_fold_identity():
     """The folded bank sinc_conv0 consumes reproduces the plain 251-tap convolution
     (cos filters even, sin filters odd: SURVEY.md A.1), and an asymmetric bank is refused."""

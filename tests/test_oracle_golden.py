@@ -94,3 +94,4 @@ def test_committed_goldens_regenerate_from_the_reference(tmp_path):
         assert set(a.files) == set(b.files), name
         for k in a.files:
             assert np.array_equal(a[k], b[k], equal_nan=True), (name, k)
+    assert (gold / "ami_0.5s_slice.rttm").read_text() == (tmp_path / "ami_0.5s_slice.rttm").read_text()

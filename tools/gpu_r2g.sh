@@ -15,7 +15,7 @@ for cfg in $GRID; do
   IFS=, read l d c0 pre <<< "$cfg"
   sh=1; [ "$l" = "valu" ] && sh=0
   echo "=== bench lstm=$l depth=$d conv0_split=$c0 pre=$pre shared_emb=$sh" >> $OUT
-  DZ_CONV0_SPLIT=$c0 DZ_GEMM_PRE=$pre DZ_SHARED_EMB=$sh DZ_LSTM=$l DZ_DEPTH=$d timeout 300 python bench.py --steps 60 --warmup 5 --no-cpu-baseline --no-exact-f32 \
+  DZ_CONV0_SPLIT=$c0 DZ_GEMM_PRE=$pre DZ_SHARED_EMB=$sh DZ_LSTM=$l DZ_DEPTH=$d timeout 300 python bench.py --steps ${STEPS:-200} --warmup 10 --no-cpu-baseline --no-exact-f32 \
       > gpurun_out/bench_${TAG}_${l}_${d}_${c0}_${pre}.json 2>gpurun_out/bench_${TAG}_${l}_${d}_${c0}_${pre}.err
   python - <<PY >> $OUT
 import json
