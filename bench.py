@@ -103,6 +103,9 @@ def device_kernel(tag, precision):
     if pre and tag in ("tdnn2", "tdnn3", "tdnn4", "tdnn5", "lstm_proj", "seg_mlp"):
         sym = {"lstm_proj": "gemm_pre_kernel<0>", "seg_mlp": "gemm_pre_kernel<1>"}.get(tag, "gemm_pre_kernel<3>")
         return sym, "mfma", PEAK_F16_MATRIX_TFLOPS / SPLIT_PRODUCTS, "TFLOP/s"
+    if tag in ("conv1_pool", "conv2_pool") and os.environ.get("DZ_CONV_POOL", "1") != "0":
+        return ("conv_pool_h_kernel<80>" if tag == "conv1_pool" else "conv_pool_h_kernel<64>"), "mfma", \
+            PEAK_F16_MATRIX_TFLOPS / SPLIT_PRODUCTS, "TFLOP/s"
     sym = {"conv1_pool": "gemm_split_kernel<3, 1, true, 4>", "conv2_pool": "gemm_split_kernel<3, 1, true, 4>",
            "lstm_proj": "gemm_split_kernel<4, 2, false, 0>", "lstm_proj0": "gemm_split_kernel<4, 2, true, 0>",
            "seg_mlp": "gemm_split_kernel<4, 2, false, 1>", "tdnn1": "gemm_split_kernel<4, 2, true, 3>",
@@ -385,14 +388,22 @@ def main():
 
         feed = torch.cuda.Stream(device)     # uploads + the launch's input event: off the default stream
 
+        hf = {"push": 0.0, "launch": 0.0, "finish": 0.0}
+
         def run_ring(first, count):
             inflight = []
             for t in range(first, first + count):
+                h0 = time.perf_counter()
                 with torch.cuda.stream(feed):
                     ring.push(pinned[S // hop - 1 + t])
+                    h1 = time.perf_counter()
                     inflight.append(pipe.launch(ring))
+                h2 = time.perf_counter()
                 if len(inflight) > pipe.depth:
                     pipe.finish(inflight.pop(0), want_scores=True)
+                hf["push"] += h1 - h0
+                hf["launch"] += h2 - h1
+                hf["finish"] += time.perf_counter() - h2
             while inflight:
                 pipe.finish(inflight.pop(0), want_scores=True)
 
@@ -402,7 +413,9 @@ def main():
                     "h2d_bytes_per_step": n * hop * 4,
                     "note": "PCIe-inclusive: per step the 8000 new samples of every stream go pinned host -> "
                             "device ring (dz_ring_push), the window is read in place; not `value`"}
-        log(f"host-fed pass: {eh:.3f}s")
+        log(f"host-fed pass: {eh:.3f}s; host time per step: push {1e3 * hf['push'] / (args.steps + args.warmup):.3f} ms, "
+            f"launch {1e3 * hf['launch'] / (args.steps + args.warmup):.3f} ms, finish "
+            f"{1e3 * hf['finish'] / (args.steps + args.warmup):.3f} ms")
 
     if rank == 0:
         cps = D.whole_job_rate(n, args.steps, elapsed, world)

@@ -216,10 +216,16 @@ static bool pre_split_enabled() {
     return !(v && v[0] == '0');
 }
 
+static bool conv_pool_enabled() {
+    const char* v = getenv("DZ_CONV_POOL");
+    return !(v && v[0] == '0');
+}
+
 // exact-f32 MFMA kernel, or the split-f16 kernel when the layer came with split planes
 static int run_gemm(DzConvGemm& p, const void* split, hipStream_t st) {
     if (split) {
         p.Wsplit = split;
+        if (p.epi == DZ_EPI_POOL3 && conv_pool_enabled()) return dz_launch_conv_pool(p, st);
         return dz_launch_gemm_split(p, st);
     }
     return dz_launch_convgemm(p, st);
@@ -708,6 +714,12 @@ extern "C" int dz_k_gemm_pre(dz_ctx* ctx, const dz_convgemm_desc* d, void* strea
     DZ_HIP(hipSetDevice(ctx->device));
     DzRangeScope range_scope(ctx->oflag_dev);
     return dz_launch_gemm_pre(*d, (hipStream_t)stream);
+}
+extern "C" int dz_k_conv_pool(dz_ctx* ctx, const dz_convgemm_desc* d, void* stream) {
+    DZ_REQUIRE(ctx && d, "dz_k_conv_pool: NULL argument");
+    DZ_HIP(hipSetDevice(ctx->device));
+    DzRangeScope range_scope(ctx->oflag_dev);
+    return dz_launch_conv_pool(*d, (hipStream_t)stream);
 }
 extern "C" int dz_k_convgemm_ntile(int t_out) { return dz_convgemm_ntile(t_out); }
 extern "C" int dz_k_wave_stats(dz_ctx* ctx, const float* d_wave, long long stride, int batch,

@@ -178,6 +178,9 @@ int dz_launch_convgemm(const DzConvGemm& p, hipStream_t st);
 // k_gemm_split.hip: the same contraction on the f16 matrix cores with both operands split into
 // (hi, lo) f16 pairs — 3 MFMAs per product, f32 accumulation
 int dz_launch_gemm_split(const DzConvGemm& p, hipStream_t st);
+// k_conv_pool.hip: SincNet stages 1 / 2 (k = 5 conv + MaxPool1d(3) + partials) with the input tile
+// resident in LDS and the weights in registers; descriptor as the POOL3 call of dz_launch_gemm_split
+int dz_launch_conv_pool(const DzConvGemm& p, hipStream_t st);
 // k_gemm_pre.hip: both operands pre-split into f16 planes, tiles loaded by LDS-DMA
 int dz_launch_gemm_pre(const DzConvGemm& p, hipStream_t st);
 int dz_convgemm_ntile(int Tout);

@@ -252,6 +252,10 @@ int dz_k_gemm_split(dz_ctx* ctx, const dz_convgemm_desc* desc, void* stream);
 /* ... with the activations pre-split as well (desc->Wsplit and desc->Xsplit set; B = 1, K = taps*Cin
  * unpadded, Cin % 32 == 0): operand tiles go global -> LDS by LDS-DMA                            */
 int dz_k_gemm_pre(dz_ctx* ctx, const dz_convgemm_desc* desc, void* stream);
+/* SincNet stages 1 / 2 (DZ_EPI_POOL3, k = 5, 64 output columns, Cin 80 or 64, norm-on-load, dense
+ * rows) on the dedicated kernel: input tile resident in LDS, weights in registers; same
+ * descriptor, outputs and partials as the POOL3 call of dz_k_gemm_split                       */
+int dz_k_conv_pool(dz_ctx* ctx, const dz_convgemm_desc* desc, void* stream);
 int dz_k_convgemm_ntile(int t_out);
 /* d_stats (B, 2) = (mean, 1/sqrt(biased var + 1e-5)) of each window: InstanceNorm1d(1).  Inside
  * the forward passes the 8 slice moments stay separate and the consumer merges them; this entry

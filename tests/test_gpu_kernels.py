@@ -167,7 +167,8 @@ def _run_convgemm(gpu, X, W, bias, *, taps, dil, epi, Npad, Nstore, Kpad, e0=Non
         ws = split_f16(W).to(gpu)
         d.Wsplit = ws.data_ptr()
         keep.append(ws)
-        _lib.check(lib.dz_k_gemm_split(_ctx(gpu), C.byref(d), None), "dz_k_gemm_split")
+        fn = lib.dz_k_conv_pool if split == "convpool" else lib.dz_k_gemm_split
+        _lib.check(fn(_ctx(gpu), C.byref(d), None), "dz_k_gemm_split / dz_k_conv_pool")
     else:
         _lib.check(lib.dz_k_convgemm(_ctx(gpu), C.byref(d), None), "dz_k_convgemm")
     _sync()
@@ -252,9 +253,11 @@ def test_convgemm_tdnn(gpu, Cin, Cout, taps, dil, Tin, split):
     assert (got - ref).abs().max().item() < 3e-5 * max(1.0, ref.abs().max().item())
 
 
-@pytest.mark.parametrize("Cin,Tin", [(80, 2658), (60, 884)])
-@pytest.mark.parametrize("split", [False, True], ids=["f32", "f16x3"])
+@pytest.mark.parametrize("Cin,Tin", [(80, 2658), (60, 884), (60, 101), (80, 389)])
+@pytest.mark.parametrize("split", [False, True, "convpool"], ids=["f32", "f16x3", "convpool"])
 def test_convgemm_pool3(gpu, Cin, Tin, split):
+    """SincNet stages 1 / 2: the exact-f32 GEMM, the split-f16 GEMM and the dedicated
+    k_conv_pool.hip kernel (input tile resident in LDS, weights in registers) — same gates."""
     g = torch.Generator().manual_seed(Cin)
     B, Cout, taps = 2, 60, 5
     cin_pad = 80 if Cin == 80 else 64

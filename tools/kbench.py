@@ -96,6 +96,15 @@ def convgemm(name, Bn, Tin, Cin, N, taps, dil, epi, Npad=None, pro=False, pool=F
         mx = ((Y - y32).abs().max() / y32.abs().max()).item()
         results[name + "_split"]["rel_l2_vs_f32"] = err
         print(f"    {name}_split vs f32 kernel: rel L2 {err:.2e}, max|d|/max|y| {mx:.2e}", flush=True)
+        if pool:
+            Y.zero_()
+            only.clear()
+            timeit(name + "_convpool", lambda: _lib.check(lib.dz_k_conv_pool(ctx, C.byref(d), st), name), flop=flop)
+            only.update(only_saved)
+            torch.cuda.synchronize()
+            err = ((Y - y32).norm() / y32.norm()).item()
+            results[name + "_convpool"]["rel_l2_vs_f32"] = err
+            print(f"    {name}_convpool vs f32 kernel: rel L2 {err:.2e}", flush=True)
     if not ksplit and not pro and not pool and Cin % 32 == 0 and Npad % 128 == 0 and (not only or name + "_pre" in only or name in only):
         # k_gemm_pre.hip: flattened rows, both operands as f16 planes, f32 and plane output
         from diart_amd.weights import split_f16
