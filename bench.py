@@ -380,7 +380,7 @@ def main():
     host_fed = None
     if not args.no_host_pass:
         from diart_amd.pipeline import AudioRing
-        ring = AudioRing(n, S, hop, slack_blocks=pipe.depth + 1, device=device)
+        ring = AudioRing(n, S, hop, slack_blocks=2 * pipe.depth + 2, device=device)   # >= steps in flight (depth + lag + 1)
         blocks = audio_cpu.unfold(1, hop, hop)                     # (n, nblocks, hop) view
         pinned = [blocks[:, i].contiguous().pin_memory() for i in range(S // hop + total_steps)]
         for i in range(S // hop - 1):

@@ -84,8 +84,17 @@ class AudioRing:
         self._keep = (self._keep + [block])[-4:]
         return self.filled == self.window
 
-    def _read_by(self, events: List[torch.cuda.Event]):
-        self._readers.append(list(events))
+    def _read_by(self, streams: List[torch.cuda.Stream]):
+        """Called right after forward passes that read the current window were enqueued on
+        ``streams``: records the ring's OWN events there (a caller's per-slot events are re-recorded
+        when the slot is reused — waiting on such an event later means waiting for the NEWEST step
+        that used the slot, which silently serialised consecutive steps)."""
+        evs = []
+        for st in streams:
+            ev = torch.cuda.Event()
+            ev.record(st)
+            evs.append(ev)
+        self._readers.append(evs)
 
     def raw(self) -> Tuple[int, int]:
         ptr, stride = _lib.vp(), C.c_longlong()
@@ -286,7 +295,7 @@ class StreamBatch:
         slot["keep"] = rows                              # keep the view alive until the GPU is done
         slot["pool"] = (lane, hembs, sa, sb, N, K, F)     # what _enqueue_pool needs
         if ring is not None:                             # pushes `slack` steps from now wait for these
-            ring._read_by(slot["ev_seg"] + slot["ev_frames"])
+            ring._read_by(list(lane["a"]) + list(lane["b"]))
         self._pending.append(slot)
         while len(self._pending) > self.lag:
             self._enqueue_pool(self._pending.pop(0))
