@@ -88,7 +88,8 @@ def device_kernel(tag, precision):
         return {"wave_stats": "wave_stats_kernel", "stats_pool": "stats_pool_kernel<3>"}[tag], "hbm", PEAK_HBM_GBPS, "GB/s"
     if k["bound"] == "rec":
         if split and lstm != "valu":
-            sym = "lstm_mfma_kernel<true>" if lstm == "0" else "lstm_mfma1_kernel<true, %d>" % (0 if lstm == "1" else 8)
+            sym = {"0": "lstm_mfma_kernel<true>", "3": "lstm_mfma_dma_kernel"}.get(
+                lstm, "lstm_mfma1_kernel<true, %d>" % (0 if lstm == "1" else 8))
             return sym, "mfma", PEAK_F16_MATRIX_TFLOPS / SPLIT_PRODUCTS, "TFLOP/s"
         return "lstm_rec_kernel<true>", "valu", PEAK_F32_VECTOR_TFLOPS, "TFLOP/s"
     if tag == "sinc_conv0" and split and os.environ.get("DZ_CONV0_SPLIT", "1") != "0":
@@ -354,12 +355,14 @@ def main():
     log("warm-up done")
     lib.dz_prof_enable(0 if os.environ.get("DZ_NO_PROF") else 1)
     host["launch"] = host["finish"] = 0.0
+    pipe.host_seconds["wait"] = pipe.host_seconds["work"] = 0.0
     # barrier + synchronize on both sides, max over ranks (diart_amd.distributed.timed_max_over_ranks)
     elapsed = D.timed_max_over_ranks(
         lambda: run(args.warmup, args.steps, profiled=not os.environ.get("DZ_NO_PROF")), device)
+    hs = pipe.host_seconds
     log(f"timed region done: {elapsed:.3f}s for {args.steps} steps; host time per step: launch "
-        f"{1e3 * host['launch'] / args.steps:.3f} ms, finish (wait + clustering + tail) "
-        f"{1e3 * host['finish'] / args.steps:.3f} ms")
+        f"{1e3 * host['launch'] / args.steps:.3f} ms, finish {1e3 * host['finish'] / args.steps:.3f} ms = waiting for "
+        f"the GPU {1e3 * hs['wait'] / args.steps:.3f} + clustering / tail {1e3 * hs['work'] / args.steps:.3f}")
     lib.dz_prof_collect()
     table = kernel_table(lib)             # read before dz_prof_enable(0) clears the accumulators
     lib.dz_prof_enable(0)
@@ -468,7 +471,7 @@ def main():
                 cus = min(256.0, 2.0 * v["chunks"] / v["launches"])   # one (chunk, direction) chain per CU
                 e["cus_occupied"] = cus
                 e["frac_of_occupied_cus_plain_fma"] = round(ach / (PEAK_F32_VECTOR_TFLOPS / 2 * cus / 256.0), 4)
-            if g.startswith("lstm_mfma_kernel"):
+            if g.startswith("lstm_mfma"):
                 e["cus_occupied"] = min(256.0, 2.0 * -(-v["chunks"] / v["launches"] // 16))  # 16 chains per workgroup
                 e["frac_of_occupied_cus"] = round(ach / (v["peak"] * e["cus_occupied"] / 256.0), 4)
             return e

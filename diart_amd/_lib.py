@@ -140,7 +140,8 @@ class ConvGemmDesc(C.Structure):
         ("xbs", C.c_longlong), ("ybs", C.c_longlong), ("norm_on_load", C.c_int), ("epi", C.c_int),
         ("ksplit", C.c_int), ("ysplit", C.c_longlong), ("agroup", C.c_int), ("pad", C.c_int),
         ("X2", vp), ("rowbias", vp), ("Wsplit", vp), ("Xsplit", vp), ("xplane", C.c_longlong),
-        ("Ysplit", vp), ("yplane", C.c_longlong), ("oflag", vp)]
+        ("Ysplit", vp), ("yplane", C.c_longlong), ("npart", vp), ("ngamma", vp), ("nbeta", vp),
+        ("npart_tiles", C.c_int), ("npart_T", C.c_int), ("oflag", vp)]
 
 
 (EPI_BIAS, EPI_BIAS_LEAKY, EPI_BIAS_SIGMOID, EPI_TDNN, EPI_POOL3, EPI_BIAS_RELU, EPI_RELU_BN,

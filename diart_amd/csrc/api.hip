@@ -216,6 +216,22 @@ static bool pre_split_enabled() {
     return !(v && v[0] == '0');
 }
 
+// DZ_SKIP=<bit mask> (timing experiments only — results are garbage): drop a class of launches to
+// measure its marginal cost inside the overlapped pipeline.  1 finalize_norm, 2 MLP + classifier,
+// 4 pooling + embedding head, 8 tdnn2..5, 16 sinc_conv0, 32 LSTM recurrence, 64 LSTM projections,
+// 128 conv1 / conv2, 256 wave_stats, 512 tdnn1
+static int skip_mask() {
+    static const int m = getenv("DZ_SKIP") ? atoi(getenv("DZ_SKIP")) : 0;
+    return m;
+}
+#define DZ_SKIPPED(bit) (skip_mask() & (bit))
+
+// DZ_FUSED_NORM=0 keeps the three finalize_norm launches of a SincNet; by default (split-f16 path)
+// every consumer derives its InstanceNorm scale / shift from the producer's tile partials itself
+static bool fused_norm_enabled() {
+    const char* v = getenv("DZ_FUSED_NORM");
+    return !(v && v[0] == '0');
+}
 static bool conv_pool_enabled() {
     const char* v = getenv("DZ_CONV_POOL");
     return !(v && v[0] == '0');
@@ -250,12 +266,29 @@ struct SincScratch {
     }
 };
 
-// wave -> y2 [B][P2][64] (pre-norm) + sc2/sh2: the consumer applies InstanceNorm + LeakyReLU
-// on load.  7 launches.
+static bool sinc_fused_norm(const dz_sincnet_weights& w) {
+    return w.w1_split && w.w2_split && conv_pool_enabled() && fused_norm_enabled();
+}
+// the consumer of y2 (first LSTM projection / tdnn1) reads its norm from part2 when fused
+static void sinc_out_norm(DzConvGemm& p, const dz_sincnet_weights& w, const SincGeom& g, const SincScratch& s,
+                          bool split_layer) {
+    p.nld = 64;
+    p.norm_on_load = 1;
+    if (split_layer && sinc_fused_norm(w)) {
+        p.npart = s.part2; p.npart_tiles = g.nt2; p.npart_T = g.P2; p.ngamma = w.in2_g; p.nbeta = w.in2_b;
+    } else {
+        p.nscale = s.sc2; p.nshift = s.sh2;
+    }
+}
+
+// wave -> y2 [B][P2][64] (pre-norm) + part2 (or sc2/sh2): the consumer applies InstanceNorm +
+// LeakyReLU on load.  4 launches (7 with the finalize_norm launches of the exact-f32 path).
 static int run_sincnet(const dz_sincnet_weights& w, const SincGeom& g, const SincScratch& s,
                        const float* wave, long long stride, int B, hipStream_t st) {
     int rc;
+    if (!DZ_SKIPPED(256))
     { ProfScope ps(T_WAVE, B); if ((rc = dz_launch_wave_stats(wave, stride, B, g.S, s.stats, st))) return rc; }
+    if (!DZ_SKIPPED(16))
     { ProfScope ps(T_CONV0, B);
     rc = w.filt_split
              ? dz_launch_sinc_conv0_split(wave, stride, B, g.S, s.stats, 1, w.wav_gamma, w.wav_beta,
@@ -263,6 +296,8 @@ static int run_sincnet(const dz_sincnet_weights& w, const SincGeom& g, const Sin
              : dz_launch_sinc_conv0(wave, stride, B, g.S, s.stats, 1, w.wav_gamma, w.wav_beta, w.filt,
                                     s.y0, g.P0, s.part0, g.nt0, st);
     if (rc) return rc; }
+    const bool fused = sinc_fused_norm(w);
+    if (!fused && !DZ_SKIPPED(1))
     { ProfScope ps(T_FIN, B);
     if ((rc = dz_launch_finalize_norm(s.part0, B, g.nt0, 80, g.P0, w.in0_g, w.in0_b, s.sc0, s.sh0,
                                       st)))
@@ -270,23 +305,31 @@ static int run_sincnet(const dz_sincnet_weights& w, const SincGeom& g, const Sin
     DzConvGemm p;
     memset(&p, 0, sizeof(p));
     // conv1: 80 -> 60(64), k5, + pool3
-    p.X = s.y0; p.W = w.w1; p.bias = w.b1; p.nscale = s.sc0; p.nshift = s.sh0; p.nld = 80;
+    p.X = s.y0; p.W = w.w1; p.bias = w.b1; p.nld = 80;
+    if (fused) { p.npart = s.part0; p.npart_tiles = g.nt0; p.npart_T = g.P0; p.ngamma = w.in0_g; p.nbeta = w.in0_b; }
+    else { p.nscale = s.sc0; p.nshift = s.sh0; }
     p.Y = s.y1; p.partials = s.part1;
     p.B = B; p.Tin = g.P0; p.Tout = g.T1; p.Cin = 80; p.taps = 5; p.dil = 1; p.K = 400;
     p.Kpad = 416; p.Npad = 64; p.Nstore = 64; p.ldx = 80; p.ldy = 64; p.Tstore = g.P1;
     p.xbs = (long long)g.P0 * 80; p.ybs = (long long)g.P1 * 64;
     p.norm_on_load = 1; p.epi = DZ_EPI_POOL3;
+    if (!DZ_SKIPPED(128))
     { ProfScope ps(T_CONV1, B); if ((rc = run_gemm(p, w.w1_split, st))) return rc; }
+    if (!fused && !DZ_SKIPPED(1))
     { ProfScope ps(T_FIN, B);
     if ((rc = dz_launch_finalize_norm(s.part1, B, g.nt1, 64, g.P1, w.in1_g, w.in1_b, s.sc1, s.sh1,
                                       st)))
         return rc; }
     // conv2: 60(64) -> 60(64), k5, + pool3
-    p.X = s.y1; p.W = w.w2; p.bias = w.b2; p.nscale = s.sc1; p.nshift = s.sh1; p.nld = 64;
+    p.X = s.y1; p.W = w.w2; p.bias = w.b2; p.nld = 64;
+    if (fused) { p.npart = s.part1; p.npart_tiles = g.nt1; p.npart_T = g.P1; p.ngamma = w.in1_g; p.nbeta = w.in1_b; }
+    else { p.nscale = s.sc1; p.nshift = s.sh1; }
     p.Y = s.y2; p.partials = s.part2;
     p.Tin = g.P1; p.Tout = g.T2; p.Cin = 64; p.K = 320; p.Kpad = 320; p.ldx = 64;
     p.Tstore = g.P2; p.xbs = (long long)g.P1 * 64; p.ybs = (long long)g.P2 * 64;
+    if (!DZ_SKIPPED(128))
     { ProfScope ps(T_CONV2, B); if ((rc = run_gemm(p, w.w2_split, st))) return rc; }
+    if (fused || DZ_SKIPPED(1)) return 0;
     ProfScope ps(T_FIN, B);
     return dz_launch_finalize_norm(s.part2, B, g.nt2, 64, g.P2, w.in2_g, w.in2_b, s.sc2, s.sh2, st);
 }
@@ -391,8 +434,8 @@ extern "C" int dz_seg_forward(dz_seg* s, const float* d_wave, long long wave_str
         p.W = s->w.wih[layer]; p.bias = s->w.bih[layer]; p.Y = s->gx;
         p.taps = 1; p.dil = 1; p.Npad = 1024; p.Nstore = 1024; p.ldy = 1024; p.epi = DZ_EPI_BIAS;
         if (layer == 0) {
-            p.X = s->ss.y2; p.nscale = s->ss.sc2; p.nshift = s->ss.sh2; p.nld = 64;
-            p.norm_on_load = 1;
+            p.X = s->ss.y2;
+            sinc_out_norm(p, s->w.sinc, s->g, s->ss, s->w.wih_split[0] != nullptr);
             p.B = B; p.Tin = p.Tout = p.Tstore = F; p.Cin = 64; p.K = 64; p.Kpad = 64; p.ldx = 64;
             p.xbs = (long long)F * 64; p.ybs = (long long)F * 1024;
         } else {
@@ -400,6 +443,7 @@ extern "C" int dz_seg_forward(dz_seg* s, const float* d_wave, long long wave_str
             p.B = 1; p.Tin = p.Tout = p.Tstore = B * F; p.Cin = 256; p.K = 256; p.Kpad = 256;
             p.ldx = 256;
         }
+        if (!DZ_SKIPPED(64))
         { ProfScope ps(layer == 0 ? T_PROJ0 : T_PROJ, B);
           if (layer > 0 && s->pre) {
               p.X = nullptr; p.Xsplit = lin; p.xplane = rows * 256; p.Wsplit = s->w.wih_split[layer];
@@ -409,6 +453,7 @@ extern "C" int dz_seg_forward(dz_seg* s, const float* d_wave, long long wave_str
           }
           if (rc) return rc; }
         float* hout = (layer & 1) ? s->h1 : s->h0;
+        if (!DZ_SKIPPED(32))
         { ProfScope ps(T_REC, B);
           // gx columns are unit-major (weights.py permutes the rows of W_ih); 16 chains per
           // workgroup on the matrix cores when the layer came with split planes of W_hh
@@ -422,6 +467,7 @@ extern "C" int dz_seg_forward(dz_seg* s, const float* d_wave, long long wave_str
         lin = hout;
     }
     // Linear(256,128)+leaky, Linear(128,128)+leaky, classifier
+    if (DZ_SKIPPED(2)) return 0;
     DzConvGemm p;
     memset(&p, 0, sizeof(p));
     p.B = 1; p.Tin = p.Tout = p.Tstore = B * F; p.taps = 1; p.dil = 1;
@@ -561,11 +607,12 @@ static int emb_frames(dz_emb* e, const float* d_wave, long long stride, int B, h
         if (i == 0) {
             p.B = B; p.Tin = P; p.Tout = p.Tstore = e->T[0];
             p.xbs = (long long)P * cin[i]; p.ybs = (long long)P * npad[i];
-            p.nscale = e->ss.sc2; p.nshift = e->ss.sh2; p.nld = 64; p.norm_on_load = 1;
+            sinc_out_norm(p, e->w.sinc, e->g, e->ss, e->w.tw_split[0] != nullptr);
             if (e->pre) { p.Y = nullptr; p.Ysplit = outp; p.yplane = plane; }
         } else {
             p.B = 1; p.Tin = B * P; p.Tout = p.Tstore = B * P - span;
         }
+        if (!DZ_SKIPPED(i == 0 ? 512 : 8))
         { ProfScope ps(T_TDNN1 + i, B);
           if (i > 0 && e->pre) {
               p.X = nullptr; p.Xsplit = in; p.xplane = plane; p.Wsplit = e->w.tw_split[i];
@@ -583,6 +630,7 @@ static int emb_frames(dz_emb* e, const float* d_wave, long long stride, int B, h
 static int emb_head(dz_emb* e, const float* d_weights, int Fw, int rows, int rows_per_x,
                     int normalize, float* d_out, hipStream_t st) {
     int rc;
+    if (DZ_SKIPPED(4)) return 0;
     { ProfScope ps(T_POOL, rows / rows_per_x);
     if ((rc = dz_launch_stats_pool(e->x5, (long long)e->g.P2 * 1536, e->T[4], 1500, 1536, d_weights, Fw,
                                    rows, rows_per_x, e->pooled, kPoolLd, st)))

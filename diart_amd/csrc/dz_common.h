@@ -118,6 +118,31 @@ __device__ __forceinline__ void dz_store_split(unsigned short* ypl, long long id
     if (store) *reinterpret_cast<unsigned*>(ypl + idx) = word;
 }
 
+// InstanceNorm1d(C, affine) scale / shift of chunk b from the producer's tile partials — the
+// arithmetic of finalize_norm_kernel (k_front.hip: f64, tiles in fixed order, biased variance,
+// eps 1e-5), done by the CONSUMER's first C threads so that no launch sits between producer and
+// consumer.  out: scale[C] | shift[C].
+__device__ __forceinline__ void dz_norm_from_partials(const float* __restrict__ partials, int b, int ntile,
+                                                      int C, int T, const float* __restrict__ gamma,
+                                                      const float* __restrict__ beta, float* out, int tid) {
+    if (tid < C) {
+        double s = 0.0, ss = 0.0;
+        const float* pp = partials + ((long long)b * ntile * C + tid) * 2;
+        for (int t = 0; t < ntile; ++t) {
+            s += (double)pp[0];
+            ss += (double)pp[1];
+            pp += 2 * C;
+        }
+        const double mean = s / T;
+        double var = ss / T - mean * mean;
+        if (var < 0.0) var = 0.0;
+        const double rstd = 1.0 / sqrt(var + 1e-5);
+        const double sc = (double)gamma[tid] * rstd;
+        out[tid] = (float)sc;
+        out[C + tid] = (float)((double)beta[tid] - mean * sc);
+    }
+}
+
 // The split-f16 representation holds |x| <= 65504; larger operands are clamped — and REPORTED: a lane
 // that saw one stores 1 into the context's flag (rare store; dz_range_check turns it into an error).
 __device__ __forceinline__ void dz_flag_range(int* oflag, float amax) {

@@ -48,7 +48,9 @@ __device__ __forceinline__ float leaky(float v) { return v > 0.f ? v : v * DZ_LE
 template <int CIN>
 __global__ __launch_bounds__(256, 2) void conv_pool_h_kernel(
     const float* __restrict__ X, int Tin, int Tout, int Tstore, const float* __restrict__ nscale,
-    const float* __restrict__ nshift, const unsigned short* __restrict__ wsp, int Kpad,
+    const float* __restrict__ nshift, const float* __restrict__ npart, int npart_tiles, int npart_T,
+    const float* __restrict__ ngamma, const float* __restrict__ nbeta,
+    const unsigned short* __restrict__ wsp, int Kpad,
     const float* __restrict__ bias, float* __restrict__ Y, float* __restrict__ partials, int ntile,
     int total, int* __restrict__ oflag) {
     using G = Geo<CIN>;
@@ -87,8 +89,11 @@ __global__ __launch_bounds__(256, 2) void conv_pool_h_kernel(
         const int t0 = tile * FR;
         if (b != cur_b) {                       // scale / shift of this chunk's InstanceNorm
             __syncthreads();                    // (nobody still reads the previous chunk's)
-            for (int i = tid; i < 2 * CIN; i += 256)
-                nrm[i] = i < CIN ? nscale[(long long)b * CIN + i] : nshift[(long long)b * CIN + i - CIN];
+            if (npart)       // straight from the producer's tile partials: no finalize launch
+                dz_norm_from_partials(npart, b, npart_tiles, CIN, npart_T, ngamma, nbeta, nrm, tid);
+            else
+                for (int i = tid; i < 2 * CIN; i += 256)
+                    nrm[i] = i < CIN ? nscale[(long long)b * CIN + i] : nshift[(long long)b * CIN + i - CIN];
             cur_b = b;
         }
         __syncthreads();                        // previous tile's fragment / exchange reads are done
@@ -192,7 +197,8 @@ int launch(const DzConvGemm& p, hipStream_t st) {
     const int total = ntile * p.B;
     const int grid = total < 512 ? total : 512;          // two resident workgroups per CU
     DZ_LAUNCH((conv_pool_h_kernel<CIN>), dim3(grid), dim3(256), G::LDS, st, p.X, p.Tin, p.Tout, p.Tstore,
-              p.nscale, p.nshift, reinterpret_cast<const unsigned short*>(p.Wsplit), p.Kpad, p.bias, p.Y,
+              p.nscale, p.nshift, p.npart, p.npart_tiles, p.npart_T, p.ngamma, p.nbeta,
+              reinterpret_cast<const unsigned short*>(p.Wsplit), p.Kpad, p.bias, p.Y,
               p.partials, ntile, total, p.oflag ? p.oflag : dz_cur_oflag);
     DZ_HIP(hipGetLastError());
     return 0;
@@ -203,8 +209,9 @@ int launch(const DzConvGemm& p, hipStream_t st) {
 // same descriptor as the POOL3 call of dz_launch_gemm_split (k = 5, dil = 1, Npad = 64, norm-on-load,
 // X / Y dense: xbs = Tin * Cin, ybs = Tstore * 64, ldx = Cin, ldy = 64)
 int dz_launch_conv_pool(const DzConvGemm& p, hipStream_t st) {
-    DZ_REQUIRE(p.Wsplit && p.X && p.Y && p.partials && p.nscale && p.nshift && p.bias,
-               "conv_pool: NULL operand");
+    DZ_REQUIRE(p.Wsplit && p.X && p.Y && p.partials && p.bias, "conv_pool: NULL operand");
+    DZ_REQUIRE((p.nscale && p.nshift) || (p.npart && p.ngamma && p.nbeta && p.npart_tiles > 0 && p.npart_T > 0),
+               "conv_pool: needs nscale / nshift or the producer's partials + affine");
     DZ_REQUIRE(p.epi == DZ_EPI_POOL3 && p.taps == 5 && p.dil == 1 && p.norm_on_load && p.Npad == 64 &&
                    p.Nstore == 64 && p.ldy == 64,
                "conv_pool: built for k = 5, dilation 1, 64 output columns, norm-on-load, MaxPool1d(3)");

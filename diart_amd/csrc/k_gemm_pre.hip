@@ -99,13 +99,19 @@ __global__ __launch_bounds__(256, 2) void gemm_pre_kernel(DzConvGemm p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) accm[mt][nt][r] = accx[mt][nt][r] = 0.f;
 
+    // timing ablations (kbench only; p.pad is otherwise unused on this path and must be 0 in product
+    // calls): 1 = no operand DMA after the first tile, 2 = no fragment reads after the first k-step,
+    // 4 = no result stores
+    const int dbg = p.pad;
+    f16x8 ah[2] = {}, al[2] = {}, bh[2] = {}, bl[2] = {};
+    bool have = false;
     auto compute = [&](int stage) {
         const char* st = smem + stage * STAGE;
         const char* sa = st + (wm * 64) * 64;
         const char* sb = st + 2 * PLANE + (wn * 64) * 64;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            f16x8 ah[2], al[2], bh[2], bl[2];
+            if (!((dbg & 2) && have))
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
                 ah[t] = *reinterpret_cast<const f16x8*>(sa + t * 2048 + foff[ks]);
@@ -113,13 +119,18 @@ __global__ __launch_bounds__(256, 2) void gemm_pre_kernel(DzConvGemm p) {
                 bh[t] = *reinterpret_cast<const f16x8*>(sb + t * 2048 + foff[ks]);
                 bl[t] = *reinterpret_cast<const f16x8*>(sb + PLANE + t * 2048 + foff[ks]);
             }
+            have = true;
+            // TRANSPOSED product: the weight fragment is the MFMA's row operand, the activation
+            // fragment its column operand, so a lane ends up with ONE output row t (= lane & 31)
+            // and, per accumulator register group, FOUR CONSECUTIVE output columns: the epilogue
+            // stores 16 bytes (f32) / 8 bytes (f16 planes) per instruction instead of 4
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
                 for (int nt = 0; nt < 2; ++nt) {
-                    accx[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[mt], bh[nt], accx[mt][nt], 0, 0, 0);
-                    accm[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mt], bh[nt], accm[mt][nt], 0, 0, 0);
-                    accx[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mt], bl[nt], accx[mt][nt], 0, 0, 0);
+                    accx[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[nt], al[mt], accx[mt][nt], 0, 0, 0);
+                    accm[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[nt], ah[mt], accm[mt][nt], 0, 0, 0);
+                    accx[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl[nt], ah[mt], accx[mt][nt], 0, 0, 0);
                 }
         }
     };
@@ -129,37 +140,71 @@ __global__ __launch_bounds__(256, 2) void gemm_pre_kernel(DzConvGemm p) {
     for (int kt = 0; kt < nk; ++kt) {
         // own DMA of tile kt has landed + every wave has finished the fragment reads of tile kt-1
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        if (kt + 1 < nk) issue(kt + 1, (kt + 1) & 1);
+        if (kt + 1 < nk && !(dbg & 1)) issue(kt + 1, (kt + 1) & 1);
         compute(kt & 1);
     }
 
-    // ---- epilogue: C/D map col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5) ---------
-    // (hi, lo) plane output: see dz_store_split; columns >= Nstore of a padded layer are written
-    // as zeros (they are K padding of the consumer)
-    unsigned short* Ypl = p.Ysplit ? dz_split_base(p.Ysplit, p.yplane, li & 1) : nullptr;
+    // ---- epilogue.  C/D map of the transposed product: column = lane & 31 = output ROW t, register r
+    // = output column n0' + (r & 3) + 8 (r >> 2) + 4 (lane >> 5): registers 4k .. 4k+3 are four
+    // consecutive columns -> one 16-byte f32 store, or one 8-byte store per f16 plane (hi = f16(v),
+    // lo = f16((v - hi) * 2^11), clamped to +-65504 and flagged beyond, like dz_store_split).
+    // Columns >= Nstore of a padded layer are written as zeros to the planes (K padding of the
+    // consumer) and not at all to the f32 output.
+    typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+    unsigned short* Yhi = reinterpret_cast<unsigned short*>(p.Ysplit);
     float amax = 0.f;
 #pragma unroll
-    for (int nt = 0; nt < 2; ++nt) {
-        const int n = n0 + wn * 64 + nt * 32 + li;
-        const float bv = p.bias[n];
-        float e0 = 1.f, e1 = 0.f;
-        if (EPI == DZ_EPI_TDNN || EPI == DZ_EPI_RELU_BN) {
-            e0 = p.e0[n];
-            e1 = p.e1[n];
-        }
-        const bool nok = n < p.Nstore;
+    for (int mt = 0; mt < 2; ++mt) {
+        const int t = t0 + wm * 64 + mt * 32 + li;
+        const bool ok = t < p.Tout;
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
+        for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int t = t0 + wm * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
-                float v = (accm[mt][nt][r] + accx[mt][nt][r] * LO_UNSCALE) + bv;
-                if (EPI == DZ_EPI_BIAS_LEAKY) v = leaky(v);
-                if (EPI == DZ_EPI_TDNN) v = leaky(v) * e0 + e1;
-                if (EPI == DZ_EPI_RELU_BN) v = fmaxf(v, 0.f) * e0 + e1;
-                const bool ok = t < p.Tout;
-                if (p.Y && ok && nok) p.Y[(long long)t * p.ldy + n] = v;
-                if (Ypl) dz_store_split(Ypl, (long long)t * p.ldy + n, nok ? v : 0.f, ok, li & 1, amax);
+            for (int k = 0; k < 4; ++k) {
+                const int n = n0 + wn * 64 + nt * 32 + 8 * k + 4 * g;
+                const f32x4 bv = *reinterpret_cast<const f32x4*>(p.bias + n);
+                f32x4 e0 = {1.f, 1.f, 1.f, 1.f}, e1 = {0.f, 0.f, 0.f, 0.f};
+                if (EPI == DZ_EPI_TDNN || EPI == DZ_EPI_RELU_BN) {
+                    e0 = *reinterpret_cast<const f32x4*>(p.e0 + n);
+                    e1 = *reinterpret_cast<const f32x4*>(p.e1 + n);
+                }
+                f32x4 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float x = (accm[mt][nt][4 * k + e] + accx[mt][nt][4 * k + e] * LO_UNSCALE) + bv[e];
+                    if (EPI == DZ_EPI_BIAS_LEAKY) x = leaky(x);
+                    if (EPI == DZ_EPI_TDNN) x = leaky(x) * e0[e] + e1[e];
+                    if (EPI == DZ_EPI_RELU_BN) x = fmaxf(x, 0.f) * e0[e] + e1[e];
+                    v[e] = x;
+                }
+                if (dbg & 4) {
+                    asm volatile("" ::"v"(v));
+                    continue;
+                }
+                const long long idx = (long long)t * p.ldy + n;
+                if (p.Y && ok) {
+                    if (n + 3 < p.Nstore) {
+                        *reinterpret_cast<f32x4*>(p.Y + idx) = v;
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            if (n + e < p.Nstore) p.Y[idx + e] = v[e];
+                    }
+                }
+                if (Yhi) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        if (n + e >= p.Nstore) v[e] = 0.f;
+                        amax = fmaxf(amax, fabsf(v[e]));
+                        v[e] = __builtin_amdgcn_fmed3f(v[e], -65504.f, 65504.f);
+                    }
+                    const f16x4 hi = __builtin_convertvector(v, f16x4);
+                    const f16x4 lo = __builtin_convertvector((v - __builtin_convertvector(hi, f32x4)) * 2048.f, f16x4);
+                    if (ok) {
+                        *reinterpret_cast<f16x4*>(Yhi + idx) = hi;
+                        *reinterpret_cast<f16x4*>(Yhi + p.yplane + idx) = lo;
+                    }
+                }
             }
     }
     dz_flag_range(p.oflag, amax);
@@ -188,12 +233,14 @@ int dz_launch_gemm_pre(const DzConvGemm& p_in, hipStream_t st) {
                "gemm_pre: K = taps * Cin without padding, Cin a multiple of 32, ldx of 8");
     DZ_REQUIRE(p.Npad % BN == 0, "gemm_pre: Npad must be a multiple of 128");
     DZ_REQUIRE(p.Tout > 0 && p.Tout == p.Tin - (p.taps - 1) * p.dil, "gemm_pre: Tout mismatch");
-    DZ_REQUIRE(p.pad == 0 && p.X2 == nullptr && p.rowbias == nullptr && p.ksplit <= 1 && !p.norm_on_load,
+    DZ_REQUIRE(p.X2 == nullptr && p.rowbias == nullptr && p.ksplit <= 1 && !p.norm_on_load,
                "gemm_pre: padding / second input / row bias / split-K / norm-on-load are not built here");
     DZ_REQUIRE((long long)p.Tin * p.ldx * 2 < (1ll << 31) && (long long)p.Npad * p.Kpad * 2 < (1ll << 31),
                "gemm_pre: operand plane exceeds the 2 GiB buffer-offset range");
-    DZ_REQUIRE(p.Ysplit == nullptr || (p.ldy % 2 == 0 && p.yplane % 2 == 0 && p.Npad <= p.ldy),
-               "gemm_pre: plane output needs even ldy / yplane and Npad <= ldy");
+    DZ_REQUIRE(p.Ysplit == nullptr || (p.ldy % 4 == 0 && p.yplane % 4 == 0 && p.Npad <= p.ldy),
+               "gemm_pre: plane output needs ldy / yplane multiples of 4 and Npad <= ldy");
+    DZ_REQUIRE(p.Y == nullptr || (p.ldy % 4 == 0 && ((uintptr_t)p.Y & 15) == 0),
+               "gemm_pre: f32 output needs ldy a multiple of 4 and a 16-byte aligned base");
     switch (p.epi) {
         case DZ_EPI_BIAS: return launch<DZ_EPI_BIAS>(p, st);
         case DZ_EPI_BIAS_LEAKY: return launch<DZ_EPI_BIAS_LEAKY>(p, st);

@@ -92,6 +92,13 @@ __global__ __launch_bounds__(128 * WM) void gemm_split_kernel(DzConvGemm p) {
     const float* Xb = p.X + (long long)b * p.xbs;
     const float* nsc = PRO ? p.nscale + (long long)b * p.nld : nullptr;
     const float* nsh = PRO ? p.nshift + (long long)b * p.nld : nullptr;
+    __shared__ __attribute__((aligned(16))) float nrm_s[PRO ? 256 : 4];   // scale[nld] | shift[nld], nld <= 128
+    if (PRO && p.npart) {   // derive them from the producer's tile partials: no finalize launch
+        dz_norm_from_partials(p.npart, b, p.npart_tiles, p.nld, p.npart_T, p.ngamma, p.nbeta, nrm_s, tid);
+        nsc = nrm_s;
+        nsh = nrm_s + p.nld;
+        __syncthreads();
+    }
     const int trow = (t0 + crow) < p.Tout ? (t0 + crow) : p.Tout - 1;
     const unsigned short* Whi = reinterpret_cast<const unsigned short*>(p.Wsplit);
     const unsigned short* Wlo = Whi + (long long)p.Npad * p.Kpad;
@@ -305,6 +312,9 @@ int dz_launch_gemm_split(const DzConvGemm& p_in, hipStream_t st) {
                "gemm_split: padding / second input / row bias / split-K are f32-path features");
     DZ_REQUIRE(p.Tout > 0 && p.Tout == p.Tin - (p.taps - 1) * p.dil, "gemm_split: Tout mismatch");
     DZ_REQUIRE(p.Y != nullptr || p.Ysplit != nullptr, "gemm_split: no output");
+    DZ_REQUIRE(!p.norm_on_load || (p.nscale && p.nshift) ||
+                   (p.npart && p.ngamma && p.nbeta && p.npart_tiles > 0 && p.npart_T > 0 && p.nld <= 128),
+               "gemm_split: norm-on-load needs nscale / nshift or the producer's partials + affine (nld <= 128)");
     DZ_REQUIRE(p.Ysplit == nullptr || (p.epi != DZ_EPI_POOL3 && p.ldy % 2 == 0 && p.yplane % 2 == 0 &&
                                        p.ybs % 2 == 0 && p.Npad <= p.ldy),
                "gemm_split: plane output needs even ldy / yplane / ybs, Npad <= ldy and no pooling");

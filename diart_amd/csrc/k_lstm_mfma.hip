@@ -292,21 +292,162 @@ __global__ __launch_bounds__(512) void lstm_mfma1_kernel(const float* __restrict
 
 }  // namespace
 
+// ---------------------------------------------------------------------------------------------
+// Variant 3 = variant 0 (two accumulators, lo planes scaled by 2^11) with the x-projection fetched
+// by LDS-DMA instead of through registers.  In the pipeline the register-prefetched kernel runs at
+// 2.1 us per step against 1.3 us alone: its loads are issued two steps (~2.6 us) ahead, which a
+// loaded memory system does not always cover, and more look-ahead has no registers left (238 of
+// 256).  LDS-DMA needs none: a 4-slot ring of [16 chains][2 KiB] rows (unit-major gx: the 512 floats
+// of one direction are contiguous) is filled three steps ahead, wave w fetching chains 2w, 2w+1
+// (4 x 1 KiB pieces per step); the end-of-step barrier is preceded by a counted vmcnt so that the
+// pieces of the NEXT step have landed.  Chain rows are 2064 bytes apart in LDS (16 B of padding:
+// the 16 chains of a read hit different bank groups).  gx must be unit-major.
+// ---------------------------------------------------------------------------------------------
+constexpr int GX_ROW = 2048 + 16;           // bytes per chain row of a ring slot
+constexpr int GX_SLOT = CH * GX_ROW;
+constexpr int GX_NSLOT = 4;
+
+__global__ __launch_bounds__(512) void lstm_mfma_dma_kernel(const float* __restrict__ gx,
+                                                            const unsigned short* __restrict__ whs,
+                                                            float* __restrict__ hout,
+                                                            unsigned short* __restrict__ hsp,
+                                                            long long hplane, int B, int T) {
+    // one LDS object: H planes [2 buf][2 plane][16][256 B] | gx ring [4][16][2064 B]
+    __shared__ __attribute__((aligned(16))) char lds[2 * 2 * PLANE + GX_NSLOT * GX_SLOT];
+    char* hs = lds;
+    char* gxr = lds + 2 * 2 * PLANE;
+    const int tid = threadIdx.x, l = tid & 63, n = l & 15, q = l >> 4;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int dir = blockIdx.y;
+    const int b = blockIdx.x * CH + n;
+    const bool valid = b < B;
+    const int bb = valid ? b : B - 1;
+
+    f16x8 wh[4][4], wl[4][4];
+    {
+        const unsigned short* Wd = whs + (long long)dir * 2 * 512 * 128;
+        const int row_base = (n & 3) * 128 + 16 * w + 4 * (n >> 2);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const long long o = (long long)(row_base + j) * 128 + 32 * ks + 8 * q;
+                wh[j][ks] = *reinterpret_cast<const f16x8*>(Wd + o);
+                wl[j][ks] = *reinterpret_cast<const f16x8*>(Wd + 512 * 128 + o);
+            }
+    }
+    for (int i = tid; i < 2 * PLANE / 16; i += 512)
+        reinterpret_cast<f32x4*>(hs)[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    int rd_off[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) rd_off[ks] = n * 256 + (((4 * ks + q) ^ n) << 4);
+    const int wr_off = n * 256 + (((2 * w + (q >> 1)) ^ n) << 4) + 8 * (q & 1);
+    const long long hbase = ((long long)bb * T + (dir ? T - 1 : 0)) * 256 + dir * 128 + 16 * w + 4 * q;
+    const long long hstep = dir ? -256 : 256;
+
+    // ---- LDS-DMA of the x-projection: this wave fetches chains 2w and 2w+1 ----------------------
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)gx, 0, (unsigned)((long long)B * T * 4096 < 0xffffffffLL ? (long long)B * T * 4096 : 0xffffffffLL),
+        0x00020000);
+    int voff[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int chain = blockIdx.x * CH + 2 * w + (i >> 1);
+        const int cb = chain < B ? chain : B - 1;
+        voff[i] = cb * T * 4096 + dir * 2048 + (i & 1) * 1024 + l * 16;
+    }
+    auto fetch = [&](int s) {                 // frame of step s: s (forward) or T-1-s (backward)
+        const int tt = dir ? T - 1 - s : s;
+        char* slot = gxr + (s & (GX_NSLOT - 1)) * GX_SLOT;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(
+                rsrc, (__attribute__((address_space(3))) void*)(slot + (2 * w + (i >> 1)) * GX_ROW + (i & 1) * 1024),
+                16, voff[i], tt * 4096, 0, 0);
+    };
+    // this lane's 16 floats (4 cells x 4 gates) of chain n: floats (16w + 4q) * 4 .. +15 of the row
+    const int g_off = n * GX_ROW + (64 * w + 16 * q) * 4;
+
+    float c[4] = {0.f, 0.f, 0.f, 0.f};
+    fetch(0);
+    if (T > 1) fetch(1);
+    if (T > 2) fetch(2);
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");       // step 0's four pieces
+    __syncthreads();
+    for (int s = 0; s < T; ++s) {
+        if (s + 3 < T) fetch(s + 3);
+        const char* hb = hs + (s & 1) * 2 * PLANE;
+        const char* gs = gxr + (s & (GX_NSLOT - 1)) * GX_SLOT + g_off;
+        f16x8 bh[4], bl[4];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            bh[ks] = *reinterpret_cast<const f16x8*>(hb + rd_off[ks]);
+            bl[ks] = *reinterpret_cast<const f16x8*>(hb + PLANE + rd_off[ks]);
+        }
+        f32x4 gv[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) gv[j] = *reinterpret_cast<const f32x4*>(gs + 16 * j);
+        f32x4 am[4], ax[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) am[j] = ax[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                am[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[j][ks], bh[ks], am[j], 0, 0, 0);
+                ax[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[j][ks], bl[ks], ax[j], 0, 0, 0);
+                ax[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[j][ks], bh[ks], ax[j], 0, 0, 0);
+            }
+        f32x4 hv;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float pre[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) pre[r] = (am[j][r] + ax[j][r] * LO_UNSCALE) + gv[j][r];
+            const float ig = fast_sigmoid(pre[0]), fg = fast_sigmoid(pre[1]), gg = fast_tanh(pre[2]),
+                        og = fast_sigmoid(pre[3]);
+            c[j] = fg * c[j] + ig * gg;
+            hv[j] = og * fast_tanh(c[j]);
+        }
+        const f16x4 hhi = __builtin_convertvector(hv, f16x4);
+        const f16x4 hlo = __builtin_convertvector((hv - __builtin_convertvector(hhi, f32x4)) * LO_SCALE, f16x4);
+        char* hn = hs + ((s + 1) & 1) * 2 * PLANE;
+        *reinterpret_cast<f16x4*>(hn + wr_off) = hhi;
+        *reinterpret_cast<f16x4*>(hn + PLANE + wr_off) = hlo;
+        if (valid) {
+            const long long o = hbase + (long long)s * hstep;
+            if (hout) *reinterpret_cast<f32x4*>(hout + o) = hv;
+            if (hsp) {
+                *reinterpret_cast<f16x4*>(hsp + o) = hhi;
+                *reinterpret_cast<f16x4*>(hsp + hplane + o) = hlo;
+            }
+        }
+        // the pieces of step s+1 (issued >= 2 steps ago) must have landed before anybody passes the
+        // barrier: at most the 8 pieces of steps s+2, s+3 may still be in flight (this step's stores
+        // are younger and only make the wait stricter)
+        asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    }
+}
+
 // variant 0: two accumulators, lo planes scaled by 2^11 (whh_split = split_f16 of W_hh);
 // variant 1 / 2: one accumulator, activation scales folded into the planes, H scaled by 2^0 / 2^8
-// (whh_split from weights.py lstm_whh_planes(whh, variant))
+// (whh_split from weights.py lstm_whh_planes(whh, variant)); variant 3: variant 0's arithmetic and
+// planes, gx by LDS-DMA (unit-major only)
 int dz_launch_lstm_mfma(const float* gx, const void* whh_split, float* hout, void* hsplit,
                         long long hplane, int B, int T, int unit_major, int variant, hipStream_t st) {
     dim3 grid((B + CH - 1) / CH, 2);
     const unsigned short* whs = reinterpret_cast<const unsigned short*>(whh_split);
     unsigned short* hsp = reinterpret_cast<unsigned short*>(hsplit);
-    DZ_REQUIRE(variant >= 0 && variant <= 2, "lstm_mfma: variant %d", variant);
+    DZ_REQUIRE(variant >= 0 && variant <= 3, "lstm_mfma: variant %d", variant);
     DZ_REQUIRE(hout || hsp, "lstm_mfma: no output");
+    DZ_REQUIRE(variant != 3 || (unit_major && (long long)B * T * 4096 < (1ll << 31)),
+               "lstm_mfma: variant 3 (LDS-DMA of gx) needs unit-major gx below 2 GiB");
     DZ_REQUIRE(hplane % 4 == 0, "lstm_mfma: plane distance must be a multiple of 4 elements");
 #define DZ_L(K) DZ_LAUNCH(K, grid, dim3(512), 0, st, gx, whs, hout, hsp, hplane, B, T)
     if (variant == 0) { if (unit_major) DZ_L(lstm_mfma_kernel<true>); else DZ_L(lstm_mfma_kernel<false>); }
     if (variant == 1) { if (unit_major) DZ_L((lstm_mfma1_kernel<true, 0>)); else DZ_L((lstm_mfma1_kernel<false, 0>)); }
     if (variant == 2) { if (unit_major) DZ_L((lstm_mfma1_kernel<true, 8>)); else DZ_L((lstm_mfma1_kernel<false, 8>)); }
+    if (variant == 3) DZ_L(lstm_mfma_dma_kernel);
 #undef DZ_L
     DZ_HIP(hipGetLastError());
     return 0;

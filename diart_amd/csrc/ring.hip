@@ -113,6 +113,19 @@ extern "C" int dz_ring_push(dz_ring* r, const float* block, long long block_stri
                "dz_ring_push: block rows must be 16-byte aligned");
     const float* src = block;
     long long sstride = block_stride;
+    if (on_device == 2) {
+        // pinned host memory: ask the runtime for its device-side address and let the scatter kernel
+        // read it in place over PCIe (32 KB per stream).  That keeps the upload off the copy queues,
+        // where it was seen to wait behind the D2H copy of a step whose results were not ready yet
+        // (-17 % with one embedding stream per lane).  Not mappable -> staged copy below.
+        void* dptr = nullptr;
+        if (hipHostGetDevicePointer(&dptr, (void*)block, 0) == hipSuccess && dptr) {
+            src = reinterpret_cast<const float*>(dptr);
+        } else {
+            (void)hipGetLastError();
+            on_device = 0;
+        }
+    }
     if (!on_device) {
         // pushes of one ring are issued in stream order, so two landing blocks used alternately
         // are never overwritten before the scatter that reads them has run

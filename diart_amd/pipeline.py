@@ -78,8 +78,13 @@ class AudioRing:
         if len(self._readers) == self.slack + 1:
             for ev in self._readers[0]:
                 cur.wait_event(ev)
-        on_dev = block.is_cuda
-        _lib.check(self._lib.dz_ring_push(self._h, block.data_ptr(), block.stride(0), int(on_dev),
+        # Pinned host memory is mapped into the GPU's address space: the scatter kernel reads it in
+        # place over PCIe (32 KB per stream per step), which keeps the upload off the SDMA queue —
+        # there it can queue behind the D2H copy of a step whose results are not ready yet, and
+        # the next step's forward passes then wait for the previous step's (measured: -17 %).
+        # mode 2 = pinned host memory read IN PLACE by the scatter kernel (if the runtime can map it)
+        mode = 1 if block.is_cuda else (2 if block.is_pinned() and os.environ.get("DZ_RING_ZERO_COPY", "1") != "0" else 0)
+        _lib.check(self._lib.dz_ring_push(self._h, block.data_ptr(), block.stride(0), mode,
                                           cur.cuda_stream), "dz_ring_push")
         self._keep = (self._keep + [block])[-4:]
         return self.filled == self.window
@@ -154,14 +159,15 @@ class StreamBatch:
         # many steps on the GPU at once (the latency-bound recurrence of one step under the GEMMs
         # of the others).  A lane is reused in stream order, which also orders its arenas.
         self.depth = max(1, int(os.environ.get("DZ_DEPTH", "2") if depth is None else depth))
-        # The embedding network does not need a lane of its own: only its last two kernels (pooling,
-        # Linear) wait for the segmentation.  With DZ_SHARED_EMB (default) ONE set of embedding
-        # streams serves every lane in step order and the pooling of step t is enqueued `lag` =
-        # depth - 1 launches later, behind the frame features of the following steps — by then the
-        # segmentation of step t has finished, so the stream never blocks on it.  Fewer HIP streams
-        # also means fewer hardware queues (the runtime multiplexes streams onto
-        # GPU_MAX_HW_QUEUES queues; streams that share one serialise).
-        self.shared_emb = os.environ.get("DZ_SHARED_EMB", "1") != "0"
+        # DZ_SHARED_EMB=1: ONE set of embedding streams serves every lane in step order and the
+        # pooling of step t is enqueued `lag` = depth - 1 launches later, behind the frame features
+        # of the following steps (only the last two kernels of the embedding network wait for the
+        # segmentation; by then it has finished, so the stream never blocks on it).  That is what a
+        # latency-heavy segmentation needs (the matrix-core recurrence, DZ_LSTM=0..3, with depth >= 3:
+        # fewer streams than lanes x 2, the runtime multiplexes streams onto GPU_MAX_HW_QUEUES hardware
+        # queues).  With the default recurrence kernel two full lanes measured 8 % faster (24.7 k vs
+        # 22.8 k xRT), so the default is one embedding stream per lane.
+        self.shared_emb = os.environ.get("DZ_SHARED_EMB", "0") != "0"
         self.lag = self.depth - 1 if self.shared_emb else 0
         mk = lambda prio, k: [torch.cuda.Stream(self.device, priority=prio) for _ in range(k)]
         shared_b = mk(pb, self.emb_split) if self.shared_emb else None
@@ -171,6 +177,8 @@ class StreamBatch:
         self.stream_a, self.stream_b = self.streams_a[0], self.streams_b[0]
         self.num_hip_streams = self.depth * self.seg_split + self.emb_split * (1 if self.shared_emb else self.depth)
         self._pending: List[dict] = []                     # launched, pooling not enqueued yet
+        # where finish() spends its time: waiting for the GPU vs clustering + output tail on the host
+        self.host_seconds = {"wait": 0.0, "work": 0.0}
         self._sub: dict = {}
         self._slots: List[dict] = []
         self._lib = _lib.load()
@@ -335,9 +343,13 @@ class StreamBatch:
         -> (segmentation (N,F,K) f32, embeddings (N,K,D) f32, scores (N,F,G) f64 | None, assign (N,K)).
         The arrays (and ``ticket["tail"]``) are views of buffers that a later ``launch`` / ``finish``
         reuses: copy what has to outlive the next step."""
+        import time as _time
+        t0 = _time.perf_counter()
         while ticket["pool"] is not None:               # its pooling is still held back: flush in order
             self._enqueue_pool(self._pending.pop(0))
         ticket["done"].synchronize()
+        t1 = _time.perf_counter()
+        self.host_seconds["wait"] += t1 - t0
         _lib.range_check(self.device.index)      # an f16x3 operand beyond +-65504 is an error, not a clamp
         N, slots = ticket["rows"], ticket["slots"]
         seg = ticket["seg_h"].numpy()[:N]
@@ -353,6 +365,7 @@ class StreamBatch:
             ticket["tail"] = self.tail(scores, ticket["starts"], self.duration / seg.shape[1], slots=slots)
         ticket["busy"] = False
         ticket["keep"] = None
+        self.host_seconds["work"] += _time.perf_counter() - t1
         return seg, emb, scores, assign
 
     def __call__(self, waves: torch.Tensor):

@@ -100,7 +100,7 @@ def lstm_whh_planes(whh: torch.Tensor, variant: int) -> torch.Tensor:
     ``lo = f16(W' - hi)`` UNSCALED, so that one accumulator holds ``hi.hi + hi.lo + lo.hi``."""
     whh = whh.detach().float().cpu()
     assert whh.shape == (2, 512, 128), whh.shape
-    if variant == 0:
+    if variant in (0, 3):       # variant 3 = variant 0's planes, x-projection fetched by LDS-DMA
         return torch.stack([split_f16(whh[0]), split_f16(whh[1])]).contiguous()
     sh = {1: 0, 2: 8}[variant]
     log2e = 1.44269504088896341

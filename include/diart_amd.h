@@ -242,6 +242,14 @@ typedef struct {
     long long xplane;
     void* Ysplit;
     long long yplane;
+    /* norm-on-load without a finalize launch: instead of nscale / nshift the kernel is handed the
+     * producer's tile partials [B][npart_tiles][nld][2] (sum, sumsq over npart_T values per channel)
+     * and the InstanceNorm affine, and derives scale / shift itself (same f64 fixed-order
+     * arithmetic as dz_k_finalize_norm).  Split-f16 path only (dz_k_gemm_split, dz_k_conv_pool).  */
+    const float* npart;
+    const float* ngamma;
+    const float* nbeta;
+    int npart_tiles, npart_T;
     int* oflag;           /* device-visible int set to 1 when an operand of the split-f16 path lies
                              outside +-65504 (it is then clamped); NULL = the context's flag, read
                              with dz_range_check                                                 */
@@ -343,7 +351,8 @@ int dz_ring_create(dz_ctx* ctx, int n_streams, int window, int hop, int slack_bl
 int dz_ring_reset(dz_ring* r);
 int dz_ring_destroy(dz_ring* r);
 /* block (n_streams, hop) with block_stride floats between rows; host memory (on_device = 0;
- * pinned memory makes the copy asynchronous) or device memory (on_device = 1).              */
+ * pinned memory makes the copy asynchronous), device memory (on_device = 1), or pinned host memory
+ * to be read in place by the GPU when the runtime can map it (on_device = 2; falls back to 0).   */
 int dz_ring_push(dz_ring* r, const float* block, long long block_stride, int on_device, void* stream);
 /* *filled = min(window, samples pushed): the window is complete once *filled == window.     */
 int dz_ring_window(const dz_ring* r, const float** d_wave, long long* stride, int* filled);

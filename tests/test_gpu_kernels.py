@@ -287,7 +287,7 @@ def test_convgemm_pool3(gpu, Cin, Tin, split):
 
 
 # --------------------------------------------------------------------------- #
-@pytest.mark.parametrize("kernel", ["valu", "mfma0", "mfma0_um", "mfma1", "mfma1_um", "mfma2", "mfma2_um"])
+@pytest.mark.parametrize("kernel", ["valu", "mfma0", "mfma0_um", "mfma1", "mfma1_um", "mfma2", "mfma2_um", "mfma3_um"])
 @pytest.mark.parametrize("B,T", [(1, 293), (3, 40), (17, 64), (32, 293)])
 def test_lstm_recurrence(gpu, B, T, kernel):
     """k_lstm.hip (one chain per CU, exact f32) and k_lstm_mfma.hip (16 chains per workgroup on the

@@ -3,6 +3,7 @@
 on an otherwise idle GPU (torch events on the stream the kernel is launched on).
 usage: python tools/kbench.py [--batch 64] [--only lstm,tdnn2,...]"""
 import argparse
+import os
 import ctypes as C
 import json
 import sys
@@ -124,6 +125,12 @@ def convgemm(name, Bn, Tin, Cin, N, taps, dil, epi, Npad=None, pro=False, pool=F
         timeit(name + "_pre_f32out", lambda: _lib.check(lib.dz_k_gemm_pre(ctx, C.byref(d2), st), name), flop=flop)
         d2.Y, d2.Ysplit, d2.yplane = None, Yp.data_ptr(), M * Npad
         timeit(name + "_pre", lambda: _lib.check(lib.dz_k_gemm_pre(ctx, C.byref(d2), st), name), flop=flop)
+        if os.environ.get("KB_ABLATE"):
+            for mask, what in ((1, "no operand DMA"), (2, "no fragment reads"), (3, "MFMA + barrier only"), (4, "no stores"), (7, "MFMA only")):
+                d2.pad = mask
+                timeit(f"{name}_pre_ablate{mask}", lambda: _lib.check(lib.dz_k_gemm_pre(ctx, C.byref(d2), st), name), flop=flop)
+                results[f"{name}_pre_ablate{mask}"]["what"] = what
+            d2.pad = 0
         only.update(only_saved)
         torch.cuda.synchronize()
         # compare the rows every chunk computes validly with the f32 kernel's result
@@ -145,10 +152,11 @@ timeit("lstm", lambda: _lib.check(lib.dz_k_lstm(ctx, gx.data_ptr(), whh.data_ptr
        flop=2.0 * B * F * 2 * 512 * 128)
 from diart_amd.weights import lstm_whh_planes  # noqa: E402
 hout2 = torch.empty(B, F, 256, device=dev)
-for variant in (0, 1, 2):
+for variant in (0, 1, 2, 3):
     whs = lstm_whh_planes(whh.cpu(), variant).to(dev)
     nm = f"lstm_mfma{variant}"
-    timeit(nm, lambda: _lib.check(lib.dz_k_lstm_mfma(ctx, gx.data_ptr(), whs.data_ptr(), hout2.data_ptr(), B, F, 0, variant, st)),
+    gxv = gx.view(B, F, 2, 4, 128).transpose(3, 4).reshape(B, F, 1024).contiguous() if variant == 3 else gx
+    timeit(nm, lambda: _lib.check(lib.dz_k_lstm_mfma(ctx, gxv.data_ptr(), whs.data_ptr(), hout2.data_ptr(), B, F, int(variant == 3), variant, st)),
            flop=2.0 * B * F * 2 * 512 * 128)
     if "lstm" in results and nm in results:
         torch.cuda.synchronize()
