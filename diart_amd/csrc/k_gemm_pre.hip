@@ -26,6 +26,7 @@
 // workgroups per CU.  One barrier per k-tile: wait own DMA, barrier, issue the DMA of tile kt+1
 // into the stage everybody has just finished reading, compute tile kt.
 #include "dz_common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -99,19 +100,13 @@ __global__ __launch_bounds__(256, 2) void gemm_pre_kernel(DzConvGemm p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) accm[mt][nt][r] = accx[mt][nt][r] = 0.f;
 
-    // timing ablations (kbench only; p.pad is otherwise unused on this path and must be 0 in product
-    // calls): 1 = no operand DMA after the first tile, 2 = no fragment reads after the first k-step,
-    // 4 = no result stores
-    const int dbg = p.pad;
-    f16x8 ah[2] = {}, al[2] = {}, bh[2] = {}, bl[2] = {};
-    bool have = false;
     auto compute = [&](int stage) {
         const char* st = smem + stage * STAGE;
         const char* sa = st + (wm * 64) * 64;
         const char* sb = st + 2 * PLANE + (wn * 64) * 64;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            if (!((dbg & 2) && have))
+            f16x8 ah[2], al[2], bh[2], bl[2];
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
                 ah[t] = *reinterpret_cast<const f16x8*>(sa + t * 2048 + foff[ks]);
@@ -119,7 +114,6 @@ __global__ __launch_bounds__(256, 2) void gemm_pre_kernel(DzConvGemm p) {
                 bh[t] = *reinterpret_cast<const f16x8*>(sb + t * 2048 + foff[ks]);
                 bl[t] = *reinterpret_cast<const f16x8*>(sb + PLANE + t * 2048 + foff[ks]);
             }
-            have = true;
             // TRANSPOSED product: the weight fragment is the MFMA's row operand, the activation
             // fragment its column operand, so a lane ends up with ONE output row t (= lane & 31)
             // and, per accumulator register group, FOUR CONSECUTIVE output columns: the epilogue
@@ -140,7 +134,7 @@ __global__ __launch_bounds__(256, 2) void gemm_pre_kernel(DzConvGemm p) {
     for (int kt = 0; kt < nk; ++kt) {
         // own DMA of tile kt has landed + every wave has finished the fragment reads of tile kt-1
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        if (kt + 1 < nk && !(dbg & 1)) issue(kt + 1, (kt + 1) & 1);
+        if (kt + 1 < nk) issue(kt + 1, (kt + 1) & 1);
         compute(kt & 1);
     }
 
@@ -176,10 +170,6 @@ __global__ __launch_bounds__(256, 2) void gemm_pre_kernel(DzConvGemm p) {
                     if (EPI == DZ_EPI_TDNN) x = leaky(x) * e0[e] + e1[e];
                     if (EPI == DZ_EPI_RELU_BN) x = fmaxf(x, 0.f) * e0[e] + e1[e];
                     v[e] = x;
-                }
-                if (dbg & 4) {
-                    asm volatile("" ::"v"(v));
-                    continue;
                 }
                 const long long idx = (long long)t * p.ldy + n;
                 if (p.Y && ok) {
@@ -233,7 +223,7 @@ int dz_launch_gemm_pre(const DzConvGemm& p_in, hipStream_t st) {
                "gemm_pre: K = taps * Cin without padding, Cin a multiple of 32, ldx of 8");
     DZ_REQUIRE(p.Npad % BN == 0, "gemm_pre: Npad must be a multiple of 128");
     DZ_REQUIRE(p.Tout > 0 && p.Tout == p.Tin - (p.taps - 1) * p.dil, "gemm_pre: Tout mismatch");
-    DZ_REQUIRE(p.X2 == nullptr && p.rowbias == nullptr && p.ksplit <= 1 && !p.norm_on_load,
+    DZ_REQUIRE(p.pad == 0 && p.X2 == nullptr && p.rowbias == nullptr && p.ksplit <= 1 && !p.norm_on_load,
                "gemm_pre: padding / second input / row bias / split-K / norm-on-load are not built here");
     DZ_REQUIRE((long long)p.Tin * p.ldx * 2 < (1ll << 31) && (long long)p.Npad * p.Kpad * 2 < (1ll << 31),
                "gemm_pre: operand plane exceeds the 2 GiB buffer-offset range");

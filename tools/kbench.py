@@ -125,12 +125,6 @@ def convgemm(name, Bn, Tin, Cin, N, taps, dil, epi, Npad=None, pro=False, pool=F
         timeit(name + "_pre_f32out", lambda: _lib.check(lib.dz_k_gemm_pre(ctx, C.byref(d2), st), name), flop=flop)
         d2.Y, d2.Ysplit, d2.yplane = None, Yp.data_ptr(), M * Npad
         timeit(name + "_pre", lambda: _lib.check(lib.dz_k_gemm_pre(ctx, C.byref(d2), st), name), flop=flop)
-        if os.environ.get("KB_ABLATE"):
-            for mask, what in ((1, "no operand DMA"), (2, "no fragment reads"), (3, "MFMA + barrier only"), (4, "no stores"), (7, "MFMA only")):
-                d2.pad = mask
-                timeit(f"{name}_pre_ablate{mask}", lambda: _lib.check(lib.dz_k_gemm_pre(ctx, C.byref(d2), st), name), flop=flop)
-                results[f"{name}_pre_ablate{mask}"]["what"] = what
-            d2.pad = 0
         only.update(only_saved)
         torch.cuda.synchronize()
         # compare the rows every chunk computes validly with the f32 kernel's result
