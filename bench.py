@@ -55,7 +55,8 @@ KERNELS = {
     "lstm_rec": dict(mac=2 * F_SEG * 512 * 128, io=F_SEG * (1024 + 256) * 4, w=2 * 512 * 128 * 4, bound="rec"),
     "seg_mlp": dict(mac=(F_SEG * 256 * 128 + F_SEG * 128 * 128) / 2, io=F_SEG * (256 + 128 + 128 + 128) * 2,
                     w=(128 * 256 + 128 * 128) * 2, bound="gemm"),
-    "seg_classifier": dict(mac=F_SEG * 128 * 3, io=F_SEG * (128 + 3) * 4, w=64 * 128 * 4, bound="mfma_f32"),
+    # Linear(128->3) + sigmoid + OverlappedSpeechPenalty weights in one launch (k_pool.hip seg_head_kernel)
+    "seg_classifier": dict(mac=F_SEG * 128 * 3, io=F_SEG * (128 + 3 + 3) * 4, w=3 * 128 * 4, bound="hbm"),
     "seg_head": dict(mac=F_SEG * (256 * 128 + 128 * 128 + 128 * 3), io=F_SEG * (256 + 3 + 3) * 4,
                      w=(128 * 256 + 128 * 128 + 8 * 128) * 4, bound="gemm"),
     "tdnn1": dict(mac=F_E1 * 512 * 300, io=F_SEG * (64 + 512) * 4, w=512 * 320 * 4, bound="gemm"),
@@ -85,7 +86,8 @@ def device_kernel(tag, precision):
     lstm = os.environ.get("DZ_LSTM", "valu")                          # weights.default_lstm_variant
     k = KERNELS[tag]
     if k["bound"] == "hbm":
-        return {"wave_stats": "wave_stats_kernel", "stats_pool": "stats_pool_kernel<3>"}[tag], "hbm", PEAK_HBM_GBPS, "GB/s"
+        return {"wave_stats": "wave_stats_kernel", "stats_pool": "stats_pool_kernel<3>",
+                "seg_classifier": "seg_head_kernel"}[tag], "hbm", PEAK_HBM_GBPS, "GB/s"
     if k["bound"] == "rec":
         if split and lstm != "valu":
             sym = {"0": "lstm_mfma_kernel<true>", "3": "lstm_mfma_dma_kernel"}.get(
@@ -98,7 +100,7 @@ def device_kernel(tag, precision):
         sym = {"sinc_conv0": "sinc_conv0_kernel", "conv1_pool": "convgemm_kernel<64, true, 4>",
                "conv2_pool": "convgemm_kernel<64, true, 4>", "lstm_proj": "convgemm_kernel<128, false, 0>",
                "lstm_proj0": "convgemm_kernel<128, true, 0>", "seg_mlp": "convgemm_kernel<128, false, 1>",
-               "seg_classifier": "convgemm_kernel<64, false, 2>", "tdnn1": "convgemm_kernel<128, true, 3>",
+               "tdnn1": "convgemm_kernel<128, true, 3>",
                "emb_linear": "convgemm_kernel<128, false, 0> (split-K)", "seg_head": "seg_head_kernel"}
         return sym.get(tag, "convgemm_kernel<128, false, 3>"), "mfma", PEAK_F32_MATRIX_TFLOPS, "TFLOP/s"
     if pre and tag in ("tdnn2", "tdnn3", "tdnn4", "tdnn5", "lstm_proj", "seg_mlp"):
@@ -500,11 +502,13 @@ def main():
             "dtype": "f32" if precision == "f32" else "f16x3",
             "dtype_note": ("exact-f32 MFMA (v_mfma_f32_16x16x4_f32), f32 VALU, f32 accumulation; clustering f64"
                            if precision == "f32" else
-                           "GEMM-shaped layers: f32 operands split into two f16 numbers (hi + lo*2^-11 = 22 "
-                           "mantissa bits), three f16 MFMAs per product, f32 accumulation (k_gemm_split.hip); error "
-                           "vs the f32 oracle is the same as the exact-f32 path's (tests/test_gpu_models.py: seg "
-                           "8.7e-6 vs 8.8e-6, emb 4.7e-7 vs 5.0e-7); sinc conv0 and the LSTM recurrence exact "
-                           "f32; clustering f64.  The exact-f32 run of the same job is in `exact_f32`."),
+                           "every GEMM-shaped layer (sinc conv0, conv1/2, LSTM projections, MLP, TDNN 1-5): f32 operands "
+                           "split into two f16 numbers (hi + lo*2^-11 = 22 mantissa bits), three f16 MFMAs per product, "
+                           "f32 accumulation; operands beyond +-65504 are flagged as an error, not silently clamped "
+                           "(dz_range_check).  LSTM recurrence, classifier, pooling, Linear(3000,512): exact f32; "
+                           "clustering / aggregation f64.  Error vs the f32 oracle equals the exact-f32 path's "
+                           "(tests/test_gpu_models.py, tests/test_gpu_parity_r2.py: same gates for both).  The "
+                           "exact-f32 run of the same job is in `exact_f32`."),
             "data": "synthetic",
             "config": {"workload": "configs[1]: single MI355X, 5 s window / 500 ms step, "
                                    "pyannote/segmentation + pyannote/embedding architectures "

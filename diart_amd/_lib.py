@@ -64,6 +64,7 @@ SIGNATURES = {
     "dz_emb_frames_for": (C.c_int, [C.c_int]),
     "dz_seg_create": (C.c_int, [vp, C.POINTER(SegWeights), C.c_int, C.c_int, C.POINTER(vp)]),
     "dz_seg_forward": (C.c_int, [vp, vp, C.c_longlong, C.c_int, vp, vp]),
+    "dz_seg_forward_osp": (C.c_int, [vp, vp, C.c_longlong, C.c_int, vp, C.c_float, C.c_float, C.c_int, vp, vp]),
     "dz_seg_destroy": (C.c_int, [vp]),
     "dz_emb_create": (C.c_int, [vp, C.POINTER(EmbWeights), C.c_int, C.c_int, C.POINTER(vp)]),
     "dz_emb_forward": (C.c_int, [vp, vp, C.c_longlong, vp, C.c_int, C.c_int, vp, vp]),

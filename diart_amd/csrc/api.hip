@@ -411,8 +411,20 @@ extern "C" int dz_seg_destroy(dz_seg* seg) {
     return 0;
 }
 
+static int seg_forward(dz_seg* s, const float* d_wave, long long wave_stride, int B, float* d_out,
+                       float* d_osp, float gamma, float beta, int normalize, void* stream);
 extern "C" int dz_seg_forward(dz_seg* s, const float* d_wave, long long wave_stride, int B,
                               float* d_out, void* stream) {
+    return seg_forward(s, d_wave, wave_stride, B, d_out, nullptr, 0.f, 0.f, 0, stream);
+}
+extern "C" int dz_seg_forward_osp(dz_seg* s, const float* d_wave, long long wave_stride, int B,
+                                  float* d_out, float gamma, float beta, int normalize,
+                                  float* d_weights, void* stream) {
+    DZ_REQUIRE(d_weights != nullptr, "dz_seg_forward_osp: d_weights is NULL");
+    return seg_forward(s, d_wave, wave_stride, B, d_out, d_weights, gamma, beta, normalize, stream);
+}
+static int seg_forward(dz_seg* s, const float* d_wave, long long wave_stride, int B, float* d_out,
+                       float* d_osp, float gamma, float beta, int normalize, void* stream) {
     DZ_REQUIRE(s && d_out, "dz_seg_forward: NULL argument");
     DZ_REQUIRE(B >= 1 && B <= s->Bm, "dz_seg_forward: batch %d outside [1, %d]", B, s->Bm);
     int rc;
@@ -490,19 +502,10 @@ extern "C" int dz_seg_forward(dz_seg* s, const float* d_wave, long long wave_str
         p.Cin = 128; p.K = 128; p.Kpad = 128; p.ldx = 128;
         { ProfScope ps(T_MLP, B); if ((rc = run_gemm(p, s->w.lin1_split, st))) return rc; }
     }
-    p.Wsplit = nullptr;
-    p.X = s->m1; p.W = s->w.cls_w; p.bias = s->w.cls_b;
-    p.Npad = 64; p.Nstore = s->w.num_classes; p.ldy = s->w.num_classes;
-    if (s->w.powerset) {
-        // log_softmax is monotone: argmax of the logits == argmax of the log-probabilities
-        p.Y = s->logit; p.epi = DZ_EPI_BIAS;
-        { ProfScope ps(T_CLS, B); if ((rc = dz_launch_convgemm(p, st))) return rc; }
-        ProfScope ps(T_PSET, B);
-        return dz_launch_powerset(s->logit, B * F, s->w.num_classes, s->w.num_speakers, d_out, st);
-    }
-    p.Y = d_out; p.epi = DZ_EPI_BIAS_SIGMOID;
+    // classifier + sigmoid / powerset decision (+ OverlappedSpeechPenalty weights): one launch
     ProfScope ps(T_CLS, B);
-    return dz_launch_convgemm(p, st);
+    return dz_launch_seg_head(s->m1, s->w.cls_w, s->w.cls_b, B, F, s->w.num_classes, s->w.num_speakers,
+                              s->w.powerset, d_out, gamma, beta, normalize, d_osp, st);
 }
 
 // ---------------------------------------------------------------------------

@@ -231,6 +231,9 @@ int dz_launch_stats_pool(const float* X, long long xstride, int T, int C, int ld
                          hipStream_t st);
 int dz_launch_osp(const float* seg, int B, int F, int K, float gamma, float beta, int normalize,
                   int speaker_major, float* out, hipStream_t st);
+int dz_launch_seg_head(const float* m1, const float* cw, const float* cb, int B, int F, int classes, int K,
+                       int powerset, float* seg, float gamma, float beta, int normalize, float* wout,
+                       hipStream_t st);
 int dz_launch_l2norm(float* x, int rows, int dim, float norm, hipStream_t st);
 int dz_launch_splitk_finish(const float* parts, int nsplit, long long stride, int rows, int dim,
                             int normalize, float* out, hipStream_t st);

@@ -207,6 +207,130 @@ __global__ __launch_bounds__(256) void osp_kernel(const float* __restrict__ seg,
 }
 
 // ---------------------------------------------------------------------------
+// seg_head: the last three launches of the segmentation chain in one — Linear(128 -> classes) + bias,
+// then sigmoid (multilabel models) or the hard powerset decision (argmax -> multilabel,
+// models.py:29-39), then, when `wout` is given, the OverlappedSpeechPenalty weights of the frames
+// (functional.py:6-13 + the optional min-max of blocks/embedding.py:102-106) in the speaker-major
+// layout the pooling kernel reads.  One workgroup per chunk, thread = frame: the chunk's rows of the
+// MLP output (F x 128 f32) are staged through LDS in slices (coalesced loads, conflict-free row
+// reads at a 129-float pitch), the 128 x classes weights are wave-uniform scalar loads.  The OSP part
+// is the arithmetic of osp_kernel above, statement by statement.
+// ---------------------------------------------------------------------------
+constexpr int SH_ROWS = 64;          // frames per LDS slice
+constexpr int SH_PITCH = 129;
+
+__global__ __launch_bounds__(256) void seg_head_kernel(const float* __restrict__ m1, const float* __restrict__ cw,
+                                                       const float* __restrict__ cb, int F, int classes, int K,
+                                                       int powerset, float* __restrict__ seg, float gamma,
+                                                       float beta, int normalize, float* __restrict__ wout) {
+    extern __shared__ float hbuf[];   // [SH_ROWS][SH_PITCH] slice | [F][K] weights | [2][K] min / max
+    float* xs = hbuf;
+    float* wbuf = hbuf + SH_ROWS * SH_PITCH;
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const float* mb = m1 + (long long)b * F * 128;
+    float* sb = seg + (long long)b * F * K;
+    for (int f0 = 0; f0 < F; f0 += SH_ROWS) {
+        const int nf = min(SH_ROWS, F - f0);
+        __syncthreads();
+        for (int i = tid; i < nf * 32; i += 256) {            // float4 per thread, coalesced
+            const int r = i >> 5, c4 = i & 31;
+            const f32x4 v = *reinterpret_cast<const f32x4*>(mb + (long long)(f0 + r) * 128 + 4 * c4);
+            float* d = xs + r * SH_PITCH + 4 * c4;
+            d[0] = v[0]; d[1] = v[1]; d[2] = v[2]; d[3] = v[3];
+        }
+        __syncthreads();
+        if (tid < nf) {
+            const float* x = xs + tid * SH_PITCH;
+            float lg[8];
+            for (int c = 0; c < classes; ++c) {
+                float acc = 0.f;
+                const float* wc = cw + c * 128;              // wave-uniform: scalar loads
+#pragma unroll 8
+                for (int k = 0; k < 128; ++k) acc = fmaf(x[k], wc[k], acc);
+                lg[c] = acc + cb[c];
+            }
+            float s[8];
+            if (powerset) {
+                // log_softmax is monotone: argmax of the logits == argmax of the log-probabilities
+                int best = 0;
+                float bv = lg[0];
+                for (int c = 1; c < classes; ++c)
+                    if (lg[c] > bv) {
+                        bv = lg[c];
+                        best = c;
+                    }
+                int a = -1, b2 = -1;
+                if (best >= 1 && best <= K) {
+                    a = best - 1;
+                } else if (best > K) {
+                    int idx = best - K - 1;
+                    for (int i = 0; i < K && a < 0; ++i) {
+                        const int cnt = K - 1 - i;
+                        if (idx < cnt) {
+                            a = i;
+                            b2 = i + 1 + idx;
+                        } else {
+                            idx -= cnt;
+                        }
+                    }
+                }
+                for (int k = 0; k < K; ++k) s[k] = (k == a || k == b2) ? 1.f : 0.f;
+            } else {
+                for (int k = 0; k < K; ++k) s[k] = 1.f / (1.f + expf(-lg[k]));
+            }
+            const int f = f0 + tid;
+            for (int k = 0; k < K; ++k) sb[f * K + k] = s[k];
+            if (wout) {
+                float e[8], m = -INFINITY;
+                for (int k = 0; k < K; ++k) m = fmaxf(m, beta * s[k]);
+                float sum = 0.f;
+                for (int k = 0; k < K; ++k) {
+                    e[k] = expf(beta * s[k] - m);
+                    sum += e[k];
+                }
+                for (int k = 0; k < K; ++k) {
+                    const float pr = e[k] / sum;
+                    float wv = powg(s[k], gamma) * powg(pr, gamma);
+                    if (wv < 1e-8f) wv = 1e-8f;
+                    wbuf[f * K + k] = wv;
+                }
+            }
+        }
+    }
+    if (!wout) return;
+    __syncthreads();
+    float* mm = wbuf + F * K;
+    if (normalize) {
+        if (tid < K) {
+            float lo = INFINITY, hi = -INFINITY;
+            bool nan = false;
+            for (int f = 0; f < F; ++f) {
+                const float v = wbuf[f * K + tid];
+                nan |= (v != v);
+                lo = fminf(lo, v);
+                hi = fmaxf(hi, v);
+            }
+            if (nan) lo = hi = NAN;
+            mm[tid] = lo;
+            mm[K + tid] = hi;
+        }
+        __syncthreads();
+    }
+    float* ob = wout + (long long)b * F * K;
+    for (int idx = tid; idx < F * K; idx += 256) {
+        const int f = idx / K, k = idx - f * K;
+        float v = wbuf[idx];
+        if (normalize) {
+            v = (v - mm[k]) / (mm[K + k] - mm[k]);
+            if (v != v) v = 1e-8f;
+            else if (v == INFINITY) v = 3.4028234663852886e38f;
+            else if (v == -INFINITY) v = -3.4028234663852886e38f;
+        }
+        ob[k * F + f] = v;                                   // speaker-major (B, K, F)
+    }
+}
+
+// ---------------------------------------------------------------------------
 // l2norm: one wave per row, in place:  x <- (norm * x) / ||x||_2
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void l2norm_kernel(float* __restrict__ x, int rows, int dim,
@@ -352,6 +476,21 @@ int dz_launch_osp(const float* seg, int B, int F, int K, float gamma, float beta
     DZ_REQUIRE(lds <= 64 * 1024, "osp: %d frames x %d speakers do not fit in LDS", F, K);
     DZ_LAUNCH(osp_kernel, dim3(B), dim3(256), lds, st, seg, F, K, gamma, beta, normalize,
                        speaker_major, out);
+    DZ_HIP(hipGetLastError());
+    return 0;
+}
+
+// m1 [B*F][128] (MLP output), cw [>= classes][128], cb [classes] -> seg [B][F][K]; wout (optional)
+// [B][K][F] OSP weights
+int dz_launch_seg_head(const float* m1, const float* cw, const float* cb, int B, int F, int classes, int K,
+                       int powerset, float* seg, float gamma, float beta, int normalize, float* wout,
+                       hipStream_t st) {
+    DZ_REQUIRE(classes >= 1 && classes <= 8 && K >= 1 && K <= 8 && (powerset || K == classes),
+               "seg_head: classes %d / speakers %d", classes, K);
+    const size_t lds = sizeof(float) * ((size_t)SH_ROWS * SH_PITCH + (size_t)F * K + 2 * K);
+    DZ_REQUIRE(lds <= 64 * 1024, "seg_head: %d frames x %d speakers do not fit in LDS", F, K);
+    DZ_LAUNCH(seg_head_kernel, dim3(B), dim3(256), lds, st, m1, cw, cb, F, classes, K, powerset, seg, gamma,
+              beta, normalize, wout);
     DZ_HIP(hipGetLastError());
     return 0;
 }

@@ -287,11 +287,11 @@ class StreamBatch:
             if i1 == i0:                                 # fewer rows than sub-batches
                 ev.record(a)
                 continue
-            _lib.check(lib.dz_seg_forward(h, base + i0 * stride * esz, stride, i1 - i0,
-                                          slot["seg"][i0:i1].data_ptr(), a.cuda_stream), "dz_seg_forward")
-            _lib.check(lib.dz_osp(self._ctx, slot["seg"][i0:i1].data_ptr(), i1 - i0, F, K, self.gamma,
-                                  self.beta, int(self.norm_w), 1, slot["w"][i0:i1].data_ptr(),
-                                  a.cuda_stream), "dz_osp")
+            # segmentation + the OSP weights of its output (one launch sequence, no dz_osp of its own)
+            _lib.check(lib.dz_seg_forward_osp(h, base + i0 * stride * esz, stride, i1 - i0,
+                                              slot["seg"][i0:i1].data_ptr(), self.gamma, self.beta,
+                                              int(self.norm_w), slot["w"][i0:i1].data_ptr(), a.cuda_stream),
+                       "dz_seg_forward_osp")
             ev.record(a)
         for (i0, i1), h, b, ev in zip(sb, hembs, lane["b"], slot["ev_frames"]):
             b.wait_event(slot["ev_in"])

@@ -115,6 +115,11 @@ typedef struct {
 int dz_seg_create(dz_ctx* ctx, const dz_seg_weights* w, int max_batch, int num_samples, dz_seg** out);
 int dz_seg_forward(dz_seg* seg, const float* d_wave, long long wave_stride, int batch,
                    float* d_out, void* stream);
+/* The same forward pass that also leaves the OverlappedSpeechPenalty weights of its output
+ * (blocks/embedding.py:98-107 -> functional.py:6-13; d_weights (B,K,F) speaker-major, the layout
+ * dz_emb_pool consumes) — the N-stream driver's seg -> OSP hand-off without a launch of its own. */
+int dz_seg_forward_osp(dz_seg* seg, const float* d_wave, long long wave_stride, int batch, float* d_out,
+                       float gamma, float beta, int normalize, float* d_weights, void* stream);
 int dz_seg_destroy(dz_seg* seg);
 
 /* ---- embedding: replaces the callable behind EmbeddingModel.__call__ --------

@@ -1,7 +1,7 @@
 #!/bin/bash
 # One GPU-box visit: PMC traffic passes, bench line (+cpu baseline), then the same command under
 # rocprofv3 --kernel-trace --stats.   usage: tools/gpu_bench.sh <tag> [steps]
-TAG=${1:-r1}
+TAG=${1:-r02_a}
 STEPS=${2:-40}
 mkdir -p gpurun_out
 export PYTHONDONTWRITEBYTECODE=1
