@@ -16,7 +16,7 @@ HERE = Path(__file__).resolve().parent
 CSRC = HERE / "csrc"
 LIB = HERE / "libdiart_amd.so"
 SOURCES = ["api.hip", "ecapa_api.hip", "k_front.hip", "k_convgemm.hip", "k_gemm_split.hip", "k_gemm_pre.hip", "k_conv_pool.hip", "k_lstm.hip", "k_lstm_mfma.hip", "k_pool.hip",
-           "k_ecapa.hip", "ring.hip", "cluster.cpp", "tail.cpp"]
+           "k_ecapa.hip", "ring.hip", "cluster.cpp", "tail.cpp", "hostpool.cpp"]
 ARCH = "gfx950"
 
 
@@ -38,7 +38,7 @@ def build(force: bool = False, verbose: bool = False) -> Path:
     hipcc = _hipcc()
     objdir = HERE / "build"
     objdir.mkdir(exist_ok=True)
-    headers = [CSRC / "dz_common.h", HERE.parent / "include" / "diart_amd.h"]
+    headers = [CSRC / "dz_common.h", CSRC / "hostpool.h", HERE.parent / "include" / "diart_amd.h"]
     flags = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function"]
 
     def compile_one(src: str) -> Path:

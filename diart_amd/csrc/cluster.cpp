@@ -17,7 +17,7 @@
 #include <limits>
 #include <new>
 #include <string>
-#include <thread>
+#include "hostpool.h"
 #include <utility>
 #include <vector>
 
@@ -468,23 +468,18 @@ extern "C" int dz_clu_step_batch(dz_clu** clus, int n, const float* seg, int fra
         return 0;
     }
     // the error text is thread local: a failing worker copies its own message (and which stream
-    // it was) before it is lost with the thread.  Streams are independent, so the ones that
+    // it was) before another stream's overwrites it.  Streams are independent, so the ones that
     // succeeded HAVE been stepped; the caller decides what to do with the failed ones.
     std::vector<int> rcs(nt, 0), who(nt, -1);
     std::vector<std::string> msgs(nt);
-    std::vector<std::thread> th;
-    for (int t = 0; t < nt; ++t)
-        th.emplace_back([&, t]() {
-            for (int i = t; i < n; i += nt) {
-                const int rc = run(i);
-                if (rc && !rcs[t]) {
-                    rcs[t] = rc;
-                    who[t] = i;
-                    msgs[t] = dz_last_error();
-                }
-            }
-        });
-    for (auto& x : th) x.join();
+    dz_host_parallel(n, nt, [&](int t, int i) {
+        const int rc = run(i);
+        if (rc && (!rcs[t] || i < who[t])) {
+            rcs[t] = rc;
+            who[t] = i;
+            msgs[t] = dz_last_error();
+        }
+    });
     int first = -1;
     for (int t = 0; t < nt; ++t)
         if (rcs[t] && (first < 0 || who[t] < who[first])) first = t;

@@ -22,7 +22,7 @@
 
 #include <deque>
 #include <new>
-#include <thread>
+#include "hostpool.h"
 #include <vector>
 
 #include "../../include/diart_amd.h"
@@ -271,15 +271,10 @@ extern "C" int dz_tail_step_batch(dz_tail** tails, int n, const double* scores,
     if (nt == 1) {
         for (int i = 0; i < n && !rcs[0]; ++i) rcs[0] = run(i);
     } else {
-        std::vector<std::thread> th;
-        for (int k = 0; k < nt; ++k)
-            th.emplace_back([&, k]() {
-                for (int i = k; i < n; i += nt) {
-                    const int rc = run(i);
-                    if (rc && !rcs[k]) rcs[k] = rc;
-                }
-            });
-        for (auto& x : th) x.join();
+        dz_host_parallel(n, nt, [&](int k, int i) {
+            const int rc = run(i);
+            if (rc && !rcs[k]) rcs[k] = rc;
+        });
     }
     for (int rc : rcs)
         if (rc) return tail_fail("dz_tail_step_batch", rc);
