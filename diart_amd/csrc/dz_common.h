@@ -69,10 +69,9 @@ extern thread_local DzLaunchProf* dz_launch_prof;
 // algorithmic bytes).  Re-order so that XCD r owns activation tiles a = r, r+8, ...; inside
 // an XCD, groups of AG activation tiles sweep the N-tiles together (weight slice reuse).
 // ---------------------------------------------------------------------------
-__device__ __forceinline__ void dz_tile_map(int agroup, int& bx, int& by, int& bz) {
-    const int gx = gridDim.x, gy = gridDim.y;
-    const int L = blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z);
-    const int NA = gx * gridDim.z, NA8 = NA & ~7;
+__device__ __forceinline__ void dz_tile_map_lin(int L, int gx, int gy, int gz, int agroup, int& bx, int& by,
+                                                int& bz) {
+    const int NA = gx * gz, NA8 = NA & ~7;
     int a;
     if (L < NA8 * gy) {
         const int xcd = L & 7, j = L >> 3;          // j-th workgroup of this XCD
@@ -89,6 +88,10 @@ __device__ __forceinline__ void dz_tile_map(int agroup, int& bx, int& by, int& b
     }
     bz = a / gx;
     bx = a - bz * gx;
+}
+__device__ __forceinline__ void dz_tile_map(int agroup, int& bx, int& by, int& bz) {
+    const int gx = gridDim.x, gy = gridDim.y;
+    dz_tile_map_lin(blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z), gx, gy, gridDim.z, agroup, bx, by, bz);
 }
 
 // ---------------------------------------------------------------------------

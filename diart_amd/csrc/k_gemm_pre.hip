@@ -25,6 +25,16 @@
 // and again on the fragment read: cdna_hip_programming.md rule 21); two stages = 64 KiB, two
 // workgroups per CU.  One barrier per k-tile: wait own DMA, barrier, issue the DMA of tile kt+1
 // into the stage everybody has just finished reading, compute tile kt.
+//
+// Small tiles.  The same tile code also runs with one 32 x 32 fragment per wave (64 x 64 tiles: a
+// quarter of the work per workgroup at twice the operand bytes per MFMA).  A launch whose 128 x 128
+// tiles would occupy less than a quarter of the chip's 512 workgroup slots (single-chunk latency
+// runs: 12 tiles for one 5 s chunk) uses them throughout.  DZ_GEMM_TAIL=1 additionally uses them for
+// the rows of a mostly empty LAST round (config 2: tdnn2 has 580 tiles = 1.13 rounds, the LSTM
+// projection 1172 = 2.29).  Measured (gpurun_out r02 visit "tail"): alone the kernels get 13 - 16 %
+// faster (tdnn2 128 -> 111 us, tdnn4 50 -> 42 us), but the 64-stream pipeline gets ~1 % SLOWER — there
+// the empty slots of a last round are filled by the kernels of the other HIP streams, and the small
+// tiles only add operand traffic.  Hence off by default.
 #include "dz_common.h"
 #include <stdlib.h>
 
@@ -42,14 +52,11 @@ constexpr float LO_UNSCALE = 1.f / 2048.f;
 
 __device__ __forceinline__ float leaky(float v) { return v > 0.f ? v : v * DZ_LEAKY_SLOPE; }
 
-template <int EPI>
-__global__ __launch_bounds__(256, 2) void gemm_pre_kernel(DzConvGemm p) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
+// One output tile of (64 MT) x (64 NT): 2 x 2 waves, MT x NT fragments of 32 x 32 per wave.
+template <int EPI, int MT, int NT>
+__device__ __forceinline__ void gemm_pre_tile(const DzConvGemm& p, const int t0, const int n0, char* smem) {
     const int tid = threadIdx.x;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6), l = tid & 63;
-    int bx, by, bz;
-    dz_tile_map(p.agroup, bx, by, bz);
-    const int t0 = bx * BM, n0 = by * BN;
 
     // ---- staging role of this wave: plane w of every stage (0 A hi, 1 A lo, 2 B hi, 3 B lo) ----
     const bool isB = w >= 2;
@@ -79,38 +86,48 @@ __global__ __launch_bounds__(256, 2) void gemm_pre_kernel(DzConvGemm p) {
             soff = (tap * p.dil * p.ldx + c) * 2;
         }
         char* dst = smem + stage * STAGE + w * PLANE;
+        if (isB) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i)
+            for (int i = 0; i < 4 * NT; ++i)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(
+                    rsrc, (__attribute__((address_space(3))) void*)(dst + i * 1024), 16, voff0 + i * vstep, soff, 0, 0);
+            return;
+        }
+#pragma unroll
+        for (int i = 0; i < 4 * MT; ++i)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(
                 rsrc, (__attribute__((address_space(3))) void*)(dst + i * 1024), 16, voff0 + i * vstep, soff, 0, 0);
     };
 
-    // ---- MFMA coordinates: 2 x 2 waves, wave tile 64 x 64 ---------------------------------------
+    // ---- MFMA coordinates: 2 x 2 waves, wave tile (32 MT) x (32 NT) -----------------------------
     const int li = l & 31, g = l >> 5;
     const int wm = w >> 1, wn = w & 1;
     const int sw = (li >> 2) & 3;
     int foff[2];                               // fragment offset of this lane inside a 32-row block
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) foff[ks] = li * 64 + (((2 * ks + g) ^ sw) << 4);
-    f32x16 accm[2][2], accx[2][2];
+    f32x16 accm[MT][NT], accx[MT][NT];
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
+    for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt)
+        for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) accm[mt][nt][r] = accx[mt][nt][r] = 0.f;
 
     auto compute = [&](int stage) {
         const char* st = smem + stage * STAGE;
-        const char* sa = st + (wm * 64) * 64;
-        const char* sb = st + 2 * PLANE + (wn * 64) * 64;
+        const char* sa = st + (wm * 32 * MT) * 64;
+        const char* sb = st + 2 * PLANE + (wn * 32 * NT) * 64;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            f16x8 ah[2], al[2], bh[2], bl[2];
+            f16x8 ah[MT], al[MT], bh[NT], bl[NT];
 #pragma unroll
-            for (int t = 0; t < 2; ++t) {
+            for (int t = 0; t < MT; ++t) {
                 ah[t] = *reinterpret_cast<const f16x8*>(sa + t * 2048 + foff[ks]);
                 al[t] = *reinterpret_cast<const f16x8*>(sa + PLANE + t * 2048 + foff[ks]);
+            }
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
                 bh[t] = *reinterpret_cast<const f16x8*>(sb + t * 2048 + foff[ks]);
                 bl[t] = *reinterpret_cast<const f16x8*>(sb + PLANE + t * 2048 + foff[ks]);
             }
@@ -119,9 +136,9 @@ __global__ __launch_bounds__(256, 2) void gemm_pre_kernel(DzConvGemm p) {
             // and, per accumulator register group, FOUR CONSECUTIVE output columns: the epilogue
             // stores 16 bytes (f32) / 8 bytes (f16 planes) per instruction instead of 4
 #pragma unroll
-            for (int mt = 0; mt < 2; ++mt)
+            for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-                for (int nt = 0; nt < 2; ++nt) {
+                for (int nt = 0; nt < NT; ++nt) {
                     accx[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[nt], al[mt], accx[mt][nt], 0, 0, 0);
                     accm[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[nt], ah[mt], accm[mt][nt], 0, 0, 0);
                     accx[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl[nt], ah[mt], accx[mt][nt], 0, 0, 0);
@@ -148,14 +165,14 @@ __global__ __launch_bounds__(256, 2) void gemm_pre_kernel(DzConvGemm p) {
     unsigned short* Yhi = reinterpret_cast<unsigned short*>(p.Ysplit);
     float amax = 0.f;
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt) {
-        const int t = t0 + wm * 64 + mt * 32 + li;
+    for (int mt = 0; mt < MT; ++mt) {
+        const int t = t0 + wm * 32 * MT + mt * 32 + li;
         const bool ok = t < p.Tout;
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt)
+        for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                const int n = n0 + wn * 64 + nt * 32 + 8 * k + 4 * g;
+                const int n = n0 + wn * 32 * NT + nt * 32 + 8 * k + 4 * g;
                 const f32x4 bv = *reinterpret_cast<const f32x4*>(p.bias + n);
                 f32x4 e0 = {1.f, 1.f, 1.f, 1.f}, e1 = {0.f, 0.f, 0.f, 0.f};
                 if (EPI == DZ_EPI_TDNN || EPI == DZ_EPI_RELU_BN) {
@@ -200,12 +217,58 @@ __global__ __launch_bounds__(256, 2) void gemm_pre_kernel(DzConvGemm p) {
     dz_flag_range(p.oflag, amax);
 }
 
+// Workgroups [0, mbig * gy): 128 x 128 tiles over the first mbig * 128 rows (XCD-aware order of
+// dz_tile_map); the rest: 64 x 64 tiles over the remaining rows — XCD r owns row tiles r, r+8, ...
+// and sweeps the N tiles of one row tile back to back (activation rows stay in that XCD's L2).
+template <int EPI>
+__global__ __launch_bounds__(256, 2) void gemm_pre_kernel(DzConvGemm p, int mbig, int msmall) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int gy = p.Npad / BN, L = blockIdx.x;
+    if (L < mbig * gy) {
+        int bx, by, bz;
+        dz_tile_map_lin(L, mbig, gy, 1, p.agroup, bx, by, bz);
+        gemm_pre_tile<EPI, 2, 2>(p, bx * BM, by * BN, smem);
+    } else {
+        const int Ls = L - mbig * gy, gys = 2 * gy;
+        const int xcd = Ls & 7, j = Ls >> 3;
+        const int ms = (j / gys) * 8 + xcd, by = j % gys;
+        if (ms >= msmall) return;
+        gemm_pre_tile<EPI, 1, 1>(p, mbig * BM + ms * 64, by * 64, smem);
+    }
+}
+
+// DZ_GEMM_TAIL=1: 64 x 64 tiles for the rows of a mostly empty last round as well (see the header)
+bool tail_tiles_enabled() {
+    static const bool on = [] {
+        const char* e = getenv("DZ_GEMM_TAIL");
+        return e && e[0] == '1';
+    }();
+    return on;
+}
+int wg_slots() {   // resident workgroups of this kernel on the chip: 2 per CU (64 KiB LDS, <= 256 VGPRs)
+    static const int slots = [] {
+        int dev = 0, cus = 256;
+        if (hipGetDevice(&dev) == hipSuccess) hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        return 2 * (cus > 0 ? cus : 256);
+    }();
+    return slots;
+}
+
 template <int EPI>
 int launch(const DzConvGemm& p, hipStream_t st) {
     static DzAttrOnce attr_once;
     DZ_HIP(attr_once.raise((const void*)gemm_pre_kernel<EPI>, (int)LDS_BYTES));
-    dim3 grid((p.Tout + BM - 1) / BM, p.Npad / BN, 1);
-    DZ_LAUNCH((gemm_pre_kernel<EPI>), grid, dim3(256), LDS_BYTES, st, p);
+    const int gx = (p.Tout + BM - 1) / BM, gy = p.Npad / BN, slots = wg_slots();
+    int mbig = gx;
+    const int tiles = gx * gy, rem = tiles % slots;
+    if (4 * tiles < slots)
+        mbig = 0;                                   // latency regime: small tiles throughout
+    else if (tail_tiles_enabled() && rem != 0 && 4 * rem < 3 * slots)
+        mbig = (tiles / slots) * slots / gy;        // a last round that is at least 3/4 full is left alone
+    const int rows_left = p.Tout - mbig * BM;
+    const int msmall = rows_left > 0 ? (rows_left + 63) / 64 : 0;
+    const int nwg = mbig * gy + ((msmall + 7) / 8) * 8 * (2 * gy);
+    DZ_LAUNCH((gemm_pre_kernel<EPI>), dim3(nwg), dim3(256), LDS_BYTES, st, p, mbig, msmall);
     DZ_HIP(hipGetLastError());
     return 0;
 }

@@ -12,37 +12,36 @@ namespace {
 
 // ---------------------------------------------------------------------------
 // stats_pool: one workgroup = (64-channel slab, one chunk).  The [T][64] slab of frame
-// features is read from HBM once (256 B coalesced rows), parked in LDS, and used for both
-// passes (weighted mean, then centred second moment) of all K speakers.  Lanes = channels,
-// the 4 waves split the frames; partial sums meet in LDS.
+// features is read from HBM once (256 B coalesced rows) and used for both passes (weighted
+// mean, then centred second moment) of all K speakers.  Lanes = channels, the 4 waves split
+// the frames; partial sums meet in LDS.
+// The frames of a lane are held in REGISTERS (lane = channel, wave ph owns frames ph, ph+4, ...,
+// at most NR of them), not in LDS: the round-1 version parked the [T][64] slab in LDS (73 KB), needed
+// half a CU's LDS to itself and could not start while the GEMM workgroups of the other HIP streams
+// (2 x 64 KB per CU) were resident — in the pipeline its launches took 0.2 - 5 ms instead of the 64 us
+// it takes alone (profiles/r02_a_kernel_stats.md).  Same arithmetic and summation order as that
+// version; 6 KB of LDS.
 // ---------------------------------------------------------------------------
-template <int K>
-__global__ __launch_bounds__(256) void stats_pool_kernel(
+template <int K, int NR>
+__global__ __launch_bounds__(256) void stats_pool_reg_kernel(
     const float* __restrict__ X, long long xstride, int T, int C, int ldx,
     const float* __restrict__ weights, int Fw, int ktot, int kofs, float* __restrict__ out, int ldo) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* xs = smem;                 // [T][64]
-    float* wk = xs + T * 64;          // [K][T]
+    float* wk = smem;                 // [K][T]
     float* red = wk + K * T;          // [4][K][64]
     const int c0 = blockIdx.x * 64, xi = blockIdx.y, tid = threadIdx.x;
     const int c = tid & 63, ph = tid >> 6;
+    const bool live = c0 + c < C;
 
-    const float* Xb = X + (long long)xi * xstride;   // chunks may sit on a wider row pitch than T
-    for (int i4 = tid; i4 < T * 16; i4 += 256) {           // 16 B per lane, 256 B rows
-        const int t = i4 >> 4, cc = (i4 & 15) << 2;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (c0 + cc + 3 < C) {
-            v = *reinterpret_cast<const float4*>(Xb + (long long)t * ldx + c0 + cc);
-        } else {
-            const float* src = Xb + (long long)t * ldx + c0 + cc;
-            if (c0 + cc < C) v.x = src[0];
-            if (c0 + cc + 1 < C) v.y = src[1];
-            if (c0 + cc + 2 < C) v.z = src[2];
+    float xr[NR];
+    {
+        const float* Xb = X + (long long)xi * xstride + c0 + c;
+#pragma unroll
+        for (int i = 0; i < NR; ++i) {
+            const int t = ph + 4 * i;
+            xr[i] = (live && t < T) ? Xb[(long long)t * ldx] : 0.f;
         }
-        reinterpret_cast<float4*>(xs)[i4] = v;
     }
-    // temporal weights, resampled to T frames like F.interpolate(mode="linear",
-    // align_corners=False) (ATen area_pixel_compute_source_index)
     const float scale = (float)Fw / (float)T;
     for (int idx = tid; idx < K * T; idx += 256) {
         const int k = idx / T, t = idx - k * T;
@@ -84,10 +83,13 @@ __global__ __launch_bounds__(256) void stats_pool_kernel(
     float mean[K], acc[K];
 #pragma unroll
     for (int k = 0; k < K; ++k) acc[k] = 0.f;
-    for (int t = ph; t < T; t += 4) {
-        const float x = xs[t * 64 + c];
 #pragma unroll
-        for (int k = 0; k < K; ++k) acc[k] += x * wk[k * T + t];
+    for (int i = 0; i < NR; ++i) {
+        const int t = ph + 4 * i;
+        if (t < T) {
+#pragma unroll
+            for (int k = 0; k < K; ++k) acc[k] += xr[i] * wk[k * T + t];
+        }
     }
 #pragma unroll
     for (int k = 0; k < K; ++k) red[(ph * K + k) * 64 + c] = acc[k];
@@ -100,18 +102,21 @@ __global__ __launch_bounds__(256) void stats_pool_kernel(
         acc[k] = 0.f;
     }
     __syncthreads();
-    for (int t = ph; t < T; t += 4) {
-        const float x = xs[t * 64 + c];
 #pragma unroll
-        for (int k = 0; k < K; ++k) {
-            const float d = x - mean[k];
-            acc[k] += (d * d) * wk[k * T + t];
+    for (int i = 0; i < NR; ++i) {
+        const int t = ph + 4 * i;
+        if (t < T) {
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                const float d = xr[i] - mean[k];
+                acc[k] += (d * d) * wk[k * T + t];
+            }
         }
     }
 #pragma unroll
     for (int k = 0; k < K; ++k) red[(ph * K + k) * 64 + c] = acc[k];
     __syncthreads();
-    if (ph == 0 && c0 + c < C) {
+    if (ph == 0 && live) {
 #pragma unroll
         for (int k = 0; k < K; ++k) {
             const float s = (red[(0 * K + k) * 64 + c] + red[(1 * K + k) * 64 + c]) +
@@ -127,12 +132,15 @@ __global__ __launch_bounds__(256) void stats_pool_kernel(
 template <int K>
 int launch_pool(const float* X, long long xstride, int T, int C, int ldx, const float* weights, int Fw, int nx,
                 int ktot, int kofs, float* out, int ldo, hipStream_t st) {
-    const size_t lds = sizeof(float) * ((size_t)T * 64 + (size_t)K * T + 4 * K * 64);
-    DZ_REQUIRE(lds <= 160 * 1024, "stats_pool: %d frames do not fit in LDS", T);
-    DZ_HIP(hipFuncSetAttribute((const void*)stats_pool_kernel<K>,
-                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    DZ_LAUNCH((stats_pool_kernel<K>), dim3((C + 63) / 64, nx), dim3(256), lds, st, X, xstride,
-                       T, C, ldx, weights, Fw, ktot, kofs, out, ldo);
+    const dim3 grid((C + 63) / 64, nx);
+    DZ_REQUIRE(T <= 4 * 160, "stats_pool: %d frames per chunk (at most 640: an 11 s chunk)", T);
+    const size_t lds = sizeof(float) * ((size_t)K * T + 4 * K * 64);
+    if (T <= 4 * 80)
+        DZ_LAUNCH((stats_pool_reg_kernel<K, 80>), grid, dim3(256), lds, st, X, xstride, T, C, ldx, weights, Fw,
+                  ktot, kofs, out, ldo);
+    else
+        DZ_LAUNCH((stats_pool_reg_kernel<K, 160>), grid, dim3(256), lds, st, X, xstride, T, C, ldx, weights, Fw,
+                  ktot, kofs, out, ldo);
     DZ_HIP(hipGetLastError());
     return 0;
 }
@@ -347,32 +355,46 @@ __global__ __launch_bounds__(256) void l2norm_kernel(float* __restrict__ x, int 
 
 // ---------------------------------------------------------------------------
 // splitk_finish: out[r][:] = sum_z parts[z][r][:] in fixed order (deterministic, unlike
-// atomics), optionally followed by x <- x / ||x||_2.  One wave per row, dim <= 512.
+// atomics), optionally followed by x <- x / ||x||_2.  One workgroup per row, thread = column
+// (dim <= 512); the partials of a column are fetched four at a time (the one-wave-per-row version
+// walked 8 x nsplit dependent L2 round trips per lane: 45 us for 192 rows).  The sum of squares is
+// formed in the order of that version (columns l, l+64, ... per lane, then the butterfly).
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void splitk_finish_kernel(const float* __restrict__ parts,
+__global__ __launch_bounds__(512) void splitk_finish_kernel(const float* __restrict__ parts,
                                                             int nsplit, long long stride, int rows,
                                                             int dim, int normalize,
                                                             float* __restrict__ out) {
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), l = threadIdx.x & 63;
-    if (row >= rows) return;
-    float v[8];
-    float ss = 0.f;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const int i = l + 64 * j;
-        float a = 0.f;
-        if (i < dim)
-            for (int z = 0; z < nsplit; ++z) a += parts[(long long)z * stride + (long long)row * dim + i];
-        v[j] = a;
-        ss += a * a;
+    __shared__ float sq[8][64];
+    __shared__ float nrm;
+    const int row = blockIdx.x, i = threadIdx.x, l = i & 63, w = i >> 6;
+    float a = 0.f;
+    if (i < dim) {
+        const float* p = parts + (long long)row * dim + i;
+        int z = 0;
+        for (; z + 4 <= nsplit; z += 4) {
+            const float x0 = p[(long long)z * stride], x1 = p[(long long)(z + 1) * stride],
+                        x2 = p[(long long)(z + 2) * stride], x3 = p[(long long)(z + 3) * stride];
+            a += x0;
+            a += x1;
+            a += x2;
+            a += x3;
+        }
+        for (; z < nsplit; ++z) a += p[(long long)z * stride];
     }
-    for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
-    const float n = sqrtf(ss);
+    if (normalize) {
+        sq[w][l] = a * a;
+        __syncthreads();
+        if (w == 0) {
+            float ss = 0.f;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const int i = l + 64 * j;
-        if (i < dim) out[(long long)row * dim + i] = normalize ? v[j] / n : v[j];
+            for (int j = 0; j < 8; ++j) ss += sq[j][l];
+            for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
+            if (l == 0) nrm = sqrtf(ss);
+        }
+        __syncthreads();
+        a = a / nrm;
     }
+    if (i < dim) out[(long long)row * dim + i] = a;
 }
 
 // ---------------------------------------------------------------------------
@@ -504,7 +526,7 @@ int dz_launch_l2norm(float* x, int rows, int dim, float norm, hipStream_t st) {
 int dz_launch_splitk_finish(const float* parts, int nsplit, long long stride, int rows, int dim,
                             int normalize, float* out, hipStream_t st) {
     DZ_REQUIRE(dim <= 512, "splitk_finish: dim %d > 512", dim);
-    DZ_LAUNCH(splitk_finish_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, parts, nsplit,
+    DZ_LAUNCH(splitk_finish_kernel, dim3(rows), dim3(512), 0, st, parts, nsplit,
                        stride, rows, dim, normalize, out);
     DZ_HIP(hipGetLastError());
     return 0;

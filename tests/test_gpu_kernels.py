@@ -327,11 +327,12 @@ def test_lstm_recurrence(gpu, B, T, kernel):
 
 
 # --------------------------------------------------------------------------- #
-@pytest.mark.parametrize("K,Fw", [(1, 293), (3, 293), (4, 293), (5, 293), (3, 279), (1, 0)])
-def test_stats_pool(gpu, K, Fw):
+@pytest.mark.parametrize("K,Fw,T", [(1, 293, 279), (3, 293, 279), (4, 293, 279), (5, 293, 279), (3, 279, 279),
+                                    (1, 0, 279), (3, 293, 321), (3, 589, 571), (2, 40, 37)])
+def test_stats_pool(gpu, K, Fw, T):
     from oracle.models_ref import stats_pool_ref
     g = torch.Generator().manual_seed(K * 7 + Fw)
-    nx, T, Cc, ld = 3, 279, 1500, 1536
+    nx, Cc, ld = 3, 1500, 1536
     x = torch.randn(nx, T, ld, generator=g) + 0.5
     rows = nx * K
     w = None
@@ -430,6 +431,7 @@ def _unplanes(p):
     (700, 512, 3, 3, 1536, 1500, "tdnn", "both"),
     (64 * 293, 512, 1, 1, 512, 512, "tdnn", "planes"),
     (5, 256, 1, 1, 128, 128, "leaky", "f32"),
+    (5157, 256, 3, 1, 512, 512, "tdnn", "both"),     # 128 x 128 tiles with a ragged last row tile
 ])
 def test_gemm_pre(gpu, M, Cin, taps, dil, N, Nstore, epi, outs):
     """k_gemm_pre.hip (both operands as f16 hi/lo planes, tiles by LDS-DMA) against an f64 torch

@@ -7,12 +7,13 @@ REPO=$PWD
 export PYTHONDONTWRITEBYTECODE=1 TMPDIR=/tmp
 cd /tmp
 for C in FETCH_SIZE WRITE_SIZE; do
-  timeout 280 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $REPO/gpurun_out/pmc_${TAG}_$C -o pmc -- \
+  timeout -s KILL 120 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $REPO/gpurun_out/pmc_${TAG}_$C -o pmc -- \
       python $REPO/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-exact-f32 --no-host-pass > $REPO/gpurun_out/pmc_${TAG}_$C.log 2>&1
-  echo "$C exit $?"
+  rc=$?; echo "$C exit $rc"
+  [ $rc -ne 0 ] && { tail -5 $REPO/gpurun_out/pmc_${TAG}_$C.log; exit 1; }   # a faulting box: do not burn the budget
 done
 # matrix-core busy cycles (north-star: "MFMA utilisation against gfx950 peak"), own pass
-timeout 280 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv \
+timeout -s KILL 120 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv \
     -d $REPO/gpurun_out/pmc_${TAG}_MFMA -o pmc -- python $REPO/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-exact-f32 --no-host-pass \
     > $REPO/gpurun_out/pmc_${TAG}_MFMA.log 2>&1
 echo "MFMA exit $?"
