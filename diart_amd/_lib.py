@@ -104,6 +104,10 @@ SIGNATURES = {
     "dz_ring_push": (C.c_int, [vp, vp, C.c_longlong, C.c_int, vp]),
     "dz_ring_window": (C.c_int, [vp, C.POINTER(vp), C.POINTER(C.c_longlong), C.POINTER(C.c_int)]),
     "dz_ring_read": (C.c_int, [vp, vp, vp]),
+    "dz_ring_push_rows": (C.c_int, [vp, vp, C.c_longlong, C.c_int, C.POINTER(C.c_int), C.c_int, vp]),
+    "dz_ring_filled_row": (C.c_int, [vp, C.c_int, C.POINTER(C.c_int)]),
+    "dz_ring_gather": (C.c_int, [vp, C.POINTER(C.c_int), C.c_int, vp, C.c_longlong, vp]),
+    "dz_ring_reset_row": (C.c_int, [vp, C.c_int]),
     "dz_tail_create": (C.c_int, [C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, C.c_int,
                                  C.c_int, vp, C.POINTER(vp)]),
     "dz_tail_reset": (C.c_int, [vp]),

@@ -16,9 +16,16 @@
 // positions (the 2-D runtime copies this replaced cost the step ~0.3 ms of host and queue time).  The slack keeps a push from overwriting samples a forward
 // pass of the previous `slack` windows may still be reading: block t+1 lands on the slot of
 // block t+1-W/hop-slack, which belongs to windows <= t-slack only.
+//
+// Streams that do NOT advance in lock step (StreamServer: every stream has its own pace) use the
+// per-row entry points: every row keeps its own write position (dz_ring_push_rows advances only the
+// listed rows) and dz_ring_gather copies the current windows of the listed rows, device to device,
+// into the dense (k, W) batch the forward passes take — 320 KB per window at HBM speed instead of
+// 320 KB per window over PCIe.
 #include "dz_common.h"
 
 #include <new>
+#include <vector>
 
 struct dz_ring {
     dz_ctx* ctx;
@@ -32,6 +39,15 @@ struct dz_ring {
     float* stage[2];   // [n][hop] landing blocks of the H2D copies, used alternately
     long long pushed;  // blocks pushed so far
     int pos;           // write position of the NEXT block, in [0, P)
+    // per-row state (dz_ring_push_rows / dz_ring_gather); a lock-step dz_ring_push moves every row
+    std::vector<int> rpos;
+    std::vector<long long> rpushed;
+};
+
+// up to 64 (row, offset) pairs per launch, passed in the kernel-argument segment
+struct DzRowList {
+    int row[64];
+    int off[64];
 };
 
 extern "C" int dz_ring_create(dz_ctx* ctx, int n_streams, int window, int hop, int slack_blocks,
@@ -48,6 +64,8 @@ extern "C" int dz_ring_create(dz_ctx* ctx, int n_streams, int window, int hop, i
     r->ctx = ctx; r->n = n_streams; r->W = window; r->hop = hop; r->buf = nullptr;
     r->P = window + slack_blocks * hop;
     r->pushed = 0; r->pos = 0;
+    r->rpos.assign(n_streams, 0);
+    r->rpushed.assign(n_streams, 0);
     r->pitch = ((2LL * r->P + 63) / 64) * 64;
     if (((r->pitch / 64) & 1) == 0) r->pitch += 64;
     const size_t bytes = (size_t)n_streams * r->pitch * sizeof(float);
@@ -84,6 +102,30 @@ __global__ __launch_bounds__(256) void ring_scatter_kernel(const float* __restri
     *reinterpret_cast<f32x4*>(row + P) = v;
 }
 
+// row j of the block -> ring row rows.row[j] at rows.off[j] and rows.off[j] + P
+__global__ __launch_bounds__(256) void ring_scatter_rows_kernel(const float* __restrict__ block, long long bstride,
+                                                                float* __restrict__ buf, long long pitch,
+                                                                int hop4, int P, DzRowList rows) {
+    const int jrow = blockIdx.y;
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= hop4) return;
+    const f32x4 v = *reinterpret_cast<const f32x4*>(block + (long long)jrow * bstride + 4 * j);
+    float* row = buf + (long long)rows.row[jrow] * pitch + rows.off[jrow] + 4 * j;
+    *reinterpret_cast<f32x4*>(row) = v;
+    *reinterpret_cast<f32x4*>(row + P) = v;
+}
+
+// out row j <- the W samples of ring row rows.row[j] starting at rows.off[j]
+__global__ __launch_bounds__(256) void ring_gather_kernel(const float* __restrict__ buf, long long pitch,
+                                                          float* __restrict__ out, long long ostride, int W4,
+                                                          DzRowList rows) {
+    const int jrow = blockIdx.y;
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= W4) return;
+    const float* src = buf + (long long)rows.row[jrow] * pitch + rows.off[jrow] + 4 * j;
+    *reinterpret_cast<f32x4*>(out + (long long)jrow * ostride + 4 * j) = *reinterpret_cast<const f32x4*>(src);
+}
+
 extern "C" int dz_ring_destroy(dz_ring* r) {
     if (r) {
         if (r->buf) (void)hipFree(r->buf);
@@ -97,6 +139,15 @@ extern "C" int dz_ring_reset(dz_ring* r) {
     DZ_REQUIRE(r, "dz_ring_reset: NULL argument");
     r->pushed = 0;
     r->pos = 0;
+    r->rpos.assign(r->n, 0);
+    r->rpushed.assign(r->n, 0);
+    return 0;
+}
+
+extern "C" int dz_ring_reset_row(dz_ring* r, int row) {
+    DZ_REQUIRE(r && row >= 0 && row < r->n, "dz_ring_reset_row: bad row");
+    r->rpos[row] = 0;
+    r->rpushed[row] = 0;
     return 0;
 }
 
@@ -147,6 +198,110 @@ extern "C" int dz_ring_push(dz_ring* r, const float* block, long long block_stri
     DZ_HIP(hipGetLastError());
     r->pos = (r->pos + r->hop) % r->P;
     r->pushed += 1;
+    for (int i = 0; i < r->n; ++i) {
+        r->rpos[i] = r->pos;
+        r->rpushed[i] += 1;
+    }
+    return 0;
+}
+
+// resolve a host block for the scatter kernels: mapped pinned memory (mode 2) or a staged copy
+static int ring_source(dz_ring* r, const float* block, long long block_stride, int rows, int& on_device,
+                       const float*& src, long long& sstride, hipStream_t st) {
+    src = block;
+    sstride = block_stride;
+    if (on_device == 2) {
+        void* dptr = nullptr;
+        if (hipHostGetDevicePointer(&dptr, (void*)block, 0) == hipSuccess && dptr) {
+            src = reinterpret_cast<const float*>(dptr);
+        } else {
+            (void)hipGetLastError();
+            on_device = 0;
+        }
+    }
+    if (!on_device) {
+        float* land = r->stage[r->pushed & 1];
+        DZ_HIP(hipMemcpy2DAsync(land, (size_t)r->hop * sizeof(float), block, (size_t)block_stride * sizeof(float),
+                                (size_t)r->hop * sizeof(float), rows, hipMemcpyHostToDevice, st));
+        src = land;
+        sstride = r->hop;
+    }
+    return 0;
+}
+
+// One new block for each of the `k` listed streams: row j of `block` (k, hop) goes to ring row
+// rows[j], at THAT row's own write position.  Rows must be distinct.
+extern "C" int dz_ring_push_rows(dz_ring* r, const float* block, long long block_stride, int on_device,
+                                 const int* rows, int k, void* stream) {
+    DZ_REQUIRE(r && block && rows, "dz_ring_push_rows: NULL argument");
+    DZ_REQUIRE(k >= 1 && k <= r->n, "dz_ring_push_rows: %d rows for %d streams", k, r->n);
+    DZ_REQUIRE(block_stride >= r->hop && ((uintptr_t)block & 15) == 0 && (block_stride & 3) == 0,
+               "dz_ring_push_rows: rows of the block must be >= hop floats apart and 16-byte aligned");
+    std::vector<char> seen(r->n, 0);
+    for (int j = 0; j < k; ++j) {
+        DZ_REQUIRE(rows[j] >= 0 && rows[j] < r->n && !seen[rows[j]], "dz_ring_push_rows: bad / repeated row %d",
+                   rows[j]);
+        seen[rows[j]] = 1;
+    }
+    DZ_HIP(hipSetDevice(r->ctx->device));
+    hipStream_t st = (hipStream_t)stream;
+    const float* src;
+    long long sstride;
+    int rc = ring_source(r, block, block_stride, k, on_device, src, sstride, st);
+    if (rc) return rc;
+    const int hop4 = r->hop / 4;
+    for (int j0 = 0; j0 < k; j0 += 64) {
+        const int m = k - j0 < 64 ? k - j0 : 64;
+        DzRowList rl;
+        for (int j = 0; j < m; ++j) {
+            rl.row[j] = rows[j0 + j];
+            rl.off[j] = r->rpos[rows[j0 + j]];
+        }
+        hipLaunchKernelGGL(ring_scatter_rows_kernel, dim3((hop4 + 255) / 256, m), dim3(256), 0, st,
+                           src + (long long)j0 * sstride, sstride, r->buf, r->pitch, hop4, r->P, rl);
+        DZ_HIP(hipGetLastError());
+    }
+    for (int j = 0; j < k; ++j) {
+        r->rpos[rows[j]] = (r->rpos[rows[j]] + r->hop) % r->P;
+        r->rpushed[rows[j]] += 1;
+    }
+    r->pushed += 1;        // alternates the landing blocks
+    return 0;
+}
+
+// samples received by one row so far, capped at the window
+extern "C" int dz_ring_filled_row(const dz_ring* r, int row, int* filled) {
+    DZ_REQUIRE(r && filled && row >= 0 && row < r->n, "dz_ring_filled_row: bad argument");
+    const long long got = r->rpushed[row] * r->hop;
+    *filled = got >= r->W ? r->W : (int)got;
+    return 0;
+}
+
+// d_out row j (out_stride floats apart) <- the current window of ring row rows[j]; every listed row
+// must hold a complete window
+extern "C" int dz_ring_gather(const dz_ring* r, const int* rows, int k, float* d_out, long long out_stride,
+                              void* stream) {
+    DZ_REQUIRE(r && rows && d_out, "dz_ring_gather: NULL argument");
+    DZ_REQUIRE(k >= 1 && out_stride >= r->W && (out_stride & 3) == 0 && ((uintptr_t)d_out & 15) == 0,
+               "dz_ring_gather: output rows must be >= window floats apart and 16-byte aligned");
+    for (int j = 0; j < k; ++j) {
+        DZ_REQUIRE(rows[j] >= 0 && rows[j] < r->n, "dz_ring_gather: bad row %d", rows[j]);
+        DZ_REQUIRE(r->rpushed[rows[j]] * r->hop >= r->W, "dz_ring_gather: the window of row %d is not complete",
+                   rows[j]);
+    }
+    DZ_HIP(hipSetDevice(r->ctx->device));
+    const int W4 = r->W / 4;
+    for (int j0 = 0; j0 < k; j0 += 64) {
+        const int m = k - j0 < 64 ? k - j0 : 64;
+        DzRowList rl;
+        for (int j = 0; j < m; ++j) {
+            rl.row[j] = rows[j0 + j];
+            rl.off[j] = (r->rpos[rows[j0 + j]] + r->P - r->W) % r->P;
+        }
+        hipLaunchKernelGGL(ring_gather_kernel, dim3((W4 + 255) / 256, m), dim3(256), 0, (hipStream_t)stream,
+                           r->buf, r->pitch, d_out + (long long)j0 * out_stride, out_stride, W4, rl);
+        DZ_HIP(hipGetLastError());
+    }
     return 0;
 }
 

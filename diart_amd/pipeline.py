@@ -101,6 +101,37 @@ class AudioRing:
             evs.append(ev)
         self._readers.append(evs)
 
+    # ---- streams that advance at their own pace (StreamServer) -------------------------------
+    def push_rows(self, block: torch.Tensor, rows: Sequence[int]) -> None:
+        """Row j of ``block`` (k, hop) is the next block of stream ``rows[j]`` (each row keeps its
+        own write position).  Enqueued on the current HIP stream; a pinned host block is read in
+        place by the GPU and must stay untouched until that stream has passed this point."""
+        k = len(rows)
+        assert block.dtype == torch.float32 and tuple(block.shape) == (k, self.hop) and block.stride(1) == 1
+        mode = 1 if block.is_cuda else (2 if block.is_pinned() and os.environ.get("DZ_RING_ZERO_COPY", "1") != "0" else 0)
+        arr = (C.c_int * k)(*[int(r) for r in rows])
+        _lib.check(self._lib.dz_ring_push_rows(self._h, block.data_ptr(), block.stride(0), mode, arr, k,
+                                               torch.cuda.current_stream(self.device).cuda_stream), "dz_ring_push_rows")
+        self._keep = (self._keep + [block])[-4:]
+
+    def filled_row(self, row: int) -> int:
+        f = C.c_int()
+        _lib.check(self._lib.dz_ring_filled_row(self._h, int(row), C.byref(f)), "dz_ring_filled_row")
+        return int(f.value)
+
+    def gather(self, rows: Sequence[int], out: torch.Tensor) -> torch.Tensor:
+        """``out[j]`` <- the current window of stream ``rows[j]`` (device to device, current HIP
+        stream); every listed stream must hold a complete window."""
+        k = len(rows)
+        assert out.is_cuda and out.dtype == torch.float32 and out.shape[0] >= k and out.shape[1] == self.window
+        arr = (C.c_int * k)(*[int(r) for r in rows])
+        _lib.check(self._lib.dz_ring_gather(self._h, arr, k, out.data_ptr(), out.stride(0),
+                                            torch.cuda.current_stream(self.device).cuda_stream), "dz_ring_gather")
+        return out[:k]
+
+    def reset_row(self, row: int) -> None:
+        _lib.check(self._lib.dz_ring_reset_row(self._h, int(row)), "dz_ring_reset_row")
+
     def raw(self) -> Tuple[int, int]:
         ptr, stride = _lib.vp(), C.c_longlong()
         _lib.check(self._lib.dz_ring_window(self._h, C.byref(ptr), C.byref(stride), None), "dz_ring_window")

@@ -12,6 +12,11 @@ stream's own clustering and aggregation state.  Streams join and leave at any ti
 their own pace; per stream the output is what a dedicated ``SpeakerDiarization`` pipeline with the
 same configuration produces.
 
+Audio reaches the GPU through per-stream device rings (``AudioRing.push_rows`` / ``gather``): a step
+uploads only the NEW 500 ms block of each stream that has one (32 KB instead of the 320 KB window the
+reference moves per chunk, ``blocks/segmentation.py:47``) and assembles the batch of windows on the
+device.  ``device_rings=False`` (and any custom ``engine``) keeps the windows on the host instead.
+
 Transport (websocket, microphone) is out of scope: ``push`` is the seam a network front-end calls
 (thread-safe), ``step`` / ``serve_forever`` is the worker loop."""
 from __future__ import annotations
@@ -25,19 +30,20 @@ import torch
 
 from .blocks.aggregation import BatchedOutputTail
 from .features import Annotation
-from .pipeline import StreamBatch
+from .pipeline import AudioRing, StreamBatch
 
 
 class _Stream:
-    __slots__ = ("slot", "buffer", "chunk", "start", "emitted", "pending", "prediction")
+    __slots__ = ("slot", "buffer", "blocks", "consumed", "chunk", "start", "emitted", "prediction")
 
     def __init__(self, slot: int):
         self.slot = slot
-        self.buffer = np.zeros(0, dtype=np.float32)   # samples not yet part of a window step
-        self.chunk: Optional[np.ndarray] = None       # the current (<= duration) window
-        self.start = 0.0                              # start time of `chunk`
+        self.buffer = np.zeros(0, dtype=np.float32)   # samples not yet a whole step block
+        self.blocks: List[np.ndarray] = []            # whole step blocks the worker has not taken yet
+        self.consumed = 0                             # step blocks taken by the worker so far
+        self.chunk: Optional[np.ndarray] = None       # host-window mode: the current (<= duration) window
+        self.start = 0.0                              # host-window mode: start time of `chunk`
         self.emitted = 0
-        self.pending: List = []                       # (window copy, start time), oldest first
         self.prediction: Optional[Annotation] = None
 
 
@@ -47,12 +53,13 @@ class StreamServer:
                  tau_active: float = 0.6, rho_update: float = 0.3, delta_new: float = 1.0,
                  gamma: float = 3, beta: float = 10, max_speakers: int = 20,
                  device: Optional[torch.device] = None, patch_collar: float = 0.05,
-                 engine: Optional[Callable] = None):
+                 engine: Optional[Callable] = None, device_rings: bool = True):
         self.duration, self.step_seconds, self.sample_rate = float(duration), float(step), int(sample_rate)
         self.latency = self.step_seconds if latency is None else float(latency)
         self.chunk_samples = int(round(sample_rate * duration))
         self.step_samples = int(round(sample_rate * step))
         self.max_streams, self.patch_collar = int(max_streams), patch_collar
+        self.blocks_per_window = -(-self.chunk_samples // self.step_samples)
         self._lock = threading.Lock()          # stream table, buffers, slot lists
         self._step_lock = threading.Lock()     # serialises step(): one engine
         self._streams: Dict[Hashable, _Stream] = {}
@@ -66,12 +73,22 @@ class StreamServer:
             self.batch = StreamBatch(segmentation, embedding, self.max_streams, tau_active, rho_update,
                                      delta_new, gamma, beta, max_speakers, device=device, tail=True,
                                      duration=duration, step=step, latency=self.latency)
-            self._pinned = torch.empty((self.max_streams, self.chunk_samples), dtype=torch.float32).pin_memory()
             self._dev = torch.empty((self.max_streams, self.chunk_samples), dtype=torch.float32,
                                     device=self.batch.device)
             self._engine, self._reset_slot = self._gpu_engine, self.batch.reset
+            # per-stream device rings need whole blocks per window (and 16-byte aligned rows)
+            self.rings: Optional[AudioRing] = None
+            if device_rings and self.chunk_samples % self.step_samples == 0 and self.step_samples % 4 == 0:
+                self.rings = AudioRing(self.max_streams, self.chunk_samples, self.step_samples, slack_blocks=0,
+                                       device=self.batch.device)
+                # a stream takes at most blocks_per_window blocks in one step (its warm-up); round r of
+                # a step stages its blocks in plane r, so no plane is rewritten while the GPU reads it
+                self._stage = torch.empty((self.blocks_per_window, self.max_streams, self.step_samples),
+                                          dtype=torch.float32).pin_memory()
+            else:
+                self._pinned = torch.empty((self.max_streams, self.chunk_samples), dtype=torch.float32).pin_memory()
         else:
-            self.batch = None
+            self.batch, self.rings = None, None
             self._engine, self._reset_slot = engine, getattr(engine, "reset", lambda slot: None)
 
     # ------------------------------------------------------------------ stream life cycle
@@ -85,6 +102,8 @@ class StreamServer:
             # still stepping), so resetting its clustering / aggregation state here is safe
             slot = self._free.pop()
             self._reset_slot(slot)
+            if self.rings is not None:
+                self.rings.reset_row(slot)
             self._streams[stream_id] = _Stream(slot)
 
     def close(self, stream_id: Hashable) -> Annotation:
@@ -113,20 +132,45 @@ class StreamServer:
     # ------------------------------------------------------------------ audio in
     def push(self, stream_id: Hashable, samples) -> int:
         """Append mono float samples (any length) to a stream; returns the number of windows now
-        pending for it.  The windowing is ``rearrange_audio_stream`` (``operators.py:44-100``)."""
+        pending for it.  The windowing is ``rearrange_audio_stream`` (``operators.py:44-100``): whole
+        ``step`` blocks, a window once ``duration`` seconds have arrived, then one per block."""
         x = np.asarray(samples, dtype=np.float32).reshape(-1)
         with self._lock:
             st = self._streams[stream_id]
             st.buffer = np.concatenate([st.buffer, x]) if st.buffer.size else x.copy()
             while st.buffer.size >= self.step_samples:
-                new, st.buffer = st.buffer[:self.step_samples], st.buffer[self.step_samples:]
-                st.chunk = new if st.chunk is None else np.concatenate([st.chunk, new])
-                if st.chunk.size > self.chunk_samples:
-                    st.chunk = st.chunk[-self.chunk_samples:]
-                    st.start += self.step_seconds
-                if st.chunk.size == self.chunk_samples:
-                    st.pending.append((st.chunk.copy(), st.start))
-            return len(st.pending)
+                st.blocks.append(st.buffer[:self.step_samples].copy())
+                st.buffer = st.buffer[self.step_samples:]
+            return self._pending(st)
+
+    def _pending(self, st: _Stream) -> int:
+        # block number c (1-based) completes a window iff c >= blocks_per_window
+        last = st.consumed + len(st.blocks)
+        return max(0, last - max(st.consumed, self.blocks_per_window - 1))
+
+    def _take_host_window(self, st: _Stream):
+        """Host-window mode: consume blocks until one completes a window -> (window copy, start)."""
+        while st.blocks:
+            new = st.blocks.pop(0)
+            st.consumed += 1
+            st.chunk = new if st.chunk is None else np.concatenate([st.chunk, new])
+            if st.chunk.size > self.chunk_samples:
+                st.chunk = st.chunk[-self.chunk_samples:]
+                st.start += self.step_seconds
+            if st.chunk.size == self.chunk_samples:
+                return st.chunk.copy(), st.start
+        return None
+
+    def _take_ring_blocks(self, st: _Stream):
+        """Ring mode: the blocks to upload this step (until one completes a window) -> (blocks,
+        start time of the completed window | None)."""
+        taken = []
+        while st.blocks:
+            taken.append(st.blocks.pop(0))
+            st.consumed += 1
+            if st.consumed >= self.blocks_per_window:
+                return taken, (st.consumed - self.blocks_per_window) * self.step_seconds
+        return taken, None
 
     # ------------------------------------------------------------------ the worker
     def step(self) -> Dict[Hashable, Annotation]:
@@ -134,17 +178,36 @@ class StreamServer:
         speech turns each of those streams gained (the per-chunk ``Annotation`` of the reference's
         pipeline); the running total is kept per stream until ``close``."""
         with self._step_lock:                       # one engine, one step at a time
+            uploads = []                            # ring mode: (slot, [blocks]) of this step
             with self._lock:
-                ready = [(sid, st) for sid, st in self._streams.items() if st.pending]
-                if not ready:
-                    return {}
-                work = [(sid, st, *st.pending.pop(0)) for sid, st in ready]
-                self._inflight = {st.slot for _, st, _, _ in work}
+                work = []                           # (stream id, stream, host window | None, start)
+                for sid, st in self._streams.items():
+                    if not st.blocks:
+                        continue
+                    if self.rings is None:
+                        got = self._take_host_window(st)
+                        if got is not None:
+                            work.append((sid, st, got[0], got[1]))
+                    else:
+                        taken, start = self._take_ring_blocks(st)
+                        uploads.append((st.slot, taken))
+                        if start is not None:
+                            work.append((sid, st, None, start))
+                # slots whose ring row / clustering state the worker touches until the step is over
+                self._inflight = {st.slot for _, st, _, _ in work} | {slot for slot, _ in uploads}
             try:
-                windows = np.stack([w for _, _, w, _ in work])
+                if uploads:
+                    self._upload(uploads)
+                if not work:
+                    if uploads:     # warm-up blocks only: the staging planes are free once the GPU has read them
+                        torch.cuda.current_stream(self.batch.device).synchronize()
+                    return {}
                 starts = np.array([t for _, _, _, t in work], dtype=np.float64)
                 slots = [st.slot for _, st, _, _ in work]
-                turns = self._engine(windows, starts, slots)
+                if self.rings is None:
+                    turns = self._engine(np.stack([w for _, _, w, _ in work]), starts, slots)
+                else:
+                    turns = self._gpu_engine(self.rings.gather(slots, self._dev), starts, slots)
             finally:
                 with self._lock:
                     self._inflight = set()
@@ -165,26 +228,47 @@ class StreamServer:
                     out[sid] = ann
             return out
 
+    def _upload(self, uploads) -> None:
+        """New blocks -> the streams' device rings: round r carries the r-th new block of every stream
+        that has one (a running stream has exactly one; a joining stream up to a whole window)."""
+        with torch.cuda.device(self.batch.device):
+            for r in range(max(len(b) for _, b in uploads)):
+                rows = [slot for slot, b in uploads if len(b) > r]
+                plane = self._stage[r]
+                for j, (slot, b) in enumerate((u for u in uploads if len(u[1]) > r)):
+                    plane[j].copy_(torch.from_numpy(b[r]))
+                self.rings.push_rows(plane[:len(rows)], rows)
+
     def drain(self) -> int:
-        """``step`` until no window is pending; returns the number of steps."""
+        """``step`` until no block is waiting; returns the number of steps."""
         n = 0
-        while self.step():
+        while True:
+            with self._lock:
+                if not any(st.blocks for st in self._streams.values()):
+                    return n
+            self.step()
             n += 1
-        return n
 
     def serve_forever(self, idle_sleep: float = 0.002) -> None:
         while not self._stop:
-            if not self.step():
+            with self._lock:
+                idle = not any(st.blocks for st in self._streams.values())
+            if idle:
                 time.sleep(idle_sleep)
+            else:
+                self.step()
 
     def shutdown(self) -> None:
         self._stop = True
 
     # ------------------------------------------------------------------ GPU engine
-    def _gpu_engine(self, windows: np.ndarray, starts: np.ndarray, slots: List[int]):
+    def _gpu_engine(self, windows, starts: np.ndarray, slots: List[int]):
+        """``windows``: (k, S) on the host (uploaded whole, like the reference) or already a device
+        batch gathered from the rings."""
         k = windows.shape[0]
-        self._pinned[:k].copy_(torch.from_numpy(windows))
-        self._dev[:k].copy_(self._pinned[:k], non_blocking=True)
+        if not torch.is_tensor(windows):
+            self._pinned[:k].copy_(torch.from_numpy(windows))
+            self._dev[:k].copy_(self._pinned[:k], non_blocking=True)
         ticket = self.batch.launch(self._dev[:k], starts, slots=slots)
         self.batch.finish(ticket, want_scores=False)
         _, _, _, _, turns, nturns = ticket["tail"]

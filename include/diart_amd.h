@@ -363,6 +363,17 @@ int dz_ring_push(dz_ring* r, const float* block, long long block_stride, int on_
 int dz_ring_window(const dz_ring* r, const float** d_wave, long long* stride, int* filled);
 /* contiguous (n_streams, window) copy of the current window, device to device.               */
 int dz_ring_read(const dz_ring* r, float* d_out, void* stream);
+/* Streams that advance at their own pace (one rearrange_audio_stream per stream,
+ * /root/reference/src/diart/inference.py:101-147 + console/serve.py:105-127, served as ONE batch):
+ * every row has its own write position.  dz_ring_push_rows: row j of block (k, hop) is the next
+ * block of stream rows[j] (distinct rows; on_device as for dz_ring_push).  dz_ring_gather: the
+ * current windows of the listed streams as a dense (k, window) device batch for dz_seg_forward /
+ * dz_emb_frames — each must be complete (dz_ring_filled_row).  dz_ring_reset_row: the stream left. */
+int dz_ring_push_rows(dz_ring* r, const float* block, long long block_stride, int on_device,
+                      const int* rows, int k, void* stream);
+int dz_ring_filled_row(const dz_ring* r, int row, int* filled);
+int dz_ring_gather(const dz_ring* r, const int* rows, int k, float* d_out, long long out_stride, void* stream);
+int dz_ring_reset_row(dz_ring* r, int row);
 
 /* ---- output tail of one stream: DelayedAggregation + Binarize, host fp64 -------------------
  * Replaces, for the N-stream driver, the per-chunk Python tail of SpeakerDiarization.__call__

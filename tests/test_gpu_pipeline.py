@@ -203,7 +203,37 @@ def test_stream_batch_on_ring_with_splits_and_tail(gpu):
                 bufs[i] = bufs[i][1:]
 
 
-def test_stream_server_equals_dedicated_pipelines(gpu):
+def test_ring_rows_advance_independently(gpu):
+    """dz_ring_push_rows / dz_ring_gather: every stream of the ring has its own write position; the
+    gathered windows equal a host-side rolling window of each stream, whatever the interleaving."""
+    from diart_amd.pipeline import AudioRing
+    n, W, hop = 5, 800, 80
+    ring = AudioRing(n, W, hop, slack_blocks=0, device=gpu)
+    rng = np.random.default_rng(11)
+    hist = [np.zeros(0, dtype=np.float32) for _ in range(n)]
+    out = torch.empty(n, W, device=gpu)
+    stage = torch.empty(n, hop).pin_memory()
+    for it in range(60):
+        rows = sorted(rng.choice(n, size=int(rng.integers(1, n + 1)), replace=False).tolist())
+        blk = rng.standard_normal((len(rows), hop)).astype(np.float32)
+        torch.cuda.synchronize()                # the previous round's zero-copy read of `stage` is over
+        stage[:len(rows)].copy_(torch.from_numpy(blk))
+        ring.push_rows(stage[:len(rows)], rows)
+        for j, r in enumerate(rows):
+            hist[r] = np.concatenate([hist[r], blk[j]])[-W:]
+        full = [r for r in range(n) if len(hist[r]) == W]
+        assert all(ring.filled_row(r) == min(W, len(hist[r])) for r in range(n))
+        if full:
+            got = ring.gather(full, out).cpu().numpy()
+            assert np.array_equal(got, np.stack([hist[r] for r in full]))
+    ring.reset_row(2)
+    assert ring.filled_row(2) == 0 and ring.filled_row(1) == W
+    with pytest.raises(RuntimeError):
+        ring.gather([2], out)                   # incomplete window: refused, not garbage
+
+
+@pytest.mark.parametrize("device_rings", [True, False])
+def test_stream_server_equals_dedicated_pipelines(gpu, device_rings):
     """diart_amd.serve.StreamServer: 4 streams of different lengths that join at different times and
     push audio in odd block sizes, windows batched ACROSS streams; every stream's accumulated RTTM is
     exactly what its own SpeakerDiarization pipeline (blocks API, batch 1, same models) produces,
@@ -216,7 +246,8 @@ def test_stream_server_equals_dedicated_pipelines(gpu):
     audio = {k: synth_streams(1, v, seed0=900 + i)[0] for i, (k, v) in enumerate(lengths.items())}
     for latency in (0.5, 1.5):
         srv = StreamServer(M.HipSegmentation(seg_sd, max_batch=4), M.HipEmbedding(emb_sd, max_batch=4),
-                           max_streams=4, latency=latency, device=gpu)
+                           max_streams=4, latency=latency, device=gpu, device_rings=device_rings)
+        assert (srv.rings is not None) == device_rings
         rng = np.random.default_rng(3)
         pos = {k: 0 for k in audio}
         join_at = {"alice": 0, "bob": 3, "carol": 3, "dave": 9}     # server ticks at which they open

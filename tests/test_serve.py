@@ -151,3 +151,41 @@ def test_close_during_a_step_defers_the_slot_and_drops_the_result():
     assert set(result) == {"b"}                 # a's window was processed but its result dropped
     srv.open("c")                               # the deferred slot is free now
     assert rec.resets == [0, 1, 0]
+
+
+def test_ring_mode_block_schedule_reproduces_the_host_windows():
+    """The device-ring path of ``step`` uploads blocks instead of windows (``_take_ring_blocks``):
+    replaying its (blocks, start) schedule into a host-side rolling buffer must give exactly the
+    windows and start times of the host-window path, for any push pattern — including a joining
+    stream that delivers several windows' worth of audio before the first step."""
+    rec = Recorder()
+    host = StreamServer(None, None, max_streams=1, engine=rec)
+    ringy = StreamServer(None, None, max_streams=1, engine=Recorder())
+    audio = ramp(16000 * 8 + 777)
+    host.open("a")
+    ringy.open("a")
+    st = ringy._streams["a"]
+    rolled, replay = np.zeros(0, dtype=np.float32), []
+    pos, sizes, i = 0, [50000, 9000, 40000, 123, 8000, 8000, 31000], 0
+    while pos < len(audio):
+        n = sizes[i % len(sizes)]
+        assert host.push("a", audio[pos:pos + n]) == ringy.push("a", audio[pos:pos + n])
+        pos += n
+        i += 1
+        host.step()                                   # ONE step per push: windows queue up behind it
+        taken, start = ringy._take_ring_blocks(st)
+        assert len(taken) <= ringy.blocks_per_window
+        for b in taken:
+            rolled = np.concatenate([rolled, b])[-ringy.chunk_samples:]
+        if start is not None:
+            replay.append((rolled.copy(), start))
+    host.drain()
+    while st.blocks:
+        taken, start = ringy._take_ring_blocks(st)
+        for b in taken:
+            rolled = np.concatenate([rolled, b])[-ringy.chunk_samples:]
+        if start is not None:
+            replay.append((rolled.copy(), start))
+    assert len(replay) == len(rec.batches) > 5
+    for (w, s), (hw, hs, _) in zip(replay, rec.batches):
+        assert np.array_equal(w, hw[0]) and abs(s - hs[0]) < 1e-9
