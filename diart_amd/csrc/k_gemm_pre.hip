@@ -47,7 +47,8 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int BM = 128, BN = 128, KT = 32;
 constexpr int PLANE = 128 * 64;            // bytes of one f16 plane of a stage
 constexpr int STAGE = 4 * PLANE;           // A hi | A lo | B hi | B lo
-constexpr size_t LDS_BYTES = 2 * STAGE;
+constexpr int PAR_OFF = 2 * STAGE;          // bias | e0 | e1 of the tile's columns, [3][128] f32
+constexpr size_t LDS_BYTES = 2 * STAGE + 3 * BN * sizeof(float);
 constexpr float LO_UNSCALE = 1.f / 2048.f;
 
 __device__ __forceinline__ float leaky(float v) { return v > 0.f ? v : v * DZ_LEAKY_SLOPE; }
@@ -148,6 +149,20 @@ __device__ __forceinline__ void gemm_pre_tile(const DzConvGemm& p, const int t0,
 
     const int nk = p.Kpad / KT;
     issue(0, 0);
+    // The epilogue's per-column parameters go to LDS now: fetched from global memory inside the
+    // epilogue they were 16 dependent round trips per lane (three 16-byte loads per column group,
+    // no registers left to hoist them into) — ~20 % of a tile's time with nothing else to run.
+    float* par = reinterpret_cast<float*>(smem + PAR_OFF);
+    {
+        constexpr bool AFF = EPI == DZ_EPI_TDNN || EPI == DZ_EPI_RELU_BN;
+        const int which = tid >> 5, c4 = (tid & 31) * 4;
+        if (which < (AFF ? 3 : 1)) {
+            const float* src = which == 0 ? p.bias : which == 1 ? p.e0 : p.e1;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (n0 + c4 + 3 < p.Npad) v = *reinterpret_cast<const f32x4*>(src + n0 + c4);
+            *reinterpret_cast<f32x4*>(par + which * BN + c4) = v;
+        }
+    }
     for (int kt = 0; kt < nk; ++kt) {
         // own DMA of tile kt has landed + every wave has finished the fragment reads of tile kt-1
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -173,11 +188,12 @@ __device__ __forceinline__ void gemm_pre_tile(const DzConvGemm& p, const int t0,
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const int n = n0 + wn * 32 * NT + nt * 32 + 8 * k + 4 * g;
-                const f32x4 bv = *reinterpret_cast<const f32x4*>(p.bias + n);
+                const int nc = n - n0;                       // column inside the tile
+                const f32x4 bv = *reinterpret_cast<const f32x4*>(par + nc);
                 f32x4 e0 = {1.f, 1.f, 1.f, 1.f}, e1 = {0.f, 0.f, 0.f, 0.f};
                 if (EPI == DZ_EPI_TDNN || EPI == DZ_EPI_RELU_BN) {
-                    e0 = *reinterpret_cast<const f32x4*>(p.e0 + n);
-                    e1 = *reinterpret_cast<const f32x4*>(p.e1 + n);
+                    e0 = *reinterpret_cast<const f32x4*>(par + BN + nc);
+                    e1 = *reinterpret_cast<const f32x4*>(par + 2 * BN + nc);
                 }
                 f32x4 v;
 #pragma unroll
