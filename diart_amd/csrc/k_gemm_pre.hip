@@ -45,34 +45,46 @@ typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int BM = 128, BN = 128, KT = 32;
-constexpr int PLANE = 128 * 64;            // bytes of one f16 plane of a stage
-constexpr int STAGE = 4 * PLANE;           // A hi | A lo | B hi | B lo
-constexpr int PAR_OFF = 2 * STAGE;          // bias | e0 | e1 of the tile's columns, [3][128] f32
-constexpr size_t LDS_BYTES = 2 * STAGE + 3 * BN * sizeof(float);
+constexpr int PLANE_B = 128 * 64;          // bytes of one f16 plane of the weight tile of a stage
+// MW = waves along M (wave tile 64 x 64, two wave columns): the activation planes of a stage hold
+// 64 MW rows.  Stage = A hi | A lo | B hi | B lo; after the two stages: bias | e0 | e1, [3][128] f32.
+constexpr int plane_a(int MW) { return 64 * MW * 64; }
+constexpr int stage_bytes(int MW) { return 2 * plane_a(MW) + 2 * PLANE_B; }
+constexpr size_t lds_bytes(int MW) { return 2 * (size_t)stage_bytes(MW) + 3 * BN * sizeof(float); }
+constexpr int MW_BIG = 6;                  // 384 x 128 tiles, 12 waves, one workgroup per CU
 constexpr float LO_UNSCALE = 1.f / 2048.f;
 
 __device__ __forceinline__ float leaky(float v) { return v > 0.f ? v : v * DZ_LEAKY_SLOPE; }
 
-// One output tile of (64 MT) x (64 NT): 2 x 2 waves, MT x NT fragments of 32 x 32 per wave.
-template <int EPI, int MT, int NT>
+// One output tile of (32 MT MW) x (64 NT): MW x 2 waves, MT x NT fragments of 32 x 32 per wave.
+template <int EPI, int MW, int MT, int NT>
 __device__ __forceinline__ void gemm_pre_tile(const DzConvGemm& p, const int t0, const int n0, char* smem) {
+    constexpr int PLANE_A = plane_a(MW), STAGE = stage_bytes(MW), PAR_OFF = 2 * STAGE;
     const int tid = threadIdx.x;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6), l = tid & 63;
 
-    // ---- staging role of this wave: plane w of every stage (0 A hi, 1 A lo, 2 B hi, 3 B lo) ----
-    const bool isB = w >= 2;
-    const int lo = w & 1;
-    const unsigned short* A = reinterpret_cast<const unsigned short*>(p.Xsplit);
-    const unsigned short* W = reinterpret_cast<const unsigned short*>(p.Wsplit);
-    const unsigned short* src = isB ? W + (long long)lo * p.Npad * p.Kpad : A + (long long)lo * p.xplane;
-    const int ld = isB ? p.Kpad : p.ldx;                          // f16 elements per row
+    // ---- staging: 16-row pieces of the four planes (A hi, A lo, B hi, B lo) by LDS-DMA ----------
+    // lane -> (row l>>2 of the piece, LDS slot l&3); the slot holds source chunk slot ^ ((row >> 2) & 3),
+    // and (row >> 2) & 3 = (l >> 4) & 3 for every piece.  The first NWA waves share the pieces of the
+    // two activation planes, the others those of the two weight planes (wave of rank r in a group of
+    // G takes pieces r, r + G, ... of "hi pieces, then lo pieces"); with 4 waves and a full tile that
+    // is one plane per wave.
+    constexpr int PA = 2 * MT * MW, PB = 4 * NT, NWAVE = 2 * MW;
+    constexpr int NWA = (NWAVE * PA + (PA + PB) / 2) / (PA + PB);          // waves on the activation planes
+    constexpr int JMAX_A = (2 * PA + NWA - 1) / NWA, JMAX_B = (2 * PB + (NWAVE - NWA) - 1) / (NWAVE - NWA);
+    constexpr int JMAX = JMAX_A > JMAX_B ? JMAX_A : JMAX_B;
+    const bool isB = w >= NWA;
+    const int rank = isB ? w - NWA : w, group = isB ? NWAVE - NWA : NWA, npc = isB ? PB : PA;
+    const unsigned short* src = isB ? reinterpret_cast<const unsigned short*>(p.Wsplit)
+                                    : reinterpret_cast<const unsigned short*>(p.Xsplit);
+    const long long plane_el = isB ? (long long)p.Npad * p.Kpad : p.xplane;     // f16 elements between hi and lo
+    const int ld = isB ? p.Kpad : p.ldx;                                        // f16 elements per row
     const unsigned nbytes = (unsigned)((isB ? (long long)p.Npad : (long long)p.Tin) * ld * 2);
-    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)src, 0, nbytes, 0x00020000);
-    // lane -> (row l>>2 [+16 i], LDS slot l&3) of each 16-row piece; the slot holds source chunk
-    // slot ^ ((row >> 2) & 3), and (row >> 2) & 3 = (l >> 4) & 3 for every piece
-    const int row0 = (isB ? n0 : t0) + (l >> 2);
-    const int voff0 = row0 * ld * 2 + (((l & 3) ^ ((l >> 4) & 3)) << 4);
+    const __amdgpu_buffer_rsrc_t rs_hi = __builtin_amdgcn_make_buffer_rsrc((void*)src, 0, nbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_lo = __builtin_amdgcn_make_buffer_rsrc((void*)(src + plane_el), 0, nbytes, 0x00020000);
+    const int voff0 = ((isB ? n0 : t0) + (l >> 2)) * ld * 2 + (((l & 3) ^ ((l >> 4) & 3)) << 4);
     const int vstep = 16 * ld * 2;
+    const int dst0 = isB ? 2 * PLANE_A : 0, dplane = isB ? PLANE_B : PLANE_A;
     auto issue = [&](int kt, int stage) {
         int soff;
         if (isB) {
@@ -86,21 +98,19 @@ __device__ __forceinline__ void gemm_pre_tile(const DzConvGemm& p, const int t0,
             }
             soff = (tap * p.dil * p.ldx + c) * 2;
         }
-        char* dst = smem + stage * STAGE + w * PLANE;
-        if (isB) {
+        char* dst = smem + stage * STAGE + dst0;
 #pragma unroll
-            for (int i = 0; i < 4 * NT; ++i)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(
-                    rsrc, (__attribute__((address_space(3))) void*)(dst + i * 1024), 16, voff0 + i * vstep, soff, 0, 0);
-            return;
+        for (int j = 0; j < JMAX; ++j) {
+            const int q = rank + j * group;                    // wave-uniform
+            if (q >= 2 * npc) break;
+            const int lo = q >= npc, i = q - lo * npc;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(lo ? rs_lo : rs_hi,
+                (__attribute__((address_space(3))) void*)(dst + lo * dplane + i * 1024), 16,
+                voff0 + i * vstep, soff, 0, 0);
         }
-#pragma unroll
-        for (int i = 0; i < 4 * MT; ++i)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(
-                rsrc, (__attribute__((address_space(3))) void*)(dst + i * 1024), 16, voff0 + i * vstep, soff, 0, 0);
     };
 
-    // ---- MFMA coordinates: 2 x 2 waves, wave tile (32 MT) x (32 NT) -----------------------------
+    // ---- MFMA coordinates: MW x 2 waves, wave tile (32 MT) x (32 NT) ----------------------------
     const int li = l & 31, g = l >> 5;
     const int wm = w >> 1, wn = w & 1;
     const int sw = (li >> 2) & 3;
@@ -118,19 +128,19 @@ __device__ __forceinline__ void gemm_pre_tile(const DzConvGemm& p, const int t0,
     auto compute = [&](int stage) {
         const char* st = smem + stage * STAGE;
         const char* sa = st + (wm * 32 * MT) * 64;
-        const char* sb = st + 2 * PLANE + (wn * 32 * NT) * 64;
+        const char* sb = st + 2 * PLANE_A + (wn * 32 * NT) * 64;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             f16x8 ah[MT], al[MT], bh[NT], bl[NT];
 #pragma unroll
             for (int t = 0; t < MT; ++t) {
                 ah[t] = *reinterpret_cast<const f16x8*>(sa + t * 2048 + foff[ks]);
-                al[t] = *reinterpret_cast<const f16x8*>(sa + PLANE + t * 2048 + foff[ks]);
+                al[t] = *reinterpret_cast<const f16x8*>(sa + PLANE_A + t * 2048 + foff[ks]);
             }
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
                 bh[t] = *reinterpret_cast<const f16x8*>(sb + t * 2048 + foff[ks]);
-                bl[t] = *reinterpret_cast<const f16x8*>(sb + PLANE + t * 2048 + foff[ks]);
+                bl[t] = *reinterpret_cast<const f16x8*>(sb + PLANE_B + t * 2048 + foff[ks]);
             }
             // TRANSPOSED product: the weight fragment is the MFMA's row operand, the activation
             // fragment its column operand, so a lane ends up with ONE output row t (= lane & 31)
@@ -243,14 +253,39 @@ __global__ __launch_bounds__(256, 2) void gemm_pre_kernel(DzConvGemm p, int mbig
     if (L < mbig * gy) {
         int bx, by, bz;
         dz_tile_map_lin(L, mbig, gy, 1, p.agroup, bx, by, bz);
-        gemm_pre_tile<EPI, 2, 2>(p, bx * BM, by * BN, smem);
+        gemm_pre_tile<EPI, 2, 2, 2>(p, bx * BM, by * BN, smem);
     } else {
         const int Ls = L - mbig * gy, gys = 2 * gy;
         const int xcd = Ls & 7, j = Ls >> 3;
         const int ms = (j / gys) * 8 + xcd, by = j % gys;
         if (ms >= msmall) return;
-        gemm_pre_tile<EPI, 1, 1>(p, mbig * BM + ms * 64, by * 64, smem);
+        gemm_pre_tile<EPI, 2, 1, 1>(p, mbig * BM + ms * 64, by * 64, smem);
     }
+}
+
+// 384 x 128 tiles, 12 waves (3 per SIMD), one workgroup per CU: a third fewer operand bytes per MFMA
+// than two 128 x 128 workgroups per CU, and the config-2 grids fit ONE round of the 256 CUs (tdnn2:
+// 49 x 4 = 196 tiles) instead of 1.13 rounds.  EXPERIMENT (DZ_GEMM_BIG=1), not the default: measured
+// alone tdnn2 122 -> 107 us but tdnn5 112 -> 152 us, projection unchanged, the 64-stream pipeline 3 %
+// slower.  A k-step of the single resident workgroup takes 2.2 us for 1.1 us of matrix work: the
+// 64 KB it has in flight per CU move at ~30 GB/s per CU (two 128 x 128 workgroups: 47 GB/s), i.e. the
+// LDS-DMA stream is latency-, not byte-bound, and neither this nor the deeper pipeline of
+// tools/experiments/k_gemm_pre2.hip buys what the byte count promised.
+template <int EPI>
+__global__ __launch_bounds__(64 * 2 * MW_BIG) void gemm_pre_big_kernel(DzConvGemm p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int gy = p.Npad / BN, gx = (p.Tout + 64 * MW_BIG - 1) / (64 * MW_BIG);
+    int bx, by, bz;
+    dz_tile_map_lin(blockIdx.x, gx, gy, 1, p.agroup, bx, by, bz);
+    gemm_pre_tile<EPI, MW_BIG, 2, 2>(p, bx * 64 * MW_BIG, by * BN, smem);
+}
+// DZ_GEMM_BIG=1: 384 x 128 tiles for every launch with at least 8 such row tiles
+int big_tiles_mode() {
+    static const int mode = [] {
+        const char* e = getenv("DZ_GEMM_BIG");
+        return e ? atoi(e) : 0;
+    }();
+    return mode;
 }
 
 // DZ_GEMM_TAIL=1: 64 x 64 tiles for the rows of a mostly empty last round as well (see the header)
@@ -272,9 +307,19 @@ int wg_slots() {   // resident workgroups of this kernel on the chip: 2 per CU (
 
 template <int EPI>
 int launch(const DzConvGemm& p, hipStream_t st) {
-    static DzAttrOnce attr_once;
-    DZ_HIP(attr_once.raise((const void*)gemm_pre_kernel<EPI>, (int)LDS_BYTES));
+    static DzAttrOnce attr_once, attr_big;
+    DZ_HIP(attr_once.raise((const void*)gemm_pre_kernel<EPI>, (int)lds_bytes(2)));
     const int gx = (p.Tout + BM - 1) / BM, gy = p.Npad / BN, slots = wg_slots();
+    {
+        const int gxb = (p.Tout + 64 * MW_BIG - 1) / (64 * MW_BIG);
+        const int mode = big_tiles_mode();
+        if (mode == 1 && gxb >= 8) {
+            DZ_HIP(attr_big.raise((const void*)gemm_pre_big_kernel<EPI>, (int)lds_bytes(MW_BIG)));
+            DZ_LAUNCH((gemm_pre_big_kernel<EPI>), dim3(gxb * gy), dim3(64 * 2 * MW_BIG), lds_bytes(MW_BIG), st, p);
+            DZ_HIP(hipGetLastError());
+            return 0;
+        }
+    }
     int mbig = gx;
     const int tiles = gx * gy, rem = tiles % slots;
     if (4 * tiles < slots)
@@ -284,7 +329,7 @@ int launch(const DzConvGemm& p, hipStream_t st) {
     const int rows_left = p.Tout - mbig * BM;
     const int msmall = rows_left > 0 ? (rows_left + 63) / 64 : 0;
     const int nwg = mbig * gy + ((msmall + 7) / 8) * 8 * (2 * gy);
-    DZ_LAUNCH((gemm_pre_kernel<EPI>), dim3(nwg), dim3(256), LDS_BYTES, st, p, mbig, msmall);
+    DZ_LAUNCH((gemm_pre_kernel<EPI>), dim3(nwg), dim3(256), lds_bytes(2), st, p, mbig, msmall);
     DZ_HIP(hipGetLastError());
     return 0;
 }
