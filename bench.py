@@ -53,8 +53,10 @@ KERNELS = {
     "lstm_proj0": dict(mac=F_SEG * 60 * 1024, io=F_SEG * (64 + 1024) * 4, w=1024 * 64 * 4, bound="gemm"),
     "lstm_proj": dict(mac=F_SEG * 256 * 1024, io=F_SEG * (256 + 1024) * 4, w=1024 * 256 * 4, bound="gemm"),
     "lstm_rec": dict(mac=2 * F_SEG * 512 * 128, io=F_SEG * (1024 + 256) * 4, w=2 * 512 * 128 * 4, bound="rec"),
-    "seg_mlp": dict(mac=(F_SEG * 256 * 128 + F_SEG * 128 * 128) / 2, io=F_SEG * (256 + 128 + 128 + 128) * 2,
-                    w=(128 * 256 + 128 * 128) * 2, bound="gemm"),
+    # default precision: linear[0] -> linear[1] -> classifier -> activation -> OSP weights, ONE launch
+    # (k_mlp_head.hip); with DZ_MLP_HEAD=0 / exact f32 the tag holds the two MLP GEMMs (half of this each)
+    "seg_mlp": dict(mac=F_SEG * (256 * 128 + 128 * 128 + 128 * 3), io=F_SEG * (256 * 4 + (3 + 3) * 4),
+                    w=(128 * 256 + 128 * 128) * 4 + 3 * 128 * 4, bound="gemm"),
     # Linear(128->3) + sigmoid + OverlappedSpeechPenalty weights in one launch (k_pool.hip seg_head_kernel)
     "seg_classifier": dict(mac=F_SEG * 128 * 3, io=F_SEG * (128 + 3 + 3) * 4, w=3 * 128 * 4, bound="hbm"),
     "seg_head": dict(mac=F_SEG * (256 * 128 + 128 * 128 + 128 * 3), io=F_SEG * (256 + 3 + 3) * 4,
@@ -103,6 +105,8 @@ def device_kernel(tag, precision):
                "tdnn1": "convgemm_kernel<128, true, 3>",
                "emb_linear": "convgemm_kernel<128, false, 0> (split-K)", "seg_head": "seg_head_kernel"}
         return sym.get(tag, "convgemm_kernel<128, false, 3>"), "mfma", PEAK_F32_MATRIX_TFLOPS, "TFLOP/s"
+    if pre and tag == "seg_mlp" and os.environ.get("DZ_MLP_HEAD", "1") != "0":
+        return "mlp_head_kernel", "mfma", PEAK_F16_MATRIX_TFLOPS / SPLIT_PRODUCTS, "TFLOP/s"
     if pre and tag in ("tdnn2", "tdnn3", "tdnn4", "tdnn5", "lstm_proj", "seg_mlp"):
         sym = {"lstm_proj": "gemm_pre_kernel<0>", "seg_mlp": "gemm_pre_kernel<1>"}.get(tag, "gemm_pre_kernel<3>")
         return sym, "mfma", PEAK_F16_MATRIX_TFLOPS / SPLIT_PRODUCTS, "TFLOP/s"

@@ -120,6 +120,10 @@ SIGNATURES = {
     "dz_k_convgemm": (C.c_int, [vp, vp, vp]),
     "dz_k_gemm_split": (C.c_int, [vp, vp, vp]),
     "dz_k_gemm_pre": (C.c_int, [vp, vp, vp]),
+    "dz_k_mlp_head": (C.c_int, [vp, vp, C.c_longlong, vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int,
+                                C.c_int, C.c_float, C.c_float, vp, vp, vp]),
+    "dz_k_seg_head": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_float,
+                                C.c_float, C.c_int, vp, vp]),
     "dz_k_conv_pool": (C.c_int, [vp, vp, vp]),
     "dz_k_convgemm_ntile": (C.c_int, [C.c_int]),
     "dz_k_wave_stats": (C.c_int, [vp, vp, C.c_longlong, C.c_int, C.c_int, vp, vp]),

@@ -413,6 +413,13 @@ extern "C" int dz_seg_destroy(dz_seg* seg) {
 
 static int seg_forward(dz_seg* s, const float* d_wave, long long wave_stride, int B, float* d_out,
                        float* d_osp, float gamma, float beta, int normalize, void* stream);
+static bool mlp_head_enabled() {
+    static const bool on = [] {
+        const char* e = getenv("DZ_MLP_HEAD");
+        return !(e && e[0] == '0');
+    }();
+    return on;
+}
 extern "C" int dz_seg_forward(dz_seg* s, const float* d_wave, long long wave_stride, int B,
                               float* d_out, void* stream) {
     return seg_forward(s, d_wave, wave_stride, B, d_out, nullptr, 0.f, 0.f, 0, stream);
@@ -486,6 +493,18 @@ static int seg_forward(dz_seg* s, const float* d_wave, long long wave_stride, in
     p.W = s->w.lin0_w; p.bias = s->w.lin0_b;
     p.Cin = 256; p.K = 256; p.Kpad = 256; p.ldx = 256; p.Npad = 128; p.Nstore = 128; p.ldy = 128;
     p.epi = DZ_EPI_BIAS_LEAKY;
+    // default precision, no min-max normalisation of the OSP weights (it needs whole chunks): MLP +
+    // classifier + activation + OSP in ONE launch (k_mlp_head.hip); DZ_MLP_HEAD=0: three launches
+    if (s->pre && mlp_head_enabled() && !(d_osp && normalize) && s->w.num_classes <= 8) {
+        DzMlpHead m{};
+        m.Xsplit = lin; m.xplane = rows * 256;
+        m.W0split = s->w.lin0_split; m.W1split = s->w.lin1_split;
+        m.b0 = s->w.lin0_b; m.b1 = s->w.lin1_b; m.cw = s->w.cls_w; m.cb = s->w.cls_b;
+        m.rows = B * F; m.F = F; m.classes = s->w.num_classes; m.K = s->w.num_speakers; m.powerset = s->w.powerset;
+        m.gamma = gamma; m.beta = beta; m.seg = d_out; m.wout = d_osp;
+        ProfScope ps(T_MLP, B);
+        return dz_launch_mlp_head(m, st);
+    }
     if (s->pre) {
         p.Xsplit = lin; p.xplane = rows * 256; p.Wsplit = s->w.lin0_split;
         p.Ysplit = s->m0; p.yplane = rows * 128;
@@ -765,6 +784,28 @@ extern "C" int dz_k_gemm_pre(dz_ctx* ctx, const dz_convgemm_desc* d, void* strea
     DZ_HIP(hipSetDevice(ctx->device));
     DzRangeScope range_scope(ctx->oflag_dev);
     return dz_launch_gemm_pre(*d, (hipStream_t)stream);
+}
+extern "C" int dz_k_mlp_head(dz_ctx* ctx, const void* xsplit, long long xplane, const void* w0split,
+                             const void* w1split, const float* b0, const float* b1, const float* cw,
+                             const float* cb, int rows, int frames, int classes, int speakers, int powerset,
+                             float gamma, float beta, float* d_seg, float* d_weights, void* stream) {
+    DZ_REQUIRE(ctx, "dz_k_mlp_head: NULL argument");
+    DZ_HIP(hipSetDevice(ctx->device));
+    DzRangeScope range_scope(ctx->oflag_dev);
+    DzMlpHead m{};
+    m.Xsplit = xsplit; m.xplane = xplane; m.W0split = w0split; m.W1split = w1split;
+    m.b0 = b0; m.b1 = b1; m.cw = cw; m.cb = cb;
+    m.rows = rows; m.F = frames; m.classes = classes; m.K = speakers; m.powerset = powerset;
+    m.gamma = gamma; m.beta = beta; m.seg = d_seg; m.wout = d_weights;
+    return dz_launch_mlp_head(m, (hipStream_t)stream);
+}
+extern "C" int dz_k_seg_head(dz_ctx* ctx, const float* m1, const float* cw, const float* cb, int batch,
+                             int frames, int classes, int speakers, int powerset, float* d_seg, float gamma,
+                             float beta, int normalize, float* d_weights, void* stream) {
+    DZ_REQUIRE(ctx && m1 && cw && cb && d_seg, "dz_k_seg_head: NULL argument");
+    DZ_HIP(hipSetDevice(ctx->device));
+    return dz_launch_seg_head(m1, cw, cb, batch, frames, classes, speakers, powerset, d_seg, gamma, beta,
+                              normalize, d_weights, (hipStream_t)stream);
 }
 extern "C" int dz_k_conv_pool(dz_ctx* ctx, const dz_convgemm_desc* d, void* stream) {
     DZ_REQUIRE(ctx && d, "dz_k_conv_pool: NULL argument");

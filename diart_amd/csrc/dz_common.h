@@ -234,9 +234,85 @@ int dz_launch_stats_pool(const float* X, long long xstride, int T, int C, int ld
                          hipStream_t st);
 int dz_launch_osp(const float* seg, int B, int F, int K, float gamma, float beta, int normalize,
                   int speaker_major, float* out, hipStream_t st);
+// ---------------------------------------------------------------------------
+// Per-frame tail of the segmentation network, shared by seg_head_kernel (k_pool.hip) and the fused
+// MLP + head kernel (k_mlp_head.hip) so that both produce the same bits.
+//   dz_seg_decide: class logits -> per-speaker activity: sigmoid (multilabel models) or the hard
+//     powerset decision argmax -> multilabel (models.py:29-39; log_softmax is monotone, so the argmax
+//     of the logits is the argmax of the log-probabilities; subsets ordered by size, then
+//     lexicographically, at most two speakers per frame).
+//   dz_osp_frame: OverlappedSpeechPenalty of one frame (functional.py:6-13), before the optional
+//     min-max normalisation.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ float dz_powg(float x, float gamma) {
+    // torch.pow(tensor, scalar) special-cases 2 and 3 as repeated products
+    if (gamma == 3.f) return (x * x) * x;
+    if (gamma == 2.f) return x * x;
+    if (gamma == 1.f) return x;
+    return powf(x, gamma);
+}
+__device__ __forceinline__ void dz_seg_decide(const float* lg, int classes, int K, int powerset, float* s) {
+    if (powerset) {
+        int best = 0;
+        float bv = lg[0];
+        for (int c = 1; c < classes; ++c)
+            if (lg[c] > bv) {
+                bv = lg[c];
+                best = c;
+            }
+        int a = -1, b2 = -1;
+        if (best >= 1 && best <= K) {
+            a = best - 1;
+        } else if (best > K) {
+            int idx = best - K - 1;
+            for (int i = 0; i < K && a < 0; ++i) {
+                const int cnt = K - 1 - i;
+                if (idx < cnt) {
+                    a = i;
+                    b2 = i + 1 + idx;
+                } else {
+                    idx -= cnt;
+                }
+            }
+        }
+        for (int k = 0; k < K; ++k) s[k] = (k == a || k == b2) ? 1.f : 0.f;
+    } else {
+        for (int k = 0; k < K; ++k) s[k] = 1.f / (1.f + expf(-lg[k]));
+    }
+}
+__device__ __forceinline__ void dz_osp_frame(const float* s, int K, float gamma, float beta, float* w) {
+    float e[8], m = -INFINITY;
+    for (int k = 0; k < K; ++k) m = fmaxf(m, beta * s[k]);
+    float sum = 0.f;
+    for (int k = 0; k < K; ++k) {
+        e[k] = expf(beta * s[k] - m);
+        sum += e[k];
+    }
+    for (int k = 0; k < K; ++k) {
+        const float pr = e[k] / sum;
+        float wv = dz_powg(s[k], gamma) * dz_powg(pr, gamma);
+        if (wv < 1e-8f) wv = 1e-8f;
+        w[k] = wv;
+    }
+}
+
 int dz_launch_seg_head(const float* m1, const float* cw, const float* cb, int B, int F, int classes, int K,
                        int powerset, float* seg, float gamma, float beta, int normalize, float* wout,
                        hipStream_t st);
+// lin0 (256 -> 128, LeakyReLU) -> lin1 (128 -> 128, LeakyReLU) -> classifier -> activation (-> OSP
+// weights, not normalised) in one launch: k_mlp_head.hip
+struct DzMlpHead {
+    const void* Xsplit;        // [2][rows][256] f16 planes of the last LSTM layer's output
+    long long xplane;
+    const void *W0split, *W1split;       // [2][128][256], [2][128][128] f16 planes
+    const float *b0, *b1, *cw, *cb;      // biases; classifier [>= classes][128], [classes]
+    int rows, F, classes, K, powerset;
+    float gamma, beta;
+    float* seg;                // [rows][K]
+    float* wout;               // [rows / F][K][F] or NULL
+    int* oflag;
+};
+int dz_launch_mlp_head(const DzMlpHead& p, hipStream_t st);
 int dz_launch_l2norm(float* x, int rows, int dim, float norm, hipStream_t st);
 int dz_launch_splitk_finish(const float* parts, int nsplit, long long stride, int rows, int dim,
                             int normalize, float* out, hipStream_t st);

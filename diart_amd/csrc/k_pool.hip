@@ -148,13 +148,6 @@ int launch_pool(const float* X, long long xstride, int T, int C, int ldx, const 
 // ---------------------------------------------------------------------------
 // osp: one workgroup per chunk, thread = frame.  K <= 8 speakers.
 // ---------------------------------------------------------------------------
-__device__ __forceinline__ float powg(float x, float gamma) {
-    // torch.pow(tensor, scalar) special-cases 2 and 3 as repeated products
-    if (gamma == 3.f) return (x * x) * x;
-    if (gamma == 2.f) return x * x;
-    if (gamma == 1.f) return x;
-    return powf(x, gamma);
-}
 
 __global__ __launch_bounds__(256) void osp_kernel(const float* __restrict__ seg, int F, int K,
                                                   float gamma, float beta, int normalize,
@@ -176,7 +169,7 @@ __global__ __launch_bounds__(256) void osp_kernel(const float* __restrict__ seg,
         }
         for (int k = 0; k < K; ++k) {
             const float pr = e[k] / sum;
-            float wv = powg(s[k], gamma) * powg(pr, gamma);
+            float wv = dz_powg(s[k], gamma) * dz_powg(pr, gamma);
             if (wv < 1e-8f) wv = 1e-8f;
             wbuf[f * K + k] = wv;
         }
@@ -258,50 +251,13 @@ __global__ __launch_bounds__(256) void seg_head_kernel(const float* __restrict__
                 lg[c] = acc + cb[c];
             }
             float s[8];
-            if (powerset) {
-                // log_softmax is monotone: argmax of the logits == argmax of the log-probabilities
-                int best = 0;
-                float bv = lg[0];
-                for (int c = 1; c < classes; ++c)
-                    if (lg[c] > bv) {
-                        bv = lg[c];
-                        best = c;
-                    }
-                int a = -1, b2 = -1;
-                if (best >= 1 && best <= K) {
-                    a = best - 1;
-                } else if (best > K) {
-                    int idx = best - K - 1;
-                    for (int i = 0; i < K && a < 0; ++i) {
-                        const int cnt = K - 1 - i;
-                        if (idx < cnt) {
-                            a = i;
-                            b2 = i + 1 + idx;
-                        } else {
-                            idx -= cnt;
-                        }
-                    }
-                }
-                for (int k = 0; k < K; ++k) s[k] = (k == a || k == b2) ? 1.f : 0.f;
-            } else {
-                for (int k = 0; k < K; ++k) s[k] = 1.f / (1.f + expf(-lg[k]));
-            }
+            dz_seg_decide(lg, classes, K, powerset, s);
             const int f = f0 + tid;
             for (int k = 0; k < K; ++k) sb[f * K + k] = s[k];
             if (wout) {
-                float e[8], m = -INFINITY;
-                for (int k = 0; k < K; ++k) m = fmaxf(m, beta * s[k]);
-                float sum = 0.f;
-                for (int k = 0; k < K; ++k) {
-                    e[k] = expf(beta * s[k] - m);
-                    sum += e[k];
-                }
-                for (int k = 0; k < K; ++k) {
-                    const float pr = e[k] / sum;
-                    float wv = powg(s[k], gamma) * powg(pr, gamma);
-                    if (wv < 1e-8f) wv = 1e-8f;
-                    wbuf[f * K + k] = wv;
-                }
+                float wv[8];
+                dz_osp_frame(s, K, gamma, beta, wv);
+                for (int k = 0; k < K; ++k) wbuf[f * K + k] = wv[k];
             }
         }
     }

@@ -268,6 +268,16 @@ int dz_k_gemm_pre(dz_ctx* ctx, const dz_convgemm_desc* desc, void* stream);
 /* SincNet stages 1 / 2 (DZ_EPI_POOL3, k = 5, 64 output columns, Cin 80 or 64, norm-on-load, dense
  * rows) on the dedicated kernel: input tile resident in LDS, weights in registers; same
  * descriptor, outputs and partials as the POOL3 call of dz_k_gemm_split                       */
+/* Tail of the segmentation network in one launch (csrc/k_mlp_head.hip: linear[0] -> linear[1] ->
+ * classifier -> activation -> OSP weights without min-max) and the stand-alone classifier + activation
+ * + OSP kernel it is checked against; inputs as the internal layers pass them (f16 hi/lo planes).  */
+int dz_k_mlp_head(dz_ctx* ctx, const void* xsplit, long long xplane, const void* w0split, const void* w1split,
+                  const float* b0, const float* b1, const float* cw, const float* cb, int rows, int frames,
+                  int classes, int speakers, int powerset, float gamma, float beta, float* d_seg,
+                  float* d_weights, void* stream);
+int dz_k_seg_head(dz_ctx* ctx, const float* m1, const float* cw, const float* cb, int batch, int frames,
+                  int classes, int speakers, int powerset, float* d_seg, float gamma, float beta,
+                  int normalize, float* d_weights, void* stream);
 int dz_k_conv_pool(dz_ctx* ctx, const dz_convgemm_desc* desc, void* stream);
 int dz_k_convgemm_ntile(int t_out);
 /* d_stats (B, 2) = (mean, 1/sqrt(biased var + 1e-5)) of each window: InstanceNorm1d(1).  Inside

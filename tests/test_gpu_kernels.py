@@ -487,6 +487,68 @@ def test_gemm_pre(gpu, M, Cin, taps, dil, N, Nstore, epi, outs):
             assert (got[:, :Nstore] - Y.cpu()[:Tout, :Nstore].double()).abs().max().item() < 2.0 ** -21 * scale
 
 
+@pytest.mark.parametrize("powerset,B,F", [(False, 5, 293), (True, 3, 293), (False, 1, 37)])
+def test_mlp_head(gpu, powerset, B, F):
+    """k_mlp_head.hip (linear[0] -> linear[1] -> classifier -> activation -> OSP weights in one
+    launch) against the three launches it replaces (two k_gemm_pre.hip GEMMs + seg_head_kernel): the
+    same arithmetic statement by statement, so the outputs must be IDENTICAL; and against an f64
+    restatement of the MLP on the 22-bit operands."""
+    g = torch.Generator().manual_seed(17 + B)
+    rows, K, classes = B * F, 3, (7 if powerset else 3)
+    h = torch.tanh(torch.randn(rows, 256, generator=g))
+    W0, b0 = torch.randn(128, 256, generator=g) / 16, torch.randn(128, generator=g) * 0.1
+    W1, b1 = torch.randn(128, 128, generator=g) / 11, torch.randn(128, generator=g) * 0.1
+    cw = torch.zeros(64, 128)
+    cw[:classes] = torch.randn(classes, 128, generator=g) / 8
+    cb = torch.zeros(64)
+    cb[:classes] = torch.randn(classes, generator=g) * 0.2
+    dh, dW0, dW1 = _planes(h).to(gpu), _planes(W0).to(gpu), _planes(W1).to(gpu)
+    db0, db1, dcw, dcb = b0.to(gpu), b1.to(gpu), cw.to(gpu), cb.to(gpu)
+    lib, ctx = _lib.load(), _ctx(gpu)
+    # --- three launches
+    m0 = torch.zeros(2, rows, 128, dtype=torch.int16, device=gpu)
+    m1 = torch.zeros(rows, 128, device=gpu)
+    d = _lib.ConvGemmDesc()
+    d.Xsplit, d.xplane, d.Wsplit, d.bias = dh.data_ptr(), rows * 256, dW0.data_ptr(), db0.data_ptr()
+    d.Ysplit, d.yplane = m0.data_ptr(), rows * 128
+    d.B, d.Tin, d.Tout, d.Tstore, d.Cin, d.taps, d.dil = 1, rows, rows, rows, 256, 1, 1
+    d.K, d.Kpad, d.Npad, d.Nstore, d.ldx, d.ldy, d.epi = 256, 256, 128, 128, 256, 128, _lib.EPI_BIAS_LEAKY
+    _lib.check(lib.dz_k_gemm_pre(ctx, C.byref(d), None), "lin0")
+    d2 = _lib.ConvGemmDesc()
+    d2.Xsplit, d2.xplane, d2.Wsplit, d2.bias, d2.Y = m0.data_ptr(), rows * 128, dW1.data_ptr(), db1.data_ptr(), m1.data_ptr()
+    d2.B, d2.Tin, d2.Tout, d2.Tstore, d2.Cin, d2.taps, d2.dil = 1, rows, rows, rows, 128, 1, 1
+    d2.K, d2.Kpad, d2.Npad, d2.Nstore, d2.ldx, d2.ldy, d2.epi = 128, 128, 128, 128, 128, 128, _lib.EPI_BIAS_LEAKY
+    _lib.check(lib.dz_k_gemm_pre(ctx, C.byref(d2), None), "lin1")
+    seg3, w3 = torch.empty(B, F, K, device=gpu), torch.empty(B, K, F, device=gpu)
+    _lib.check(lib.dz_k_seg_head(ctx, m1.data_ptr(), dcw.data_ptr(), dcb.data_ptr(), B, F, classes, K, int(powerset),
+                                 seg3.data_ptr(), 3.0, 10.0, 0, w3.data_ptr(), None), "seg_head")
+    # --- one launch
+    seg1 = torch.full((B, F, K), float("nan"), device=gpu)
+    w1 = torch.full((B, K, F), float("nan"), device=gpu)
+    _lib.check(lib.dz_k_mlp_head(ctx, dh.data_ptr(), rows * 256, dW0.data_ptr(), dW1.data_ptr(), db0.data_ptr(),
+                                 db1.data_ptr(), dcw.data_ptr(), dcb.data_ptr(), rows, F, classes, K, int(powerset),
+                                 3.0, 10.0, seg1.data_ptr(), w1.data_ptr(), None), "mlp_head")
+    _sync()
+    assert torch.equal(seg1, seg3) and torch.equal(w1, w3)
+    # without the OSP output
+    seg0 = torch.empty(B, F, K, device=gpu)
+    _lib.check(lib.dz_k_mlp_head(ctx, dh.data_ptr(), rows * 256, dW0.data_ptr(), dW1.data_ptr(), db0.data_ptr(),
+                                 db1.data_ptr(), dcw.data_ptr(), dcb.data_ptr(), rows, F, classes, K, int(powerset),
+                                 3.0, 10.0, seg0.data_ptr(), None, None), "mlp_head")
+    _sync()
+    assert torch.equal(seg0, seg3)
+    # --- f64 restatement of the MLP (sigmoid case: a smooth function of the logits)
+    if not powerset:
+        a0 = F_leaky(_unplanes(_planes(h)) @ _unplanes(_planes(W0)).t() + b0.double())
+        a1 = F_leaky(a0 @ _unplanes(_planes(W1)).t() + b1.double())
+        ref = torch.sigmoid(a1 @ cw[:classes].double().t() + cb[:classes].double())
+        assert (seg1.cpu().double().view(rows, K) - ref).abs().max().item() < 2e-6
+
+
+def F_leaky(x):
+    return F.leaky_relu(x, 0.01)
+
+
 def test_gemm_split_plane_output(gpu):
     """k_gemm_split.hip (f32 input, norm-on-load, per-chunk batches: the tdnn1 call) writing its
     output as f16 planes for a k_gemm_pre.hip consumer."""
