@@ -196,6 +196,26 @@ pooled = torch.empty(B * 3, 3008, device=dev)
 timeit("stats_pool", lambda: _lib.check(lib.dz_k_stats_pool(ctx, x5.data_ptr(), 279, 1500, 1536, w.data_ptr(), F, B * 3, 3,
                                                            pooled.data_ptr(), 3008, st)),
        bytes_=B * 279 * 1536 * 4.0)
+# ---- segmentation tail: two MLP GEMMs + head (three launches) vs k_mlp_head.hip (one) --------
+if not only or "mlp_head" in only:
+    from diart_amd.weights import split_f16
+    rows = B * F
+    hs = split_f16(torch.tanh(torch.randn(rows, 256))).to(dev)
+    w0s, w1s = split_f16(torch.randn(128, 256) / 16).to(dev), split_f16(torch.randn(128, 128) / 11).to(dev)
+    b0, b1 = torch.zeros(128, device=dev), torch.zeros(128, device=dev)
+    cw, cb = torch.randn(64, 128, device=dev) / 8, torch.zeros(64, device=dev)
+    segb, wb = torch.empty(B, F, 3, device=dev), torch.empty(B, 3, F, device=dev)
+    m1 = torch.randn(rows, 128, device=dev)
+    only_saved = set(only)
+    only.clear()
+    timeit("mlp_head", lambda: _lib.check(lib.dz_k_mlp_head(ctx, hs.data_ptr(), rows * 256, w0s.data_ptr(), w1s.data_ptr(),
+                                                            b0.data_ptr(), b1.data_ptr(), cw.data_ptr(), cb.data_ptr(), rows, F, 3, 3, 0,
+                                                            3.0, 10.0, segb.data_ptr(), wb.data_ptr(), st)),
+           flop=2.0 * rows * (256 * 128 + 128 * 128 + 128 * 3))
+    timeit("seg_head", lambda: _lib.check(lib.dz_k_seg_head(ctx, m1.data_ptr(), cw.data_ptr(), cb.data_ptr(), B, F, 3, 3, 0,
+                                                            segb.data_ptr(), 3.0, 10.0, 0, wb.data_ptr(), st)),
+           bytes_=rows * 134 * 4.0)
+    only.update(only_saved)
 out = Path("gpurun_out")
 out.mkdir(exist_ok=True)
 (out / "kbench.json").write_text(json.dumps(results, indent=1))
