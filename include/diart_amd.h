@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define DZ_VERSION 200
+#define DZ_VERSION 210   /* 2.1: dz_seg_forward_osp, per-row rings, dz_k_mlp_head / dz_k_seg_head */
 
 typedef struct dz_ctx dz_ctx;
 typedef struct dz_seg dz_seg;
