@@ -156,3 +156,47 @@ def test_more_first_chunk_speakers_than_slots_stay_unmapped():
     assert clu.active_centers == {0, 1}
     out2 = clu(_swf(seg), torch.from_numpy(emb))                             # and the stream continues
     assert out2.data.shape == (20, 2) and np.isfinite(out2.data).all()
+
+
+def _run_batches(seed, N, T, threads, out):
+    rng = np.random.default_rng(seed)
+    batch = BatchedSpeakerClustering(N, 0.5, 0.2, 0.9, 20, num_threads=threads)
+    single = [OnlineSpeakerClustering(0.5, 0.2, 0.9, "cosine", 20) for _ in range(N)]
+    ok = True
+    for _ in range(T):
+        seg = rng.random((N, 16, 3)).astype(np.float32)
+        emb = rng.standard_normal((N, 3, 24)).astype(np.float32)
+        scores, _ = batch(seg, emb)
+        for i in range(N):
+            ok &= bool(np.array_equal(scores[i], single[i](_swf(seg[i]), torch.from_numpy(emb[i])).data))
+    out.append(ok)
+
+
+def test_host_worker_pool_is_shared_safely_between_callers_and_survives_fork():
+    """csrc/hostpool.cpp: one process-wide pool behind dz_clu_step_batch / dz_tail_step_batch.
+    Callers on different host threads (two StreamBatch objects driven by two threads), with different
+    thread counts, must each get their own results; a forked child (threads do not survive fork)
+    must build its own pool instead of waiting for workers that no longer exist."""
+    import multiprocessing as mp
+    import threading
+    out = []
+    th = [threading.Thread(target=_run_batches, args=(s, 5 + s, 60, 2 + 3 * s, out)) for s in range(3)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(60)
+    assert out == [True, True, True]
+    # the pool now exists in this process: fork and use it from the child
+    ctx = mp.get_context("fork")
+    q = ctx.Queue()
+
+    def child():
+        res = []
+        _run_batches(9, 6, 20, 4, res)
+        q.put(res[0])
+
+    p = ctx.Process(target=child)
+    p.start()
+    p.join(60)
+    assert not p.is_alive(), "forked child hung in the host worker pool"
+    assert p.exitcode == 0 and q.get(timeout=5) is True
