@@ -216,16 +216,6 @@ static bool pre_split_enabled() {
     return !(v && v[0] == '0');
 }
 
-// DZ_SKIP=<bit mask> (timing experiments only — results are garbage): drop a class of launches to
-// measure its marginal cost inside the overlapped pipeline.  1 finalize_norm, 2 MLP + classifier,
-// 4 pooling + embedding head, 8 tdnn2..5, 16 sinc_conv0, 32 LSTM recurrence, 64 LSTM projections,
-// 128 conv1 / conv2, 256 wave_stats, 512 tdnn1
-static int skip_mask() {
-    static const int m = getenv("DZ_SKIP") ? atoi(getenv("DZ_SKIP")) : 0;
-    return m;
-}
-#define DZ_SKIPPED(bit) (skip_mask() & (bit))
-
 // DZ_FUSED_NORM=0 keeps the three finalize_norm launches of a SincNet; by default (split-f16 path)
 // every consumer derives its InstanceNorm scale / shift from the producer's tile partials itself
 static bool fused_norm_enabled() {
@@ -286,9 +276,7 @@ static void sinc_out_norm(DzConvGemm& p, const dz_sincnet_weights& w, const Sinc
 static int run_sincnet(const dz_sincnet_weights& w, const SincGeom& g, const SincScratch& s,
                        const float* wave, long long stride, int B, hipStream_t st) {
     int rc;
-    if (!DZ_SKIPPED(256))
     { ProfScope ps(T_WAVE, B); if ((rc = dz_launch_wave_stats(wave, stride, B, g.S, s.stats, st))) return rc; }
-    if (!DZ_SKIPPED(16))
     { ProfScope ps(T_CONV0, B);
     rc = w.filt_split
              ? dz_launch_sinc_conv0_split(wave, stride, B, g.S, s.stats, 1, w.wav_gamma, w.wav_beta,
@@ -297,7 +285,7 @@ static int run_sincnet(const dz_sincnet_weights& w, const SincGeom& g, const Sin
                                     s.y0, g.P0, s.part0, g.nt0, st);
     if (rc) return rc; }
     const bool fused = sinc_fused_norm(w);
-    if (!fused && !DZ_SKIPPED(1))
+    if (!fused)
     { ProfScope ps(T_FIN, B);
     if ((rc = dz_launch_finalize_norm(s.part0, B, g.nt0, 80, g.P0, w.in0_g, w.in0_b, s.sc0, s.sh0,
                                       st)))
@@ -313,9 +301,8 @@ static int run_sincnet(const dz_sincnet_weights& w, const SincGeom& g, const Sin
     p.Kpad = 416; p.Npad = 64; p.Nstore = 64; p.ldx = 80; p.ldy = 64; p.Tstore = g.P1;
     p.xbs = (long long)g.P0 * 80; p.ybs = (long long)g.P1 * 64;
     p.norm_on_load = 1; p.epi = DZ_EPI_POOL3;
-    if (!DZ_SKIPPED(128))
     { ProfScope ps(T_CONV1, B); if ((rc = run_gemm(p, w.w1_split, st))) return rc; }
-    if (!fused && !DZ_SKIPPED(1))
+    if (!fused)
     { ProfScope ps(T_FIN, B);
     if ((rc = dz_launch_finalize_norm(s.part1, B, g.nt1, 64, g.P1, w.in1_g, w.in1_b, s.sc1, s.sh1,
                                       st)))
@@ -327,9 +314,8 @@ static int run_sincnet(const dz_sincnet_weights& w, const SincGeom& g, const Sin
     p.Y = s.y2; p.partials = s.part2;
     p.Tin = g.P1; p.Tout = g.T2; p.Cin = 64; p.K = 320; p.Kpad = 320; p.ldx = 64;
     p.Tstore = g.P2; p.xbs = (long long)g.P1 * 64; p.ybs = (long long)g.P2 * 64;
-    if (!DZ_SKIPPED(128))
     { ProfScope ps(T_CONV2, B); if ((rc = run_gemm(p, w.w2_split, st))) return rc; }
-    if (fused || DZ_SKIPPED(1)) return 0;
+    if (fused) return 0;
     ProfScope ps(T_FIN, B);
     return dz_launch_finalize_norm(s.part2, B, g.nt2, 64, g.P2, w.in2_g, w.in2_b, s.sc2, s.sh2, st);
 }
@@ -462,7 +448,6 @@ static int seg_forward(dz_seg* s, const float* d_wave, long long wave_stride, in
             p.B = 1; p.Tin = p.Tout = p.Tstore = B * F; p.Cin = 256; p.K = 256; p.Kpad = 256;
             p.ldx = 256;
         }
-        if (!DZ_SKIPPED(64))
         { ProfScope ps(layer == 0 ? T_PROJ0 : T_PROJ, B);
           if (layer > 0 && s->pre) {
               p.X = nullptr; p.Xsplit = lin; p.xplane = rows * 256; p.Wsplit = s->w.wih_split[layer];
@@ -472,7 +457,6 @@ static int seg_forward(dz_seg* s, const float* d_wave, long long wave_stride, in
           }
           if (rc) return rc; }
         float* hout = (layer & 1) ? s->h1 : s->h0;
-        if (!DZ_SKIPPED(32))
         { ProfScope ps(T_REC, B);
           // gx columns are unit-major (weights.py permutes the rows of W_ih); 16 chains per
           // workgroup on the matrix cores when the layer came with split planes of W_hh
@@ -486,7 +470,6 @@ static int seg_forward(dz_seg* s, const float* d_wave, long long wave_stride, in
         lin = hout;
     }
     // Linear(256,128)+leaky, Linear(128,128)+leaky, classifier
-    if (DZ_SKIPPED(2)) return 0;
     DzConvGemm p;
     memset(&p, 0, sizeof(p));
     p.B = 1; p.Tin = p.Tout = p.Tstore = B * F; p.taps = 1; p.dil = 1;
@@ -634,7 +617,6 @@ static int emb_frames(dz_emb* e, const float* d_wave, long long stride, int B, h
         } else {
             p.B = 1; p.Tin = B * P; p.Tout = p.Tstore = B * P - span;
         }
-        if (!DZ_SKIPPED(i == 0 ? 512 : 8))
         { ProfScope ps(T_TDNN1 + i, B);
           if (i > 0 && e->pre) {
               p.X = nullptr; p.Xsplit = in; p.xplane = plane; p.Wsplit = e->w.tw_split[i];
@@ -652,7 +634,6 @@ static int emb_frames(dz_emb* e, const float* d_wave, long long stride, int B, h
 static int emb_head(dz_emb* e, const float* d_weights, int Fw, int rows, int rows_per_x,
                     int normalize, float* d_out, hipStream_t st) {
     int rc;
-    if (DZ_SKIPPED(4)) return 0;
     { ProfScope ps(T_POOL, rows / rows_per_x);
     if ((rc = dz_launch_stats_pool(e->x5, (long long)e->g.P2 * 1536, e->T[4], 1500, 1536, d_weights, Fw,
                                    rows, rows_per_x, e->pooled, kPoolLd, st)))

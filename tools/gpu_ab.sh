@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round-2 GPU visit K: kernel tests, kbench subset, bench A/B over env toggles.
-#   usage: tools/gpu_r2k.sh <tag> "<kbench --only list>" "ENV1=a,ENV2=b ENV1=c ..."   (each grid entry: comma-separated env assignments)
+#   usage: tools/gpu_ab.sh <tag> "<kbench --only list>" "ENV1=a,ENV2=b ENV1=c ..."   (each grid entry: comma-separated env assignments)
 TAG=${1:-r2k}
 KB=${2:-conv1_pool,conv2_pool}
 GRID=${3:-"DZ_CONV_POOL=1 DZ_CONV_POOL=0 DZ_CONV_POOL=1 DZ_CONV_POOL=0"}
