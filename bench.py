@@ -88,7 +88,7 @@ def device_kernel(tag, precision):
     lstm = os.environ.get("DZ_LSTM", "valu")                          # weights.default_lstm_variant
     k = KERNELS[tag]
     if k["bound"] == "hbm":
-        return {"wave_stats": "wave_stats_kernel", "stats_pool": "stats_pool_reg_kernel<3, 80>",
+        return {"wave_stats": "wave_stats_kernel", "stats_pool": "stats_pool_reg_kernel<3, 72>",
                 "seg_classifier": "seg_head_kernel"}[tag], "hbm", PEAK_HBM_GBPS, "GB/s"
     if k["bound"] == "rec":
         if split and lstm != "valu":

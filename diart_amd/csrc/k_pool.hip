@@ -135,7 +135,11 @@ int launch_pool(const float* X, long long xstride, int T, int C, int ldx, const 
     const dim3 grid((C + 63) / 64, nx);
     DZ_REQUIRE(T <= 4 * 160, "stats_pool: %d frames per chunk (at most 640: an 11 s chunk)", T);
     const size_t lds = sizeof(float) * ((size_t)K * T + 4 * K * 64);
-    if (T <= 4 * 80)
+    if (T <= 4 * 72)              // 5 s chunks (279 frames): 172 VGPRs, i.e. a workgroup fits beside a
+                                  // recurrence workgroup on its CU (2 x 168 of the 512 registers per SIMD)
+        DZ_LAUNCH((stats_pool_reg_kernel<K, 72>), grid, dim3(256), lds, st, X, xstride, T, C, ldx, weights, Fw,
+                  ktot, kofs, out, ldo);
+    else if (T <= 4 * 80)
         DZ_LAUNCH((stats_pool_reg_kernel<K, 80>), grid, dim3(256), lds, st, X, xstride, T, C, ldx, weights, Fw,
                   ktot, kofs, out, ldo);
     else
