@@ -113,9 +113,10 @@ def device_kernel(tag, precision):
     if tag in ("conv1_pool", "conv2_pool") and os.environ.get("DZ_CONV_POOL", "1") != "0":
         return ("conv_pool_h_kernel<80>" if tag == "conv1_pool" else "conv_pool_h_kernel<64>"), "mfma", \
             PEAK_F16_MATRIX_TFLOPS / SPLIT_PRODUCTS, "TFLOP/s"
+    wm = "2, 1" if os.environ.get("DZ_SPLIT_WM", "4") == "2" else "4, 2"      # norm-on-load layers
     sym = {"conv1_pool": "gemm_split_kernel<3, 1, true, 4>", "conv2_pool": "gemm_split_kernel<3, 1, true, 4>",
-           "lstm_proj": "gemm_split_kernel<4, 2, false, 0>", "lstm_proj0": "gemm_split_kernel<4, 2, true, 0>",
-           "seg_mlp": "gemm_split_kernel<4, 2, false, 1>", "tdnn1": "gemm_split_kernel<4, 2, true, 3>",
+           "lstm_proj": "gemm_split_kernel<4, 2, false, 0>", "lstm_proj0": f"gemm_split_kernel<{wm}, true, 0>",
+           "seg_mlp": "gemm_split_kernel<4, 2, false, 1>", "tdnn1": f"gemm_split_kernel<{wm}, true, 3>",
            "seg_head": "seg_head_kernel"}
     return sym.get(tag, "gemm_split_kernel<4, 2, false, 3>"), "mfma", PEAK_F16_MATRIX_TFLOPS / SPLIT_PRODUCTS, "TFLOP/s"
 

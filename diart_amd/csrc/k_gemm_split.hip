@@ -32,6 +32,7 @@
 // lanes 32..63 take the upper 8 of a 16-wide k-step), so the contraction is correct for any
 // hardware k-ordering; the C/D map is cdna_hip_programming.md "Fragment layout".
 #include "dz_common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -326,11 +327,23 @@ int dz_launch_gemm_split(const DzConvGemm& p_in, hipStream_t st) {
         DZ_SP(3, 1, true, DZ_EPI_POOL3);
     }
     DZ_REQUIRE(p.Npad % 128 == 0, "gemm_split: Npad must be a multiple of 128");
+    // DZ_SPLIT_WM=2: the two norm-on-load launches of the default path (LSTM projection 0, tdnn1) as
+    // 64 x 64 tiles with 4 waves (54 VGPRs, one wave per SIMD), whose workgroups fit on CUs that
+    // already hold a recurrence workgroup or two k_gemm_pre.hip workgroups.  Their launches get
+    // shorter in the pipeline (projection 0: 276 -> 164 us, tdnn1 219 -> 161 us; alone 28 -> 31.5 and
+    // 46 -> 53 us), the step time does not change beyond noise (4 same-visit pairs: 2 wins, 2 losses),
+    // so the 128 x 128 / 8-wave tiles stay the default.
+    static const bool small_wg = [] {
+        const char* e = getenv("DZ_SPLIT_WM");
+        return e && e[0] == '2';
+    }();
     switch (p.epi) {
         case DZ_EPI_TDNN:
+            if (pro && small_wg) DZ_SP(2, 1, true, DZ_EPI_TDNN);
             if (pro) DZ_SP(4, 2, true, DZ_EPI_TDNN);
             DZ_SP(4, 2, false, DZ_EPI_TDNN);
         case DZ_EPI_BIAS:
+            if (pro && small_wg) DZ_SP(2, 1, true, DZ_EPI_BIAS);
             if (pro) DZ_SP(4, 2, true, DZ_EPI_BIAS);
             DZ_SP(4, 2, false, DZ_EPI_BIAS);
         case DZ_EPI_BIAS_LEAKY:
