@@ -273,3 +273,62 @@ def test_stream_server_equals_dedicated_pipelines(gpu, device_rings):
             usable = len(audio[k]) // 8000 * 8000       # the server never sees a zero-padded last block
             want = StreamingInference(SpeakerDiarization(cfg), audio[k][:usable], 16000, k, (0, 0), 1)()
             assert want is not None and got.to_rttm() == want.to_rttm(), (k, latency)
+
+
+def test_websocket_front_end_streams_rttm_from_the_gpu(gpu):
+    """diart_amd.ws.WebSocketFrontEnd over real sockets on top of a GPU StreamServer: two clients send
+    the reference's message format (base64 float32 text); the RTTM lines each gets back are, in order,
+    exactly the per-chunk ``Annotation.to_rttm()`` lines (console/serve.py:124) of an identical
+    StreamServer stepped directly with the same audio."""
+    import sys
+    import time
+    from pathlib import Path
+    sys.path.insert(0, str(Path(__file__).resolve().parent))
+    from test_ws import Client
+    from diart_amd.serve import StreamServer
+    from diart_amd.ws import WebSocketFrontEnd
+    seg_sd, emb_sd = synth_segmentation_state(), synth_embedding_state()
+    audio = {k: synth_streams(1, 9.0, seed0=700 + i)[0] for i, k in enumerate(("ann", "ben"))}
+
+    def make():
+        return StreamServer(M.HipSegmentation(seg_sd, max_batch=2), M.HipEmbedding(emb_sd, max_batch=2),
+                            max_streams=2, device=gpu)
+
+    direct, want = make(), {k: [] for k in audio}
+    for k in audio:
+        direct.open(k)
+        direct.push(k, audio[k])
+    while True:
+        out = direct.step()
+        if not out:
+            break
+        for k, ann in out.items():
+            want[k] += [l for l in ann.to_rttm().splitlines() if l]
+    assert all(want.values())
+
+    srv = make()
+    fe = WebSocketFrontEnd(srv, port=0).start()
+    try:
+        clients = {k: Client(fe.port, k) for k in audio}
+        for k, c in clients.items():
+            for pos in range(0, len(audio[k]), 16000):
+                c.send_audio(audio[k][pos:pos + 16000])
+        deadline = time.time() + 30
+        while time.time() < deadline and sum(s.emitted for s in list(srv._streams.values())) < 18:
+            time.sleep(0.05)
+        assert sum(s.emitted for s in srv._streams.values()) == 18      # 9 s = 9 windows per stream
+        time.sleep(0.3)
+        got = {k: [] for k in audio}
+        for k, c in clients.items():
+            c.s.settimeout(0.5)
+            try:
+                while True:
+                    op, data = c.recv()
+                    assert op == 0x1
+                    got[k] += [l for l in data.decode().splitlines() if l]
+            except (TimeoutError, OSError):
+                pass
+        assert not fe.errors
+        assert got == want
+    finally:
+        fe.stop()
