@@ -200,7 +200,7 @@ class StreamServer:
                     self._upload(uploads)
                 if not work:
                     if uploads:     # warm-up blocks only: the staging planes are free once the GPU has read them
-                        torch.cuda.current_stream(self.batch.device).synchronize()
+                        self._sync_uploads()
                     return {}
                 starts = np.array([t for _, _, _, t in work], dtype=np.float64)
                 slots = [st.slot for _, st, _, _ in work]
@@ -228,10 +228,15 @@ class StreamServer:
                     out[sid] = ann
             return out
 
+    def _sync_uploads(self) -> None:
+        if self._dev.is_cuda:
+            torch.cuda.current_stream(self._dev.device).synchronize()
+
     def _upload(self, uploads) -> None:
         """New blocks -> the streams' device rings: round r carries the r-th new block of every stream
         that has one (a running stream has exactly one; a joining stream up to a whole window)."""
-        with torch.cuda.device(self.batch.device):
+        import contextlib
+        with (torch.cuda.device(self._dev.device) if self._dev.is_cuda else contextlib.nullcontext()):
             for r in range(max(len(b) for _, b in uploads)):
                 rows = [slot for slot, b in uploads if len(b) > r]
                 plane = self._stage[r]

@@ -189,3 +189,80 @@ def test_ring_mode_block_schedule_reproduces_the_host_windows():
     assert len(replay) == len(rec.batches) > 5
     for (w, s), (hw, hs, _) in zip(replay, rec.batches):
         assert np.array_equal(w, hw[0]) and abs(s - hs[0]) < 1e-9
+
+
+class FakeRings:
+    """Host stand-in for ``AudioRing``'s per-row interface (push_rows / gather / reset_row): the
+    server's ring-mode control flow can then run without a GPU."""
+
+    def __init__(self, n, window, hop):
+        self.window, self.hop = window, hop
+        self.rows = [np.zeros(0, dtype=np.float32) for _ in range(n)]
+        self.pushed_blocks = 0
+
+    def push_rows(self, block, rows):
+        assert tuple(block.shape) == (len(rows), self.hop) and len(set(rows)) == len(rows)
+        for j, r in enumerate(rows):
+            self.rows[r] = np.concatenate([self.rows[r], block[j].numpy()])[-self.window:]
+        self.pushed_blocks += len(rows)
+
+    def gather(self, rows, out):
+        import torch
+        for j, r in enumerate(rows):
+            assert len(self.rows[r]) == self.window, "gather of an incomplete window"
+            out[j].copy_(torch.from_numpy(self.rows[r]))
+        return out[:len(rows)]
+
+    def reset_row(self, r):
+        self.rows[r] = np.zeros(0, dtype=np.float32)
+
+
+def _ring_server(max_streams, rec):
+    """A StreamServer whose ring-mode ``step`` runs on the host: fake rings, the recording engine
+    behind ``_gpu_engine``."""
+    import torch
+    srv = StreamServer(None, None, max_streams=max_streams, engine=rec)
+    srv.rings = FakeRings(max_streams, srv.chunk_samples, srv.step_samples)
+    srv._stage = torch.empty((srv.blocks_per_window, max_streams, srv.step_samples), dtype=torch.float32)
+    srv._dev = torch.empty((max_streams, srv.chunk_samples), dtype=torch.float32)
+    srv._gpu_engine = lambda windows, starts, slots: rec(windows.numpy(), starts, slots)
+    return srv
+
+
+def test_ring_mode_step_equals_host_window_mode_for_streams_that_join_and_leave():
+    rng = np.random.default_rng(5)
+    rec_h, rec_r = Recorder(), Recorder()
+    host = StreamServer(None, None, max_streams=3, engine=rec_h)
+    ring = _ring_server(3, rec_r)
+    audio = {k: ramp(int(16000 * d), offset=1000 * i) * (1 if i % 2 == 0 else -1)
+             for i, (k, d) in enumerate({"a": 9.3, "b": 7.1, "c": 12.0, "d": 6.4}.items())}
+    pos = {k: 0 for k in audio}
+    join = {"a": 0, "b": 2, "c": 2, "d": 11}
+    closed, tick, outs_h, outs_r = set(), 0, [], []
+    while len(closed) < len(audio):
+        for k in audio:
+            if tick == join[k]:
+                host.open(k)
+                ring.open(k)
+            if tick >= join[k] and k not in closed:
+                n = int(rng.integers(1000, 40000))
+                blk = audio[k][pos[k]:pos[k] + n]
+                pos[k] += n
+                if len(blk):
+                    assert host.push(k, blk) == ring.push(k, blk)
+                if pos[k] >= len(audio[k]) and not host._pending(host._streams[k]):
+                    th, tr = host.close(k), ring.close(k)      # a slot is handed to "d" later
+                    assert th.to_rttm() == tr.to_rttm()
+                    closed.add(k)
+        oh, orr = host.step(), ring.step()
+        outs_h.append({k: v.to_rttm() for k, v in oh.items()})
+        outs_r.append({k: v.to_rttm() for k, v in orr.items()})
+        tick += 1
+        assert tick < 500
+    assert outs_h == outs_r and any(len(o) >= 2 for o in outs_r)
+    # the engine saw the same windows, start times and slots, batch by batch
+    assert len(rec_h.batches) == len(rec_r.batches) > 10
+    for (wh, sh, lh), (wr, sr, lr) in zip(rec_h.batches, rec_r.batches):
+        assert np.array_equal(wh, wr) and np.allclose(sh, sr) and lh == lr
+    # only new blocks crossed the "bus": one 8000-sample block per consumed step block
+    assert ring.rings.pushed_blocks == sum(len(a) // 8000 for a in audio.values())
