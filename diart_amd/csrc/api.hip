@@ -367,6 +367,12 @@ extern "C" int dz_seg_create(dz_ctx* ctx, const dz_seg_weights* w, int max_batch
         DZ_REQUIRE(w->num_classes == 1 + w->num_speakers + w->num_speakers * (w->num_speakers - 1) / 2,
                    "dz_seg_create: powerset with %d classes / %d speakers", w->num_classes,
                    w->num_speakers);
+    // run_sincnet leaves the last InstanceNorm to the consumer's prologue whenever conv1 / conv2 came
+    // with split planes; a first projection WITHOUT planes would then read sc2 / sh2 nobody wrote
+    DZ_REQUIRE((w->sinc.w1_split != nullptr) == (w->sinc.w2_split != nullptr) &&
+                   (w->sinc.w1_split != nullptr) == (w->wih_split[0] != nullptr),
+               "dz_seg_create: the split planes of SincNet conv1 / conv2 and of the first LSTM projection "
+               "must be all present or all absent");
     DZ_HIP(hipSetDevice(ctx->device));
     dz_seg* s = new (std::nothrow) dz_seg;
     DZ_REQUIRE(s != nullptr, "dz_seg_create: out of memory");
@@ -547,6 +553,10 @@ extern "C" int dz_emb_create(dz_ctx* ctx, const dz_emb_weights* w, int max_batch
     DZ_REQUIRE(w->dimension == 512, "dz_emb_create: dimension %d (only 512 is built)", w->dimension);
     const SincGeom g = sinc_geom(num_samples, w->sinc.filt_split != nullptr);
     DZ_REQUIRE(g.ok && g.P2 > 14, "dz_emb_create: %d samples is too short", num_samples);
+    DZ_REQUIRE((w->sinc.w1_split != nullptr) == (w->sinc.w2_split != nullptr) &&
+                   (w->sinc.w1_split != nullptr) == (w->tw_split[0] != nullptr),
+               "dz_emb_create: the split planes of SincNet conv1 / conv2 and of tdnn1 must be all present "
+               "or all absent (the consumer of the last SincNet stage finalises its InstanceNorm)");
     DZ_HIP(hipSetDevice(ctx->device));
     dz_emb* e = new (std::nothrow) dz_emb;
     DZ_REQUIRE(e != nullptr, "dz_emb_create: out of memory");

@@ -39,8 +39,12 @@ void drain(Pool* p, int worker) {
     }
 }
 
-void worker_main(Pool* p, int id) {
-    unsigned long long seen = 0;
+// `seen` starts at the generation current when the worker was spawned (read under `callers`, where
+// gen cannot move): a worker never looks at — or acknowledges — a job published before it existed.
+// Starting every worker at 0 let one spawned into a pool with gen > 0 acknowledge the job that was
+// about to be published, and then that job again (`left` ended one short, the caller
+// returned while a worker was still inside fn()).
+void worker_main(Pool* p, int id, unsigned long long seen) {
     for (;;) {
         // wait for a job newer than the last one this worker looked at: spin briefly, then sleep
         const auto t0 = std::chrono::steady_clock::now();
@@ -82,7 +86,7 @@ void dz_host_parallel(int n, int threads, const std::function<void(int, int)>& f
     std::lock_guard<std::mutex> one(p->callers);
     while (p->spawned < threads - 1) {
         const int id = ++p->spawned;
-        std::thread(worker_main, p, id).detach();
+        std::thread(worker_main, p, id, p->gen.load(std::memory_order_acquire)).detach();
     }
     // every spawned worker looks at and acknowledges every job (so the job fields are never rewritten
     // while a worker may still read them); only the first `helpers` of them take indices

@@ -381,22 +381,32 @@ class StreamBatch:
         ticket["done"].synchronize()
         t1 = _time.perf_counter()
         self.host_seconds["wait"] += t1 - t0
-        _lib.range_check(self.device.index)      # an f16x3 operand beyond +-65504 is an error, not a clamp
-        N, slots = ticket["rows"], ticket["slots"]
-        seg = ticket["seg_h"].numpy()[:N]
-        emb = ticket["emb_h"].numpy()[:N]
-        scores, assign = self.clustering(seg, emb, want_scores or self.with_tail, slots=slots)
-        if self.with_tail:
-            # diarization.py:190,203-232 for every stream: aggregate the overlapping windows of the
-            # region [t - latency, t - latency + step) and binarise it
-            if self.tail is None:
-                self.tail = BatchedOutputTail(self.n, seg.shape[1], self.max_speakers, self.step,
-                                              self.latency, self.tau_active,
-                                              num_threads=self.cluster_threads)
-            ticket["tail"] = self.tail(scores, ticket["starts"], self.duration / seg.shape[1], slots=slots)
-        ticket["busy"] = False
-        ticket["keep"] = None
-        self.host_seconds["work"] += _time.perf_counter() - t1
+        # The ticket's slot is ALWAYS handed back: an exception between here and the end
+        # used to leak it, and every later launch then allocated a new pinned slot while kernels were
+        # running.  The range flag (an f16x3 operand beyond +-65504 is an error, not a clamp) is
+        # checked first: a flagged step's results are clamped garbage and must not reach the
+        # clustering state of the streams; the caller gets error 6 for THIS step and the streams
+        # skip one window.  The flag is one word per device: with `depth` steps in flight it may have
+        # been raised by a kernel of a later step, whose own finish() then passes — over-reporting by
+        # at most `depth - 1` steps, never under-reporting.
+        try:
+            _lib.range_check(self.device.index)
+            N, slots = ticket["rows"], ticket["slots"]
+            seg = ticket["seg_h"].numpy()[:N]
+            emb = ticket["emb_h"].numpy()[:N]
+            scores, assign = self.clustering(seg, emb, want_scores or self.with_tail, slots=slots)
+            if self.with_tail:
+                # diarization.py:190,203-232 for every stream: aggregate the overlapping windows of the
+                # region [t - latency, t - latency + step) and binarise it
+                if self.tail is None:
+                    self.tail = BatchedOutputTail(self.n, seg.shape[1], self.max_speakers, self.step,
+                                                  self.latency, self.tau_active,
+                                                  num_threads=self.cluster_threads)
+                ticket["tail"] = self.tail(scores, ticket["starts"], self.duration / seg.shape[1], slots=slots)
+        finally:
+            ticket["busy"] = False
+            ticket["keep"] = None
+            self.host_seconds["work"] += _time.perf_counter() - t1
         return seg, emb, scores, assign
 
     def __call__(self, waves: torch.Tensor):

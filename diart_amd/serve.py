@@ -67,6 +67,8 @@ class StreamServer:
         self._inflight: set = set()            # slots whose window the worker is processing now
         self._deferred: List[int] = []         # slots closed while in flight: freed after the step
         self._stop = False
+        import collections
+        self.step_errors = collections.deque(maxlen=64)   # (time, repr) of failed steps, newest last
         # `engine(windows (k, S) float32, starts (k,), slots [k]) -> list of k (turns (m, 3) array)`;
         # the default engine is a StreamBatch with the C++ output tail
         if engine is None:
@@ -143,6 +145,12 @@ class StreamServer:
                 st.buffer = st.buffer[self.step_samples:]
             return self._pending(st)
 
+    def pending(self, stream_id: Hashable) -> int:
+        """Windows of the stream still waiting for the worker (0 for an unknown / closed stream)."""
+        with self._lock:
+            st = self._streams.get(stream_id)
+            return 0 if st is None else self._pending(st)
+
     def _pending(self, st: _Stream) -> int:
         # block number c (1-based) completes a window iff c >= blocks_per_window
         last = st.consumed + len(st.blocks)
@@ -179,11 +187,14 @@ class StreamServer:
         pipeline); the running total is kept per stream until ``close``."""
         with self._step_lock:                       # one engine, one step at a time
             uploads = []                            # ring mode: (slot, [blocks]) of this step
+            undo = []                               # (stream, blocks, consumed, chunk, start) before the take
+            pushed: Dict[int, int] = {}             # ring mode: blocks of a slot that reached its ring
             with self._lock:
                 work = []                           # (stream id, stream, host window | None, start)
                 for sid, st in self._streams.items():
                     if not st.blocks:
                         continue
+                    undo.append((st, list(st.blocks), st.consumed, st.chunk, st.start))
                     if self.rings is None:
                         got = self._take_host_window(st)
                         if got is not None:
@@ -197,7 +208,7 @@ class StreamServer:
                 self._inflight = {st.slot for _, st, _, _ in work} | {slot for slot, _ in uploads}
             try:
                 if uploads:
-                    self._upload(uploads)
+                    self._upload(uploads, pushed)
                 if not work:
                     if uploads:     # warm-up blocks only: the staging planes are free once the GPU has read them
                         self._sync_uploads()
@@ -208,6 +219,9 @@ class StreamServer:
                     turns = self._engine(np.stack([w for _, _, w, _ in work]), starts, slots)
                 else:
                     turns = self._gpu_engine(self.rings.gather(slots, self._dev), starts, slots)
+            except BaseException as exc:
+                self._roll_back(undo, pushed, exc)
+                raise
             finally:
                 with self._lock:
                     self._inflight = set()
@@ -228,13 +242,35 @@ class StreamServer:
                     out[sid] = ann
             return out
 
+    def _roll_back(self, undo, pushed: Dict[int, int], exc: BaseException) -> None:
+        """A step failed (upload, gather or the engine raised).  The blocks it took must not vanish
+        and the host-side block count of a stream must keep matching what its device ring holds:
+        otherwise every later step of that stream computes wrong start times or fails in
+        ``dz_ring_gather`` — which rejects the whole batch, i.e. one desynchronised stream would fail
+        every step of every stream.  Host-window mode: the taken blocks go back to the
+        front of the queue and the window state is restored; the step can simply be retried.  Ring
+        mode: blocks that already reached the ring stay consumed (``consumed`` = count before + pushed,
+        the ring's own per-row counter), the others go back; a window whose blocks were all pushed
+        but whose engine run failed is lost for that stream (recorded in ``step_errors``)."""
+        with self._lock:
+            for st, blocks, consumed, chunk, start in undo:
+                taken = len(blocks) - len(st.blocks)          # push() may have appended meanwhile
+                keep = pushed.get(st.slot, 0) if self.rings is not None else 0
+                keep = min(keep, taken)
+                st.blocks = blocks[keep:taken] + st.blocks
+                st.consumed = consumed + keep
+                if self.rings is None:
+                    st.chunk, st.start = chunk, start
+            self.step_errors.append((time.time(), repr(exc)))
+
     def _sync_uploads(self) -> None:
         if self._dev.is_cuda:
             torch.cuda.current_stream(self._dev.device).synchronize()
 
-    def _upload(self, uploads) -> None:
+    def _upload(self, uploads, pushed: Optional[Dict[int, int]] = None) -> None:
         """New blocks -> the streams' device rings: round r carries the r-th new block of every stream
-        that has one (a running stream has exactly one; a joining stream up to a whole window)."""
+        that has one (a running stream has exactly one; a joining stream up to a whole window).
+        ``pushed[slot]`` counts the blocks of a slot whose ring push was enqueued (for ``_roll_back``)."""
         import contextlib
         with (torch.cuda.device(self._dev.device) if self._dev.is_cuda else contextlib.nullcontext()):
             for r in range(max(len(b) for _, b in uploads)):
@@ -243,6 +279,9 @@ class StreamServer:
                 for j, (slot, b) in enumerate((u for u in uploads if len(u[1]) > r)):
                     plane[j].copy_(torch.from_numpy(b[r]))
                 self.rings.push_rows(plane[:len(rows)], rows)
+                if pushed is not None:
+                    for slot in rows:
+                        pushed[slot] = pushed.get(slot, 0) + 1
 
     def drain(self) -> int:
         """``step`` until no block is waiting; returns the number of steps."""

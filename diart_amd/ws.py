@@ -68,20 +68,32 @@ class _ProtocolError(Exception):
     pass
 
 
+class _PolicyViolation(Exception):
+    pass
+
+
 class WebSocketFrontEnd:
     """``WebSocketFrontEnd(StreamServer(...), port=7007).start()`` — see the module docstring."""
 
     def __init__(self, server: StreamServer, host: str = "127.0.0.1", port: int = 7007,
-                 idle_sleep: float = 0.002, max_message: int = 16 << 20):
+                 idle_sleep: float = 0.002, max_message: int = 16 << 20, max_backlog_seconds: float = 30.0,
+                 backlog_timeout: float = 10.0):
         self.server, self.host, self.port = server, host, int(port)
         self.idle_sleep, self.max_message = idle_sleep, int(max_message)
+        # back-pressure: a connection whose stream holds more than this much unprocessed audio is not
+        # read from (TCP flow control then slows the sender); if the backlog has not drained after
+        # `backlog_timeout` seconds (stalled worker, or a client far ahead of real time) the
+        # connection is closed with 1008 instead of growing the queue without bound
+        self.max_backlog_windows = max(1, int(max_backlog_seconds / server.step_seconds))
+        self.backlog_timeout = float(backlog_timeout)
         self._loop: Optional[asyncio.AbstractEventLoop] = None
         self._writers: Dict[Hashable, asyncio.StreamWriter] = {}
         self._threads = []
         self._stop = threading.Event()
         self._ready = threading.Event()
         self._anon = 0
-        self.errors = []                       # (stream id, message) of connections dropped on an error
+        import collections
+        self.errors = collections.deque(maxlen=256)   # (stream id, message) of dropped connections / failed steps
 
     # ------------------------------------------------------------------ life cycle
     def start(self) -> "WebSocketFrontEnd":
@@ -150,6 +162,9 @@ class WebSocketFrontEnd:
         if hdr.get("upgrade", "").lower() != "websocket" or "sec-websocket-key" not in hdr:
             writer.write(b"HTTP/1.1 400 Bad Request\r\nConnection: close\r\n\r\n")
             raise _ProtocolError("not a websocket upgrade")
+        if hdr.get("sec-websocket-version", "13") != "13":            # RFC 6455 §4.2.2 / §4.4
+            writer.write(b"HTTP/1.1 426 Upgrade Required\r\nSec-WebSocket-Version: 13\r\nConnection: close\r\n\r\n")
+            raise _ProtocolError("unsupported Sec-WebSocket-Version")
         writer.write(("HTTP/1.1 101 Switching Protocols\r\nUpgrade: websocket\r\nConnection: Upgrade\r\n"
                       f"Sec-WebSocket-Accept: {accept_key(hdr['sec-websocket-key'])}\r\n\r\n").encode("ascii"))
         return parts[1]
@@ -157,6 +172,10 @@ class WebSocketFrontEnd:
     async def _read_frame(self, reader: asyncio.StreamReader):
         b0, b1 = await reader.readexactly(2)
         n = b1 & 0x7F
+        if b0 & 0x70:
+            raise _ProtocolError("RSV bits set but no extension was negotiated")   # RFC 6455 §5.2
+        if b0 & 0x08 and (not b0 & 0x80 or n > 125):
+            raise _ProtocolError("control frames must be unfragmented and at most 125 bytes")   # §5.5
         if n == 126:
             n, = struct.unpack("!H", await reader.readexactly(2))
         elif n == 127:
@@ -171,6 +190,16 @@ class WebSocketFrontEnd:
             data = (np.frombuffer(data, np.uint8) ^ np.resize(np.frombuffer(mask, np.uint8), n)).tobytes()
         return bool(b0 & 0x80), b0 & 0x0F, data
 
+    @staticmethod
+    def _close_with(writer: asyncio.StreamWriter, code: int, reason: str) -> None:
+        """A close frame (status code + reason) before the socket goes away (RFC 6455 §7.1.6);
+        harmless when the handshake never completed (the peer just sees the connection close)."""
+        try:
+            if not writer.is_closing():
+                writer.write(encode_frame(_OP_CLOSE, struct.pack("!H", code) + reason.encode("utf-8")[:100]))
+        except Exception:
+            pass
+
     async def _client(self, reader: asyncio.StreamReader, writer: asyncio.StreamWriter) -> None:
         sid, opened = None, False
         try:
@@ -179,7 +208,8 @@ class WebSocketFrontEnd:
             if sid is None:
                 self._anon += 1
                 sid = f"stream-{self._anon}"
-            self.server.open(sid)                                    # ValueError: id in use; RuntimeError: full
+            # open() resets the slot's clustering / aggregation state under the server lock: off the I/O thread
+            await asyncio.get_running_loop().run_in_executor(None, self.server.open, sid)   # ValueError: id in use; RuntimeError: full
             opened = True
             self._writers[sid] = writer
             buf, kind = b"", None
@@ -203,12 +233,26 @@ class WebSocketFrontEnd:
                     raise _ProtocolError(f"unexpected opcode {op}")
                 if fin:
                     samples = decode_audio(buf.decode("utf-8") if kind == _OP_TEXT else buf)
-                    self.server.push(sid, samples)
+                    pending = self.server.push(sid, samples)
                     buf, kind = b"", None
+                    waited = 0.0
+                    while pending > self.max_backlog_windows:          # stop reading: back-pressure
+                        if waited >= self.backlog_timeout:
+                            raise _PolicyViolation(f"backlog of {pending} windows did not drain")
+                        await asyncio.sleep(0.02)
+                        waited += 0.02
+                        pending = self.server.pending(sid)
         except (asyncio.IncompleteReadError, ConnectionError):
             pass                                                     # the peer went away
+        except _PolicyViolation as e:
+            self.errors.append((sid, repr(e)))
+            self._close_with(writer, 1008, str(e))
+        except _ProtocolError as e:
+            self.errors.append((sid, repr(e)))
+            self._close_with(writer, 1009 if "max_message" in str(e) else 1002, str(e))
         except Exception as e:
             self.errors.append((sid, repr(e)))
+            self._close_with(writer, 1011, "internal error")
         finally:
             if opened:                      # (a refused duplicate id must not close the other connection's stream)
                 self._writers.pop(sid, None)

@@ -200,3 +200,27 @@ def test_host_worker_pool_is_shared_safely_between_callers_and_survives_fork():
     p.join(60)
     assert not p.is_alive(), "forked child hung in the host worker pool"
     assert p.exitcode == 0 and q.get(timeout=5) is True
+
+
+def test_host_worker_pool_grows_between_jobs_without_losing_an_acknowledgement():
+    """ADVICE r2 (hostpool.cpp): a worker spawned into a pool that has already run jobs must not
+    acknowledge the job that is about to be published (it starts at the CURRENT generation).  The
+    thread count alternates and ramps so the pool keeps growing after its first job; a lost
+    acknowledgement returns from the parallel-for while a worker is still inside a stream's step —
+    results would differ from the single-stream objects — or hangs a later job."""
+    import threading
+    out = []
+
+    def ramp():
+        ok = True
+        for threads in (2, 3, 2, 5, 4, 7, 9, 6, 12, 16):
+            res = []
+            _run_batches(100 + threads, 17, 12, threads, res)
+            ok &= res[0]
+        out.append(ok)
+
+    th = threading.Thread(target=ramp)
+    th.start()
+    th.join(120)
+    assert not th.is_alive(), "parallel-for hung after the pool grew"
+    assert out == [True]

@@ -266,3 +266,103 @@ def test_ring_mode_step_equals_host_window_mode_for_streams_that_join_and_leave(
         assert np.array_equal(wh, wr) and np.allclose(sh, sr) and lh == lr
     # only new blocks crossed the "bus": one 8000-sample block per consumed step block
     assert ring.rings.pushed_blocks == sum(len(a) // 8000 for a in audio.values())
+
+
+class FlakyEngine(Recorder):
+    """Raises on the calls listed in ``fail_on`` (0-based), records the others."""
+
+    def __init__(self, fail_on):
+        super().__init__()
+        self.fail_on, self.calls = set(fail_on), 0
+
+    def __call__(self, windows, starts, slots):
+        i = self.calls
+        self.calls += 1
+        if i in self.fail_on:
+            raise RuntimeError("engine down")
+        return super().__call__(windows, starts, slots)
+
+
+def test_failed_step_in_host_window_mode_can_be_retried_without_losing_a_window():
+    """step() takes blocks before the engine runs; if the engine raises, the
+    blocks go back and the window state is restored, so the retry sees the same window."""
+    good = Recorder()
+    ref = StreamServer(None, None, max_streams=2, engine=good)
+    flaky = FlakyEngine(fail_on={1, 4})
+    srv = StreamServer(None, None, max_streams=2, engine=flaky)
+    audio = {"a": ramp(16000 * 8), "b": -ramp(16000 * 7, 500)}
+    for s in (ref, srv):
+        for k, x in audio.items():
+            s.open(k)
+            s.push(k, x)
+    ref.drain()
+    failures = 0
+    for _ in range(100):
+        try:
+            if not srv.step() and not any(st.blocks for st in srv._streams.values()):
+                break
+        except RuntimeError:
+            failures += 1
+    assert failures == 2 and len(srv.step_errors) == 2
+    assert len(flaky.batches) == len(good.batches)
+    for (w, s, l), (rw, rs, rl) in zip(flaky.batches, good.batches):
+        assert np.array_equal(w, rw) and np.allclose(s, rs) and l == rl
+    for k in audio:
+        assert srv.close(k).to_rttm() == ref.close(k).to_rttm()
+
+
+def test_failed_step_in_ring_mode_keeps_host_block_count_equal_to_the_ring():
+    """Ring mode: blocks that reached the ring before the failure stay consumed (the ring cannot be
+    rewound), blocks that did not go back to the queue — the stream's later windows and start times
+    are the ones of an undisturbed run, and the other stream in the batch is not poisoned."""
+    good, flaky = Recorder(), FlakyEngine(fail_on={2})
+    ref, srv = _ring_server(2, good), _ring_server(2, flaky)
+    # ring push that fails once, before anything of that round is written
+    real_push, state = srv.rings.push_rows, {"n": 0}
+
+    def push_rows(block, rows):
+        state["n"] += 1
+        if state["n"] == 3:
+            raise OSError("bus error")
+        return real_push(block, rows)
+
+    srv.rings.push_rows = push_rows
+    audio = {"a": ramp(16000 * 8), "b": -ramp(16000 * 9, 500)}
+    for s in (ref, srv):
+        for k in audio:
+            s.open(k)
+    pos = 0
+    while pos < 16000 * 9:
+        for s in (ref, srv):
+            for k, x in audio.items():
+                if pos < len(x):
+                    s.push(k, x[pos:pos + 8000])
+        pos += 8000
+        ref.step()
+        try:
+            srv.step()
+        except (RuntimeError, OSError):
+            pass
+    ref.drain()
+    for _ in range(50):
+        try:
+            if not srv.drain():
+                break
+        except (RuntimeError, OSError):
+            pass
+    for st in srv._streams.values():      # host count == what the ring received, per stream
+        assert not st.blocks
+    assert srv.rings.pushed_blocks == ref.rings.pushed_blocks
+    assert len(srv.step_errors) == 2
+    # every window the flaky server did process is a window of the undisturbed run, same start
+    ref_by_start = {}
+    for w, s, l in good.batches:
+        for wi, si, li in zip(w, s, l):
+            ref_by_start[(li, round(float(si), 6))] = wi
+    seen = 0
+    for w, s, l in flaky.batches:
+        for wi, si, li in zip(w, s, l):
+            assert np.array_equal(wi, ref_by_start[(li, round(float(si), 6))])
+            seen += 1
+    total = sum(len(w) for w, _, _ in good.batches)
+    assert total - 2 <= seen < total            # only the failed engine step's windows are missing

@@ -161,3 +161,57 @@ def test_a_duplicate_stream_id_is_refused_without_touching_the_first(front):
     op, data = a.recv()
     assert op == 0x1 and data.decode().split()[1] == "room"
     assert any("already open" in msg for _, msg in fe.errors)
+
+
+def _close_code(client):
+    client.s.settimeout(5)
+    while True:
+        op, data = client.recv()
+        if op == 0x8:
+            return struct.unpack("!H", data[:2])[0]
+
+
+def test_protocol_violations_get_a_close_frame(front):
+    """RSV bits, fragmented / oversized control frames are rejected with a close
+    frame (1002) instead of a silent disconnect; the error list is bounded."""
+    fe, srv = front
+    c = Client(fe.port, "rsv")
+    frame = bytearray(encode_frame(0x1, b"abcd", mask=os.urandom(4)))
+    frame[0] |= 0x40                                          # RSV1 without a negotiated extension
+    c.s.sendall(bytes(frame))
+    assert _close_code(c) == 1002
+    c = Client(fe.port, "ping")
+    c.send(0x9, b"x", fin=False)                              # a control frame must not be fragmented
+    assert _close_code(c) == 1002
+    c = Client(fe.port, "bigping")
+    c.send(0x9, b"y" * 126)                                   # nor longer than 125 bytes
+    assert _close_code(c) == 1002
+    assert fe.errors.maxlen is not None and len(fe.errors) == 3
+    # an unsupported protocol version is refused during the upgrade
+    s = socket.create_connection(("127.0.0.1", fe.port), timeout=5)
+    s.sendall(b"GET /v HTTP/1.1\r\nHost: x\r\nUpgrade: websocket\r\nConnection: Upgrade\r\n"
+              b"Sec-WebSocket-Key: AAAAAAAAAAAAAAAAAAAAAA==\r\nSec-WebSocket-Version: 8\r\n\r\n")
+    assert b"426" in s.recv(200)
+
+
+def test_backlog_is_bounded_by_back_pressure_then_policy_close():
+    """A client far ahead of real time with a worker that never catches up: the connection is not
+    read from beyond the backlog cap and is closed with 1008 after the timeout."""
+    class Stuck(Engine):
+        def __call__(self, windows, starts, slots):
+            time.sleep(0.2)
+            return super().__call__(windows, starts, slots)
+
+    srv = StreamServer(None, None, max_streams=2, engine=Stuck())
+    fe = WebSocketFrontEnd(srv, port=0, max_backlog_seconds=2.0, backlog_timeout=0.3).start()
+    try:
+        c = Client(fe.port, "flood")
+        c.send_audio(ramp(16000 * 30))                        # 30 s at once: 51 windows >> the cap of 4
+        assert _close_code(c) == 1008
+        for _ in range(200):
+            if not srv.open_streams:
+                break
+            time.sleep(0.01)
+        assert srv.open_streams == []
+    finally:
+        fe.stop()
