@@ -264,7 +264,13 @@ def main():
     args = parse()
     if args.cpu_worker:
         return cpu_baseline_worker(args.cpu_chunks, args.cpu_threads, 12.0)
-    from diart_amd import _lib, distributed as D
+    from diart_amd import distributed as D
+    # `python bench.py --gpus N` as ONE process: start the N ranks ourselves (torch.distributed.run,
+    # one rank per GPU, RCCL); under the driver's own torchrun WORLD_SIZE is set and this is a no-op
+    rc = D.self_launch(args.gpus, str(ROOT / "bench.py"), sys.argv[1:])
+    if rc is not None:
+        raise SystemExit(rc)
+    from diart_amd import _lib
     from diart_amd.models import HipEmbedding, HipSegmentation, default_precision
     from diart_amd.pipeline import StreamBatch
     from diart_amd.synth import synth_embedding_state, synth_segmentation_state, synth_streams
@@ -274,9 +280,16 @@ def main():
     from diart_amd.hostinfo import limit_host_threads
     limit_host_threads()
     rank, world, local = D.init_from_env()
-    assert world == args.gpus or world == 1, f"WORLD_SIZE={world} but --gpus {args.gpus}"
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: WORLD_SIZE={world} but --gpus {args.gpus}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X GPU (the HIP path has no CPU fallback)")
+    if world > 1:
+        log(f"rank {rank}/{world}: process group up, backend {torch.distributed.get_backend()} "
+            f"({'RCCL' if torch.distributed.get_backend() == 'nccl' else 'rehearsal'}), "
+            f"device {os.environ.get('DZ_FORCE_DEVICE', local)} of {torch.cuda.device_count()}")
+        if "DZ_FORCE_DEVICE" not in os.environ and torch.cuda.device_count() < world:
+            raise SystemExit(f"bench.py: {world} ranks but {torch.cuda.device_count()} GPU(s) visible")
     # DZ_FORCE_DEVICE: every rank on one GPU (single-GPU rehearsal of the multi-rank path, with
     # DZ_DIST_BACKEND=gloo); the driver's real runs use one GPU per rank over RCCL
     device = torch.device("cuda", int(os.environ.get("DZ_FORCE_DEVICE", local)))
@@ -293,6 +306,10 @@ def main():
         seg_state = D.broadcast_state(seg_state, segmentation_spec(), device)
         emb_state = D.broadcast_state(emb_state, embedding_spec(), device)
 
+    # every rank must hold the same weights after the broadcast: a checksum per rank goes into the line
+    wsum = float(sum(v.double().abs().sum().item() for v in list(seg_state.values()) + list(emb_state.values())))
+    wsums = [w[0] for w in D.gather_counts([wsum], device)] if world > 1 else [wsum]
+
     # ---- synthetic streams of this rank, resident in HBM -------------------------------
     n = args.streams
     hop, S = 8000, 80000
@@ -304,12 +321,14 @@ def main():
     log("streams resident in HBM")
     assert audio.stride(0) % 4 == 0
 
-    # host threads of the clustering / output tail: the usable cores are shared by the ranks of
-    # the node (every rank runs its own 64 clustering states between two GPU steps)
+    # host threads of the clustering / output tail: sized from the MEASURED host work of a step
+    # (below, after the settling steps), not from cores // ranks: at 8 ranks on a 16-core grant that
+    # rule left 2 threads for ~1.5 ms of CPU work per 1.3 ms step.  The ranks' host phases are short
+    # (15-30 % duty) and not synchronised, so the node's cores are time-shared; a rank may use up to
+    # twice its even share as long as the node-wide demand (ranks x CPU-ms per step / step) fits.
     from diart_amd.hostinfo import usable_cores
-    host_threads = max(1, min(8, usable_cores() // max(1, world)))
-    log(f"host threads per rank for clustering / tail: {host_threads}")
-
+    usable = usable_cores()
+    host_threads = max(1, min(8, usable))
     def make_pipe(prec):
         return StreamBatch(HipSegmentation(seg_state, max_batch=n, precision=prec),
                            HipEmbedding(emb_state, max_batch=n, precision=prec),
@@ -355,8 +374,29 @@ def main():
 
     # untimed: settle clocks, page in the scratch arenas and both output slots, then the W warm-up
     # steps the contract asks for
-    run(0, min(total_steps, 20))
+    run(0, min(total_steps, 10))
     torch.cuda.synchronize()
+    # ---- size the host threads from what the second batch of settling steps measures -----------
+    n_settle = min(total_steps, 10)
+    host["launch"] = host["finish"] = 0.0
+    pipe.host_seconds["wait"] = pipe.host_seconds["work"] = 0.0
+    run(0, n_settle)
+    torch.cuda.synchronize()
+    hs0 = pipe.host_seconds
+    work_wall_ms = 1e3 * hs0["work"] / n_settle                 # clustering + tail, wall, on host_threads
+    step_ms0 = 1e3 * (hs0["work"] + hs0["wait"] + host["launch"]) / n_settle
+    cpu_ms = work_wall_ms * host_threads                        # upper bound of the CPU time in it
+    # enough threads to keep the host half under ~30 % of the step ...
+    need = max(1, int(np.ceil(cpu_ms / max(1e-3, 0.3 * step_ms0))))
+    # ... capped by twice this rank's even share of the node's usable cores (and by the pool's 8)
+    cap = max(2, min(8, int(np.ceil(2.0 * usable / max(1, world)))))
+    if os.environ.get("DZ_HOST_THREADS"):
+        need = cap = int(os.environ["DZ_HOST_THREADS"])
+    host_threads_used = pipe.set_host_threads(min(need, cap))
+    log(f"host work per step {work_wall_ms:.3f} ms wall on {host_threads} threads (<= {cpu_ms:.2f} CPU-ms) of a "
+        f"{step_ms0:.2f} ms step; {usable} usable cores, {world} rank(s): {host_threads_used} host threads per rank "
+        f"(node-wide demand ~{world * cpu_ms / max(1e-3, step_ms0):.1f} cores)")
+    host_threads = host_threads_used
     run(0, args.warmup)
     torch.cuda.synchronize()
     log("warm-up done")
@@ -519,6 +559,8 @@ def main():
                                    "pyannote/segmentation + pyannote/embedding architectures "
                                    "(random-init weights), %d concurrent synthetic 16 kHz streams per GPU" % n,
                        "streams_per_gpu": n, "chunks_per_step": world * n, "parallelism": f"streams x{world}",
+                       "dist_backend": torch.distributed.get_backend() if world > 1 else None,
+                       "weights_abs_sum_per_rank": wsums, "host_threads_per_rank": host_threads,
                        "steps_in_flight": pipe.depth, "seg_sub_batches": pipe.seg_split,
                        "hip_streams": pipe.num_hip_streams,
                        "exact_f32_value": exact["value"] if exact else None,

@@ -31,13 +31,52 @@ def init_from_env(backend: Optional[str] = None) -> Tuple[int, int, int]:
     return rank, world, local
 
 
+def free_port() -> int:
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        return so.getsockname()[1]
+
+
+def torchrun_command(n: int, script: str, argv: Sequence[str], port: Optional[int] = None) -> List[str]:
+    """The command the driver itself uses for N > 1 (one rank per GPU, single node, 127.0.0.1)."""
+    import sys
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+            "--master-addr", "127.0.0.1", "--master-port", str(port or free_port()), script, *argv]
+
+
+def self_launch(n: int, script: str, argv: Sequence[str]) -> Optional[int]:
+    """``script --gpus N`` started as ONE process (no WORLD_SIZE in the environment) starts its own
+    N ranks, the way the reference's ``Parallelize`` spawns its pool from inside the call
+    (``/root/reference/src/diart/inference.py:526-559``): re-runs the same command line under
+    ``torch.distributed.run`` — one rank per GPU, RCCL — and returns the launcher's exit code.
+    Returns None when there is nothing to do (N == 1, or this process already is a rank).
+
+    Fails loudly when the node shows fewer than N GPUs: N ranks squeezed onto fewer devices would
+    print an N-GPU line for a job that never had N GPUs.  The single-GPU rehearsal of the multi-rank
+    code path asks for exactly that, explicitly: ``DZ_FORCE_DEVICE=<ordinal>`` (every rank on that
+    GPU; RCCL refuses two ranks on one device, so the rehearsal needs ``DZ_DIST_BACKEND=gloo``)."""
+    import subprocess
+    if n <= 1 or "WORLD_SIZE" in os.environ:
+        return None
+    have = torch.cuda.device_count()
+    if have < n and "DZ_FORCE_DEVICE" not in os.environ:
+        raise SystemExit(f"{script}: --gpus {n} but this node shows {have} GPU(s); refusing to run {n} ranks on "
+                         f"fewer devices (single-GPU rehearsal: DZ_FORCE_DEVICE=0 DZ_DIST_BACKEND=gloo)")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    env.setdefault("OMP_NUM_THREADS", "1")      # torchrun would set (and warn about) it anyway
+    return subprocess.call(torchrun_command(n, script, argv), env=env)
+
+
 def broadcast_state(state: Optional[Dict[str, torch.Tensor]], spec: Sequence[Tuple[str, Tuple[int, ...], torch.dtype]],
                     device: torch.device, src: int = 0) -> Dict[str, torch.Tensor]:
     """Ship a state dict from ``src`` to every rank as ONE flat fp32 buffer (a single
     broadcast: xGMI is point-to-point, so one large message beats hundreds of small ones).
     ``spec`` = [(key, shape, dtype)] must be known on every rank (it is a property of the
     architecture, see ``state_spec``); non-float entries travel as float and are cast back."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    # no process group: nothing to ship.  A group of ONE rank still goes through the collective (on
+    # a single-GPU box that is the only way the RCCL broadcast itself can be executed and tested).
+    if not (dist.is_available() and dist.is_initialized()):
         assert state is not None
         return state
     total = sum(int(torch.Size(shape).numel()) for _, shape, _ in spec)
@@ -96,7 +135,7 @@ def timed_max_over_ranks(fn, device: Optional[torch.device] = None) -> float:
     then the MAXIMUM elapsed time over the ranks (the job is as slow as its slowest rank).  Works
     without a process group (world 1) and without a GPU (``device`` None / CPU: gloo tests)."""
     import time
-    multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    multi = dist.is_available() and dist.is_initialized()      # also a group of one rank (see broadcast_state)
     on_gpu = device is not None and device.type == "cuda"
 
     def fence():

@@ -215,6 +215,14 @@ class StreamBatch:
         self._lib = _lib.load()
         self._ctx = _lib.context(self.device.index)
 
+    def set_host_threads(self, n: int) -> int:
+        """Host threads of the per-stream CPU stages (clustering, aggregation + binarisation) from now on."""
+        n = max(1, int(n))
+        self.cluster_threads = self.clustering.num_threads = n
+        if self.tail is not None:
+            self.tail.num_threads = n
+        return n
+
     def reset(self, slot: Optional[int] = None):
         """Forget the clustering / aggregation state of every stream, or of one slot."""
         self.clustering.reset(slot)

@@ -2,7 +2,7 @@
 """BASELINE.json configs 1 / 4: the file-parallel evaluation (`diart.benchmark`) on MI355X.
 
     python tools/benchmark_files.py --files 1 --seconds 30                      # config 1 shape
-    torchrun --nproc-per-node 8 ... tools/benchmark_files.py --files 16 --seconds 600   # config 4 shape
+    python tools/benchmark_files.py --gpus 8 --files 16 --seconds 600           # config 4 shape (starts its 8 ranks)
 
 AMI-SDM audio and the gated pyannote checkpoints are not available offline, so the corpus is
 synthetic (same generator as bench.py, written as 16-bit WAV) and the weights are the seeded
@@ -28,6 +28,8 @@ from diart_amd.synth import (synth_ecapa_state, synth_embedding_state, synth_seg
                              synth_stream)
 
 ap = argparse.ArgumentParser()
+ap.add_argument("--gpus", type=int, default=0,
+                help="start this many ranks (one per GPU, torch.distributed.run) when not already under torchrun")
 ap.add_argument("--files", type=int, default=1)
 ap.add_argument("--seconds", type=float, default=30.0, help="duration of the first file; file i is 7 %% shorter than i-1")
 ap.add_argument("--batch-size", type=int, default=32)
@@ -39,8 +41,13 @@ ap.add_argument("--config3", action="store_true",
                      "normalised OSP weights")
 args = ap.parse_args()
 
+rc = D.self_launch(args.gpus, str(Path(__file__).resolve()), sys.argv[1:])
+if rc is not None:
+    raise SystemExit(rc)
 limit_host_threads()
 rank, world, local = D.init_from_env()
+if args.gpus and world != args.gpus:
+    raise SystemExit(f"benchmark_files.py: WORLD_SIZE={world} but --gpus {args.gpus}")
 import os  # noqa: E402
 device = torch.device("cuda", int(os.environ.get("DZ_FORCE_DEVICE", local)))   # see bench.py
 torch.cuda.set_device(device)
