@@ -144,6 +144,10 @@ def parse():
     ap.add_argument("--precision", type=str, default="", help="f16x3 | f32 (default: DZ_PRECISION or f16x3)")
     ap.add_argument("--no-host-pass", action="store_true",
                     help="skip the extra pass that uploads each step's new audio from pinned host memory")
+    ap.add_argument("--pmc", choices=["on", "all", "off"], default=os.environ.get("DZ_BENCH_PMC", "on"),
+                    help="N = 1: measure HBM traffic / matrix-core busy per kernel LIVE with rocprofv3 --pmc child "
+                         "passes of this command (on: headline precision, ~2 min; all: also the exact-f32 pass; "
+                         "off: use the committed passes under profiles/)")
     ap.add_argument("--no-exact-f32", action="store_true",
                     help="skip the second, untimed-for-`value` pass on the exact-f32 MFMA path")
     return ap.parse_args()
@@ -258,6 +262,136 @@ def cpu_baseline(n_chunks):
         return {"value": None, "unit": "xRT 16 kHz streams (chunks/s / 2)", "cores": threads,
                 "kind": "port", "sample": "child failed: " + r.stderr[-200:]}
     return json.loads(lines[-1])
+
+
+def _match_pmc(files, groups, key):
+    """{device kernel symbol -> value} from a per-kernel PMC summary ({"kernels": {full name: {...}}})."""
+    got = {}
+    for name, v in files.get("kernels", {}).items():
+        for g in groups:
+            if g.split(" (")[0] in name and v.get(key) is not None:
+                got[g] = v[key]
+    return got
+
+
+def pmc_live(precision):
+    """HBM traffic and matrix-core busy time of every kernel FROM THIS RUN'S BOX: rocprofv3 --pmc
+    passes of this same command (short: 3 steps) as child processes, collected as
+    MI355X_MICROARCH.md prescribes — separate passes (FETCH_SIZE / WRITE_SIZE / matrix-core busy),
+    --kernel-trace only, FETCH_SIZE doubled (gfx950 half-count) — each under a hard timeout.
+    Returns {"traffic": {...}, "mfma": {...}, "source": "..."} or None (no rocprofv3, a pass failed,
+    or the time budget ran out: the committed passes under profiles/ are used instead)."""
+    import shutil
+    import subprocess
+    import tempfile
+    rocprof = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if Path("/opt/rocm/bin/rocprofv3").exists() else None)
+    if rocprof is None:
+        return None
+    t_start, budget = time.monotonic(), float(os.environ.get("DZ_PMC_BUDGET_S", "200"))
+    work = Path(tempfile.mkdtemp(prefix="dz_pmc_"))
+    cmd = [sys.executable, str(ROOT / "bench.py"), "--steps", "3", "--warmup", "1", "--no-cpu-baseline",
+           "--no-exact-f32", "--no-host-pass", "--pmc", "off", "--precision", precision]
+    env = dict(os.environ, PYTHONDONTWRITEBYTECODE="1", TMPDIR="/tmp")
+    passes = {"FETCH_SIZE": ["FETCH_SIZE"], "WRITE_SIZE": ["WRITE_SIZE"],
+              "MFMA": ["SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CYCLES", "GRBM_GUI_ACTIVE"]}
+    for tag, counters in passes.items():
+        left = budget - (time.monotonic() - t_start)
+        if left < 30:
+            log(f"pmc: time budget spent before the {tag} pass")
+            return None
+        try:
+            r = subprocess.run([rocprof, "--pmc", *counters, "--kernel-trace", "--output-format", "csv", "-d",
+                                str(work / tag), "-o", "pmc", "--", *cmd], cwd="/tmp", env=env, capture_output=True,
+                               text=True, timeout=min(left, 100))
+        except subprocess.TimeoutExpired:
+            log(f"pmc: {tag} pass timed out")
+            return None
+        if r.returncode != 0:
+            log(f"pmc: {tag} pass failed: " + r.stderr[-300:])
+            return None
+        log(f"pmc: {tag} pass done (+{time.monotonic() - t_start:.0f}s)")
+    out = {}
+    try:
+        for script, argv, key in (("pmc_summary.py", [work / "FETCH_SIZE", work / "WRITE_SIZE", work / "traffic.json"], "traffic"),
+                                  ("mfma_summary.py", [work / "MFMA", work / "mfma.json"], "mfma")):
+            r = subprocess.run([sys.executable, str(ROOT / "tools" / script), *map(str, argv)], capture_output=True,
+                               text=True, timeout=60)
+            if r.returncode != 0:
+                log(f"pmc: {script} failed: " + r.stderr[-300:])
+                return None
+            out[key] = json.loads(Path(argv[-1]).read_text())
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
+    out["source"] = (f"live: rocprofv3 --pmc passes (FETCH_SIZE / WRITE_SIZE / SQ_VALU_MFMA_BUSY_CYCLES, separate runs, "
+                     f"--kernel-trace only) of `bench.py --steps 3 --precision {precision}` on this box during this run; "
+                     "bytes per launch = (2 x FETCH_SIZE + WRITE_SIZE) KiB (gfx950 half-count correction)")
+    return out
+
+
+def build_roofline(table, precision, n_sampled, pmc):
+    """Per DEVICE kernel: achieved vs the CHIP peak of its binding resource -> (dominant, all)."""
+    groups = {}
+    for r in table:
+        if r["kernel"] not in KERNELS:
+            continue
+        sym, bound, peak, unit = device_kernel(r["kernel"], precision)
+        g = groups.setdefault(sym, {"ms": 0.0, "launches": 0, "gflop": 0.0, "bytes": 0.0, "chunks": 0.0,
+                                    "tags": [], "bound": bound, "peak": peak, "unit": unit})
+        g["ms"] += r["total_ms"]
+        g["launches"] += r["launches"]
+        g["gflop"] += r["alg_gflop_per_launch"] * r["launches"]
+        g["bytes"] += float(r["alg_bytes_per_launch"]) * r["launches"]
+        g["chunks"] += r["chunks_per_launch"] * r["launches"]
+        g["tags"].append(r["kernel"])
+    if pmc is not None:
+        traffic_of = _match_pmc(pmc["traffic"], groups, "hbm_bytes_per_launch")
+        mfma_util_of = _match_pmc(pmc["mfma"], groups, "mfma_util")
+        source = pmc["source"]
+    else:
+        # fall-back: the committed passes of the same command (profiles/, named per round in README.md)
+        suffix = "_f32" if precision == "f32" else ""
+        tfile, mfile = ROOT / "profiles" / f"traffic{suffix}.json", ROOT / "profiles" / f"mfma_util{suffix}.json"
+        traffic_of = _match_pmc(json.loads(tfile.read_text()), groups, "hbm_bytes_per_launch") if tfile.exists() else {}
+        mfma_util_of = _match_pmc(json.loads(mfile.read_text()), groups, "mfma_util") if mfile.exists() else {}
+        source = (f"committed: profiles/{tfile.name} / {mfile.name} (rocprofv3 --pmc passes of `bench.py --steps 3` from an "
+                  "earlier visit; NOT measured in this run)") if traffic_of else None
+    total_ms = sum(v["ms"] for v in groups.values()) or 1.0
+
+    def entry(g, v):
+        if v["bound"] == "hbm":
+            ach = v["bytes"] / v["ms"] / 1e6          # bytes / ms -> GB/s
+        else:
+            ach = v["gflop"] / v["ms"]                # GFLOP / ms = TFLOP/s
+        e = {"kernel": g, "layers": v["tags"], "bound": v["bound"], "achieved": round(ach, 2),
+             "peak": round(v["peak"], 1), "unit": v["unit"], "frac": round(ach / v["peak"], 4),
+             "avg_launch_us": round(1e3 * v["ms"] / v["launches"], 2),
+             "chunks_per_launch": round(v["chunks"] / v["launches"], 2),
+             "launches_per_step": round(v["launches"] / max(1, n_sampled), 2),
+             "share_of_kernel_time": round(v["ms"] / total_ms, 4),
+             "alg_gflop_per_launch": round(v["gflop"] / v["launches"], 3),
+             "alg_bytes_per_launch": int(v["bytes"] / v["launches"]),
+             "traffic": traffic_of.get(g), "mfma_util_pmc": mfma_util_of.get(g)}
+        if e["traffic"]:
+            e["traffic_over_alg_bytes"] = round(e["traffic"] / max(1, e["alg_bytes_per_launch"]), 2)
+        if g.startswith("lstm_rec_kernel"):
+            cus = min(256.0, 2.0 * v["chunks"] / v["launches"])   # one (chunk, direction) chain per CU
+            e["cus_occupied"] = cus
+            e["frac_of_occupied_cus_plain_fma"] = round(ach / (PEAK_F32_VECTOR_TFLOPS / 2 * cus / 256.0), 4)
+        if g.startswith("lstm_mfma"):
+            e["cus_occupied"] = min(256.0, 2.0 * -(-v["chunks"] / v["launches"] // 16))  # 16 chains per workgroup
+            e["frac_of_occupied_cus"] = round(ach / (v["peak"] * e["cus_occupied"] / 256.0), 4)
+        return e
+
+    per_kernel = [entry(g, v) for g, v in sorted(groups.items(), key=lambda kv: -kv[1]["ms"])]
+    # the dominant kernel = the device kernel with the largest total time, whatever bounds it
+    roof = dict(per_kernel[0])
+    roof["peak_note"] = {
+        "mfma": ("f16 matrix peak 2500 TFLOP/s / 3: the split-f16 path spends three f16 MFMAs per algorithmic "
+                 "product; `achieved` counts algorithmic FLOPs only" if roof["peak"] > 200 else "exact-f32 matrix peak"),
+        "valu": "chip f32 vector peak (256 CUs); the kernel occupies `cus_occupied` CUs, one latency-bound chain each",
+        "hbm": "HBM3E peak"}[roof["bound"]]
+    roof["traffic_source"] = source
+    return roof, per_kernel
 
 
 def main():
@@ -400,30 +534,39 @@ def main():
     run(0, args.warmup)
     torch.cuda.synchronize()
     log("warm-up done")
-    lib.dz_prof_enable(0 if os.environ.get("DZ_NO_PROF") else 1)
-    host["launch"] = host["finish"] = 0.0
-    pipe.host_seconds["wait"] = pipe.host_seconds["work"] = 0.0
-    # barrier + synchronize on both sides, max over ranks (diart_amd.distributed.timed_max_over_ranks)
-    elapsed = D.timed_max_over_ranks(
-        lambda: run(args.warmup, args.steps, profiled=not os.environ.get("DZ_NO_PROF")), device)
-    hs = pipe.host_seconds
-    log(f"timed region done: {elapsed:.3f}s for {args.steps} steps; host time per step: launch "
-        f"{1e3 * host['launch'] / args.steps:.3f} ms, finish {1e3 * host['finish'] / args.steps:.3f} ms = waiting for "
-        f"the GPU {1e3 * hs['wait'] / args.steps:.3f} + clustering / tail {1e3 * hs['work'] / args.steps:.3f}")
-    lib.dz_prof_collect()
-    table = kernel_table(lib)             # read before dz_prof_enable(0) clears the accumulators
-    lib.dz_prof_enable(0)
+    def timed_pass(p, label):
+        """K timed steps of pipeline `p` (barrier + synchronize on both sides, max over ranks) with the
+        per-kernel event pairs on every PROF_EVERY-th step -> (elapsed s, kernel table, sampled steps)."""
+        prof = not os.environ.get("DZ_NO_PROF")
+        lib.dz_prof_enable(1 if prof else 0)
+        sampled[0] = 0
+        host["launch"] = host["finish"] = 0.0
+        p.host_seconds["wait"] = p.host_seconds["work"] = 0.0
+        el = D.timed_max_over_ranks(lambda: run(args.warmup, args.steps, p, profiled=prof), device)
+        hs = p.host_seconds
+        log(f"{label}: {el:.3f}s for {args.steps} steps; host time per step: launch "
+            f"{1e3 * host['launch'] / args.steps:.3f} ms, finish {1e3 * host['finish'] / args.steps:.3f} ms = waiting for "
+            f"the GPU {1e3 * hs['wait'] / args.steps:.3f} + clustering / tail {1e3 * hs['work'] / args.steps:.3f}")
+        lib.dz_prof_collect()
+        tab = kernel_table(lib)           # read before dz_prof_enable(0) clears the accumulators
+        lib.dz_prof_enable(0)
+        return el, tab, sampled[0]
 
-    # ---- the same job on the exact-f32 MFMA path, for the record (not `value`) -----------------
+    elapsed, table, n_sampled = timed_pass(pipe, f"timed region ({precision})")
+
+    # ---- the same job on the exact-f32 MFMA path: the number at the reference's own arithmetic,
+    # measured the same way (own per-kernel brackets, own roofline), not `value` ----------------------
     exact = None
     if precision != "f32" and not args.no_exact_f32:
         p32 = make_pipe("f32")
         run(0, args.warmup, p32)
-        e32 = D.timed_max_over_ranks(lambda: run(args.warmup, args.steps, p32), device)
-        exact = {"value": round(D.whole_job_rate(n, args.steps, e32, world) / 2, 2), "ms_per_step": round(1e3 * e32 / args.steps, 3),
-                 "note": "same job with precision='f32' (v_mfma_f32_16x16x4_f32 everywhere), no per-kernel "
-                         "event brackets in this pass"}
-        log(f"exact-f32 pass: {e32:.3f}s")
+        torch.cuda.synchronize()
+        e32, table32, n_sampled32 = timed_pass(p32, "exact-f32 pass")
+        exact = {"value": round(D.whole_job_rate(n, args.steps, e32, world) / 2, 2),
+                 "ms_per_step": round(1e3 * e32 / args.steps, 3), "dtype": "f32",
+                 "note": "same job with precision='f32' (v_mfma_f32_16x16x4_f32 everywhere): the reference's own "
+                         "arithmetic; per-kernel brackets and roofline collected exactly like the headline pass",
+                 "_table": table32, "_sampled": n_sampled32}
 
     # ---- the same job fed from HOST buffers: every step uploads the 500 ms of new audio of each
     # stream (pinned memory -> device ring, dz_ring_push) instead of finding it in HBM ------------
@@ -469,76 +612,18 @@ def main():
 
     if rank == 0:
         cps = D.whole_job_rate(n, args.steps, elapsed, world)
-        # ---- per DEVICE kernel: achieved vs the CHIP peak of its binding resource -------------
-        groups = {}
-        for r in table:
-            if r["kernel"] not in KERNELS:
-                continue
-            sym, bound, peak, unit = device_kernel(r["kernel"], precision)
-            g = groups.setdefault(sym, {"ms": 0.0, "launches": 0, "gflop": 0.0, "bytes": 0.0, "chunks": 0.0,
-                                        "tags": [], "bound": bound, "peak": peak, "unit": unit})
-            g["ms"] += r["total_ms"]
-            g["launches"] += r["launches"]
-            g["gflop"] += r["alg_gflop_per_launch"] * r["launches"]
-            g["bytes"] += float(r["alg_bytes_per_launch"]) * r["launches"]
-            g["chunks"] += r["chunks_per_launch"] * r["launches"]
-            g["tags"].append(r["kernel"])
-        traffic_of, mfma_util_of = {}, {}
-        tfile = ROOT / "profiles" / "traffic.json"      # rocprofv3 --pmc passes of this command
-        if tfile.exists():
-            for name, v in json.loads(tfile.read_text())["kernels"].items():
-                for g in groups:
-                    if g.split(" (")[0] in name:
-                        traffic_of[g] = v["hbm_bytes_per_launch"]
-        mfile = ROOT / "profiles" / "mfma_util.json"
-        if mfile.exists():
-            for name, v in json.loads(mfile.read_text())["kernels"].items():
-                for g in groups:
-                    if g.split(" (")[0] in name:
-                        mfma_util_of[g] = v.get("mfma_util")
-        total_ms = sum(v["ms"] for v in groups.values()) or 1.0
-
-        def entry(g, v):
-            if v["bound"] == "hbm":
-                ach = v["bytes"] / v["ms"] / 1e6          # bytes / ms -> GB/s
-            else:
-                ach = v["gflop"] / v["ms"]                # GFLOP / ms = TFLOP/s
-            e = {"kernel": g, "layers": v["tags"], "bound": v["bound"], "achieved": round(ach, 2),
-                 "peak": round(v["peak"], 1), "unit": v["unit"], "frac": round(ach / v["peak"], 4),
-                 "avg_launch_us": round(1e3 * v["ms"] / v["launches"], 2),
-                 "chunks_per_launch": round(v["chunks"] / v["launches"], 2),
-                 "launches_per_step": round(v["launches"] / max(1, sampled[0]), 2),
-                 "share_of_kernel_time": round(v["ms"] / total_ms, 4),
-                 "alg_gflop_per_launch": round(v["gflop"] / v["launches"], 3),
-                 "alg_bytes_per_launch": int(v["bytes"] / v["launches"]),
-                 "traffic": traffic_of.get(g), "mfma_util_pmc": mfma_util_of.get(g)}
-            if e["traffic"]:
-                e["traffic_over_alg_bytes"] = round(e["traffic"] / max(1, e["alg_bytes_per_launch"]), 2)
-            if g.startswith("lstm_rec_kernel"):
-                cus = min(256.0, 2.0 * v["chunks"] / v["launches"])   # one (chunk, direction) chain per CU
-                e["cus_occupied"] = cus
-                e["frac_of_occupied_cus_plain_fma"] = round(ach / (PEAK_F32_VECTOR_TFLOPS / 2 * cus / 256.0), 4)
-            if g.startswith("lstm_mfma"):
-                e["cus_occupied"] = min(256.0, 2.0 * -(-v["chunks"] / v["launches"] // 16))  # 16 chains per workgroup
-                e["frac_of_occupied_cus"] = round(ach / (v["peak"] * e["cus_occupied"] / 256.0), 4)
-            return e
-
-        per_kernel = [entry(g, v) for g, v in sorted(groups.items(), key=lambda kv: -kv[1]["ms"])]
-        # the dominant kernel = the device kernel with the largest total time, whatever bounds it
-        roof = dict(per_kernel[0])
-        roof["peak_note"] = {
-            "mfma": ("f16 matrix peak 2500 TFLOP/s / 3: the split-f16 path spends three f16 MFMAs per algorithmic "
-                     "product; `achieved` counts algorithmic FLOPs only" if roof["peak"] > 200 else "exact-f32 matrix peak"),
-            "valu": "chip f32 vector peak (256 CUs); the kernel occupies `cus_occupied` CUs, one latency-bound chain each",
-            "hbm": "HBM3E peak"}[roof["bound"]]
-        roof["traffic_source"] = ("profiles/traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of `bench.py "
-                                  "--steps 3`, avg bytes per launch, FETCH doubled per the gfx950 correction)"
-                                  if roof["traffic"] is not None else None)
+        pmc = pmc_live(precision) if (world == 1 and args.pmc != "off") else None
+        pmc32 = pmc_live("f32") if (pmc is not None and exact is not None and args.pmc == "all") else None
+        roof, per_kernel = build_roofline(table, precision, n_sampled, pmc)
         roof["whole_path_tflops"] = round(cps / world * ALG_GFLOP_PER_CHUNK / 1e3, 2)
         roof["concurrency_note"] = ("per-kernel durations are measured while the kernels of %d HIP streams overlap on the "
                                     "chip: their sum per step exceeds ms_per_step" % pipe.num_hip_streams)
         roof["exact_f32_value"] = exact["value"] if exact else None
         roof["host_fed_value"] = host_fed["value"] if host_fed else None
+        if exact is not None:
+            r32, pk32 = build_roofline(exact.pop("_table"), "f32", exact.pop("_sampled"), pmc32)
+            r32["whole_path_tflops"] = round(2 * exact["value"] / world * ALG_GFLOP_PER_CHUNK / 1e3, 2)
+            exact["roofline"], exact["roofline_kernels"] = r32, pk32
         out = {
             "metric": "real-time-factor xRT streams/GPU @500ms step", "value": round(cps / 2, 2),
             "unit": "xRT 16 kHz streams (chunks/s / 2)", "n_gpus": world, "steps": args.steps,
@@ -566,7 +651,7 @@ def main():
                        "exact_f32_value": exact["value"] if exact else None,
                        "host_fed_value": host_fed["value"] if host_fed else None},
             "roofline": roof, "roofline_kernels": per_kernel,
-            "roofline_sampling": f"{sampled[0]} of the {args.steps} timed steps (every {PROF_EVERY}th) carried the "
+            "roofline_sampling": f"{n_sampled} of the {args.steps} timed steps (every {PROF_EVERY}th) carried the "
                                  "per-kernel event pairs; instrumenting every launch costs ~15 % of throughput",
             "exact_f32": exact,
             "host_fed": host_fed,

@@ -116,6 +116,8 @@ SIGNATURES = {
     "dz_tail_step": (C.c_int, [vp, vp, C.c_double, C.c_double, vp, vp, vp, vp, vp, C.c_int, vp]),
     "dz_tail_step_batch": (C.c_int, [C.POINTER(vp), C.c_int, vp, vp, vp, vp, vp, vp, vp, vp,
                                      C.c_int, vp, C.c_int]),
+    "dz_file_step_batch": (C.c_int, [C.POINTER(vp), C.POINTER(vp), C.c_int, vp, vp, vp, C.c_int, C.c_int, vp, C.c_int,
+                                     C.c_int, vp, C.c_double, vp, C.c_int, vp, vp, C.c_int]),
     # kernel-level entry points
     "dz_k_convgemm": (C.c_int, [vp, vp, vp]),
     "dz_k_gemm_split": (C.c_int, [vp, vp, vp]),

@@ -16,7 +16,8 @@ import torch
 from .. import models as m
 from ..features import Annotation, Segment, SlidingWindow, SlidingWindowFeature
 from . import base
-from .aggregation import DelayedAggregation
+from .. import _lib
+from .aggregation import BatchedOutputTail, DelayedAggregation
 from .clustering import OnlineSpeakerClustering
 from .embedding import OverlapAwareSpeakerEmbedding
 from .segmentation import SpeakerSegmentation
@@ -89,6 +90,7 @@ class SpeakerDiarization(base.Pipeline):
         self.timestamp_shift = 0
         self.clustering = None
         self.chunk_buffer, self.pred_buffer = [], []
+        self._tail = None
         self.reset()
 
     @staticmethod
@@ -116,6 +118,8 @@ class SpeakerDiarization(base.Pipeline):
         c = self.config
         self.clustering = OnlineSpeakerClustering(c.tau_active, c.rho_update, c.delta_new, "cosine", c.max_speakers)
         self.chunk_buffer, self.pred_buffer = [], []
+        if self._tail is not None:
+            self._tail.reset()
 
     def __call__(self, waveforms: Sequence[SlidingWindowFeature]) -> Sequence[Tuple[Annotation, SlidingWindowFeature]]:
         batch_size = len(waveforms)
@@ -126,21 +130,58 @@ class SpeakerDiarization(base.Pipeline):
 
         segmentations = self.segmentation(batch)                 # (batch, frames, speakers), host
         embeddings = self.embedding(batch, segmentations)        # (batch, speakers, emb_dim), host
+        return self.finalise(waveforms, segmentations, embeddings)
+
+    def finalise(self, waveforms: Sequence[SlidingWindowFeature], segmentations: torch.Tensor,
+                 embeddings: torch.Tensor) -> Sequence[Tuple[Annotation, SlidingWindowFeature]]:
+        """The host half of ``__call__`` (reference diarization.py:190-232): given the chunks and the
+        segmentation / embeddings the models produced for them, step this stream's clustering,
+        aggregation and binarisation once per chunk, in order.  Split out so that it can be driven
+        with the outputs of the REFERENCE's own blocks (tests/test_reference_pipeline.py)."""
         seg_resolution = waveforms[0].extent.duration / segmentations.shape[1]
 
+        # Clustering -> DelayedAggregation -> Binarize of the B consecutive chunks, in order, in ONE
+        # C++ call (dz_file_step_batch on this stream's own clustering / aggregation state): what the
+        # reference does chunk by chunk in Python (diarization.py:193-232).  The C++ tail is
+        # bit-identical to the Python blocks of this package (tests/test_tail.py), which remain the
+        # stand-alone DelayedAggregation / Binarize of the API.
+        seg_np = np.ascontiguousarray(segmentations.detach().cpu().numpy(), dtype=np.float32)
+        emb_np = np.ascontiguousarray(embeddings.detach().cpu().numpy(), dtype=np.float32)
+        if emb_np.ndim == 2:
+            emb_np = emb_np[None]
+        B, F, K = seg_np.shape
+        if emb_np.shape[:2] != (B, K):
+            raise ValueError(f"expected embeddings (batch, speakers, dim) for segmentation {seg_np.shape}, "
+                             f"got {emb_np.shape}")
+        tail = self._output_tail(F)
+        starts = np.array([w.extent.start for w in waveforms], dtype=np.float64)
+        turns = np.empty((B, tail.max_turns, 3), dtype=np.float64)
+        nturns = np.zeros(B, dtype=np.int32)
+        lib = _lib.load()
+        row0, count = np.zeros(1, dtype=np.int32), np.array([B], dtype=np.int32)   # (kept alive across the call)
+        rc = lib.dz_file_step_batch(
+            (_lib.vp * 1)(self.clustering._h), (_lib.vp * 1)(tail._hs[0]), 1,
+            row0.ctypes.data, count.ctypes.data,
+            seg_np.ctypes.data, F, K, emb_np.ctypes.data, emb_np.shape[2], self.config.max_speakers,
+            starts.ctypes.data, float(seg_resolution), turns.ctypes.data, tail.max_turns, nturns.ctypes.data,
+            None, 1)
+        if rc == 3:   # the reference raises here too (assert / scipy ValueError)
+            raise AssertionError(lib.dz_last_error().decode())
+        _lib.check(rc, "dz_file_step_batch")
+
         outputs = []
-        for wav, seg, emb in zip(waveforms, segmentations, embeddings):
-            sw = SlidingWindow(start=wav.extent.start, duration=seg_resolution, step=seg_resolution)
-            seg = SlidingWindowFeature(seg.cpu().numpy(), sw)
-            permuted_seg = self.clustering(seg, emb)
+        for i, wav in enumerate(waveforms):
             self.chunk_buffer.append(wav)
-            self.pred_buffer.append(permuted_seg)
             agg_waveform = self.audio_aggregation(self.chunk_buffer)
-            agg_prediction = self.binarize(self.pred_aggregation(self.pred_buffer))
-            if self.timestamp_shift != 0:
-                agg_prediction = shift_annotation(agg_prediction, self.timestamp_shift)
+            agg_prediction = BatchedOutputTail.annotation(turns[i], int(nturns[i]),
+                                                          shift=self.timestamp_shift if self.timestamp_shift != 0 else 0.0)
             outputs.append((agg_prediction, agg_waveform))
             if len(self.chunk_buffer) == self.pred_aggregation.num_overlapping_windows:
                 self.chunk_buffer = self.chunk_buffer[1:]
-                self.pred_buffer = self.pred_buffer[1:]
         return outputs
+
+    def _output_tail(self, frames: int) -> "BatchedOutputTail":
+        c = self.config
+        if self._tail is None or self._tail.F != frames:
+            self._tail = BatchedOutputTail(1, frames, c.max_speakers, c.step, c.latency, c.tau_active, num_threads=1)
+        return self._tail

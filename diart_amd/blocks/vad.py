@@ -91,7 +91,10 @@ class VoiceActivityDetection(base.Pipeline):
         batch = torch.stack([torch.from_numpy(w.data) for w in waveforms])
         expected = int(np.rint(self.config.duration * self.config.sample_rate))
         assert batch.shape[1] == expected, f"Expected {expected} samples per chunk, but got {batch.shape[1]}"
-        segmentations = self.segmentation(batch)
+        return self.finalise(waveforms, self.segmentation(batch))
+
+    def finalise(self, waveforms: Sequence[SlidingWindowFeature], segmentations: torch.Tensor):
+        """The host half of ``__call__`` (reference vad.py:146-191) for given segmentation scores."""
         voice_detection = torch.max(segmentations, dim=-1, keepdim=True)[0]   # (batch, frames, 1)
         seg_resolution = waveforms[0].extent.duration / segmentations.shape[1]
         outputs = []

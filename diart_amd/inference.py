@@ -84,6 +84,21 @@ def file_blocks(waveform: np.ndarray, sample_rate: int, padding: Tuple[float, fl
         yield np.concatenate([last[None, :], np.zeros((1, size - last.shape[0]))], axis=-1)
 
 
+def padded_file(waveform: np.ndarray, sample_rate: int, padding: Tuple[float, float] = (0, 0),
+                block_duration: float = 0.5) -> np.ndarray:
+    """The concatenation of everything ``file_blocks`` emits, as one float32 array: zero padding
+    left / right, the trailing incomplete block zero-filled.  (``file_blocks`` up-casts that last
+    block to float64 like the reference; every consumer casts back with ``.float()``,
+    ``features.py:124``, so float32 zeros are the same samples.)"""
+    wav = np.asarray(waveform, dtype=np.float32).reshape(-1)
+    left, right = (int(np.rint(p * sample_rate)) for p in padding)
+    size = int(np.rint(block_duration * sample_rate))
+    total = left + wav.shape[0] + right
+    out = np.zeros(-(-total // size) * size, dtype=np.float32)
+    out[left:left + wav.shape[0]] = wav
+    return out
+
+
 def rolling_windows(blocks: Iterable[np.ndarray], duration: float = 5.0, step: float = 0.5,
                     sample_rate: int = 16000) -> Iterator[SlidingWindowFeature]:
     """``rearrange_audio_stream``: buffer blocks until ``step`` seconds are available, append them
@@ -178,7 +193,7 @@ class Benchmark:
 
     def __init__(self, speech_path: FilePath, reference_path: Optional[FilePath] = None,
                  output_path: Optional[FilePath] = None, show_progress: bool = False,
-                 show_report: bool = True, batch_size: int = 32):
+                 show_report: bool = True, batch_size: int = 32, concurrent_files: Optional[int] = None):
         self.speech_path = Path(speech_path).expanduser()
         assert self.speech_path.is_dir(), "Speech path must be a directory"
         assert reference_path is not None or output_path is not None, \
@@ -192,6 +207,13 @@ class Benchmark:
             self.output_path = Path(output_path).expanduser()
             self.output_path.mkdir(parents=True, exist_ok=True)
         self.show_progress, self.show_report, self.batch_size = show_progress, show_report, batch_size
+        # files of this process that share one GPU batch (``FileBatch``); None = DZ_CONCURRENT_FILES or 16,
+        # 0 = the reference's one-file-at-a-time loop.  Only the HIP x-vector diarization pipeline has
+        # the batched path; anything else falls back to the loop.
+        import os
+        self.concurrent_files = int(os.environ.get("DZ_CONCURRENT_FILES", "16")) if concurrent_files is None \
+            else int(concurrent_files)
+        self.last_path = None      # "file_batch" | "one_file_at_a_time": which path the last call took
 
     def get_file_paths(self) -> List[Path]:
         return sorted(p for p in self.speech_path.iterdir() if p.suffix.lower() == ".wav")
@@ -212,6 +234,53 @@ class Benchmark:
             print(f"[benchmark] {filepath.stem}: {len(pred)} turns", flush=True)
         return pred
 
+    def file_batch(self, pipeline_class: type, config):
+        """A ``FileBatch`` for (pipeline_class, config), or None when this combination has to go
+        through the one-file-at-a-time loop (custom pipeline classes, non-HIP or ECAPA models, CPU)."""
+        from .blocks.diarization import SpeakerDiarization
+        from .models import HipEmbedding, HipSegmentation
+        if self.concurrent_files <= 0 or pipeline_class is not SpeakerDiarization:
+            return None
+        if getattr(config.device, "type", "cpu") != "cuda":
+            return None
+        seg, emb = config.segmentation, config.embedding
+        seg.load()
+        emb.load()
+        if type(seg.model) is not HipSegmentation or type(emb.model) is not HipEmbedding:
+            return None
+        from .pipeline import FileBatch
+        return FileBatch(seg.model, emb.model, rows=max(64, self.batch_size), max_files=self.concurrent_files,
+                         tau_active=config.tau_active, rho_update=config.rho_update, delta_new=config.delta_new,
+                         gamma=config.gamma, beta=config.beta, max_speakers=config.max_speakers,
+                         normalize_embedding_weights=config.normalize_embedding_weights,
+                         duration=config.duration, step=config.step, latency=config.latency,
+                         sample_rate=config.sample_rate, device=config.device)
+
+    def run_batched(self, fb, config, paths: Sequence[Path]) -> List[Annotation]:
+        """``paths`` through one ``FileBatch``: same padding, timestamp shift, RTTM files and
+        progress lines as ``run_single``, files read lazily as slots free up."""
+        def feed():
+            for fp in paths:
+                waveform, sr = read_wav(fp)
+                if sr != config.sample_rate:
+                    raise ValueError(f"audio source has sample rate {sr}, the pipeline's is "
+                                     f"{config.sample_rate}; resample the file first")
+                padding = config.get_padding(len(waveform) / sr)
+                yield fp.stem, padded_file(waveform, sr, padding, config.step), -padding[0]
+
+        got = fb.run(feed())
+        preds = []
+        for fp in paths:
+            pred = got[fp.stem]
+            pred.uri = fp.stem
+            if self.output_path is not None:
+                with open(self.output_path / f"{fp.stem}.rttm", "w") as out_file:
+                    pred.write_rttm(out_file)
+            if self.show_progress:
+                print(f"[benchmark] {fp.stem}: {len(pred)} turns", flush=True)
+            preds.append(pred)
+        return preds
+
     def evaluate(self, predictions: List[Annotation], metric):
         if self.reference_path is None:
             return predictions
@@ -224,10 +293,15 @@ class Benchmark:
 
     def __call__(self, pipeline_class: type, config, metric=None):
         pipeline = pipeline_class(config)
-        predictions = []
-        for filepath in self.get_file_paths():
-            pipeline.reset()
-            predictions.append(self.run_single(pipeline, filepath))
+        fb = self.file_batch(pipeline_class, config)
+        self.last_path = "file_batch" if fb is not None else "one_file_at_a_time"
+        if fb is not None:
+            predictions = self.run_batched(fb, config, self.get_file_paths())
+        else:
+            predictions = []
+            for filepath in self.get_file_paths():
+                pipeline.reset()
+                predictions.append(self.run_single(pipeline, filepath))
         metric = pipeline.suggest_metric() if metric is None else metric
         return self.evaluate(predictions, metric)
 
@@ -252,9 +326,16 @@ class DistributedBenchmark:
         pipeline = pipeline_class(config)
         metric = pipeline.suggest_metric() if metric is None else metric
         local: Dict[str, Optional[dict]] = {}
+        fb = b.file_batch(pipeline_class, config)
+        b.last_path = "file_batch" if fb is not None else "one_file_at_a_time"
+        # longest first: the short files fill the slots the long ones leave at the end
+        batched = {h.uri: h for h in b.run_batched(fb, config, [files[i] for i in mine])} if fb is not None else None
         for i in sorted(mine):
-            pipeline.reset()
-            hyp = b.run_single(pipeline, files[i])
+            if batched is not None:
+                hyp = batched[files[i].stem]
+            else:
+                pipeline.reset()
+                hyp = b.run_single(pipeline, files[i])
             comp = None
             if b.reference_path is not None:
                 ref = load_rttm(b.reference_path / f"{hyp.uri}.rttm").popitem()[1]

@@ -33,6 +33,7 @@ import torch
 from . import _lib
 from .blocks.aggregation import BatchedOutputTail
 from .blocks.clustering import BatchedSpeakerClustering
+from .features import Annotation, Segment
 from .models import HipEmbedding, HipSegmentation, _as_rows
 
 
@@ -304,6 +305,19 @@ class StreamBatch:
             slots = [int(i) for i in slots]
             assert N == len(slots) and 1 <= N <= self.n and len(set(slots)) == N, "bad slots"
             assert all(0 <= i < self.n for i in slots), "slot out of range"
+        slot = self._launch_rows(base, stride, N, S, rows, ring)
+        slot["slots"] = slots
+        idx = np.arange(self.n) if slots is None else np.asarray(slots, dtype=np.int64)
+        slot["starts"] = self._steps[idx] * self.step if starts is None else starts
+        self._steps[idx] += 1
+        return slot
+
+    def _launch_rows(self, base: int, stride: int, N: int, S: int, keep=None, ring: Optional[AudioRing] = None) -> dict:
+        """The GPU half of a step for N <= num_streams rows of S samples at ``base + i * stride``
+        floats: segmentation (+ OSP weights) and frame features on this step's lane, pooling behind
+        them.  Knows nothing about which stream / file a row belongs to (``launch`` and ``FileBatch``
+        decide that)."""
+        assert 1 <= N <= self.n
         F, K, D = self.seg.num_frames(S), None, self.emb.dimension
         lane = self.lanes[self._t % self.depth]
         hsegs, hembs, _, _ = self._handles(S, self._t % self.depth)
@@ -338,17 +352,14 @@ class StreamBatch:
                 _lib.check(lib.dz_emb_frames(h, base + i0 * stride * esz, stride, i1 - i0, b.cuda_stream),
                            "dz_emb_frames")
             ev.record(b)
-        slot["rows"], slot["slots"] = N, slots
-        slot["keep"] = rows                              # keep the view alive until the GPU is done
+        slot["rows"], slot["slots"] = N, None
+        slot["keep"] = keep                              # keep the view alive until the GPU is done
         slot["pool"] = (lane, hembs, sa, sb, N, K, F)     # what _enqueue_pool needs
         if ring is not None:                             # pushes `slack` steps from now wait for these
             ring._read_by(list(lane["a"]) + list(lane["b"]))
         self._pending.append(slot)
         while len(self._pending) > self.lag:
             self._enqueue_pool(self._pending.pop(0))
-        idx = np.arange(self.n) if slots is None else np.asarray(slots, dtype=np.int64)
-        slot["starts"] = self._steps[idx] * self.step if starts is None else starts
-        self._steps[idx] += 1
         self._t += 1
         return slot
 
@@ -383,12 +394,8 @@ class StreamBatch:
         The arrays (and ``ticket["tail"]``) are views of buffers that a later ``launch`` / ``finish``
         reuses: copy what has to outlive the next step."""
         import time as _time
-        t0 = _time.perf_counter()
-        while ticket["pool"] is not None:               # its pooling is still held back: flush in order
-            self._enqueue_pool(self._pending.pop(0))
-        ticket["done"].synchronize()
+        self._wait(ticket)
         t1 = _time.perf_counter()
-        self.host_seconds["wait"] += t1 - t0
         # The ticket's slot is ALWAYS handed back (ADVICE r2): an exception between here and the end
         # used to leak it, and every later launch then allocated a new pinned slot while kernels were
         # running.  The range flag (an f16x3 operand beyond +-65504 is an error, not a clamp) is
@@ -417,6 +424,15 @@ class StreamBatch:
             self.host_seconds["work"] += _time.perf_counter() - t1
         return seg, emb, scores, assign
 
+    def _wait(self, ticket: dict) -> None:
+        """Block until the GPU half of the step is done and its results are in pinned host memory."""
+        import time as _time
+        t0 = _time.perf_counter()
+        while ticket["pool"] is not None:               # its pooling is still held back: flush in order
+            self._enqueue_pool(self._pending.pop(0))
+        ticket["done"].synchronize()
+        self.host_seconds["wait"] += _time.perf_counter() - t0
+
     def __call__(self, waves: torch.Tensor):
         return self.finish(self.launch(waves))
 
@@ -429,3 +445,190 @@ class StreamBatch:
         self.finish(ticket, want_scores=False)
         _, _, _, _, turns, nturns = ticket["tail"]
         return [BatchedOutputTail.annotation(turns[i], int(nturns[i])) for i in range(self.n)]
+
+
+class FileBatch:
+    """Several FILES of one rank through the hot path at once — the file-parallel evaluation
+    (BASELINE.json configs 1 / 4) at the batcher's rate.
+
+    The reference's ``Benchmark`` (``inference.py:392-432``) feeds one file at a time: batches of 32
+    consecutive windows go through ``SpeakerDiarization.__call__``, whose per-chunk Python loop
+    (``blocks/diarization.py:193-232``) then runs clustering, aggregation and binarisation.  Only
+    that loop is sequential, and only within a file.  Here one GPU step carries ``rows`` windows:
+    the next ``rows // k`` CONSECUTIVE windows of each of the ``k`` files that are open (file-major
+    rows, copied device to device from the file's resident audio); the host half hands every file
+    to a thread that walks its windows in order through that file's own clustering / aggregation
+    state (``dz_file_step_batch``), ``depth`` GPU steps in flight.  A file that ends frees its slot
+    for the next one.  Per file the speech turns — hence the RTTM — are those of the
+    one-file-at-a-time path (``tests/test_gpu_der.py``).
+
+    ``run(files)``: ``files`` = iterable of ``(uri, padded waveform float32 (samples,), shift)``;
+    the waveform already carries ``config.get_padding`` and a zero-filled last block (what
+    ``file_blocks`` emits), ``shift`` is the pipeline's ``timestamp_shift``.  Returns
+    ``{uri: Annotation}`` (``PredictionAccumulator`` semantics: every chunk's turns, then
+    ``support(patch_collar)``)."""
+
+    def __init__(self, segmentation: HipSegmentation, embedding: HipEmbedding, *, rows: int = 64,
+                 max_files: int = 16, tau_active: float = 0.6, rho_update: float = 0.3, delta_new: float = 1.0,
+                 gamma: float = 3, beta: float = 10, max_speakers: int = 20,
+                 normalize_embedding_weights: bool = False, duration: float = 5.0, step: float = 0.5,
+                 latency: Optional[float] = None, sample_rate: int = 16000,
+                 device: Optional[torch.device] = None, threads: int = 8, patch_collar: float = 0.05):
+        self.rows, self.max_files = int(rows), max(1, min(int(max_files), int(rows)))
+        self.engine = StreamBatch(segmentation, embedding, self.rows, tau_active, rho_update, delta_new, gamma,
+                                  beta, max_speakers, normalize_embedding_weights, device=device,
+                                  cluster_threads=threads, tail=False, duration=duration, step=step,
+                                  latency=latency)
+        self.device = self.engine.device
+        self.duration, self.step, self.sr = float(duration), float(step), int(sample_rate)
+        self.latency = self.step if latency is None else float(latency)
+        self.S, self.hop = int(round(sample_rate * duration)), int(round(sample_rate * step))
+        assert self.hop % 4 == 0, "the step must be a multiple of 4 samples (16-byte aligned windows)"
+        self.tau, self.rho, self.delta, self.G = tau_active, rho_update, delta_new, int(max_speakers)
+        self.threads, self.patch_collar = int(threads), patch_collar
+        self._lib = _lib.load()
+        self._clu: List = []          # per file slot: dz_clu handle
+        self._tails: Optional[BatchedOutputTail] = None
+        self._stage: List[torch.Tensor] = []
+        self.chunks_done = 0
+
+    # ------------------------------------------------------------------ per-slot state
+    def _ensure_state(self, F: int) -> None:
+        if self._tails is not None:
+            return
+        for _ in range(self.max_files):
+            h = _lib.vp()
+            _lib.check(self._lib.dz_clu_create(self.tau, self.rho, self.delta, self.G, C.byref(h)), "dz_clu_create")
+            self._clu.append(h)
+        self._tails = BatchedOutputTail(self.max_files, F, self.G, self.step, self.latency, self.tau,
+                                        num_threads=self.threads)
+        self._F = F
+        self._max_turns = self._tails.max_turns
+        n = self.engine.depth + 2
+        self._stage = [torch.empty((self.rows, self.S), dtype=torch.float32, device=self.device) for _ in range(n)]
+        self._turns = [np.empty((self.rows, self._max_turns, 3), dtype=np.float64) for _ in range(2)]
+        self._nturns = [np.empty(self.rows, dtype=np.int32) for _ in range(2)]
+
+    def __del__(self):
+        try:
+            for h in self._clu:
+                self._lib.dz_clu_destroy(h)
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------ the run
+    def run(self, files) -> dict:
+        files = iter(files)
+        F = self.engine.seg.to(self.device).num_frames(self.S)
+        self._ensure_state(F)
+        K, D = None, self.engine.emb.dimension
+        res = self.duration / F
+        open_files: List[Optional[dict]] = [None] * self.max_files
+        done: dict = {}
+        exhausted = False
+        inflight: List[tuple] = []
+        step_no = 0
+
+        def admit():
+            nonlocal exhausted
+            for slot in range(self.max_files):
+                if exhausted:
+                    return
+                if open_files[slot] is None:
+                    try:
+                        uri, wav, shift = next(files)
+                    except StopIteration:
+                        exhausted = True
+                        return
+                    wav = np.ascontiguousarray(wav, dtype=np.float32).reshape(-1)
+                    nwin = (len(wav) - self.S) // self.hop + 1 if len(wav) >= self.S else 0
+                    _lib.check(self._lib.dz_clu_reset(self._clu[slot]), "dz_clu_reset")
+                    self._tails.reset(slot)
+                    if nwin <= 0:
+                        done[uri] = []
+                        return admit()
+                    open_files[slot] = dict(uri=uri, shift=float(shift), nwin=nwin, sent=0, got=0, turns=[], start=0,
+                                            audio=torch.from_numpy(wav).to(self.device, non_blocking=False))
+
+        def launch_step():
+            nonlocal step_no
+            active = [(slot, f) for slot, f in enumerate(open_files) if f is not None and f["sent"] < f["nwin"]]
+            if not active:
+                return False
+            per = max(1, self.rows // len(active))
+            stage = self._stage[step_no % len(self._stage)]
+            plan, r = [], 0
+            for slot, f in active:
+                c = min(per, f["nwin"] - f["sent"], self.rows - r)
+                if c <= 0:
+                    break
+                w0 = f["sent"]
+                # c consecutive windows of this file: a strided view of its resident audio -> dense rows
+                view = f["audio"][w0 * self.hop: w0 * self.hop + (c - 1) * self.hop + self.S].unfold(0, self.S, self.hop)
+                stage[r:r + c].copy_(view, non_blocking=True)
+                # window start times by repeated addition, exactly as rearrange_audio_stream counts them
+                # (`start += step`, operators.py:82-84): bit-identical for steps that are not dyadic
+                starts = np.empty(c, dtype=np.float64)
+                for j in range(c):
+                    starts[j] = f["start"]
+                    f["start"] += self.step
+                plan.append((slot, f, r, c, starts))
+                f["sent"] += c
+                r += c
+            ticket = self.engine._launch_rows(stage.data_ptr(), stage.stride(0), r, self.S, keep=stage)
+            inflight.append((ticket, plan, r))
+            step_no += 1
+            return True
+
+        def finish_step():
+            ticket, plan, r = inflight.pop(0)
+            self.engine._wait(ticket)
+            try:
+                _lib.range_check(self.device.index)
+                seg = ticket["seg_h"].numpy()[:r]
+                emb = ticket["emb_h"].numpy()[:r]
+                k = len(plan)
+                clus = (_lib.vp * k)(*[self._clu[slot] for slot, *_ in plan])
+                tails = (_lib.vp * k)(*[self._tails._hs[slot] for slot, *_ in plan])
+                row0 = np.array([p[2] for p in plan], dtype=np.int32)
+                count = np.array([p[3] for p in plan], dtype=np.int32)
+                starts = np.concatenate([p[4] for p in plan]).astype(np.float64)
+                turns, nturns = self._turns[0], self._nturns[0]
+                _lib.check(self._lib.dz_file_step_batch(
+                    clus, tails, k, row0.ctypes.data, count.ctypes.data, seg.ctypes.data, seg.shape[1], seg.shape[2],
+                    emb.ctypes.data, emb.shape[2], self.G, starts.ctypes.data, float(res), turns.ctypes.data,
+                    self._max_turns, nturns.ctypes.data, None, self.threads), "dz_file_step_batch")
+            finally:
+                ticket["busy"] = False
+                ticket["keep"] = None
+            for slot, f, r0, c, _ in plan:
+                for j in range(r0, r0 + c):
+                    if nturns[j]:
+                        f["turns"].append(turns[j, :nturns[j]].copy())
+                f["got"] += c
+                self.chunks_done += c
+                if f["got"] == f["nwin"]:
+                    done[f["uri"]] = (f["turns"], f["shift"])
+                    open_files[slot] = None
+
+        admit()
+        while True:
+            while len(inflight) <= self.engine.depth and launch_step():
+                pass
+            if not inflight:
+                admit()
+                if not any(f is not None for f in open_files):
+                    break
+                continue
+            finish_step()
+            admit()
+        out = {}
+        for uri, rec in done.items():
+            ann = Annotation(uri=uri, modality="speech")
+            if rec:
+                chunks, shift = rec
+                for arr in chunks:
+                    for s, e, g in arr:
+                        ann[Segment(s + shift, e + shift), int(g)] = f"speaker{int(g)}"
+            out[uri] = ann.support(self.patch_collar)
+        return out

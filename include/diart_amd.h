@@ -418,6 +418,21 @@ int dz_tail_step_batch(dz_tail** tails, int n, const double* scores, const doubl
                        double* res_out, double* turns_out, int max_turns, int* nturns_out,
                        int num_threads);
 
+/* ---- file-parallel evaluation: the host half of a GPU step over several files --------------
+ * Replaces the per-chunk Python loop of SpeakerDiarization.__call__
+ * (/root/reference/src/diart/blocks/diarization.py:193-232) as driven by Benchmark, one file at a
+ * time in batches of consecutive windows (/root/reference/src/diart/inference.py:392-432).  The rows
+ * of the GPU batch are file-major: file i contributes its next count[i] CONSECUTIVE windows, rows
+ * row0[i] .. row0[i] + count[i] - 1 of seg (rows, frames, k_local) / emb (rows, k_local, dim) /
+ * chunk_start (rows).  Per file, in window order: dz_clu_step -> dz_tail_step on that file's own
+ * handles; files run in parallel on host threads.  turns_out (rows, max_turns, 3), nturns_out (rows):
+ * the speech turns each window finalises; assign_out (rows, k_local) or NULL.                    */
+int dz_file_step_batch(dz_clu** clus, dz_tail** tails, int n_files, const int* row0, const int* count,
+                       const float* seg, int frames, int k_local, const float* emb, int dim,
+                       int max_speakers, const double* chunk_start, double resolution,
+                       double* turns_out, int max_turns, int* nturns_out, int* assign_out,
+                       int num_threads);
+
 /* sizeof() of the five structs that cross this boundary, in declaration order
  * (dz_sincnet_weights, dz_seg_weights, dz_emb_weights, dz_ecapa_weights, dz_convgemm_desc): a
  * binding checks its own mirror of the layouts against the library it loaded.            */

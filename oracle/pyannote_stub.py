@@ -136,6 +136,41 @@ class Annotation:
             yield (seg, track, label) if yield_label else (seg, track)
 
 
+class Timeline:
+    """Sorted set of segments (what VoiceActivityDetection's tail touches: vad.py:169-183)."""
+
+    def __init__(self, segments=None, uri=None):
+        self.uri = uri
+        self.segments = []
+        for seg in segments or ():
+            self.add(seg)
+
+    def add(self, segment):
+        if segment.end - segment.start > 1e-6 and not any(
+                s.start == segment.start and s.end == segment.end for s in self.segments):
+            self.segments.append(segment)
+        return self
+
+    def __iter__(self):
+        return iter(sorted(self.segments, key=lambda s: (s.start, s.end)))
+
+    def __len__(self):
+        return len(self.segments)
+
+    def to_annotation(self, generator="string", modality=None):
+        ann = Annotation(uri=self.uri, modality=modality)
+        for n, seg in enumerate(self):
+            ann[seg, "_"] = next(generator) if hasattr(generator, "__next__") else str(n)
+        return ann
+
+
+def _annotation_get_timeline(self, copy=True):
+    return Timeline([seg for seg, _, _ in self.tracks], uri=self.uri)
+
+
+Annotation.get_timeline = _annotation_get_timeline
+
+
 def install() -> None:
     """Register the stand-in as ``pyannote.core`` (only if the real one is absent)."""
     if "pyannote.core" in sys.modules:
@@ -146,13 +181,17 @@ def install() -> None:
     core = types.ModuleType("pyannote.core")
     core.__path__ = []
     core.SlidingWindow, core.SlidingWindowFeature, core.Segment = SlidingWindow, SlidingWindowFeature, Segment
-    core.Annotation = Annotation
+    core.Annotation, core.Timeline = Annotation, Timeline
+    core.notebook = types.SimpleNamespace()      # diart/utils.py imports the plotting helper object
     if "torchaudio" not in sys.modules:   # blocks/utils.py imports torchaudio.transforms for Resample
         ta = types.ModuleType("torchaudio")
         ta.__path__ = []
         tat = types.ModuleType("torchaudio.transforms")
-        ta.transforms = tat
-        sys.modules.update({"torchaudio": ta, "torchaudio.transforms": tat})
+        taf = types.ModuleType("torchaudio.functional")   # audio.py imports it for resampling (never called here)
+        taf.resample = lambda *a, **k: (_ for _ in ()).throw(RuntimeError("torchaudio is not installed"))
+        ta.set_audio_backend = lambda name: None          # audio.py calls it at import
+        ta.transforms, ta.functional = tat, taf
+        sys.modules.update({"torchaudio": ta, "torchaudio.transforms": tat, "torchaudio.functional": taf})
     utils = types.ModuleType("pyannote.core.utils")
     utils.__path__ = []
     dist = types.ModuleType("pyannote.core.utils.distance")
@@ -197,4 +236,42 @@ def load_reference(root: str = "/root/reference/src/diart"):
     ns.segmentation = _load("blocks.segmentation", "blocks/segmentation.py")
     ns.aggregation = _load("blocks.aggregation", "blocks/aggregation.py")
     ns.blocks_utils = _load("blocks.utils", "blocks/utils.py")
+    return ns
+
+
+def load_reference_pipelines(root: str = "/root/reference/src/diart"):
+    """``load_reference`` plus the reference's PIPELINE classes — ``blocks/base.py``,
+    ``blocks/diarization.py``, ``blocks/vad.py`` (and the ``utils.py`` / ``audio.py`` / ``progress.py``
+    they import) — by path, unmodified.  ``pyannote.metrics`` is absent: the two metric classes the
+    pipelines only hand out from ``suggest_metric`` are replaced by name-carrying placeholders."""
+    ns = load_reference(root)
+    rootp = Path(root)
+    if "pyannote.metrics" not in sys.modules:
+        pm = types.ModuleType("pyannote.metrics")
+        pm.__path__ = []
+        pmb = types.ModuleType("pyannote.metrics.base")
+        pmb.BaseMetric = type("BaseMetric", (), {})
+        pmd = types.ModuleType("pyannote.metrics.diarization")
+        pmd.DiarizationErrorRate = type("DiarizationErrorRate", (pmb.BaseMetric,), {"__init__": lambda self, **kw: setattr(self, "kw", kw)})
+        pmt = types.ModuleType("pyannote.metrics.detection")
+        pmt.DetectionErrorRate = type("DetectionErrorRate", (pmb.BaseMetric,), {"__init__": lambda self, **kw: setattr(self, "kw", kw)})
+        sys.modules.update({"pyannote.metrics": pm, "pyannote.metrics.base": pmb,
+                            "pyannote.metrics.diarization": pmd, "pyannote.metrics.detection": pmt})
+
+    def _load(name: str, rel: str):
+        full = f"diart_ref.{name}"
+        if full in sys.modules:
+            return sys.modules[full]
+        spec = importlib.util.spec_from_file_location(full, rootp / rel)
+        mod = importlib.util.module_from_spec(spec)
+        sys.modules[full] = mod
+        spec.loader.exec_module(mod)
+        return mod
+
+    _load("progress", "progress.py")
+    ns.utils = _load("utils", "utils.py")
+    _load("audio", "audio.py")
+    ns.base = _load("blocks.base", "blocks/base.py")
+    ns.diarization = _load("blocks.diarization", "blocks/diarization.py")
+    ns.vad = _load("blocks.vad", "blocks/vad.py")
     return ns

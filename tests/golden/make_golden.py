@@ -138,6 +138,73 @@ def tail(ref):
     print("tail:", len(out), "arrays")
 
 
+def pipelines():
+    """The reference's OWN pipeline classes — blocks/diarization.py SpeakerDiarization and
+    blocks/vad.py VoiceActivityDetection, loaded by path, unmodified — around the toy models of
+    scenarios.py, driven like StreamingInference drives them (rolling 5 s windows, batches of
+    consecutive chunks, optional timestamp shift).  Stored per case: what the reference's blocks
+    handed to the clustering (segmentation, overlap-aware normalised embeddings) and what the
+    pipeline returned per chunk (speech turns, a digest of the aggregated waveform)."""
+    from oracle.pyannote_stub import load_reference_pipelines
+    ref = load_reference_pipelines()
+    stream = scenarios.pipeline_stream()
+    S, H = 80000, 8000
+    chunks = [SlidingWindowFeature(stream[i * H:i * H + S, None],
+                                   SlidingWindow(start=i * 0.5, duration=1 / 16000, step=1 / 16000))
+              for i in range((len(stream) - S) // H + 1)]
+    out = {"num_chunks": np.array(len(chunks))}
+
+    class Rec:
+        def __init__(self, inner):
+            self.inner, self.got = inner, []
+
+        def __call__(self, *a):
+            r = self.inner(*a)
+            self.got.append(r.numpy().copy())
+            return r
+
+    def table(outputs):
+        rows = []
+        for i, (ann, _) in enumerate(outputs):
+            for seg, _, label in ann.itertracks(yield_label=True):
+                rows.append([i, seg.start, seg.end, float(label[len("speaker"):]) if label.startswith("speaker") else 0.0])
+        return np.array(rows, dtype=np.float64).reshape(-1, 4)
+
+    def digest(outputs):
+        return np.array([[w.data.shape[0], w.sliding_window.start, w.sliding_window.step,
+                          float(np.asarray(w.data, dtype=np.float64).sum()), w.data[0, 0], w.data[-1, 0]]
+                         for _, w in outputs], dtype=np.float64)
+
+    for name, (latency, bs, shift, tau, rho, delta) in scenarios.PIPE_CASES.items():
+        seg_m = ref.models.SegmentationModel(lambda: scenarios.ToySegmentation())
+        emb_m = ref.models.EmbeddingModel(lambda: scenarios.ToyEmbedding())
+        cfg = ref.diarization.SpeakerDiarizationConfig(segmentation=seg_m, embedding=emb_m, latency=latency,
+                                                       tau_active=tau, rho_update=rho, delta_new=delta,
+                                                       device=torch.device("cpu"))
+        pipe = ref.diarization.SpeakerDiarization(cfg)
+        pipe.set_timestamp_shift(shift)
+        pipe.segmentation, pipe.embedding = Rec(pipe.segmentation), Rec(pipe.embedding)
+        outputs = []
+        for i in range(0, len(chunks), bs):
+            outputs += pipe(chunks[i:i + bs])
+        out[f"{name}_seg"] = np.concatenate(pipe.segmentation.got)
+        out[f"{name}_emb"] = np.concatenate([e if e.ndim == 3 else e[None] for e in pipe.embedding.got])
+        out[f"{name}_turns"] = table(outputs)
+        out[f"{name}_audio"] = digest(outputs)
+        # VoiceActivityDetection with the same segmentation model (config 5's pipeline)
+        vcfg = ref.vad.VoiceActivityDetectionConfig(segmentation=ref.models.SegmentationModel(lambda: scenarios.ToySegmentation()),
+                                                    latency=latency, tau_active=tau, device=torch.device("cpu"))
+        vad = ref.vad.VoiceActivityDetection(vcfg)
+        vad.set_timestamp_shift(shift)
+        vouts = []
+        for i in range(0, len(chunks), bs):
+            vouts += vad(chunks[i:i + bs])
+        out[f"{name}_vad_turns"] = table(vouts)
+        print(f"pipeline {name}: {len(chunks)} chunks, {len(out[name + '_turns'])} diarization turns, "
+              f"{int(out[name + '_turns'][:, 3].max()) + 1} speakers, {len(out[name + '_vad_turns'])} speech regions")
+    np.savez_compressed(OUT / "pipeline_toy.npz", **out)
+
+
 def rttm_slice():
     """The first 40 lines of two meetings of the reference's expected_outputs/online/0.5s/AMI.rttm
     (paper-implementation output): an RTTM I/O fixture for features.load_rttm / Annotation.to_rttm."""
@@ -158,7 +225,10 @@ if __name__ == "__main__":
         rttm_slice()
     elif "--tail-only" in sys.argv:
         tail(load_reference())
+    elif "--pipelines-only" in sys.argv:
+        pipelines()
     else:
         main()
         tail(load_reference())
+        pipelines()
         rttm_slice()

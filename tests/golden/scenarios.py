@@ -82,3 +82,78 @@ def tail_inputs(start_time: float = 0.0):
     scores[3, 100:110, 0] = 0.5            # exactly tau: Binarize is strict (>)
     starts = start_time + TAIL_STEP * np.arange(TAIL_STEPS)
     return scores, starts, res
+
+
+# ---- whole pipelines (blocks/diarization.py, blocks/vad.py) around toy models -------------------
+# Deterministic stand-ins with the surface the reference's LazyModel expects of a loaded model and
+# that HipSegmentation / HipEmbedding offer: ``__call__`` + ``.to(device)``, not an nn.Module
+# (README.md:186-209, models.py:112-139).  Plain torch arithmetic, device agnostic.
+PIPE_SR, PIPE_SECONDS, PIPE_FRAMES, PIPE_DIM = 16000, 24.0, 100, 16
+PIPE_CASES = {   # name -> (latency, batch size, timestamp shift, tau, rho, delta)
+    "lat0.5_b4":       (0.5, 4, 0.0, 0.6, 0.3, 1.0),
+    "lat2.0_b7_shift": (2.0, 7, -1.25, 0.55, 0.2, 0.8),
+    "lat5.0_b1":       (5.0, 1, 0.0, 0.6, 0.3, 1.0),
+}
+
+
+def pipeline_stream():
+    """24 s, three "speakers" = sinusoids at 300 / 1100 / 2700 Hz taking turns (some overlap, some
+    silence), float32 in [-1, 1]."""
+    rng = np.random.default_rng(2025)
+    n = int(PIPE_SR * PIPE_SECONDS)
+    t = np.arange(n) / PIPE_SR
+    x = np.zeros(n)
+    for k, f in enumerate((300.0, 1100.0, 2700.0)):
+        on, pos, state = np.zeros(n), 0, rng.random() < 0.5
+        while pos < n:
+            length = int(PIPE_SR * (0.6 + 2.4 * rng.random()))
+            if state:
+                on[pos:pos + length] = 0.25 + 0.1 * rng.random()
+            state, pos = not state, pos + length
+        x += on * np.sin(2 * np.pi * f * t + k)
+    x += 0.01 * rng.standard_normal(n)
+    return np.clip(x, -1, 1).astype(np.float32)
+
+
+def _toy_frames(wave):
+    """(B, 1, S) -> per-frame energy of three band-pass-ish projections, (B, F, 3)."""
+    import torch
+    B, _, S = wave.shape
+    L = S // PIPE_FRAMES
+    fr = wave[:, 0, :L * PIPE_FRAMES].reshape(B, PIPE_FRAMES, L)
+    tt = torch.arange(L, dtype=wave.dtype, device=wave.device) / PIPE_SR
+    out = []
+    for f in (300.0, 1100.0, 2700.0):
+        c, s = torch.cos(2 * np.pi * f * tt), torch.sin(2 * np.pi * f * tt)
+        out.append(torch.sqrt((fr * c).mean(-1) ** 2 + (fr * s).mean(-1) ** 2))
+    return torch.stack(out, -1)
+
+
+class ToySegmentation:
+    def to(self, device):
+        return self
+
+    def __call__(self, waveform):
+        import torch
+        return torch.sigmoid(120.0 * (_toy_frames(waveform) - 0.05))          # (B, F, 3) in (0, 1)
+
+
+class ToyEmbedding:
+    def __init__(self):
+        self.proj = None
+
+    def to(self, device):
+        return self
+
+    def __call__(self, waveform, weights=None):
+        import torch
+        e = _toy_frames(waveform)                                              # (N, F, 3)
+        if self.proj is None or self.proj.device != e.device:
+            g = np.random.default_rng(99).standard_normal((3, PIPE_DIM)).astype(np.float32)
+            self.proj = torch.from_numpy(g).to(e.device)
+        if weights is None:
+            pooled = e.mean(1)
+        else:
+            w = weights.to(e.dtype)
+            pooled = (e * w[..., None]).sum(1) / w.sum(1, keepdim=True)
+        return torch.tanh(8.0 * pooled) @ self.proj                           # (N, D)

@@ -252,3 +252,32 @@ def test_benchmark_over_wav_files_matches_cpu_chain(gpu, models, tmp_path):
     m2 = DistributedBenchmark(Benchmark(speech, refs, tmp_path / "out2", show_report=False))(SpeakerDiarization, cfg)
     assert m2.accumulated == metric.accumulated
     assert (tmp_path / "out2" / "meeting_a.rttm").read_text() == (out / "meeting_a.rttm").read_text()
+
+
+@pytest.mark.parametrize("latency", [0.5, 2.0])
+def test_files_batched_together_give_the_rttm_files_of_the_one_file_at_a_time_loop(gpu, tmp_path, latency):
+    """``Benchmark`` runs the files of a rank concurrently through ``FileBatch``
+    (consecutive windows of several files per GPU step, the C++ clustering + output tail walking each
+    file in order) — the RTTM files must be BYTE-identical to the reference-shaped loop (one file at a
+    time, batches of 32 windows, per-chunk Python tail), whatever the number of concurrent files; file
+    lengths include one that ends mid-block, one shorter than a window (left padding) and one with
+    fewer windows than the others have per step."""
+    from diart_amd.inference import Benchmark, write_wav
+    speech = tmp_path / "wav"
+    speech.mkdir()
+    for name, seed, dur in (("a", 11, 21.3), ("b", 12, 9.05), ("c", 13, 33.0), ("d", 14, 3.2), ("e", 15, 5.5),
+                            ("f", 16, 14.77)):
+        write_wav(speech / f"{name}.wav", synth_stream(seed, dur), SR)
+    seg = M.SegmentationModel.from_state(synth_segmentation_state(), max_batch=64)
+    emb = M.EmbeddingModel.from_state(synth_embedding_state(), max_batch=64)
+    cfg = SpeakerDiarizationConfig(segmentation=seg, embedding=emb, latency=latency, device=gpu)
+    outs = {}
+    for tag, k in (("loop", 0), ("k1", 1), ("k4", 4), ("k16", 16)):
+        b = Benchmark(speech, None, tmp_path / tag, show_report=False, batch_size=32, concurrent_files=k)
+        b(SpeakerDiarization, cfg)
+        assert b.last_path == ("one_file_at_a_time" if k == 0 else "file_batch")
+        outs[tag] = {p.name: p.read_text() for p in sorted((tmp_path / tag).iterdir())}
+    assert sorted(outs["loop"]) == [f"{n}.rttm" for n in "abcdef"]
+    assert any(len(t) > 0 for t in outs["loop"].values())
+    for tag in ("k1", "k4", "k16"):
+        assert outs[tag] == outs["loop"], f"{tag}: RTTM files differ from the one-file-at-a-time loop"

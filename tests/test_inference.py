@@ -195,3 +195,24 @@ def test_distributed_benchmark_world_size_2_gloo(tmp_path):
         assert f"rank {rank} ok" in o
     # every file was written exactly once, by the rank that owned it
     assert sorted(p.name for p in out.iterdir()) == [f"file{i}.rttm" for i in range(5)]
+
+
+def test_padded_file_is_the_concatenation_of_file_blocks():
+    """FileBatch keeps every file of a rank resident as ONE array and reads consecutive windows in
+    place: that array must be exactly what FileAudioSource emits block by block (sources.py:85-135)
+    and its windows exactly rearrange_audio_stream's (operators.py:44-100), incl. left padding of a
+    short file and the zero-filled last block."""
+    from diart_amd.inference import file_blocks, padded_file, rolling_windows
+    rng = np.random.default_rng(3)
+    for n, padding in ((80000, (0, 0)), (123457, (0, 1.5)), (30000, (3.125, 0)), (8000, (4.5, 0.0)), (95999, (0, 0))):
+        wav = rng.standard_normal(n).astype(np.float32)
+        whole = padded_file(wav, 16000, padding, 0.5)
+        blocks = np.concatenate([b.astype(np.float32) for b in file_blocks(wav, 16000, padding, 0.5)], axis=1)[0]
+        assert whole.dtype == np.float32 and np.array_equal(whole, blocks)
+        wins = list(rolling_windows(file_blocks(wav, 16000, padding, 0.5), 5.0, 0.5, 16000))
+        assert len(wins) == max(0, (len(whole) - 80000) // 8000 + 1)
+        start = 0.0
+        for i, w in enumerate(wins):
+            assert np.array_equal(w.data[:, 0].astype(np.float32), whole[i * 8000:i * 8000 + 80000])
+            assert w.sliding_window.start == start
+            start += 0.5

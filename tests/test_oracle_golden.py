@@ -88,7 +88,7 @@ def test_committed_goldens_regenerate_from_the_reference(tmp_path):
                        capture_output=True, text=True, env=dict(__import__("os").environ, PYTHONDONTWRITEBYTECODE="1"))
     assert r.returncode == 0, r.stderr[-2000:]
     names = sorted(p.name for p in gold.glob("*.npz"))
-    assert names == sorted(p.name for p in tmp_path.glob("*.npz")) and len(names) == 7
+    assert names == sorted(p.name for p in tmp_path.glob("*.npz")) and len(names) == 8
     for name in names:
         a, b = np.load(gold / name), np.load(tmp_path / name)
         assert set(a.files) == set(b.files), name
