@@ -71,6 +71,10 @@ SIGNATURES = {
     "dz_emb_forward_multi": (C.c_int, [vp, vp, C.c_longlong, vp, C.c_int, C.c_int, C.c_int,
                                        C.c_int, vp, vp]),
     "dz_emb_frames": (C.c_int, [vp, vp, C.c_longlong, C.c_int, vp]),
+    "dz_wave_stats_floats": (C.c_int, []),
+    "dz_wave_stats": (C.c_int, [vp, vp, C.c_longlong, C.c_int, C.c_int, vp, vp]),
+    "dz_seg_use_wave_stats": (C.c_int, [vp, vp]),
+    "dz_emb_use_wave_stats": (C.c_int, [vp, vp]),
     "dz_emb_pool": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]),
     "dz_emb_destroy": (C.c_int, [vp]),
     "dz_ecapa_frames_for": (C.c_int, [C.c_int]),

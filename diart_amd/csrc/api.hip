@@ -273,15 +273,21 @@ static void sinc_out_norm(DzConvGemm& p, const dz_sincnet_weights& w, const Sinc
 
 // wave -> y2 [B][P2][64] (pre-norm) + part2 (or sc2/sh2): the consumer applies InstanceNorm +
 // LeakyReLU on load.  4 launches (7 with the finalize_norm launches of the exact-f32 path).
+// ext_stats: slice moments of these B windows somebody already computed (dz_wave_stats: the
+// segmentation and the embedding network normalise the SAME waveform, InstanceNorm1d(1) statistics
+// do not depend on the network) — NULL: compute them here.
 static int run_sincnet(const dz_sincnet_weights& w, const SincGeom& g, const SincScratch& s,
-                       const float* wave, long long stride, int B, hipStream_t st) {
+                       const float* wave, long long stride, int B, hipStream_t st,
+                       const float* ext_stats = nullptr) {
     int rc;
+    const float* stats = ext_stats ? ext_stats : s.stats;
+    if (!ext_stats)
     { ProfScope ps(T_WAVE, B); if ((rc = dz_launch_wave_stats(wave, stride, B, g.S, s.stats, st))) return rc; }
     { ProfScope ps(T_CONV0, B);
     rc = w.filt_split
-             ? dz_launch_sinc_conv0_split(wave, stride, B, g.S, s.stats, 1, w.wav_gamma, w.wav_beta,
+             ? dz_launch_sinc_conv0_split(wave, stride, B, g.S, stats, 1, w.wav_gamma, w.wav_beta,
                                           w.filt_split, s.y0, g.P0, s.part0, g.nt0, st)
-             : dz_launch_sinc_conv0(wave, stride, B, g.S, s.stats, 1, w.wav_gamma, w.wav_beta, w.filt,
+             : dz_launch_sinc_conv0(wave, stride, B, g.S, stats, 1, w.wav_gamma, w.wav_beta, w.filt,
                                     s.y0, g.P0, s.part0, g.nt0, st);
     if (rc) return rc; }
     const bool fused = sinc_fused_norm(w);
@@ -339,6 +345,7 @@ struct dz_seg {
     SincGeom g;
     int Bm;
     bool pre;    // wide layers on k_gemm_pre.hip (activations travel as f16 hi/lo planes)
+    const float* ext_stats;   // dz_seg_use_wave_stats: consumed (and cleared) by the next forward
     char* arena;
     SincScratch ss;
     float *gx, *h0, *h1, *m0, *m1, *logit;
@@ -376,7 +383,7 @@ extern "C" int dz_seg_create(dz_ctx* ctx, const dz_seg_weights* w, int max_batch
     DZ_HIP(hipSetDevice(ctx->device));
     dz_seg* s = new (std::nothrow) dz_seg;
     DZ_REQUIRE(s != nullptr, "dz_seg_create: out of memory");
-    s->ctx = ctx; s->w = *w; s->g = g; s->Bm = max_batch; s->arena = nullptr;
+    s->ctx = ctx; s->w = *w; s->g = g; s->Bm = max_batch; s->arena = nullptr; s->ext_stats = nullptr;
     s->pre = pre_split_enabled() && w->wih_split[1] && w->wih_split[2] && w->wih_split[3] &&
              w->lin0_split && w->lin1_split;
     Arena measure;
@@ -432,7 +439,9 @@ static int seg_forward(dz_seg* s, const float* d_wave, long long wave_stride, in
     DzRangeScope range_scope(s->ctx->oflag_dev);
     hipStream_t st = (hipStream_t)stream;
     const int F = s->g.P2;
-    if ((rc = run_sincnet(s->w.sinc, s->g, s->ss, d_wave, wave_stride, B, st))) return rc;
+    const float* ext = s->ext_stats;
+    s->ext_stats = nullptr;
+    if ((rc = run_sincnet(s->w.sinc, s->g, s->ss, d_wave, wave_stride, B, st, ext))) return rc;
 
     // 4 x { x-projection of both directions as one GEMM (N = 1024); persistent recurrence }.
     // With s->pre the hidden states travel as f16 (hi, lo) planes (same bytes as f32, same buffers)
@@ -525,6 +534,7 @@ struct dz_emb {
     SincGeom g;
     int Bm, T[5];
     bool pre;    // tdnn2..5 on k_gemm_pre.hip (tdnn1 writes f16 hi/lo planes)
+    const float* ext_stats;   // dz_emb_use_wave_stats: consumed (and cleared) by the next forward
     char* arena;
     SincScratch ss;
     float *a, *b, *x5, *pooled, *parts;
@@ -560,7 +570,7 @@ extern "C" int dz_emb_create(dz_ctx* ctx, const dz_emb_weights* w, int max_batch
     DZ_HIP(hipSetDevice(ctx->device));
     dz_emb* e = new (std::nothrow) dz_emb;
     DZ_REQUIRE(e != nullptr, "dz_emb_create: out of memory");
-    e->ctx = ctx; e->w = *w; e->g = g; e->Bm = max_batch; e->arena = nullptr;
+    e->ctx = ctx; e->w = *w; e->g = g; e->Bm = max_batch; e->arena = nullptr; e->ext_stats = nullptr;
     e->pre = pre_split_enabled() && w->tw_split[0] && w->tw_split[1] && w->tw_split[2] &&
              w->tw_split[3] && w->tw_split[4];
     int t = g.P2;
@@ -595,7 +605,9 @@ extern "C" int dz_emb_destroy(dz_emb* emb) {
 // frame features: wave (B) -> x5 [B][T5][1536]
 static int emb_frames(dz_emb* e, const float* d_wave, long long stride, int B, hipStream_t st) {
     int rc;
-    if ((rc = run_sincnet(e->w.sinc, e->g, e->ss, d_wave, stride, B, st))) return rc;
+    const float* ext = e->ext_stats;
+    e->ext_stats = nullptr;
+    if ((rc = run_sincnet(e->w.sinc, e->g, e->ss, d_wave, stride, B, st, ext))) return rc;
     const int cin[5] = {64, 512, 512, 512, 512};
     const int npad[5] = {512, 512, 512, 512, 1536};
     // Row pitch P = P2 for every activation.  tdnn1 normalises on load with per-chunk statistics, so
@@ -720,6 +732,31 @@ extern "C" int dz_emb_pool(dz_emb* e, const float* d_weights, int batch, int num
     DzRangeScope range_scope(e->ctx->oflag_dev);
     return emb_head(e, d_weights, weight_frames, batch * num_speakers, num_speakers, normalize,
                     d_out, (hipStream_t)stream);
+}
+
+// ---------------------------------------------------------------------------
+// InstanceNorm1d(1) statistics of the windows, shared by both networks
+// ---------------------------------------------------------------------------
+extern "C" int dz_wave_stats_floats(void) { return 2 * DZ_WS_G; }
+extern "C" int dz_wave_stats(dz_ctx* ctx, const float* d_wave, long long wave_stride, int batch,
+                             int num_samples, float* d_moments, void* stream) {
+    DZ_REQUIRE(ctx && d_moments, "dz_wave_stats: NULL argument");
+    DZ_REQUIRE(batch >= 1 && num_samples >= 1, "dz_wave_stats: empty input");
+    int rc;
+    if ((rc = check_wave("dz_wave_stats", d_wave, wave_stride, num_samples))) return rc;
+    DZ_HIP(hipSetDevice(ctx->device));
+    ProfScope ps(T_WAVE, batch);
+    return dz_launch_wave_stats(d_wave, wave_stride, batch, num_samples, d_moments, (hipStream_t)stream);
+}
+extern "C" int dz_seg_use_wave_stats(dz_seg* seg, const float* d_moments) {
+    DZ_REQUIRE(seg != nullptr, "dz_seg_use_wave_stats: NULL handle");
+    seg->ext_stats = d_moments;
+    return 0;
+}
+extern "C" int dz_emb_use_wave_stats(dz_emb* emb, const float* d_moments) {
+    DZ_REQUIRE(emb != nullptr, "dz_emb_use_wave_stats: NULL handle");
+    emb->ext_stats = d_moments;
+    return 0;
 }
 
 // ---------------------------------------------------------------------------

@@ -249,6 +249,19 @@ class Benchmark:
         if type(seg.model) is not HipSegmentation or type(emb.model) is not HipEmbedding:
             return None
         from .pipeline import FileBatch
+        # one engine per (models, hyper-parameters): its scratch arenas (~1 GB) and pinned slots are
+        # allocated once, not per call
+        key = (id(seg.model), id(emb.model), config.tau_active, config.rho_update, config.delta_new, config.gamma,
+               config.beta, config.max_speakers, config.normalize_embedding_weights, config.duration, config.step,
+               config.latency, config.sample_rate, str(config.device), self.batch_size, self.concurrent_files)
+        cached = getattr(self, "_fb_cache", None)
+        if cached is not None and cached[0] == key:
+            return cached[1]
+        fb = self._new_file_batch(FileBatch, seg, emb, config)
+        self._fb_cache = (key, fb)
+        return fb
+
+    def _new_file_batch(self, FileBatch, seg, emb, config):
         return FileBatch(seg.model, emb.model, rows=max(64, self.batch_size), max_files=self.concurrent_files,
                          tau_active=config.tau_active, rho_update=config.rho_update, delta_new=config.delta_new,
                          gamma=config.gamma, beta=config.beta, max_speakers=config.max_speakers,

@@ -199,6 +199,7 @@ class StreamBatch:
         # fewer streams than lanes x 2, the runtime multiplexes streams onto GPU_MAX_HW_QUEUES hardware
         # queues).  With the default recurrence kernel two full lanes measured 8 % faster (24.7 k vs
         # 22.8 k xRT), so the default is one embedding stream per lane.
+        self.shared_stats = os.environ.get("DZ_SHARED_STATS", "1") != "0"
         self.shared_emb = os.environ.get("DZ_SHARED_EMB", "0") != "0"
         self.lag = self.depth - 1 if self.shared_emb else 0
         mk = lambda prio, k: [torch.cuda.Stream(self.device, priority=prio) for _ in range(k)]
@@ -247,6 +248,7 @@ class StreamBatch:
                  seg=torch.empty((n, F, K), dtype=torch.float32, device=dev),
                  w=torch.empty((n, K, F), dtype=torch.float32, device=dev),
                  emb=torch.empty((n, K, D), dtype=torch.float32, device=dev),
+                 stats=torch.empty((n, self._lib.dz_wave_stats_floats()), dtype=torch.float32, device=dev),
                  seg_h=torch.empty((n, F, K), dtype=torch.float32).pin_memory(),
                  emb_h=torch.empty((n, K, D), dtype=torch.float32).pin_memory(),
                  ev_seg=[torch.cuda.Event() for _ in range(self.seg_split)],
@@ -334,12 +336,20 @@ class StreamBatch:
         slot["busy"] = True
         lib, esz = self._lib, 4
         cur = torch.cuda.current_stream(self.device)
+        # InstanceNorm1d(1) statistics of the windows ONCE for both networks (each SincNet would
+        # otherwise make its own pass over the same 20 MB): on the caller's stream, ahead of `ev_in`
+        stats = slot["stats"] if self.shared_stats else None
+        if stats is not None:
+            _lib.check(lib.dz_wave_stats(self._ctx, base, stride, N, S, stats.data_ptr(), cur.cuda_stream),
+                       "dz_wave_stats")
         slot["ev_in"].record(cur)                       # inputs produced on the caller's stream
         for (i0, i1), h, a, ev in zip(sa, hsegs, lane["a"], slot["ev_seg"]):
             a.wait_event(slot["ev_in"])
             if i1 == i0:                                 # fewer rows than sub-batches
                 ev.record(a)
                 continue
+            if stats is not None:
+                _lib.check(lib.dz_seg_use_wave_stats(h, stats[i0:].data_ptr()), "dz_seg_use_wave_stats")
             # segmentation + the OSP weights of its output (one launch sequence, no dz_osp of its own)
             _lib.check(lib.dz_seg_forward_osp(h, base + i0 * stride * esz, stride, i1 - i0,
                                               slot["seg"][i0:i1].data_ptr(), self.gamma, self.beta,
@@ -349,6 +359,8 @@ class StreamBatch:
         for (i0, i1), h, b, ev in zip(sb, hembs, lane["b"], slot["ev_frames"]):
             b.wait_event(slot["ev_in"])
             if i1 > i0:
+                if stats is not None:
+                    _lib.check(lib.dz_emb_use_wave_stats(h, stats[i0:].data_ptr()), "dz_emb_use_wave_stats")
                 _lib.check(lib.dz_emb_frames(h, base + i0 * stride * esz, stride, i1 - i0, b.cuda_stream),
                            "dz_emb_frames")
             ev.record(b)
@@ -517,8 +529,51 @@ class FileBatch:
             pass
 
     # ------------------------------------------------------------------ the run
+    class _Loader:
+        """Reads / pads the next files on a background thread while the GPU works (reading a WAV and
+        converting it to float32 takes ~10 ms per 5 minutes of audio: done serially in front of the
+        first launch it cost more than the GPU time of the whole file).  ``get(block)`` ->
+        (uri, pinned float32 tensor, samples, shift) in the order of ``files``, None when nothing is
+        ready yet (``block=False``), ``StopIteration`` at the end."""
+
+        def __init__(self, files, depth: int = 4):
+            import queue
+            import threading
+            self.q: "queue.Queue" = queue.Queue(maxsize=depth)
+            self.done = False
+            self._END = object()
+
+            def work():
+                try:
+                    for uri, wav, shift in files:
+                        wav = np.ascontiguousarray(wav, dtype=np.float32).reshape(-1)
+                        t = torch.empty(max(1, len(wav)), dtype=torch.float32).pin_memory()
+                        t[:len(wav)].copy_(torch.from_numpy(wav))
+                        self.q.put((uri, t, len(wav), shift))
+                    self.q.put(self._END)
+                except BaseException as exc:       # surfaces in the consumer
+                    self.q.put(exc)
+
+            threading.Thread(target=work, name="dz-file-loader", daemon=True).start()
+
+        def get(self, block: bool):
+            import queue
+            if self.done:
+                raise StopIteration
+            try:
+                item = self.q.get(block=block)
+            except queue.Empty:
+                return None
+            if item is self._END:
+                self.done = True
+                raise StopIteration
+            if isinstance(item, BaseException):
+                self.done = True
+                raise item
+            return item
+
     def run(self, files) -> dict:
-        files = iter(files)
+        files = FileBatch._Loader(files)
         F = self.engine.seg.to(self.device).num_frames(self.S)
         self._ensure_state(F)
         K, D = None, self.engine.emb.dimension
@@ -530,25 +585,28 @@ class FileBatch:
         step_no = 0
 
         def admit():
+            """Fill free slots with files that are READY; wait for one only when nothing is open."""
             nonlocal exhausted
             for slot in range(self.max_files):
                 if exhausted:
                     return
                 if open_files[slot] is None:
                     try:
-                        uri, wav, shift = next(files)
+                        item = files.get(block=not any(f is not None for f in open_files))
                     except StopIteration:
                         exhausted = True
                         return
-                    wav = np.ascontiguousarray(wav, dtype=np.float32).reshape(-1)
-                    nwin = (len(wav) - self.S) // self.hop + 1 if len(wav) >= self.S else 0
+                    if item is None:
+                        return
+                    uri, pinned, nsamp, shift = item
+                    nwin = (nsamp - self.S) // self.hop + 1 if nsamp >= self.S else 0
                     _lib.check(self._lib.dz_clu_reset(self._clu[slot]), "dz_clu_reset")
                     self._tails.reset(slot)
                     if nwin <= 0:
                         done[uri] = []
                         return admit()
                     open_files[slot] = dict(uri=uri, shift=float(shift), nwin=nwin, sent=0, got=0, turns=[], start=0,
-                                            audio=torch.from_numpy(wav).to(self.device, non_blocking=False))
+                                            audio=pinned[:nsamp].to(self.device, non_blocking=True), host=pinned)
 
         def launch_step():
             nonlocal step_no

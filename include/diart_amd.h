@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define DZ_VERSION 210   /* 2.1: dz_seg_forward_osp, per-row rings, dz_k_mlp_head / dz_k_seg_head */
+#define DZ_VERSION 220   /* 2.2: dz_file_step_batch, dz_wave_stats shared by both networks */
 
 typedef struct dz_ctx dz_ctx;
 typedef struct dz_seg dz_seg;
@@ -138,6 +138,18 @@ int dz_emb_forward(dz_emb* emb, const float* d_wave, long long wave_stride,
 int dz_emb_forward_multi(dz_emb* emb, const float* d_wave, long long wave_stride,
                          const float* d_weights, int batch, int num_speakers,
                          int weight_frames, int normalize, float* d_out, void* stream);
+/* InstanceNorm1d(1) statistics of `batch` windows (the first op of BOTH networks' SincNet: the
+ * reference computes them once per model, models.py:133 and :262 each run their own front end) as
+ * dz_wave_stats_floats() floats per window (slice means and M2s, merged by the consumer).  A handle
+ * told about them with dz_*_use_wave_stats skips its own pass over the waveform in its NEXT forward /
+ * dz_emb_frames call (one use, rows in the same order as that call's windows; the caller orders the
+ * streams).                                                                                      */
+int dz_wave_stats_floats(void);
+int dz_wave_stats(dz_ctx* ctx, const float* d_wave, long long wave_stride, int batch, int num_samples,
+                  float* d_moments, void* stream);
+int dz_seg_use_wave_stats(dz_seg* seg, const float* d_moments);
+int dz_emb_use_wave_stats(dz_emb* emb, const float* d_moments);
+
 /* The two halves of dz_emb_forward_multi.  dz_emb_frames (SincNet + TDNN stack, 99.5 % of the
  * embedding FLOPs) does not depend on the segmentation, so it can run on a second stream while
  * dz_seg_forward's latency-bound LSTM occupies a handful of CUs; dz_emb_pool then consumes the

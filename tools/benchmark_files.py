@@ -80,6 +80,10 @@ bench = DistributedBenchmark(Benchmark(speech, None, out, show_report=False, bat
 # warm-up: weights packed, arenas allocated, kernels loaded
 SpeakerDiarization(cfg)
 cfg.segmentation(torch.zeros(1, 1, 80000, device=device))
+fb = bench.benchmark.file_batch(SpeakerDiarization, cfg)
+if fb is not None:      # the batched engine's arenas / pinned slots, like the models' above
+    import numpy as np  # noqa: E402
+    fb.run([("warm-up", np.zeros(16000 * 12, dtype=np.float32), 0.0)])
 torch.cuda.synchronize()
 if world > 1:
     torch.distributed.barrier()
@@ -97,7 +101,7 @@ if rank == 0:
                                 "pyannote/segmentation + pyannote/embedding",
                       "workload": f"{args.files} synthetic 16 kHz files, {audio_s:.0f} s of audio, batch "
                                   f"{args.batch_size}, latency {args.latency}", "n_gpus": world, "files": len(uris),
-                      "wall_s": round(dt, 3), "audio_seconds_per_second": round(audio_s / dt, 1),
+                      "path": bench.benchmark.last_path, "wall_s": round(dt, 3), "audio_seconds_per_second": round(audio_s / dt, 1),
                       "chunks_per_second": round(chunks / dt, 1), "rttm_dir": str(out)}), flush=True)
 if world > 1:
     torch.distributed.destroy_process_group()
