@@ -31,6 +31,30 @@ FilePath = Union[str, Path]
 
 
 # ------------------------------------------------------------------------------------- audio
+def read_wav_into(path: FilePath, alloc, padding_of, block_duration: float = 0.5):
+    """``padded_file(read_wav(path))`` in ONE pass: decode the PCM samples straight into
+    ``alloc(n_total)`` (e.g. a pinned upload buffer) at their padded position.  ``padding_of(duration
+    seconds) -> (left, right)`` seconds.  -> (array, sample rate, (left, right)); same samples as the
+    two-step form (the 2^-15 / 2^-31 / 2^-7 scalings are exact in float32)."""
+    with wave.open(str(path), "rb") as f:
+        sr, nch, width, n = f.getframerate(), f.getnchannels(), f.getsampwidth(), f.getnframes()
+        raw = f.readframes(n)
+    padding = padding_of(n / sr)
+    left, right = (int(np.rint(p * sr)) for p in padding)
+    size = int(np.rint(block_duration * sr))
+    total = left + n + right
+    out = alloc(-(-total // size) * size)
+    out[:left] = 0.0
+    out[left + n:] = 0.0
+    dst = out[left:left + n]
+    if nch == 1 and width == 2:
+        np.multiply(np.frombuffer(raw, dtype="<i2"), np.float32(1.0 / 32768.0), out=dst, dtype=np.float32, casting="unsafe")
+    else:
+        x, _ = read_wav(path)
+        dst[:] = x
+    return out, sr, padding
+
+
 def read_wav(path: FilePath) -> Tuple[np.ndarray, int]:
     """PCM WAV (8/16/32-bit integer) -> (mono float32 in [-1, 1], sample rate); channels are
     averaged like ``AudioLoader(mono=True)`` (reference ``audio.py:36-40``)."""
@@ -272,14 +296,13 @@ class Benchmark:
     def run_batched(self, fb, config, paths: Sequence[Path]) -> List[Annotation]:
         """``paths`` through one ``FileBatch``: same padding, timestamp shift, RTTM files and
         progress lines as ``run_single``, files read lazily as slots free up."""
-        def feed():
+        def feed():      # runs on the FileBatch's loader thread: decode straight into pinned memory
             for fp in paths:
-                waveform, sr = read_wav(fp)
+                padded, sr, padding = read_wav_into(fp, fb.host_buffer, config.get_padding, config.step)
                 if sr != config.sample_rate:
                     raise ValueError(f"audio source has sample rate {sr}, the pipeline's is "
                                      f"{config.sample_rate}; resample the file first")
-                padding = config.get_padding(len(waveform) / sr)
-                yield fp.stem, padded_file(waveform, sr, padding, config.step), -padding[0]
+                yield fp.stem, padded, -padding[0]
 
         got = fb.run(feed())
         preds = []

@@ -216,3 +216,16 @@ def test_padded_file_is_the_concatenation_of_file_blocks():
             assert np.array_equal(w.data[:, 0].astype(np.float32), whole[i * 8000:i * 8000 + 80000])
             assert w.sliding_window.start == start
             start += 0.5
+
+
+def test_read_wav_into_equals_read_then_pad(tmp_path):
+    from diart_amd.inference import padded_file, read_wav, read_wav_into, write_wav
+    rng = np.random.default_rng(4)
+    for n in (30000, 81234, 160000):
+        p = tmp_path / f"f{n}.wav"
+        write_wav(p, rng.uniform(-1, 1, n), 16000)
+        pad_of = lambda d: (max(0.0, 5.0 - d - 1.5), 1.5)   # noqa: E731
+        got, sr, padding = read_wav_into(p, lambda m: np.full(m, 7.0, dtype=np.float32), pad_of, 0.5)
+        wav, sr2 = read_wav(p)
+        assert sr == sr2 == 16000 and padding == pad_of(n / 16000)
+        assert np.array_equal(got, padded_file(wav, sr, padding, 0.5))
