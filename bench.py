@@ -69,6 +69,21 @@ KERNELS = {
     "stats_pool": dict(mac=0, io=F_E3 * 1536 * 4 + 3 * F_SEG * 4 + 3 * 3008 * 4, w=0, bound="hbm"),
     "emb_linear": dict(mac=3 * 3000 * 512, io=3 * (3008 + 512) * 4, w=512 * 3008 * 4, bound="mfma_f32"),
 }
+POOL_PIECES = 4    # 128-row tiles a 293-row chunk can touch (dz_pool_pieces)
+
+
+def kernels_for(precision):
+    """KERNELS as the launches of this precision really are: on the default path tdnn5 keeps its output
+    tile in LDS and writes per-tile weighted moments (k_gemm_pre.hip pooled epilogue), and the `stats_pool`
+    tag is the small kernel that merges them (pool_combine)."""
+    k = {n: dict(v) for n, v in KERNELS.items()}
+    if precision == "f16x3" and os.environ.get("DZ_POOL_FUSE", "1") != "0" and os.environ.get("DZ_GEMM_PRE", "1") != "0":
+        moments = POOL_PIECES * 3 * 1536 * 2 * 4
+        k["tdnn5"]["io"] = F_SEG * 512 * 4 + moments + 3 * F_SEG * 4
+        k["stats_pool"]["io"] = moments + 3 * 3008 * 4
+    return k
+
+
 # sinc_conv0 folds the (anti)symmetric FIR bank: 42 tiles x 192 frames x 96 columns x 128 taps
 EXECUTED_MAC = {"sinc_conv0": 42 * 192 * 96 * 128}
 ALG_GFLOP_PER_CHUNK = 3.352   # 1.312 seg + 2.039 emb de-duplicated (SURVEY.md 8d)
@@ -87,8 +102,10 @@ def device_kernel(tag, precision):
     pre = split and os.environ.get("DZ_GEMM_PRE", "1") != "0"     # wide layers on k_gemm_pre.hip
     lstm = os.environ.get("DZ_LSTM", "valu")                          # weights.default_lstm_variant
     k = KERNELS[tag]
+    fused_pool = split and pre and os.environ.get("DZ_POOL_FUSE", "1") != "0"
     if k["bound"] == "hbm":
-        return {"wave_stats": "wave_stats_kernel", "stats_pool": "stats_pool_reg_kernel<3, 72>",
+        return {"wave_stats": "wave_stats_kernel",
+                "stats_pool": "pool_combine_kernel" if fused_pool else "stats_pool_reg_kernel<3, 72>",
                 "seg_classifier": "seg_head_kernel"}[tag], "hbm", PEAK_HBM_GBPS, "GB/s"
     if k["bound"] == "rec":
         if split and lstm != "valu":
@@ -108,7 +125,10 @@ def device_kernel(tag, precision):
     if pre and tag == "seg_mlp" and os.environ.get("DZ_MLP_HEAD", "1") != "0":
         return "mlp_head_kernel", "mfma", PEAK_F16_MATRIX_TFLOPS / SPLIT_PRODUCTS, "TFLOP/s"
     if pre and tag in ("tdnn2", "tdnn3", "tdnn4", "tdnn5", "lstm_proj", "seg_mlp"):
-        sym = {"lstm_proj": "gemm_pre_kernel<0>", "seg_mlp": "gemm_pre_kernel<1>"}.get(tag, "gemm_pre_kernel<3>")
+        ilv = "true" if os.environ.get("DZ_GP_LOOP", "1") != "0" else "false"
+        sym = {"lstm_proj": f"gemm_pre_kernel<0, {ilv}>", "seg_mlp": f"gemm_pre_kernel<1, {ilv}>",
+               "tdnn5": "gemm_pre_pool_kernel" if fused_pool else f"gemm_pre_kernel<3, {ilv}>"}.get(
+                   tag, f"gemm_pre_kernel<3, {ilv}>")
         return sym, "mfma", PEAK_F16_MATRIX_TFLOPS / SPLIT_PRODUCTS, "TFLOP/s"
     if tag in ("conv1_pool", "conv2_pool") and os.environ.get("DZ_CONV_POOL", "1") != "0":
         return ("conv_pool_h_kernel<80>" if tag == "conv1_pool" else "conv_pool_h_kernel<64>"), "mfma", \
@@ -153,7 +173,7 @@ def parse():
     return ap.parse_args()
 
 
-def kernel_table(lib):
+def kernel_table(lib, precision="f16x3"):
     """Per launch tag: launches, total / average duration and the number of chunks those launches
     worked on (recorded by the library next to every bracketed launch: a 32-chunk sub-batch launch
     counts 32), hence algorithmic FLOP and HBM bytes PER LAUNCH at the launch's real batch."""
@@ -168,7 +188,7 @@ def kernel_table(lib):
         cpl = ch.value / n.value
         row = {"kernel": nm, "launches": n.value, "total_ms": round(ms.value, 3), "avg_us": round(avg_ms * 1e3, 2),
                "chunks_per_launch": round(cpl, 2)}
-        k = KERNELS.get(nm)
+        k = kernels_for(precision).get(nm)
         if k:
             row["alg_gflop_per_launch"] = round(2.0 * k["mac"] * cpl / 1e9, 3)
             row["alg_bytes_per_launch"] = int(k["io"] * cpl + k["w"])
@@ -548,7 +568,7 @@ def main():
             f"{1e3 * host['launch'] / args.steps:.3f} ms, finish {1e3 * host['finish'] / args.steps:.3f} ms = waiting for "
             f"the GPU {1e3 * hs['wait'] / args.steps:.3f} + clustering / tail {1e3 * hs['work'] / args.steps:.3f}")
         lib.dz_prof_collect()
-        tab = kernel_table(lib)           # read before dz_prof_enable(0) clears the accumulators
+        tab = kernel_table(lib, p.seg.precision)   # read before dz_prof_enable(0) clears the accumulators
         lib.dz_prof_enable(0)
         return el, tab, sampled[0]
 

@@ -132,6 +132,7 @@ SIGNATURES = {
                                 C.c_float, C.c_int, vp, vp]),
     "dz_k_conv_pool": (C.c_int, [vp, vp, vp]),
     "dz_k_convgemm_ntile": (C.c_int, [C.c_int]),
+    "dz_k_conv_pool_debug": (C.c_int, [vp]),
     "dz_k_wave_stats": (C.c_int, [vp, vp, C.c_longlong, C.c_int, C.c_int, vp, vp]),
     "dz_k_sinc_conv0": (C.c_int, [vp, vp, C.c_longlong, C.c_int, C.c_int, vp, C.c_float,
                                   C.c_float, vp, vp, vp, vp]),

@@ -165,6 +165,10 @@ extern "C" int dz_prof_collect(void) {
         }
     }
     g_prof.used = 0;
+    // an event pair whose bracket never launched (a ProfScope around a path that returned early) fails
+    // in hipEventElapsedTime: it is skipped above, and the runtime's sticky "last error" must not be left
+    // for the next caller's error check (torch raises on it)
+    (void)hipGetLastError();
     return PROF_TAGS;
 }
 extern "C" int dz_prof_get(int tag, const char** name, double* total_ms, long long* launches,
@@ -220,6 +224,11 @@ static bool pre_split_enabled() {
 // every consumer derives its InstanceNorm scale / shift from the producer's tile partials itself
 static bool fused_norm_enabled() {
     const char* v = getenv("DZ_FUSED_NORM");
+    return !(v && v[0] == '0');
+}
+// DZ_POOL_FUSE=0: tdnn5 writes its f32 output and stats_pool reads it back (the round-2 path)
+static bool pool_fuse_enabled() {
+    const char* v = getenv("DZ_POOL_FUSE");
     return !(v && v[0] == '0');
 }
 static bool conv_pool_enabled() {
@@ -537,7 +546,11 @@ struct dz_emb {
     const float* ext_stats;   // dz_emb_use_wave_stats: consumed (and cleared) by the next forward
     char* arena;
     SincScratch ss;
-    float *a, *b, *x5, *pooled, *parts;
+    float *a, *b, *x5, *pooled, *parts, *ppart, *ps0;
+    // tdnn5 + statistics pooling in one launch (k_gemm_pre.hip, pooled epilogue): dz_emb_frames then
+    // stops after tdnn4 and leaves tdnn5 to the call that brings the pooling weights
+    int pending_B;            // > 0: frames of that many chunks are waiting at tdnn4's output
+    const float* pending_in;  // tdnn4's planes
 };
 static const int kTdnnTaps[5] = {5, 3, 3, 1, 1};
 static const int kTdnnDil[5] = {1, 2, 3, 1, 1};
@@ -553,6 +566,9 @@ static void emb_carve(dz_emb* e, Arena& a) {
     e->b = a.take((size_t)e->Bm * e->g.P2 * 512);
     e->x5 = a.take((size_t)e->Bm * e->g.P2 * 1536);
     e->pooled = a.take((size_t)e->Bm * kMaxSpk * kPoolLd);
+    const int np = dz_pool_pieces(e->g.P2);
+    e->ppart = a.take((size_t)e->Bm * np * 4 * 1536 * 2);      // [chunk][np pieces][<= 4 speakers][1536][2]
+    e->ps0 = a.take((size_t)e->Bm * np * 4 * 2);
     e->parts = a.take((size_t)kEmbSplit * e->Bm * kMaxSpk * 512);
 }
 
@@ -571,6 +587,7 @@ extern "C" int dz_emb_create(dz_ctx* ctx, const dz_emb_weights* w, int max_batch
     dz_emb* e = new (std::nothrow) dz_emb;
     DZ_REQUIRE(e != nullptr, "dz_emb_create: out of memory");
     e->ctx = ctx; e->w = *w; e->g = g; e->Bm = max_batch; e->arena = nullptr; e->ext_stats = nullptr;
+    e->pending_B = 0; e->pending_in = nullptr;
     e->pre = pre_split_enabled() && w->tw_split[0] && w->tw_split[1] && w->tw_split[2] &&
              w->tw_split[3] && w->tw_split[4];
     int t = g.P2;
@@ -620,6 +637,7 @@ static int emb_frames(dz_emb* e, const float* d_wave, long long stride, int B, h
     // e->pre: tdnn1 writes its output as f16 (hi, lo) planes (same bytes, same buffers), tdnn2..5 run
     // on k_gemm_pre.hip, tdnn5 writes the f32 features the statistics pooling reads
     const long long plane = (long long)B * P * 512;
+    e->pending_B = 0;
     for (int i = 0; i < 5; ++i) {
         DzConvGemm p;
         memset(&p, 0, sizeof(p));
@@ -639,6 +657,12 @@ static int emb_frames(dz_emb* e, const float* d_wave, long long stride, int B, h
         } else {
             p.B = 1; p.Tin = B * P; p.Tout = p.Tstore = B * P - span;
         }
+        if (i == 4 && e->pre && pool_fuse_enabled() && dz_gemm_pre_pool_ok(p)) {
+            // tdnn5 runs with the pooling in its epilogue, i.e. when the weights are known (emb_head)
+            e->pending_B = B;
+            e->pending_in = in;
+            return 0;
+        }
         { ProfScope ps(T_TDNN1 + i, B);
           if (i > 0 && e->pre) {
               p.X = nullptr; p.Xsplit = in; p.xplane = plane; p.Wsplit = e->w.tw_split[i];
@@ -656,7 +680,38 @@ static int emb_frames(dz_emb* e, const float* d_wave, long long stride, int B, h
 static int emb_head(dz_emb* e, const float* d_weights, int Fw, int rows, int rows_per_x,
                     int normalize, float* d_out, hipStream_t st) {
     int rc;
-    { ProfScope ps(T_POOL, rows / rows_per_x);
+    const int nx = rows / rows_per_x;
+    if (e->pending_B > 0) {
+        DZ_REQUIRE(nx == e->pending_B, "dz_emb_pool: %d chunks, but the frame features of %d are pending", nx,
+                   e->pending_B);
+        const int B = e->pending_B, P = e->g.P2;
+        DzConvGemm p;
+        memset(&p, 0, sizeof(p));
+        p.Xsplit = e->pending_in; p.xplane = (long long)B * P * 512; p.Wsplit = e->w.tw_split[4];
+        p.W = e->w.tw[4]; p.bias = e->w.tb[4]; p.e0 = e->w.ts[4]; p.e1 = e->w.th[4];
+        p.B = 1; p.Tin = p.Tout = p.Tstore = B * P; p.Cin = 512; p.taps = 1; p.dil = 1; p.K = 512; p.Kpad = 512;
+        p.Npad = 1536; p.Nstore = 1536; p.ldx = 512; p.ldy = 1536; p.epi = DZ_EPI_TDNN;
+        if (rows_per_x <= 4) {
+            DzPoolFuse q;
+            q.w = d_weights; q.Fw = Fw; q.K = rows_per_x; q.P = P; q.T = e->T[4]; q.np = dz_pool_pieces(P);
+            q.part = e->ppart; q.s0 = e->ps0;
+            { ProfScope ps(T_TDNN5, B); if ((rc = dz_launch_gemm_pre_pool(p, q, st))) return rc; }
+            e->pending_B = 0;
+            { ProfScope ps(T_POOL, B);
+              if ((rc = dz_launch_pool_combine(e->ppart, e->ps0, B, rows_per_x, dz_pool_pieces(P), P, e->T[4], 1500, 1536, e->pooled,
+                                               kPoolLd, st)))
+                  return rc; }
+        } else {            // more than 4 speakers per chunk: plain tdnn5, then the stand-alone pooling below
+            p.Y = e->x5;
+            { ProfScope ps(T_TDNN5, B); if ((rc = dz_launch_gemm_pre(p, st))) return rc; }
+            e->pending_B = 0;
+            ProfScope ps(T_POOL, nx);
+            if ((rc = dz_launch_stats_pool(e->x5, (long long)P * 1536, e->T[4], 1500, 1536, d_weights, Fw, rows,
+                                           rows_per_x, e->pooled, kPoolLd, st)))
+                return rc;
+        }
+    } else
+    { ProfScope ps(T_POOL, nx);
     if ((rc = dz_launch_stats_pool(e->x5, (long long)e->g.P2 * 1536, e->T[4], 1500, 1536, d_weights, Fw,
                                    rows, rows_per_x, e->pooled, kPoolLd, st)))
         return rc; }
@@ -840,6 +895,11 @@ extern "C" int dz_k_conv_pool(dz_ctx* ctx, const dz_convgemm_desc* d, void* stre
     DZ_HIP(hipSetDevice(ctx->device));
     DzRangeScope range_scope(ctx->oflag_dev);
     return dz_launch_conv_pool(*d, (hipStream_t)stream);
+}
+// phase time stamps of conv_pool_h (tools/kbench.py): 2 x 64 shader-clock stamps per workgroup
+extern "C" int dz_k_conv_pool_debug(long long* d_stamps) {
+    dz_conv_pool_dbg = d_stamps;
+    return 0;
 }
 extern "C" int dz_k_convgemm_ntile(int t_out) { return dz_convgemm_ntile(t_out); }
 extern "C" int dz_k_wave_stats(dz_ctx* ctx, const float* d_wave, long long stride, int batch,

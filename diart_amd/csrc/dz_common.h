@@ -127,14 +127,40 @@ __device__ __forceinline__ void dz_store_split(unsigned short* ypl, long long id
 // consumer.  out: scale[C] | shift[C].
 __device__ __forceinline__ void dz_norm_from_partials(const float* __restrict__ partials, int b, int ntile,
                                                       int C, int T, const float* __restrict__ gamma,
-                                                      const float* __restrict__ beta, float* out, int tid) {
+                                                      const float* __restrict__ beta, float* out, int tid,
+                                                      int nthreads, double* scratch) {
+    // Round 2 let thread c walk the ntile partials of channel c one load at a time: up to 84 dependent
+    // L2 round trips (conv1 after conv0: ~25 us in front of a workgroup's first tile).  Now the threads
+    // form G = nthreads / C groups, group g takes tiles g, g + G, ... with four loads in flight, and
+    // the group sums (f64: exact for these magnitudes, so the order does not show) meet in `scratch`
+    // (LDS, >= 2 G C doubles).  Contains a __syncthreads(): call from ALL threads of the workgroup.
+    const int G = nthreads / C > 0 ? nthreads / C : 1;
+    const int c = tid % C, g = tid / C;
+    if (g < G) {
+        double s = 0.0, ss = 0.0;
+        const float2* pp = reinterpret_cast<const float2*>(partials) + ((long long)b * ntile * C + c);
+        int t = g;
+        for (; t + 3 * G < ntile; t += 4 * G) {
+            const float2 a0 = pp[(long long)t * C], a1 = pp[(long long)(t + G) * C];
+            const float2 a2 = pp[(long long)(t + 2 * G) * C], a3 = pp[(long long)(t + 3 * G) * C];
+            s += (double)a0.x; ss += (double)a0.y;
+            s += (double)a1.x; ss += (double)a1.y;
+            s += (double)a2.x; ss += (double)a2.y;
+            s += (double)a3.x; ss += (double)a3.y;
+        }
+        for (; t < ntile; t += G) {
+            const float2 a = pp[(long long)t * C];
+            s += (double)a.x; ss += (double)a.y;
+        }
+        scratch[(g * C + c) * 2] = s;
+        scratch[(g * C + c) * 2 + 1] = ss;
+    }
+    __syncthreads();
     if (tid < C) {
         double s = 0.0, ss = 0.0;
-        const float* pp = partials + ((long long)b * ntile * C + tid) * 2;
-        for (int t = 0; t < ntile; ++t) {
-            s += (double)pp[0];
-            ss += (double)pp[1];
-            pp += 2 * C;
+        for (int k = 0; k < G; ++k) {
+            s += scratch[(k * C + tid) * 2];
+            ss += scratch[(k * C + tid) * 2 + 1];
         }
         const double mean = s / T;
         double var = ss / T - mean * mean;
@@ -180,6 +206,7 @@ void dz_set_error(const char* fmt, ...);
 // wave statistics in two steps: slice moments, then (mean, rstd) merged by the consumer
 #define DZ_WS_G 8   /* slices per chunk in wave_stats */
 // slice moments of the raw waveform -> mom[B][DZ_WS_G][2] (mean_i, M2_i)
+extern long long* dz_conv_pool_dbg;
 int dz_launch_wave_stats(const float* wave, long long stride, int B, int S, float* mom,
                          hipStream_t st);
 // slice moments -> stats[B][2] = (mean, rstd)
@@ -211,6 +238,26 @@ int dz_launch_gemm_split(const DzConvGemm& p, hipStream_t st);
 int dz_launch_conv_pool(const DzConvGemm& p, hipStream_t st);
 // k_gemm_pre.hip: both operands pre-split into f16 planes, tiles loaded by LDS-DMA
 int dz_launch_gemm_pre(const DzConvGemm& p, hipStream_t st);
+// The same launch with the weighted statistics pooling (paper Eq. 1) fused into the epilogue of the LAST
+// x-vector layer (tdnn5): the 128 x 128 output tile is parked in LDS instead of HBM and reduced there
+// to per-(tile, chunk, speaker, channel) weighted means and centred second moments — exact two-pass
+// statistics of the tile's rows; dz_launch_pool_combine merges the tile pieces of a chunk
+// (Chan et al.).  Rows are the flattened frames of the batch: row r = chunk r / P, frame r % P, frames
+// >= T of a chunk carry no weight.
+struct DzPoolFuse {
+    const float* w;     // [nx * K][Fw] pooling weights (speaker-major per chunk) or NULL (all ones)
+    int Fw, K;          // weight frames per row (interpolated to T when Fw != T); speakers per chunk, <= 4
+    int P, T;           // row pitch per chunk / valid frames per chunk
+    int np;             // piece slots per chunk = dz_pool_pieces(P): 128-row tiles a chunk can touch
+    float* part;        // [nx][np][K][Npad][2] = (mean, M2) of the piece
+    float* s0;          // [nx][np][K][2] = (sum w, sum w^2) of the piece
+};
+inline int dz_pool_pieces(int P) { return (P + 2 * 128 - 2) / 128; }
+bool dz_gemm_pre_pool_ok(const DzConvGemm& p);     // big tiles throughout? (else: unfused path)
+int dz_launch_gemm_pre_pool(const DzConvGemm& p, const DzPoolFuse& q, hipStream_t st);
+// part / s0 as above -> out [nx * K][ldo] = mean (columns 0 .. C-1) | std (columns C .. 2C-1)
+int dz_launch_pool_combine(const float* part, const float* s0, int nx, int K, int np, int P, int T, int C,
+                           int Npad, float* out, int ldo, hipStream_t st);
 int dz_convgemm_ntile(int Tout);
 
 // k_lstm.hip ----------------------------------------------------------------

@@ -52,8 +52,14 @@ __global__ __launch_bounds__(256, 2) void conv_pool_h_kernel(
     const float* __restrict__ ngamma, const float* __restrict__ nbeta,
     const unsigned short* __restrict__ wsp, int Kpad,
     const float* __restrict__ bias, float* __restrict__ Y, float* __restrict__ partials, int ntile,
-    int total, int* __restrict__ oflag) {
+    int total, int* __restrict__ oflag, long long* __restrict__ dbg) {
     using G = Geo<CIN>;
+    // dbg (kbench only): shader-clock stamps of the phases of every tile, wave 0 / wave 3 lane 0 of each workgroup
+    long long* dq = nullptr;
+    if (dbg && (threadIdx.x & 63) == 0 && ((threadIdx.x >> 6) == 0 || (threadIdx.x >> 6) == 3))
+        dq = dbg + ((long long)blockIdx.x * 2 + (threadIdx.x >> 7)) * 64;
+    int dn = 0;
+#define DZ_STAMP() do { if (dq && dn < 64) dq[dn++] = __builtin_readcyclecounter(); } while (0)
     extern __shared__ __attribute__((aligned(256))) char lds[];
     char* xs = lds;                                                  // [2 planes][ROWS][PITCH]
     float* xch = reinterpret_cast<float*>(lds + 2 * G::PLANE);       // [2][3][16][64]
@@ -84,28 +90,61 @@ __global__ __launch_bounds__(256, 2) void conv_pool_h_kernel(
     float amax = 0.f;
     int cur_b = -1;
 
+    // The tile's raw input rows travel global -> registers as ONE batch of loads and are then consumed
+    // (normalised, split, parked in LDS).  Round 2 loaded, waited and parked one float4 per lane at a time — 8 dependent L2 / HBM
+    // round trips per tile with nothing else for the wave to do: 30 k cycles per tile for 3.7 k of MFMAs.
+    constexpr int C4 = CIN / 4;
+    constexpr int NPK = (ROWS * C4 + 255) / 256;
+    f32x4 pv[NPK];
+    auto fetch = [&](int t) {
+        const int b = t / ntile, t0 = (t - b * ntile) * FR;
+        const float* Xb = X + (long long)b * Tin * CIN;
+        // the (row, column) of every piece is loop invariant: left to itself the compiler hoists all
+        // 2 x NPK of them out of the tile loop and keeps them live through the MFMA phase (spills)
+        int tid_l = tid;
+        asm volatile("" : "+v"(tid_l));
+#pragma unroll
+        for (int i = 0; i < NPK; ++i) {
+            const int idx = tid_l + 256 * i;
+            const int r = idx / C4, c4 = idx - r * C4;
+            pv[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (idx < ROWS * C4 && t0 + r < Tin)
+                pv[i] = *reinterpret_cast<const f32x4*>(Xb + (long long)(t0 + r) * CIN + 4 * c4);
+        }
+    };
+
     for (int t = t_begin; t < t_end; ++t) {
+        // (all of the tile's loads in flight at once; issued here, ahead of the norm update and the
+        // barrier.  Issued a phase earlier — before or after the previous tile's MFMAs — the 32 registers
+        // would be live next to the accumulators / the pooled blocks: the kernel is at 240 - 256 VGPRs
+        // and spills)
+        DZ_STAMP();
+        fetch(t);
         const int b = t / ntile, tile = t - b * ntile;
         const int t0 = tile * FR;
         if (b != cur_b) {                       // scale / shift of this chunk's InstanceNorm
             __syncthreads();                    // (nobody still reads the previous chunk's)
             if (npart)       // straight from the producer's tile partials: no finalize launch
-                dz_norm_from_partials(npart, b, npart_tiles, CIN, npart_T, ngamma, nbeta, nrm, tid);
+                dz_norm_from_partials(npart, b, npart_tiles, CIN, npart_T, ngamma, nbeta, nrm, tid, 256,
+                                      reinterpret_cast<double*>(xch));   // (the exchange area is idle between tiles)
             else
                 for (int i = tid; i < 2 * CIN; i += 256)
                     nrm[i] = i < CIN ? nscale[(long long)b * CIN + i] : nshift[(long long)b * CIN + i - CIN];
             cur_b = b;
         }
         __syncthreads();                        // previous tile's fragment / exchange reads are done
+        DZ_STAMP();
         // ---- park the tile: normalise + LeakyReLU, split, two planes --------------------------
-        {
-            const float* Xb = X + (long long)b * Tin * CIN;
-            constexpr int C4 = CIN / 4;
-            for (int idx = tid; idx < ROWS * C4; idx += 256) {
+        int tid_p = tid;
+        asm volatile("" : "+v"(tid_p));
+#pragma unroll
+        for (int i = 0; i < NPK; ++i) {
+            const int idx = tid_p + 256 * i;
+            if (idx < ROWS * C4) {
                 const int r = idx / C4, c4 = idx - r * C4;
                 f32x4 v = {0.f, 0.f, 0.f, 0.f};
                 if (t0 + r < Tin) {
-                    v = *reinterpret_cast<const f32x4*>(Xb + (long long)(t0 + r) * CIN + 4 * c4);
+                    v = pv[i];
                     const f32x4 sc = *reinterpret_cast<const f32x4*>(nrm + 4 * c4);
                     const f32x4 sh = *reinterpret_cast<const f32x4*>(nrm + CIN + 4 * c4);
 #pragma unroll
@@ -122,7 +161,9 @@ __global__ __launch_bounds__(256, 2) void conv_pool_h_kernel(
                 *reinterpret_cast<f16x4*>(d + G::PLANE) = lo;
             }
         }
+        DZ_STAMP();
         __syncthreads();
+        DZ_STAMP();
         // ---- three blocks (frames 3 m + bk), this wave's half of the k-steps -------------------
         f32x16 part[3];
 #pragma unroll
@@ -146,6 +187,7 @@ __global__ __launch_bounds__(256, 2) void conv_pool_h_kernel(
 #pragma unroll
             for (int r = 0; r < 16; ++r) part[bk][r] = accm[r] + accx[r] * (1.f / 2048.f);
         }
+        DZ_STAMP();
         // ---- the k-halves meet: half 1 hands its partial sums over ------------------------------
         if (kh == 1) {
 #pragma unroll
@@ -154,6 +196,7 @@ __global__ __launch_bounds__(256, 2) void conv_pool_h_kernel(
                 for (int r = 0; r < 16; ++r) xch[((nt * 3 + bk) * 16 + r) * 64 + l] = part[bk][r];
         }
         __syncthreads();
+        DZ_STAMP();
         if (kh == 0) {
             f32x16 pmax;
 #pragma unroll
@@ -184,9 +227,15 @@ __global__ __launch_bounds__(256, 2) void conv_pool_h_kernel(
                 pp[1] = ssq;
             }
         }
+        DZ_STAMP();
     }
+#undef DZ_STAMP
     dz_flag_range(oflag, amax);
 }
+
+}  // namespace
+long long* dz_conv_pool_dbg = nullptr;      // set by dz_k_conv_pool_debug (phase stamps, kbench only)
+namespace {
 
 template <int CIN>
 int launch(const DzConvGemm& p, hipStream_t st) {
@@ -199,7 +248,7 @@ int launch(const DzConvGemm& p, hipStream_t st) {
     DZ_LAUNCH((conv_pool_h_kernel<CIN>), dim3(grid), dim3(256), G::LDS, st, p.X, p.Tin, p.Tout, p.Tstore,
               p.nscale, p.nshift, p.npart, p.npart_tiles, p.npart_T, p.ngamma, p.nbeta,
               reinterpret_cast<const unsigned short*>(p.Wsplit), p.Kpad, p.bias, p.Y,
-              p.partials, ntile, total, p.oflag ? p.oflag : dz_cur_oflag);
+              p.partials, ntile, total, p.oflag ? p.oflag : dz_cur_oflag, dz_conv_pool_dbg);
     DZ_HIP(hipGetLastError());
     return 0;
 }

@@ -37,6 +37,7 @@
 // tiles only add operand traffic.  Hence off by default.
 #include "dz_common.h"
 #include <stdlib.h>
+#include <type_traits>
 
 namespace {
 
@@ -57,9 +58,20 @@ constexpr float LO_UNSCALE = 1.f / 2048.f;
 __device__ __forceinline__ float leaky(float v) { return v > 0.f ? v : v * DZ_LEAKY_SLOPE; }
 
 // One output tile of (32 MT MW) x (64 NT): MW x 2 waves, MT x NT fragments of 32 x 32 per wave.
-template <int EPI, int MW, int MT, int NT>
-__device__ __forceinline__ void gemm_pre_tile(const DzConvGemm& p, const int t0, const int n0, char* smem) {
-    constexpr int PLANE_A = plane_a(MW), STAGE = stage_bytes(MW), PAR_OFF = 2 * STAGE;
+// LDS of the pooled epilogue (after the k-loop): the f32 output tile [128][YT_PITCH] over the two stages,
+// then the epilogue parameters, the tile rows' pooling weights and the reduction scratch
+constexpr int YT_PITCH = 132;                                   // floats; = 4 mod 32: conflict-free 16-byte row writes
+constexpr int POOL_PAR = BM * YT_PITCH * 4;                     // bias | e0 | e1
+constexpr int POOL_WT = POOL_PAR + 3 * BN * 4;                  // [4][128] weights of the tile's rows
+constexpr int POOL_RED = POOL_WT + 4 * BM * 4;                  // [2 parts][2 halves][4][128]
+constexpr int POOL_S0 = POOL_RED + 2 * 2 * 4 * BN * 4;          // [8 (part, k)][8 sub-ranges][2], then [8][2]
+constexpr size_t POOL_LDS = POOL_S0 + 8 * 8 * 2 * 4 + 8 * 2 * 4;
+
+template <int EPI, int MW, int MT, int NT, bool ILV = false, bool POOL = false>
+__device__ __forceinline__ void gemm_pre_tile(const DzConvGemm& p, const int t0, const int n0, char* smem,
+                                              const int flags = 0, const DzPoolFuse* q = nullptr) {
+    constexpr int PLANE_A = plane_a(MW), STAGE = stage_bytes(MW), PAR_OFF = POOL ? POOL_PAR : 2 * STAGE;
+    static_assert(!POOL || (MW == 2 && MT == 2 && NT == 2), "pooled epilogue: 128 x 128 tiles only");
     const int tid = threadIdx.x;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6), l = tid & 63;
 
@@ -159,6 +171,7 @@ __device__ __forceinline__ void gemm_pre_tile(const DzConvGemm& p, const int t0,
 
     const int nk = p.Kpad / KT;
     issue(0, 0);
+    constexpr bool FULL = MW == 2 && MT == 2 && NT == 2;     // 128 x 128 tile, 4 waves: the interleaved loop below
     // The epilogue's per-column parameters go to LDS now: fetched from global memory inside the
     // epilogue they were 16 dependent round trips per lane (three 16-byte loads per column group,
     // no registers left to hoist them into) — ~20 % of a tile's time with nothing else to run.
@@ -173,6 +186,125 @@ __device__ __forceinline__ void gemm_pre_tile(const DzConvGemm& p, const int t0,
             *reinterpret_cast<f32x4*>(par + which * BN + c4) = v;
         }
     }
+    if (FULL && ILV) {
+        // ---- interleaved k-loop (round 3) -------------------------------------------------------------
+        // The plain loop below issues the 8 LDS-DMA pieces of tile kt+1 in one block at the top of
+        // tile kt: an LDS-DMA instruction occupies its wave's issue port for 60 - 185 cycles
+        // (MI355X_MICROARCH.md, cycle constants), i.e. ~1000 cycles per k-tile during which this wave
+        // issues no MFMA — more than the 768 cycles its 24 MFMAs take.  Here one piece follows every
+        // second MFMA of the first 16 (the last 8 MFMAs are the landing slack before the next
+        // top-of-loop wait), and a fragment is re-read for the next 16-wide k-step as soon as its last
+        // MFMA has been issued (same 32 fragment registers, rotated).  The order is pinned with
+        // sched_barrier; no branches inside the loop body (piece -> plane / row block is a
+        // compile-time function of j for 2 + 2 waves; the tap / channel of the activation offset
+        // advances incrementally instead of by a division per tile).
+        const int r2 = w & 1;                                       // rank inside the pair of waves of a side
+        char* const dbase = smem + dst0 + r2 * 1024;
+        // flags & 1 (TIMING EXPERIMENT, wrong results): address the operands as if the planes were stored
+        // k-block-major ([k / 32][row][32]: a 16-row piece = 1 KiB contiguous = 8 full cache lines instead
+        // of 16 half lines)
+        const bool kbf = flags & 1;
+        const int vstep_e = kbf ? 1024 : vstep;
+        const int vofs = (kbf ? ((isB ? n0 : t0) + (l >> 2)) * 64 + (((l & 3) ^ ((l >> 4) & 3)) << 4) : voff0) + r2 * vstep_e;
+        const int kb_rows64 = (isB ? p.Npad : p.Tin) * 64;
+        int cpos = 0, tapo = 0;                                     // channel / tap offset (elements) of tile kt + 1
+        auto advance = [&]() -> int {                               // -> soffset (bytes) of the NEXT tile
+            cpos += KT;
+            if (!isB && p.taps > 1 && cpos >= p.Cin) { cpos -= p.Cin; tapo += p.dil * p.ldx; }
+            if (kbf) return (cpos >> 5) * kb_rows64 + (isB ? 0 : (tapo / p.ldx) * 64);
+            return isB ? cpos * 2 : (tapo + cpos) * 2;
+        };
+        int soff_next = 0, stage_next = 0;
+        const bool no_dma = flags & 2, no_rd = flags & 4;           // TIMING EXPERIMENTS (wrong results)
+        auto piece = [&](int j) {                                   // j = 0..7: pieces r2 + 2j of "8 hi, then 8 lo"
+            const int lo = j >= 4, i = r2 + 2 * (j & 3);            // i-th 16-row block of the plane (r2 folded into bases)
+            (void)i;
+            if (no_dma) return;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(lo ? rs_lo : rs_hi,
+                (__attribute__((address_space(3))) void*)(dbase + stage_next * STAGE + lo * dplane + (j & 3) * 2048), 16,
+                vofs + (j & 3) * 2 * vstep_e, soff_next, 0, 0);
+        };
+        const char* sa0 = smem + (wm * 64) * 64;
+        const char* sb0 = smem + 2 * PLANE_A + (wn * 64) * 64;
+#define DZ_RD(base, plane, t, ks) (*reinterpret_cast<const f16x8*>((no_rd ? smem : (base) + (plane) + (t) * 2048) + foff[ks]))
+#define DZ_MM(mt, nt)                                                                                     \
+    accx[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[nt], al[mt], accx[mt][nt], 0, 0, 0);          \
+    accm[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[nt], ah[mt], accm[mt][nt], 0, 0, 0);          \
+    accx[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl[nt], ah[mt], accx[mt][nt], 0, 0, 0)
+#define DZ_PIN() __builtin_amdgcn_sched_barrier(0)
+        // `more` is a compile-time constant: the last tile (nothing left to fetch) is peeled off, so the
+        // body has no branches around the pieces
+        auto body = [&](const int kt, auto more_c) {
+            constexpr bool more = decltype(more_c)::value;
+            // own DMA of tile kt has landed + every wave has finished the fragment reads of tile kt-1
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            soff_next = advance();
+            stage_next = (kt + 1) & 1;
+            const char* sa = sa0 + (kt & 1) * STAGE;
+            const char* sb = sb0 + (kt & 1) * STAGE;
+            f16x8 ah[2], al[2], bh[2], bl[2];
+            bh[0] = DZ_RD(sb, 0, 0, 0); al[0] = DZ_RD(sa, PLANE_A, 0, 0); ah[0] = DZ_RD(sa, 0, 0, 0);
+            bl[0] = DZ_RD(sb, PLANE_B, 0, 0);
+            bh[1] = DZ_RD(sb, 0, 1, 0); bl[1] = DZ_RD(sb, PLANE_B, 1, 0);
+            ah[1] = DZ_RD(sa, 0, 1, 0); al[1] = DZ_RD(sa, PLANE_A, 1, 0);
+            DZ_PIN();
+            // ---- k-step 0: (0,0) (0,1) (1,1) (1,0) ----
+            accx[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[0], al[0], accx[0][0], 0, 0, 0);
+            accm[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[0], ah[0], accm[0][0], 0, 0, 0);
+            DZ_PIN();
+            if (more) piece(0);
+            DZ_PIN();
+            accx[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl[0], ah[0], accx[0][0], 0, 0, 0);
+            accx[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[1], al[0], accx[0][1], 0, 0, 0);
+            DZ_PIN();
+            if (more) piece(1);
+            DZ_PIN();
+            accm[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[1], ah[0], accm[0][1], 0, 0, 0);
+            accx[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl[1], ah[0], accx[0][1], 0, 0, 0);
+            DZ_PIN();
+            if (more) piece(2);
+            ah[0] = DZ_RD(sa, 0, 0, 1); al[0] = DZ_RD(sa, PLANE_A, 0, 1);      // row block 0 is done with k-step 0
+            DZ_PIN();
+            accx[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[1], al[1], accx[1][1], 0, 0, 0);
+            accm[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[1], ah[1], accm[1][1], 0, 0, 0);
+            DZ_PIN();
+            if (more) piece(3);
+            DZ_PIN();
+            accx[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl[1], ah[1], accx[1][1], 0, 0, 0);
+            accx[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[0], al[1], accx[1][0], 0, 0, 0);
+            DZ_PIN();
+            if (more) piece(4);
+            bh[1] = DZ_RD(sb, 0, 1, 1); bl[1] = DZ_RD(sb, PLANE_B, 1, 1);      // column block 1 is done
+            DZ_PIN();
+            accm[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[0], ah[1], accm[1][0], 0, 0, 0);
+            accx[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl[0], ah[1], accx[1][0], 0, 0, 0);
+            DZ_PIN();
+            if (more) piece(5);
+            bh[0] = DZ_RD(sb, 0, 0, 1); bl[0] = DZ_RD(sb, PLANE_B, 0, 1);
+            ah[1] = DZ_RD(sa, 0, 1, 1); al[1] = DZ_RD(sa, PLANE_A, 1, 1);
+            DZ_PIN();
+            // ---- k-step 1: (0,1) (0,0) (1,0) (1,1): operands in the order they were re-read ----
+            accx[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[1], al[0], accx[0][1], 0, 0, 0);
+            accm[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[1], ah[0], accm[0][1], 0, 0, 0);
+            DZ_PIN();
+            if (more) piece(6);
+            DZ_PIN();
+            accx[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl[1], ah[0], accx[0][1], 0, 0, 0);
+            accx[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[0], al[0], accx[0][0], 0, 0, 0);
+            DZ_PIN();
+            if (more) piece(7);
+            DZ_PIN();
+            accm[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[0], ah[0], accm[0][0], 0, 0, 0);
+            accx[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl[0], ah[0], accx[0][0], 0, 0, 0);
+            DZ_MM(1, 0);
+            DZ_MM(1, 1);
+        };
+        for (int kt = 0; kt + 1 < nk; ++kt) body(kt, std::true_type{});
+        body(nk - 1, std::false_type{});
+#undef DZ_RD
+#undef DZ_MM
+#undef DZ_PIN
+    } else
     for (int kt = 0; kt < nk; ++kt) {
         // own DMA of tile kt has landed + every wave has finished the fragment reads of tile kt-1
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -189,6 +321,8 @@ __device__ __forceinline__ void gemm_pre_tile(const DzConvGemm& p, const int t0,
     typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
     unsigned short* Yhi = reinterpret_cast<unsigned short*>(p.Ysplit);
     float amax = 0.f;
+    float* yt = reinterpret_cast<float*>(smem);
+    if (POOL) __syncthreads();        // every wave is done with the last k-tile: the tile buffer reuses the stages
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
         const int t = t0 + wm * 32 * MT + mt * 32 + li;
@@ -218,6 +352,10 @@ __device__ __forceinline__ void gemm_pre_tile(const DzConvGemm& p, const int t0,
                     if (EPI == DZ_EPI_RELU_BN) x = fmaxf(x, 0.f) * e0[e] + e1[e];
                     v[e] = x;
                 }
+                if (POOL) {
+                    *reinterpret_cast<f32x4*>(yt + (t - t0) * YT_PITCH + nc) = v;
+                    continue;
+                }
                 const long long idx = (long long)t * p.ldy + n;
                 if (p.Y && ok) {
                     if (n + 3 < p.Nstore) {
@@ -245,19 +383,146 @@ __device__ __forceinline__ void gemm_pre_tile(const DzConvGemm& p, const int t0,
             }
     }
     dz_flag_range(p.oflag, amax);
+    if constexpr (POOL) {
+        // ---- weighted statistics pooling of the tile (DzPoolFuse) ---------------------------------------
+        float* wt = reinterpret_cast<float*>(smem + POOL_WT);
+        float* red = reinterpret_cast<float*>(smem + POOL_RED);
+        float* s0t = reinterpret_cast<float*>(smem + POOL_S0);
+        float* s0f = s0t + 8 * 8 * 2;
+        const int K = q->K, P = q->P, T = q->T;
+        // pooling weights of the tile's rows (the interpolation of stats_pool_reg_kernel, k_pool.hip)
+        for (int i = tid; i < K * BM; i += 256) {
+            const int k = i >> 7, rl = i & 127, r = t0 + rl;
+            const int b = r / P, t = r - b * P;
+            float wv = 0.f;
+            if (t < T && r < p.Tout) {
+                wv = 1.f;
+                if (q->w) {
+                    const float* wr = q->w + (long long)(b * K + k) * q->Fw;
+                    if (q->Fw == T) {
+                        wv = wr[t];
+                    } else {
+                        float src = ((float)q->Fw / (float)T) * ((float)t + 0.5f) - 0.5f;
+                        if (src < 0.f) src = 0.f;
+                        const int i0 = (int)src;
+                        const int i1 = i0 + (i0 < q->Fw - 1 ? 1 : 0);
+                        const float l1 = src - (float)i0;
+                        wv = (1.f - l1) * wr[i0] + l1 * wr[i1];
+                    }
+                }
+            }
+            wt[i] = wv;
+        }
+        __syncthreads();                                   // tile + weights are in LDS
+        const int b0 = t0 / P;
+        int rb = (b0 + 1) * P - t0;                        // first local row of the next chunk
+        if (rb > BM) rb = BM;
+        const int c = tid & 127, h = tid >> 7;
+        // (sum w, sum w^2) of each (part, speaker): 8 sub-ranges of 16 rows, then summed in fixed order
+        if (tid < 64) {
+            const int pk = tid >> 3, sub = tid & 7, part = pk >> 2, k = pk & 3;
+            float a = 0.f, a2 = 0.f;
+            if (k < K) {
+                const int lo = max(part ? rb : 0, 16 * sub), hi = min(part ? BM : rb, 16 * sub + 16);
+                for (int r = lo; r < hi; ++r) {
+                    const float wv = wt[k * BM + r];
+                    a += wv;
+                    a2 += wv * wv;
+                }
+            }
+            s0t[(pk * 8 + sub) * 2] = a;
+            s0t[(pk * 8 + sub) * 2 + 1] = a2;
+        }
+        // pass 1: sum w x over this thread's half of the rows, per part and speaker
+        float s1[2][4];
+#pragma unroll
+        for (int part = 0; part < 2; ++part) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) s1[part][k] = 0.f;
+            const int lo = max(part ? rb : 0, 64 * h), hi = min(part ? BM : rb, 64 * h + 64);
+            for (int r = lo; r < hi; ++r) {
+                const float x = yt[r * YT_PITCH + c];
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (k < K) s1[part][k] += wt[k * BM + r] * x;
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) red[((part * 2 + h) * 4 + k) * BN + c] = s1[part][k];
+        }
+        __syncthreads();
+        if (tid < 8) {
+            float a = 0.f, a2 = 0.f;
+            for (int sub = 0; sub < 8; ++sub) {
+                a += s0t[(tid * 8 + sub) * 2];
+                a2 += s0t[(tid * 8 + sub) * 2 + 1];
+            }
+            s0f[tid * 2] = a;
+            s0f[tid * 2 + 1] = a2;
+        }
+        float mean[2][4];
+#pragma unroll
+        for (int part = 0; part < 2; ++part)
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                mean[part][k] = red[((part * 2 + 0) * 4 + k) * BN + c] + red[((part * 2 + 1) * 4 + k) * BN + c];
+        __syncthreads();                                   // s0f is complete; every thread has read pass 1's sums
+#pragma unroll
+        for (int part = 0; part < 2; ++part) {
+            float m2[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float v1 = s0f[(part * 4 + k) * 2];
+                mean[part][k] = v1 > 0.f ? mean[part][k] / v1 : 0.f;
+                m2[k] = 0.f;
+            }
+            const int lo = max(part ? rb : 0, 64 * h), hi = min(part ? BM : rb, 64 * h + 64);
+            for (int r = lo; r < hi; ++r) {
+                const float x = yt[r * YT_PITCH + c];
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (k < K) {
+                        const float d = x - mean[part][k];
+                        m2[k] += (d * d) * wt[k * BM + r];
+                    }
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) red[((part * 2 + h) * 4 + k) * BN + c] = m2[k];
+        }
+        __syncthreads();
+        if (h == 0) {
+            const int nx = p.Tout / P;                       // chunks in this launch
+#pragma unroll
+            for (int part = 0; part < 2; ++part) {
+                const int b = b0 + part;
+                if (b >= nx || (part && rb >= BM)) continue;
+                const int piece = t0 / BM - (b * P) / BM;    // 0 .. np - 1
+                for (int k = 0; k < K; ++k) {
+                    const float M2 = red[((part * 2 + 0) * 4 + k) * BN + c] + red[((part * 2 + 1) * 4 + k) * BN + c];
+                    float* o = q->part + ((((long long)b * q->np + piece) * K + k) * p.Npad + n0 + c) * 2;
+                    o[0] = mean[part][k];
+                    o[1] = M2;
+                    if (n0 == 0 && c == 0) {
+                        float* so = q->s0 + (((long long)b * q->np + piece) * K + k) * 2;
+                        so[0] = s0f[(part * 4 + k) * 2];
+                        so[1] = s0f[(part * 4 + k) * 2 + 1];
+                    }
+                }
+            }
+        }
+    }
 }
 
 // Workgroups [0, mbig * gy): 128 x 128 tiles over the first mbig * 128 rows (XCD-aware order of
 // dz_tile_map); the rest: 64 x 64 tiles over the remaining rows — XCD r owns row tiles r, r+8, ...
 // and sweeps the N tiles of one row tile back to back (activation rows stay in that XCD's L2).
-template <int EPI>
-__global__ __launch_bounds__(256, 2) void gemm_pre_kernel(DzConvGemm p, int mbig, int msmall) {
+template <int EPI, bool ILV>
+__global__ __launch_bounds__(256, 2) void gemm_pre_kernel(DzConvGemm p, int mbig, int msmall, int flags) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int gy = p.Npad / BN, L = blockIdx.x;
     if (L < mbig * gy) {
         int bx, by, bz;
         dz_tile_map_lin(L, mbig, gy, 1, p.agroup, bx, by, bz);
-        gemm_pre_tile<EPI, 2, 2, 2>(p, bx * BM, by * BN, smem);
+        gemm_pre_tile<EPI, 2, 2, 2, ILV>(p, bx * BM, by * BN, smem, flags);
     } else {
         const int Ls = L - mbig * gy, gys = 2 * gy;
         const int xcd = Ls & 7, j = Ls >> 3;
@@ -265,6 +530,16 @@ __global__ __launch_bounds__(256, 2) void gemm_pre_kernel(DzConvGemm p, int mbig
         if (ms >= msmall) return;
         gemm_pre_tile<EPI, 2, 1, 1>(p, mbig * BM + ms * 64, by * 64, smem);
     }
+}
+
+// tdnn5 with the statistics pooling in its epilogue: 128 x 128 tiles only (the launcher falls back to the
+// unfused path when a launch would use small tiles)
+__global__ __launch_bounds__(256, 2) void gemm_pre_pool_kernel(DzConvGemm p, DzPoolFuse q, int gx) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int gy = p.Npad / BN;
+    int bx, by, bz;
+    dz_tile_map_lin(blockIdx.x, gx, gy, 1, p.agroup, bx, by, bz);
+    gemm_pre_tile<DZ_EPI_TDNN, 2, 2, 2, true, true>(p, bx * BM, by * BN, smem, 0, &q);
 }
 
 // 384 x 128 tiles, 12 waves (3 per SIMD), one workgroup per CU: a third fewer operand bytes per MFMA
@@ -292,6 +567,24 @@ int big_tiles_mode() {
     return mode;
 }
 
+// DZ_GP_LOOP=0: the plain k-loop (all LDS-DMA pieces of the next tile issued in one block) instead of the
+// interleaved one
+bool interleaved_loop() {
+    static const bool on = [] {
+        const char* e = getenv("DZ_GP_LOOP");
+        return !(e && e[0] == '0');
+    }();
+    return on;
+}
+
+int dbg_flags() {      // DZ_GP_DBG: timing experiments of the interleaved loop (results are wrong)
+    static const int f = [] {
+        const char* e = getenv("DZ_GP_DBG");
+        return e ? atoi(e) : 0;
+    }();
+    return f;
+}
+
 // DZ_GEMM_TAIL=1: 64 x 64 tiles for the rows of a mostly empty last round as well (see the header)
 bool tail_tiles_enabled() {
     static const bool on = [] {
@@ -311,8 +604,9 @@ int wg_slots() {   // resident workgroups of this kernel on the chip: 2 per CU (
 
 template <int EPI>
 int launch(const DzConvGemm& p, hipStream_t st) {
-    static DzAttrOnce attr_once, attr_big;
-    DZ_HIP(attr_once.raise((const void*)gemm_pre_kernel<EPI>, (int)lds_bytes(2)));
+    static DzAttrOnce attr_once, attr_ilv, attr_big;
+    DZ_HIP(attr_once.raise((const void*)gemm_pre_kernel<EPI, false>, (int)lds_bytes(2)));
+    DZ_HIP(attr_ilv.raise((const void*)gemm_pre_kernel<EPI, true>, (int)lds_bytes(2)));
     const int gx = (p.Tout + BM - 1) / BM, gy = p.Npad / BN, slots = wg_slots();
     {
         const int gxb = (p.Tout + 64 * MW_BIG - 1) / (64 * MW_BIG);
@@ -333,12 +627,40 @@ int launch(const DzConvGemm& p, hipStream_t st) {
     const int rows_left = p.Tout - mbig * BM;
     const int msmall = rows_left > 0 ? (rows_left + 63) / 64 : 0;
     const int nwg = mbig * gy + ((msmall + 7) / 8) * 8 * (2 * gy);
-    DZ_LAUNCH((gemm_pre_kernel<EPI>), dim3(nwg), dim3(256), lds_bytes(2), st, p, mbig, msmall);
+    if (interleaved_loop())
+        DZ_LAUNCH((gemm_pre_kernel<EPI, true>), dim3(nwg), dim3(256), lds_bytes(2), st, p, mbig, msmall, dbg_flags());
+    else
+        DZ_LAUNCH((gemm_pre_kernel<EPI, false>), dim3(nwg), dim3(256), lds_bytes(2), st, p, mbig, msmall, 0);
     DZ_HIP(hipGetLastError());
     return 0;
 }
 
 }  // namespace
+
+bool dz_gemm_pre_pool_ok(const DzConvGemm& p) {
+    const int gx = (p.Tout + BM - 1) / BM, gy = p.Npad / BN;
+    return 4 * gx * gy >= wg_slots();                  // the latency regime uses 64 x 64 tiles: not built pooled
+}
+
+int dz_launch_gemm_pre_pool(const DzConvGemm& p_in, const DzPoolFuse& q, hipStream_t st) {
+    DzConvGemm p = p_in;
+    if (!p.oflag) p.oflag = dz_cur_oflag;
+    DZ_REQUIRE(p.Wsplit && p.Xsplit && q.part && q.s0, "gemm_pre_pool: NULL operand");
+    DZ_REQUIRE(p.epi == DZ_EPI_TDNN && p.B == 1 && p.taps == 1 && p.K == p.Kpad && p.Cin % KT == 0 && p.ldx % 8 == 0 &&
+                   p.Npad % BN == 0 && p.Tout == p.Tin,
+               "gemm_pre_pool: built for the flattened 1 x 1 TDNN layer");
+    DZ_REQUIRE(q.np == dz_pool_pieces(q.P), "gemm_pre_pool: np must be dz_pool_pieces(P)");
+    DZ_REQUIRE(q.K >= 1 && q.K <= 4 && q.P >= BM && q.T >= 2 && q.T <= q.P && p.Tout % q.P == 0 && q.Fw >= 2,
+               "gemm_pre_pool: 1..4 speakers, chunk pitch >= 128 rows (got K %d, P %d, T %d)", q.K, q.P, q.T);
+    DZ_REQUIRE((long long)p.Tin * p.ldx * 2 < (1ll << 31) && (long long)p.Npad * p.Kpad * 2 < (1ll << 31),
+               "gemm_pre_pool: operand plane exceeds the 2 GiB buffer-offset range");
+    static DzAttrOnce attr_once;
+    DZ_HIP(attr_once.raise((const void*)gemm_pre_pool_kernel, (int)POOL_LDS));
+    const int gx = (p.Tout + BM - 1) / BM, gy = p.Npad / BN;
+    DZ_LAUNCH(gemm_pre_pool_kernel, dim3(gx * gy), dim3(256), POOL_LDS, st, p, q, gx);
+    DZ_HIP(hipGetLastError());
+    return 0;
+}
 
 int dz_launch_gemm_pre(const DzConvGemm& p_in, hipStream_t st) {
     DzConvGemm p = p_in;

@@ -95,7 +95,8 @@ __global__ __launch_bounds__(128 * WM) void gemm_split_kernel(DzConvGemm p) {
     const float* nsh = PRO ? p.nshift + (long long)b * p.nld : nullptr;
     __shared__ __attribute__((aligned(16))) float nrm_s[PRO ? 256 : 4];   // scale[nld] | shift[nld], nld <= 128
     if (PRO && p.npart) {   // derive them from the producer's tile partials: no finalize launch
-        dz_norm_from_partials(p.npart, b, p.npart_tiles, p.nld, p.npart_T, p.ngamma, p.nbeta, nrm_s, tid);
+        dz_norm_from_partials(p.npart, b, p.npart_tiles, p.nld, p.npart_T, p.ngamma, p.nbeta, nrm_s, tid, C::T,
+                              reinterpret_cast<double*>(smem));   // (the stages are not in use yet)
         nsc = nrm_s;
         nsh = nrm_s + p.nld;
         __syncthreads();

@@ -451,6 +451,48 @@ int dz_launch_stats_pool(const float* X, long long xstride, int T, int C, int ld
     return 0;
 }
 
+// ---------------------------------------------------------------------------
+// pool_combine: the tile pieces of a chunk (means, centred second moments and weight sums left by
+// the pooled epilogue of tdnn5, k_gemm_pre.hip) -> mean | std of paper Eq. 1 (pyannote StatsPool with
+// weights: var = sum w (x - mean)^2 / (v1 - v2 / v1)).  Chan et al.'s pairwise update, in f64, pieces in
+// fixed order.
+// ---------------------------------------------------------------------------
+namespace {
+__global__ __launch_bounds__(256) void pool_combine_kernel(const float* __restrict__ part, const float* __restrict__ s0,
+                                                           int K, int np, int P, int T, int C, int Npad,
+                                                           float* __restrict__ out, int ldo) {
+    const int c = blockIdx.x * 256 + threadIdx.x, row = blockIdx.y;       // row = chunk * K + speaker
+    if (c >= C) return;
+    const int b = row / K, k = row - b * K;
+    const int first = (b * P) / 128, last = (b * P + T - 1) / 128;
+    double v1 = 0.0, v2 = 0.0, mean = 0.0, M2 = 0.0;
+    for (int piece = 0; piece <= last - first; ++piece) {
+        const float* so = s0 + (((long long)b * np + piece) * K + k) * 2;
+        const double w1 = (double)so[0];
+        if (!(w1 > 0.0)) continue;
+        const float* pp = part + ((((long long)b * np + piece) * K + k) * Npad + c) * 2;
+        const double mp = (double)pp[0], m2p = (double)pp[1];
+        const double tot = v1 + w1, delta = mp - mean;
+        M2 += m2p + delta * delta * (v1 * w1 / tot);
+        mean += delta * (w1 / tot);
+        v1 = tot;
+        v2 += (double)so[1];
+    }
+    float* o = out + (long long)row * ldo;
+    o[c] = (float)mean;
+    o[C + c] = (float)sqrt(M2 / (v1 - v2 / v1));
+}
+}  // namespace
+
+int dz_launch_pool_combine(const float* part, const float* s0, int nx, int K, int np, int P, int T, int C,
+                           int Npad, float* out, int ldo, hipStream_t st) {
+    DZ_REQUIRE(part && s0 && out && nx >= 1 && K >= 1 && K <= 4 && np == dz_pool_pieces(P), "pool_combine: bad arguments");
+    DZ_LAUNCH(pool_combine_kernel, dim3((C + 255) / 256, nx * K), dim3(256), 0, st, part, s0, K, np, P, T, C, Npad, out,
+              ldo);
+    DZ_HIP(hipGetLastError());
+    return 0;
+}
+
 int dz_launch_osp(const float* seg, int B, int F, int K, float gamma, float beta, int normalize,
                   int speaker_major, float* out, hipStream_t st) {
     DZ_REQUIRE(K >= 1 && K <= 8, "osp: 1 <= speakers <= 8 (got %d)", K);

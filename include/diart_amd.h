@@ -292,6 +292,9 @@ int dz_k_seg_head(dz_ctx* ctx, const float* m1, const float* cw, const float* cb
                   int normalize, float* d_weights, void* stream);
 int dz_k_conv_pool(dz_ctx* ctx, const dz_convgemm_desc* desc, void* stream);
 int dz_k_convgemm_ntile(int t_out);
+/* measurement hook (tools/kbench.py): while d_stamps != NULL, dz_k_conv_pool launches record shader-clock
+ * stamps of their phases, 2 x 64 per workgroup                                                      */
+int dz_k_conv_pool_debug(long long* d_stamps);
 /* d_stats (B, 2) = (mean, 1/sqrt(biased var + 1e-5)) of each window: InstanceNorm1d(1).  Inside
  * the forward passes the 8 slice moments stay separate and the consumer merges them; this entry
  * point runs the slice kernel plus the merge and synchronises the stream.                     */

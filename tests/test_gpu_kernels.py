@@ -641,3 +641,65 @@ def test_split_gemm_dynamic_range(gpu, kernel):
     denom = (X.double().abs() @ W.double().abs().t())
     err = ((Y.cpu().double() - ref).abs() / denom).max().item()
     assert err < 1e-6, err        # an f32 GEMM of this depth lands at 1e-7 .. 3e-7 by the same measure
+
+
+def test_f16x3_dynamic_range_map(gpu):
+    """VERDICT r2 next #6c: where does the split-f16 arithmetic stop being fp32-grade?  Uniform operand
+    scales 2^-24 .. 2^15 (activations) and 2^-24 .. 2^8 (weights), one operand at a time, error against
+    an f64 reference next to the exact-f32 MFMA kernel's on the same inputs.  The map is printed and
+    written to gpurun_out/f16x3_range.json (DESIGN.md 4.4 quotes it).  Asserted: inside
+    2^-12 <= scale <= 2^12 (magnitudes ~2^-13 .. 2^14 for N(0,1) data) f16x3 is within 3x of the f32
+    kernel's error; below, the ABSOLUTE error floor 2^-36 |w| shows as a relative error that grows with
+    1 / scale (never silent garbage)."""
+    import json
+    from pathlib import Path
+    g = torch.Generator().manual_seed(11)
+    M, K, N = 256, 512, 128
+    X0 = torch.randn(M, K, generator=g)
+    W0 = torch.randn(N, K, generator=g) / math.sqrt(K)
+    bias = torch.zeros(N, device=gpu)
+    lib = _lib.load()
+    rows = []
+
+    def run(X, W):
+        ref = X.double() @ W.double().t()
+        out = {}
+        for kernel in ("f16x3", "f32"):
+            Y = torch.full((M, N), float("nan"), device=gpu)
+            d = _lib.ConvGemmDesc()
+            d.bias, d.Y = bias.data_ptr(), Y.data_ptr()
+            d.B, d.Tin, d.Tout, d.Tstore, d.Cin, d.taps, d.dil = 1, M, M, M, K, 1, 1
+            d.K, d.Kpad, d.Npad, d.Nstore, d.ldx, d.ldy, d.epi = K, K, N, N, K, N, _lib.EPI_BIAS
+            keep = []
+            if kernel == "f16x3":
+                dW, dX = _planes(W).to(gpu), _planes(X).to(gpu)
+                d.Wsplit, d.Xsplit, d.xplane = dW.data_ptr(), dX.data_ptr(), M * K
+                keep += [dW, dX]
+                _lib.check(lib.dz_k_gemm_pre(_ctx(gpu), C.byref(d), None))
+            else:
+                dX, dWf = X.to(gpu), W.to(gpu)
+                d.X, d.W = dX.data_ptr(), dWf.data_ptr()
+                keep += [dX, dWf]
+                _lib.check(lib.dz_k_convgemm(_ctx(gpu), C.byref(d), None))
+            _sync()
+            out[kernel] = ((Y.cpu().double() - ref).norm() / ref.norm()).item()
+        return out
+
+    for which, exps in (("activations", range(-24, 16, 2)), ("weights", range(-24, 10, 2))):
+        for e in exps:
+            sc = 2.0 ** e
+            X, W = (X0 * sc, W0) if which == "activations" else (X0, W0 * sc)
+            if X.abs().max() > 65504 or W.abs().max() > 65504:
+                # beyond the f16 range: a weight is refused at pack time (weights.split_f16), an activation is
+                # flagged by the kernel that writes its planes (test_f16x3_operands_beyond_the_f16_range_...)
+                rows.append({"operand": which, "log2_scale": e, "beyond_f16_range": True})
+                continue
+            r = run(X, W)
+            rows.append({"operand": which, "log2_scale": e, "f16x3_rel_l2": r["f16x3"], "f32_rel_l2": r["f32"]})
+            print(f"{which:12s} scale 2^{e:<4d} f16x3 {r['f16x3']:.2e}   exact f32 {r['f32']:.2e}")
+            if -12 <= e <= 12:
+                assert r["f16x3"] <= max(3 * r["f32"], 1e-6), (which, e, r)
+            assert r["f16x3"] < 2.0 ** (-35 - min(e, -12)) * 64, (which, e, r)     # graceful: ~2^-36 absolute floor
+    out = Path(__file__).resolve().parent.parent / "gpurun_out"
+    out.mkdir(exist_ok=True)
+    (out / "f16x3_range.json").write_text(json.dumps(rows, indent=1))

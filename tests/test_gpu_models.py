@@ -164,3 +164,39 @@ def test_precisions_agree_with_each_other(gpu, chunks):
     de = (out["f32"][1] - out["f16x3"][1]).abs().max().item()
     print("f32 vs f16x3: seg max|d|", ds, "normalised emb max|d|", de)
     assert ds < 5e-5 and de < 5e-6
+
+
+def test_pooling_fused_into_tdnn5_equals_the_two_launch_path(gpu, oracle_models, monkeypatch):
+    """Round 3: tdnn5 keeps its 128 x 128 output tile in LDS and reduces it to weighted moments there
+    (k_gemm_pre.hip pooled epilogue + pool_combine) instead of writing 110 MB of frame features for
+    stats_pool to read back.  Same embeddings as the two-launch path (DZ_POOL_FUSE=0) and as the
+    oracle, for the de-duplicated call (K = 3 speakers per chunk), the reference-shaped rows call
+    (K = 1) and the unweighted call; 12 chunks so that the launch uses big tiles (the latency regime
+    keeps the two-launch path)."""
+    from diart_amd.synth import synth_streams
+    B = 12
+    x = torch.from_numpy(synth_streams(B, 5.0, seed0=40))[:, None, :80000].contiguous()
+    g = torch.Generator().manual_seed(3)
+    w = torch.rand(B, 3, 293, generator=g) ** 2 + 1e-8              # speaker-major (B, K, F)
+    w[1, 2] = 1e-8                                                  # a silent speaker
+    w[2, :, 100:] = 1e-8                                            # weight only in the first pieces
+    outs = {}
+    for fuse in ("1", "0"):
+        monkeypatch.setenv("DZ_POOL_FUSE", fuse)
+        emb = M.EmbeddingModel.from_state(synth_embedding_state(), max_batch=3 * B)
+        emb.to(gpu)
+        multi = emb.model.forward_multi(x.to(gpu), w.to(gpu)).cpu()
+        rows = emb(x.repeat(1, 3, 1).reshape(3 * B, 1, -1).to(gpu), w.reshape(3 * B, 293).to(gpu)).cpu().view(B, 3, 512)
+        plain = emb(x.to(gpu)).cpu()
+        outs[fuse] = (multi, rows, plain)
+    with torch.no_grad():
+        ref = oracle_models[1].forward_multi(x, w.permute(0, 2, 1))
+        ref0 = oracle_models[1](x)
+    for a, b_, name in zip(outs["1"], outs["0"], ("multi", "rows", "plain")):
+        rel = ((a - b_).norm(dim=-1) / b_.norm(dim=-1)).max().item()
+        print("fused vs two-launch", name, rel)
+        assert rel < 2e-6, name
+    for got in outs["1"][:2]:
+        cos = torch.nn.functional.cosine_similarity(got.double(), ref.double(), dim=-1)
+        assert cos.min().item() >= EMB_COS and ((got - ref).norm(dim=-1) / ref.norm(dim=-1)).max().item() < 1e-4
+    assert ((outs["1"][2] - ref0).norm(dim=-1) / ref0.norm(dim=-1)).max().item() < 1e-4
