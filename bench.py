@@ -47,6 +47,8 @@ F_SEG, F_E1, F_E2, F_E3 = 293, 289, 285, 279
 # (the layer's input + output read / written once, f32) and weight bytes per LAUNCH.
 KERNELS = {
     "wave_stats": dict(mac=0, io=320_000, w=0, bound="hbm"),
+    # InstanceNorm + LeakyReLU of the last SincNet stage -> f16 planes (k_front.hip norm_split_kernel), once per network
+    "finalize_norm": dict(mac=0, io=F_SEG * 64 * 4 * 2, w=0, bound="hbm"),
     "sinc_conv0": dict(mac=160_138_000, io=320_000 + 2658 * 80 * 4, w=128 * 96 * 4, bound="mfma_f32"),
     "conv1_pool": dict(mac=63_696_000, io=(2658 * 80 + 884 * 64) * 4, w=64 * 416 * 4, bound="gemm"),
     "conv2_pool": dict(mac=15_840_000, io=(884 * 64 + 293 * 64) * 4, w=64 * 320 * 4, bound="gemm"),
@@ -104,7 +106,7 @@ def device_kernel(tag, precision):
     k = KERNELS[tag]
     fused_pool = split and pre and os.environ.get("DZ_POOL_FUSE", "1") != "0"
     if k["bound"] == "hbm":
-        return {"wave_stats": "wave_stats_kernel",
+        return {"wave_stats": "wave_stats_kernel", "finalize_norm": "norm_split_kernel",
                 "stats_pool": "pool_combine_kernel" if fused_pool else "stats_pool_reg_kernel<3, 72>",
                 "seg_classifier": "seg_head_kernel"}[tag], "hbm", PEAK_HBM_GBPS, "GB/s"
     if k["bound"] == "rec":
@@ -124,9 +126,11 @@ def device_kernel(tag, precision):
         return sym.get(tag, "convgemm_kernel<128, false, 3>"), "mfma", PEAK_F32_MATRIX_TFLOPS, "TFLOP/s"
     if pre and tag == "seg_mlp" and os.environ.get("DZ_MLP_HEAD", "1") != "0":
         return "mlp_head_kernel", "mfma", PEAK_F16_MATRIX_TFLOPS / SPLIT_PRODUCTS, "TFLOP/s"
-    if pre and tag in ("tdnn2", "tdnn3", "tdnn4", "tdnn5", "lstm_proj", "seg_mlp"):
+    nsplit = pre and os.environ.get("DZ_NORM_SPLIT", "1") != "0" and os.environ.get("DZ_CONV_POOL", "1") != "0"
+    if pre and (tag in ("tdnn2", "tdnn3", "tdnn4", "tdnn5", "lstm_proj", "seg_mlp") or (nsplit and tag in ("lstm_proj0", "tdnn1"))):
         ilv = "true" if os.environ.get("DZ_GP_LOOP", "1") != "0" else "false"
-        sym = {"lstm_proj": f"gemm_pre_kernel<0, {ilv}>", "seg_mlp": f"gemm_pre_kernel<1, {ilv}>",
+        sym = {"lstm_proj": f"gemm_pre_kernel<0, {ilv}>", "lstm_proj0": f"gemm_pre_kernel<0, {ilv}>",
+               "seg_mlp": f"gemm_pre_kernel<1, {ilv}>",
                "tdnn5": "gemm_pre_pool_kernel" if fused_pool else f"gemm_pre_kernel<3, {ilv}>"}.get(
                    tag, f"gemm_pre_kernel<3, {ilv}>")
         return sym, "mfma", PEAK_F16_MATRIX_TFLOPS / SPLIT_PRODUCTS, "TFLOP/s"
@@ -168,6 +172,10 @@ def parse():
                     help="N = 1: measure HBM traffic / matrix-core busy per kernel LIVE with rocprofv3 --pmc child "
                          "passes of this command (on: headline precision, ~2 min; all: also the exact-f32 pass; "
                          "off: use the committed passes under profiles/)")
+    ap.add_argument("--config", type=int, default=2, choices=[2, 3],
+                    help="BASELINE.json configs index + 1: 2 = 64 streams, pyannote/segmentation + pyannote/embedding "
+                         "(the metric's config, default); 3 = segmentation-3.0 (powerset) + ECAPA-TDNN through the "
+                         "blocks pipeline, batches of 32 consecutive windows")
     ap.add_argument("--no-exact-f32", action="store_true",
                     help="skip the second, untimed-for-`value` pass on the exact-f32 MFMA path")
     return ap.parse_args()
@@ -414,10 +422,84 @@ def build_roofline(table, precision, n_sampled, pmc):
     return roof, per_kernel
 
 
+# ---- BASELINE.json configs[2]: segmentation-3.0 (powerset) + speechbrain ECAPA-TDNN -------------------
+# algorithmic MACs per 5 s chunk: the segmentation trunk as configs[1] (the classifier has 7 outputs) + 3
+# ECAPA rows per chunk (reference-shaped call, blocks/embedding.py:56-61: one row per local speaker; the
+# mask-selected samples differ per speaker, nothing to de-duplicate): fbank STFT-as-GEMM 498 x 400 x 402,
+# block 0 80 -> 1024 k5, three SE-Res2Net blocks (two 1024 x 1024 1 x 1 + seven 128 x 128 k3 + SE), MFA
+# 3072 x 3072, attentive pooling 9216 -> 128 -> 3072, fc 6144 -> 192; ~498 frames for a full 5 s mask
+ECAPA_MAC_PER_ROW = (498 * (400 * 402 + 201 * 80) + 498 * (80 * 5 * 1024) + 3 * 498 * (2 * 1024 * 1024 + 7 * 128 * 128 * 3 + 2 * 1024 * 128)
+                     + 498 * 3072 * 3072 + 498 * (9216 * 128 + 128 * 3072) + 6144 * 192)
+
+
+def config3(args):
+    """`bench.py --config 3`: one step = SpeakerDiarization.__call__ on 32 CONSECUTIVE windows of one
+    synthetic stream (Benchmark's batch: inference.py:259-266) with the config-3 models: powerset
+    segmentation -> hard multilabel, min-max normalised OSP weights as masks, ECAPA-TDNN on 96 rows,
+    clustering + aggregation + binarisation (C++).  Same JSON contract; value = chunks/s / 2."""
+    from diart_amd import models as M
+    from diart_amd.blocks import SpeakerDiarization, SpeakerDiarizationConfig
+    from diart_amd.features import SlidingWindow, SlidingWindowFeature
+    from diart_amd.hostinfo import limit_host_threads
+    from diart_amd.models import default_precision
+    from diart_amd.synth import synth_ecapa_state, synth_segmentation_state, synth_stream
+    limit_host_threads()
+    if args.gpus != 1:
+        raise SystemExit("bench.py --config 3 is a single-GPU line (one pipeline = one stream)")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X GPU (the HIP path has no CPU fallback)")
+    device = torch.device("cuda", 0)
+    precision = args.precision or default_precision()
+    B = 32
+    cfg = SpeakerDiarizationConfig(
+        segmentation=M.SegmentationModel.from_state(synth_segmentation_state(seed=77, powerset=True), max_batch=B,
+                                                    powerset=True, precision=precision),
+        embedding=M.EmbeddingModel.from_state(synth_ecapa_state(), max_batch=3 * B, precision=precision),
+        latency=0.5, tau_active=0.5, normalize_embedding_weights=True, device=device)
+    pipe = SpeakerDiarization(cfg)
+    total = args.steps + args.warmup
+    S, H = 80000, 8000
+    stream = synth_stream(4242, 5.0 + 0.5 * (B * total + 1))
+    chunks = [SlidingWindowFeature(stream[i * H:i * H + S, None], SlidingWindow(start=i * 0.5, duration=1 / 16000, step=1 / 16000))
+              for i in range(B * total)]
+    log(f"config 3: {len(chunks)} windows of one {len(stream) / 16000:.0f} s stream, batches of {B}, precision {precision}")
+    for i in range(args.warmup):
+        pipe(chunks[i * B:(i + 1) * B])
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    turns = 0
+    for i in range(args.warmup, total):
+        turns += sum(len(a) for a, _ in pipe(chunks[i * B:(i + 1) * B]))
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    cps = B * args.steps / elapsed
+    gflop_chunk = 2.0 * (656_230_928 + 3 * ECAPA_MAC_PER_ROW) / 1e9
+    out = {
+        "metric": "real-time-factor xRT streams/GPU @500ms step", "value": round(cps / 2, 2),
+        "unit": "xRT 16 kHz streams (chunks/s / 2)", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32" if precision == "f32" else "f16x3", "data": "synthetic",
+        "config": {"workload": "configs[2]: single MI355X, pyannote/segmentation-3.0 (powerset) + speechbrain ECAPA-TDNN "
+                               "architectures (random-init weights), 5 s window / 500 ms step, one synthetic stream through "
+                               "the blocks pipeline in batches of 32 consecutive windows (96 embedding rows per step)",
+                   "chunks_per_step": B, "speech_turns_emitted": turns},
+        "roofline": {"kernel": "whole path (no per-kernel brackets on the ECAPA launches)", "bound": "mfma",
+                     "achieved": round(cps * gflop_chunk / 1e3, 2), "peak": round(PEAK_F16_MATRIX_TFLOPS / SPLIT_PRODUCTS, 1),
+                     "unit": "TFLOP/s", "frac": round(cps * gflop_chunk / 1e3 / (PEAK_F16_MATRIX_TFLOPS / SPLIT_PRODUCTS), 4),
+                     "traffic": None, "alg_gflop_per_chunk": round(gflop_chunk, 2),
+                     "peak_note": "f16 matrix peak / 3 (the wide 1 x 1 layers run split-f16; block 0, the Res2Net 128-channel "
+                                  "convolutions, SE and attentive pooling are exact f32 — priced against the faster pipe)"},
+        "cpu_baseline": None,
+    }
+    print(json.dumps(out), flush=True)
+
+
 def main():
     args = parse()
     if args.cpu_worker:
         return cpu_baseline_worker(args.cpu_chunks, args.cpu_threads, 12.0)
+    if args.config == 3:
+        return config3(args)
     from diart_amd import distributed as D
     # `python bench.py --gpus N` as ONE process: start the N ranks ourselves (torch.distributed.run,
     # one rank per GPU, RCCL); under the driver's own torchrun WORLD_SIZE is set and this is a no-op

@@ -231,6 +231,12 @@ static bool pool_fuse_enabled() {
     const char* v = getenv("DZ_POOL_FUSE");
     return !(v && v[0] == '0');
 }
+// DZ_NORM_SPLIT=0: the first consumer of a SincNet normalises and splits on load (k_gemm_split.hip) as in
+// round 2; default: one norm_split launch, then the pre-split kernel
+static bool norm_split_enabled() {
+    const char* v = getenv("DZ_NORM_SPLIT");
+    return !(v && v[0] == '0');
+}
 static bool conv_pool_enabled() {
     const char* v = getenv("DZ_CONV_POOL");
     return !(v && v[0] == '0');
@@ -247,7 +253,7 @@ static int run_gemm(DzConvGemm& p, const void* split, hipStream_t st) {
 }
 
 struct SincScratch {
-    float *stats, *y0, *part0, *sc0, *sh0, *y1, *part1, *sc1, *sh1, *y2, *part2, *sc2, *sh2;
+    float *stats, *y0, *part0, *sc0, *sh0, *y1, *part1, *sc1, *sh1, *y2, *part2, *sc2, *sh2, *xn;
     void carve(Arena& a, const SincGeom& g, int Bm) {
         stats = a.take((size_t)Bm * 2 * DZ_WS_G);   // slice moments of the waveform
         y0 = a.take((size_t)Bm * g.P0 * 80);
@@ -262,6 +268,7 @@ struct SincScratch {
         part2 = a.take((size_t)Bm * g.nt2 * 64 * 2);
         sc2 = a.take((size_t)Bm * 64);
         sh2 = a.take((size_t)Bm * 64);
+        xn = a.take((size_t)Bm * g.P2 * 64);       // normalised output as f16 planes [2][Bm * P2][64]
     }
 };
 
@@ -472,6 +479,20 @@ static int seg_forward(dz_seg* s, const float* d_wave, long long wave_stride, in
             p.B = 1; p.Tin = p.Tout = p.Tstore = B * F; p.Cin = 256; p.K = 256; p.Kpad = 256;
             p.ldx = 256;
         }
+        if (layer == 0 && s->pre && s->w.wih_split[0] && sinc_fused_norm(s->w.sinc) && norm_split_enabled()) {
+            { ProfScope ps(T_FIN, B);
+              if ((rc = dz_launch_norm_split(s->ss.y2, B, F, s->ss.part2, s->g.nt2, s->w.sinc.in2_g, s->w.sinc.in2_b,
+                                             s->ss.xn, rows * 64, st)))
+                  return rc; }
+            DzConvGemm q;
+            memset(&q, 0, sizeof(q));
+            q.W = s->w.wih[0]; q.bias = s->w.bih[0]; q.Y = s->gx; q.Wsplit = s->w.wih_split[0];
+            q.Xsplit = s->ss.xn; q.xplane = rows * 64;
+            q.B = 1; q.Tin = q.Tout = q.Tstore = B * F; q.Cin = 64; q.taps = 1; q.dil = 1; q.K = 64; q.Kpad = 64;
+            q.Npad = 1024; q.Nstore = 1024; q.ldx = 64; q.ldy = 1024; q.epi = DZ_EPI_BIAS;
+            ProfScope ps(T_PROJ0, B);
+            if ((rc = dz_launch_gemm_pre(q, st))) return rc;
+        } else
         { ProfScope ps(layer == 0 ? T_PROJ0 : T_PROJ, B);
           if (layer > 0 && s->pre) {
               p.X = nullptr; p.Xsplit = lin; p.xplane = rows * 256; p.Wsplit = s->w.wih_split[layer];
@@ -656,6 +677,19 @@ static int emb_frames(dz_emb* e, const float* d_wave, long long stride, int B, h
             if (e->pre) { p.Y = nullptr; p.Ysplit = outp; p.yplane = plane; }
         } else {
             p.B = 1; p.Tin = B * P; p.Tout = p.Tstore = B * P - span;
+        }
+        if (i == 0 && e->pre && sinc_fused_norm(e->w.sinc) && norm_split_enabled()) {
+            { ProfScope ps(T_FIN, B);
+              if ((rc = dz_launch_norm_split(e->ss.y2, B, P, e->ss.part2, e->g.nt2, e->w.sinc.in2_g, e->w.sinc.in2_b,
+                                             e->ss.xn, (long long)B * P * 64, st)))
+                  return rc; }
+            p.X = nullptr; p.Xsplit = e->ss.xn; p.xplane = (long long)B * P * 64; p.Wsplit = e->w.tw_split[0];
+            p.norm_on_load = 0; p.npart = nullptr; p.nscale = p.nshift = nullptr; p.nld = 0;
+            p.B = 1; p.Tin = B * P; p.Tout = p.Tstore = B * P - span; p.xbs = p.ybs = 0;
+            p.Y = nullptr; p.Ysplit = outp; p.yplane = plane;
+            { ProfScope ps(T_TDNN1, B); if ((rc = dz_launch_gemm_pre(p, st))) return rc; }
+            in = outp;
+            continue;
         }
         if (i == 4 && e->pre && pool_fuse_enabled() && dz_gemm_pre_pool_ok(p)) {
             // tdnn5 runs with the pooling in its epilogue, i.e. when the weights are known (emb_head)

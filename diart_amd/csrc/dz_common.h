@@ -222,6 +222,9 @@ int dz_launch_sinc_conv0_split(const float* wave, long long stride, int B, int S
                                int stats_are_moments, float gamma, float beta, const void* filt_split,
                                float* y0, int P0, float* partials, int ntile, hipStream_t st);
 int dz_conv0_split_ntile(int F0);
+// y [B][T][64] + tile partials -> InstanceNorm + LeakyReLU -> f16 (hi, lo * 2^11) planes [2][B * T][64]
+int dz_launch_norm_split(const float* y, int B, int T, const float* partials, int ntile, const float* gamma,
+                         const float* beta, void* planes, long long plane, hipStream_t st);
 // partial (sum,sumsq) -> per (b,c) scale/shift of InstanceNorm1d(C, affine)
 int dz_launch_finalize_norm(const float* partials, int B, int ntile, int C, int T,
                             const float* gamma, const float* beta, float* scale, float* shift,

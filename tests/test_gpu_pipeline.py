@@ -205,7 +205,9 @@ def test_stream_batch_on_ring_with_splits_and_tail(gpu):
         seg0, emb0, sc0, as0 = plain(d_audio[:, t * hop:t * hop + W])
         ticket = split.launch(ring)
         seg1, emb1, sc1, as1 = split.finish(ticket)
-        assert np.array_equal(seg0, seg1) and np.array_equal(emb0, emb1)
+        # (the 6-chunk launch pools inside tdnn5's epilogue, the 3-chunk sub-batches are in the latency
+        # regime and pool in a launch of their own: the same embeddings to a few f32 ulps)
+        assert np.array_equal(seg0, seg1) and np.abs(emb0 - emb1).max() < 5e-7
         assert np.array_equal(sc0, sc1) and np.array_equal(as0, as1)
         agg, rows, t0, r, turns, nturns = ticket["tail"]
         for i in range(n):
