@@ -126,7 +126,7 @@ def device_kernel(tag, precision):
         return sym.get(tag, "convgemm_kernel<128, false, 3>"), "mfma", PEAK_F32_MATRIX_TFLOPS, "TFLOP/s"
     if pre and tag == "seg_mlp" and os.environ.get("DZ_MLP_HEAD", "1") != "0":
         return "mlp_head_kernel", "mfma", PEAK_F16_MATRIX_TFLOPS / SPLIT_PRODUCTS, "TFLOP/s"
-    nsplit = pre and os.environ.get("DZ_NORM_SPLIT", "1") != "0" and os.environ.get("DZ_CONV_POOL", "1") != "0"
+    nsplit = pre and os.environ.get("DZ_NORM_SPLIT", "0") == "1" and os.environ.get("DZ_CONV_POOL", "1") != "0"
     if pre and (tag in ("tdnn2", "tdnn3", "tdnn4", "tdnn5", "lstm_proj", "seg_mlp") or (nsplit and tag in ("lstm_proj0", "tdnn1"))):
         ilv = "true" if os.environ.get("DZ_GP_LOOP", "1") != "0" else "false"
         sym = {"lstm_proj": f"gemm_pre_kernel<0, {ilv}>", "lstm_proj0": f"gemm_pre_kernel<0, {ilv}>",

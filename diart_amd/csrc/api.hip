@@ -231,11 +231,15 @@ static bool pool_fuse_enabled() {
     const char* v = getenv("DZ_POOL_FUSE");
     return !(v && v[0] == '0');
 }
-// DZ_NORM_SPLIT=0: the first consumer of a SincNet normalises and splits on load (k_gemm_split.hip) as in
-// round 2; default: one norm_split launch, then the pre-split kernel
+// DZ_NORM_SPLIT=1 (EXPERIMENT, off by default): one norm_split launch applies the last SincNet norm into f16
+// planes and the first LSTM projection / tdnn1 run on the pre-split kernel instead of normalising and
+// splitting on load (k_gemm_split.hip).  Measured in a same-visit A/B (gpurun_out/visit_r3j.log): the two
+// launches get shorter in the pipeline (proj0 157 -> ~150 us as part of gemm_pre<0>, tdnn1 190 -> ~170) and now
+// fit beside a recurrence workgroup — and the STEP gets 2 % slower (1.225 - 1.232 vs 1.201 ms): what they
+// gain is taken from the recurrence and the other GEMMs on the same CUs.
 static bool norm_split_enabled() {
     const char* v = getenv("DZ_NORM_SPLIT");
-    return !(v && v[0] == '0');
+    return v && v[0] == '1';
 }
 static bool conv_pool_enabled() {
     const char* v = getenv("DZ_CONV_POOL");

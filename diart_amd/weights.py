@@ -16,7 +16,7 @@ from __future__ import annotations
 
 import ctypes as C
 import math
-from typing import Dict, List
+from typing import Dict, List, Optional
 
 import torch
 
@@ -76,7 +76,7 @@ def fold_sinc_filters(filt: torch.Tensor) -> torch.Tensor:
     return out
 
 
-def split_f16(w: torch.Tensor) -> torch.Tensor:
+def split_f16(w: torch.Tensor, name: Optional[str] = None) -> torch.Tensor:
     """f32 matrix ``[N][K]`` -> int16 ``[2][N][K]`` of IEEE f16 bit patterns: plane 0 ``hi = f16(w)``,
     plane 1 ``lo = f16((w - hi) * 2^11)`` — the two-term split ``k_gemm_split.hip`` multiplies with
     (``w = hi + lo * 2^-11`` to 22 mantissa bits; the scale keeps ``lo`` a normal f16)."""
@@ -87,7 +87,33 @@ def split_f16(w: torch.Tensor) -> torch.Tensor:
                          "\"f16x3\" arithmetic; load the model with precision=\"f32\"")
     hi = w.to(torch.float16)
     lo = ((w - hi.float()) * 2048.0).to(torch.float16)
+    # How well do the two planes hold THIS matrix?  hi + lo * 2^-11 carries 22 mantissa bits while
+    # |w| >= 2^-14; below, the f16 subnormal spacing leaves an ABSOLUTE error of 2^-36 per element
+    # (tests/test_gpu_kernels.py::test_f16x3_dynamic_range_map: fp32-grade for magnitudes 2^-13 .. 2^15,
+    # 4x worse per factor 4 below).  A layer whose energy sits in such tiny weights (nothing in the
+    # published architectures does; a checkpoint with, say, a BatchNorm scale of 1e6 folded elsewhere
+    # could) is measured here, once, at pack time: relative representation error of the layer, RMS.
+    if w.numel():
+        rep = (hi.double() + lo.double() / 2048.0 - w.double()).norm() / max(float(w.double().norm()), 1e-300)
+        rep = float(rep)
+        SPLIT_REPORT.append((name or f"matrix{len(SPLIT_REPORT)}", tuple(w.shape), rep))
+        if rep > SPLIT_LIMIT:
+            import os
+            msg = (f"split_f16({name or 'matrix'}): the f16x3 planes represent this layer to {rep:.2e} (relative, RMS) — "
+                   f"an f32 copy rounds to ~3e-8; its weights lie below the range the split holds to 22 bits "
+                   f"(|w| >= 2^-14).  Load the model with precision=\"f32\"")
+            if os.environ.get("DZ_SPLIT_STRICT", "1") != "0":
+                raise ValueError(msg + " (DZ_SPLIT_STRICT=0 turns this into a warning)")
+            import warnings
+            warnings.warn(msg)
     return torch.stack([hi, lo]).view(torch.int16).contiguous()
+
+
+# (name, shape, relative RMS representation error) of every matrix split so far in this process, and
+# the error above which a layer is refused: 2^-20 = 9.5e-7 is ~30x an f32 rounding and about where the
+# whole-network gates of this package (segmentation 1e-4 abs, embedding 1e-4 rel) would start to notice
+SPLIT_REPORT: list = []
+SPLIT_LIMIT = 2.0 ** -20
 
 
 def lstm_whh_planes(whh: torch.Tensor, variant: int) -> torch.Tensor:
@@ -152,9 +178,9 @@ class _Packed:
         self.tensors.append(d)
         return d.data_ptr()
 
-    def put_split(self, t: torch.Tensor) -> int:
+    def put_split(self, t: torch.Tensor, name: Optional[str] = None) -> int:
         """The matrix as two f16 planes (hi, lo * 2^11) for the split-f16 GEMM path."""
-        d = split_f16(t).to(self.device)
+        d = split_f16(t, name).to(self.device)
         self.tensors.append(d)
         return d.data_ptr()
 
@@ -175,12 +201,12 @@ def _pack_sincnet(sd: Dict[str, torch.Tensor], pk: _Packed, prefix: str = "sincn
     import os
     if split and os.environ.get("DZ_CONV0_SPLIT", "1") != "0":
         # the unfolded bank, zero padded to [96][256], as f16 planes for the matrix-core kernel
-        w.filt_split = pk.put_split(_pad2(filt, 96, 256))
+        w.filt_split = pk.put_split(_pad2(filt, 96, 256), prefix + "sinc filter bank")
     w.in0_g, w.in0_b = pk.put(g("norm1d.0.weight")), pk.put(g("norm1d.0.bias"))
     w.w1 = pk.put(_conv_pack(g("conv1d.1.weight"), 80, 64, 416))
     if split:
-        w.w1_split = pk.put_split(_conv_pack(g("conv1d.1.weight"), 80, 64, 416))
-        w.w2_split = pk.put_split(_conv_pack(g("conv1d.2.weight"), 64, 64, 320))
+        w.w1_split = pk.put_split(_conv_pack(g("conv1d.1.weight"), 80, 64, 416), prefix + "conv1d.1")
+        w.w2_split = pk.put_split(_conv_pack(g("conv1d.2.weight"), 64, 64, 320), prefix + "conv1d.2")
     w.b1 = pk.put(_pad1(g("conv1d.1.bias"), 64))
     w.in1_g, w.in1_b = pk.put(_pad1(g("norm1d.1.weight"), 64)), pk.put(_pad1(g("norm1d.1.bias"), 64))
     w.w2 = pk.put(_conv_pack(g("conv1d.2.weight"), 64, 64, 320))
@@ -210,7 +236,7 @@ class PackedSegmentation:
             kpad = 64 if layer == 0 else 256
             w.wih[layer] = pk.put(_pad2(wih, 1024, kpad))
             if split:
-                w.wih_split[layer] = pk.put_split(_pad2(wih, 1024, kpad))
+                w.wih_split[layer] = pk.put_split(_pad2(wih, 1024, kpad), f"lstm.weight_ih_l{layer}")
             bias = torch.cat([g(f"lstm.bias_ih_l{layer}") + g(f"lstm.bias_hh_l{layer}"),
                               g(f"lstm.bias_ih_l{layer}_reverse") + g(f"lstm.bias_hh_l{layer}_reverse")], 0)
             w.bih[layer] = pk.put(um(bias))
@@ -225,7 +251,8 @@ class PackedSegmentation:
         w.lin0_w, w.lin0_b = pk.put(g("linear.0.weight")), pk.put(g("linear.0.bias"))
         w.lin1_w, w.lin1_b = pk.put(g("linear.1.weight")), pk.put(g("linear.1.bias"))
         if split:
-            w.lin0_split, w.lin1_split = pk.put_split(g("linear.0.weight")), pk.put_split(g("linear.1.weight"))
+            w.lin0_split = pk.put_split(g("linear.0.weight"), "linear.0")
+            w.lin1_split = pk.put_split(g("linear.1.weight"), "linear.1")
         cls_w, cls_b = g("classifier.weight"), g("classifier.bias")
         ncls = cls_w.shape[0]
         w.cls_w, w.cls_b = pk.put(_pad2(cls_w, 64, 128)), pk.put(_pad1(cls_b, 64))
@@ -259,7 +286,7 @@ class PackedEmbedding:
             k = cw.shape[2] * cin_pad
             w.tw[i] = pk.put(_conv_pack(cw, cin_pad, npad, (k + 31) // 32 * 32))
             if split:
-                w.tw_split[i] = pk.put_split(_conv_pack(cw, cin_pad, npad, (k + 31) // 32 * 32))
+                w.tw_split[i] = pk.put_split(_conv_pack(cw, cin_pad, npad, (k + 31) // 32 * 32), f"tdnn{i + 1}")
             w.tb[i] = pk.put(_pad1(g(f"tdnns.{3 * i}.bias"), npad))
             bn = f"tdnns.{3 * i + 2}."
             scale = g(bn + "weight") / torch.sqrt(g(bn + "running_var") + BN_EPS)
