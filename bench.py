@@ -97,6 +97,16 @@ PEAK_F32_VECTOR_TFLOPS = 157.3   # f32 vector peak (packed FMA); plain v_fma_f32
 PEAK_HBM_GBPS = 8000.0
 
 
+STREAMS_PER_GPU = [64]
+
+
+def lstm_chains_per_wg():
+    """k_lstm.hip: DZ_LSTM_NC, else two chunks per workgroup once one chain per CU would take more than
+    half the chip."""
+    e = os.environ.get("DZ_LSTM_NC", "")
+    return int(e) if e in ("1", "2") else (2 if 2 * STREAMS_PER_GPU[0] > 128 else 1)
+
+
 def device_kernel(tag, precision):
     """bench tag -> (rocprofv3 kernel symbol, bound, chip peak, unit): the roofline is reported per
     DEVICE kernel, so the layers that share one instantiation are one entry."""
@@ -114,7 +124,7 @@ def device_kernel(tag, precision):
             sym = {"0": "lstm_mfma_kernel<true>", "3": "lstm_mfma_dma_kernel"}.get(
                 lstm, "lstm_mfma1_kernel<true, %d>" % (0 if lstm == "1" else 8))
             return sym, "mfma", PEAK_F16_MATRIX_TFLOPS / SPLIT_PRODUCTS, "TFLOP/s"
-        return "lstm_rec_kernel<true>", "valu", PEAK_F32_VECTOR_TFLOPS, "TFLOP/s"
+        return f"lstm_rec_kernel<true, {lstm_chains_per_wg()}>", "valu", PEAK_F32_VECTOR_TFLOPS, "TFLOP/s"
     if tag == "sinc_conv0" and split and os.environ.get("DZ_CONV0_SPLIT", "1") != "0":
         return "sinc_conv0_h_kernel", "mfma", PEAK_F16_MATRIX_TFLOPS / SPLIT_PRODUCTS, "TFLOP/s"
     if k["bound"] == "mfma_f32" or not split:
@@ -402,7 +412,7 @@ def build_roofline(table, precision, n_sampled, pmc):
         if e["traffic"]:
             e["traffic_over_alg_bytes"] = round(e["traffic"] / max(1, e["alg_bytes_per_launch"]), 2)
         if g.startswith("lstm_rec_kernel"):
-            cus = min(256.0, 2.0 * v["chunks"] / v["launches"])   # one (chunk, direction) chain per CU
+            cus = min(256.0, 2.0 * v["chunks"] / v["launches"] / lstm_chains_per_wg())   # (chunk[s], direction) per CU
             e["cus_occupied"] = cus
             e["frac_of_occupied_cus_plain_fma"] = round(ach / (PEAK_F32_VECTOR_TFLOPS / 2 * cus / 256.0), 4)
         if g.startswith("lstm_mfma"):
@@ -548,6 +558,7 @@ def main():
 
     # ---- synthetic streams of this rank, resident in HBM -------------------------------
     n = args.streams
+    STREAMS_PER_GPU[0] = n
     hop, S = 8000, 80000
     total_steps = args.steps + args.warmup
     seconds = (S + hop * (total_steps + 1)) / 16000.0

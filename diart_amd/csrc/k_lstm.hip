@@ -21,6 +21,7 @@
 // With one chain per CU, 64 chunks x 2 directions occupy 128 of the 256 CUs and the x-vector
 // TDNN stack of the same step runs beside it on the rest.
 #include "dz_common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -52,20 +53,36 @@ constexpr int PF = 4;      // x-projection prefetch distance in steps
 // UM: gx columns are unit-major (dir*512 + unit*4 + gate: what dz_seg_forward's projection GEMM
 // writes, one fully contiguous 2 KiB row read per step) instead of PyTorch's gate-major
 // (dir*512 + gate*128 + unit)
-template <bool UM>
+//
+// NC = chains (chunks) per workgroup.  NC = 1: one chain per CU, the shortest step (config 5 latency,
+// small batches).  NC = 2 (round 3): two chunks share the W_hh registers of one
+// workgroup — the 64 packed FMAs of a lane run once per chain (16 independent accumulator chains
+// instead of 8, the second chain's LDS / DPP / transcendental latencies under the first one's FMAs) and
+// one barrier serves both; a 64-chunk batch then occupies 64 CUs instead of 128 for ~1.25x the layer
+// time, i.e. 0.63x the CU-time, and leaves the other CUs ENTIRELY to the GEMM / convolution workgroups
+// (which at 240 - 256 registers cannot sit beside a recurrence workgroup at all).
+template <bool UM, int NC>
 __global__ __launch_bounds__(512) void lstm_rec_kernel(const float* __restrict__ gx,
                                                        const float* __restrict__ whh,
                                                        float* __restrict__ hout,
                                                        unsigned short* __restrict__ hsp,
                                                        long long hplane, int B, int T) {
-    __shared__ __attribute__((aligned(16))) float hs[RING][128];
-    const int b = blockIdx.x, dir = blockIdx.y;
+    __shared__ __attribute__((aligned(16))) float hs[NC][RING][128];
+    const int dir = blockIdx.y;
     const int tid = threadIdx.x, p = tid & 3, u = tid >> 2;
+    int bc[NC];                               // chunk of chain c (an odd batch's last workgroup repeats its chunk)
+    bool live[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        const int b = blockIdx.x * NC + c;
+        live[c] = b < B;
+        bc[c] = live[c] ? b : B - 1;
+    }
 
     // slot j of lane p holds gate (j ^ p): the three DPP adds below then need no selects.
     // Weights are kept as k-PAIRS (f32x2 in an even-aligned register pair) so the contraction is
-    // 64 v_pk_fma_f32 per step instead of 128 v_fma_f32: the 157 TFLOP/s f32 vector peak of
-    // gfx950 is the packed rate, scalar v_fma_f32 tops out at half of it.
+    // 64 v_pk_fma_f32 per step instead of 128 v_fma_f32 (measured, tools/ubench/fma_rate.hip: the packed
+    // form retires 1.3 - 1.4x the FLOPs of plain v_fma_f32 per cycle at two waves per SIMD).
     f32x2 wreg[4][16];
     {
         const float* Wd = whh + (long long)dir * 512 * 128;
@@ -80,49 +97,68 @@ __global__ __launch_bounds__(512) void lstm_rec_kernel(const float* __restrict__
             }
         }
     }
-    if (tid < 128) hs[0][tid] = 0.f;
+    if (tid < 128) {
+#pragma unroll
+        for (int c = 0; c < NC; ++c) hs[c][0][tid] = 0.f;
+    }
 
     // lane p owns gate p (PyTorch order i, f, g, o); g = tanh(x) = 2*sigmoid(2x) - 1
     const float act_scale = (p == 2) ? 2.f : 1.f;
     const float act_shift = (p == 2) ? -1.f : 0.f;
     // step s works on frame tt(s) = s (forward) or T-1-s (backward)
     const long long tstep = dir ? -1024 : 1024;
-    const float* gptr = gx + ((long long)b * T + (dir ? T - 1 : 0)) * 1024 + dir * 512 + (UM ? u * 4 + p : p * 128 + u);
-    // h_t goes out as f32 (hout) and / or as the two f16 planes a k_gemm_pre.hip consumer reads
-    // (hsp: hi = f16(h), lo = f16((h - hi) * 2^11) hplane elements further)
-    const long long hbase = (long long)b * T * 256 + dir * 128;
+    const float* gptr[NC];
+    long long hbase[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        gptr[c] = gx + ((long long)bc[c] * T + (dir ? T - 1 : 0)) * 1024 + dir * 512 + (UM ? u * 4 + p : p * 128 + u);
+        // h_t goes out as f32 (hout) and / or as the two f16 planes a k_gemm_pre.hip consumer reads
+        // (hsp: hi = f16(h), lo = f16((h - hi) * 2^11) hplane elements further)
+        hbase[c] = (long long)bc[c] * T * 256 + dir * 128;
+    }
     // flush role of this thread: step i = tid / 64 of the block, units 2*(tid % 64), +1
     const int fl_i = tid >> 6, fl_u = (tid & 63) * 2;
 
-    float c = 0.f;
-    auto gload = [&](int s) { return gptr[(long long)(s < T ? s : T - 1) * tstep]; };
-    auto step = [&](int s, float gcur) {
-        // acc[j] = (sum over even k, sum over odd k) of gate slot j
-        f32x2 acc[4];
+    float cst[NC];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[j] = (f32x2){0.f, 0.f};
-        const float* hp = &hs[s & (RING - 1)][4 * p];
+    for (int c = 0; c < NC; ++c) cst[c] = 0.f;
+    auto gload = [&](int c, int s) { return gptr[c][(long long)(s < T ? s : T - 1) * tstep]; };
+    auto step = [&](int s, const float (&gcur)[NC]) {
+        // acc[c][j] = (sum over even k, sum over odd k) of gate slot j of chain c
+        f32x2 acc[NC][4];
+#pragma unroll
+        for (int c = 0; c < NC; ++c)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[c][j] = (f32x2){0.f, 0.f};
 #pragma unroll
         for (int jj = 0; jj < 8; ++jj) {
-            const f32x4 hv = *reinterpret_cast<const f32x4*>(hp + 16 * jj);
-            const f32x2 h01 = {hv[0], hv[1]}, h23 = {hv[2], hv[3]};
+            f32x4 hv[NC];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                acc[j] = __builtin_elementwise_fma(wreg[j][2 * jj + 0], h01, acc[j]);
-                acc[j] = __builtin_elementwise_fma(wreg[j][2 * jj + 1], h23, acc[j]);
+            for (int c = 0; c < NC; ++c) hv[c] = *reinterpret_cast<const f32x4*>(&hs[c][s & (RING - 1)][4 * p + 16 * jj]);
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                const f32x2 h01 = {hv[c][0], hv[c][1]}, h23 = {hv[c][2], hv[c][3]};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    acc[c][j] = __builtin_elementwise_fma(wreg[j][2 * jj + 0], h01, acc[c][j]);
+                    acc[c][j] = __builtin_elementwise_fma(wreg[j][2 * jj + 1], h23, acc[c][j]);
+                }
             }
         }
-        const float s0_ = acc[0][0] + acc[0][1], s1_ = acc[1][0] + acc[1][1],
-                    s2_ = acc[2][0] + acc[2][1], s3_ = acc[3][0] + acc[3][1];
-        // fold the k-quarters: lane p ends with gate p (slot j of lane q is gate j ^ q)
-        const float a0 = s0_ + dpp<DPP_XOR1>(s1_);
-        const float a1 = s2_ + dpp<DPP_XOR1>(s3_);
-        const float pre = a0 + dpp<DPP_XOR2>(a1) + gcur;
-        const float act = act_scale * fast_sigmoid(act_scale * pre) + act_shift;
-        const float ig = dpp<0x00>(act), fg = dpp<0x55>(act), gg = dpp<0xAA>(act),
-                    og = dpp<0xFF>(act);
-        c = fg * c + ig * gg;
-        if (p == 0) hs[(s + 1) & (RING - 1)][u] = og * (2.f * fast_sigmoid(2.f * c) - 1.f);
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const float s0_ = acc[c][0][0] + acc[c][0][1], s1_ = acc[c][1][0] + acc[c][1][1],
+                        s2_ = acc[c][2][0] + acc[c][2][1], s3_ = acc[c][3][0] + acc[c][3][1];
+            // fold the k-quarters: lane p ends with gate p (slot j of lane q is gate j ^ q)
+            const float a0 = s0_ + dpp<DPP_XOR1>(s1_);
+            const float a1 = s2_ + dpp<DPP_XOR1>(s3_);
+            const float pre = a0 + dpp<DPP_XOR2>(a1) + gcur[c];
+            const float act = act_scale * fast_sigmoid(act_scale * pre) + act_shift;
+            const float ig = dpp<0x00>(act), fg = dpp<0x55>(act), gg = dpp<0xAA>(act),
+                        og = dpp<0xFF>(act);
+            cst[c] = fg * cst[c] + ig * gg;
+            if (p == 0) hs[c][(s + 1) & (RING - 1)][u] = og * (2.f * fast_sigmoid(2.f * cst[c]) - 1.f);
+        }
         lds_barrier();
     };
     // h of steps s0 .. s0+n-1 -> global (coalesced 256 B per step-row).  Nothing waits on these
@@ -131,39 +167,53 @@ __global__ __launch_bounds__(512) void lstm_rec_kernel(const float* __restrict__
         const int s = s0 + fl_i;
         if (fl_i < n) {
             const int tt = dir ? T - 1 - s : s;
-            const float2 v = *reinterpret_cast<const float2*>(&hs[(s + 1) & (RING - 1)][fl_u]);
-            const long long o = hbase + (long long)tt * 256 + fl_u;
-            if (hout) *reinterpret_cast<float2*>(hout + o) = v;
-            if (hsp) {
-                const f32x2 x = {v.x, v.y};
-                const f16x2 hi = __builtin_convertvector(x, f16x2);
-                const f16x2 lo = __builtin_convertvector((x - __builtin_convertvector(hi, f32x2)) * 2048.f, f16x2);
-                *reinterpret_cast<f16x2*>(hsp + o) = hi;
-                *reinterpret_cast<f16x2*>(hsp + hplane + o) = lo;
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                if (!live[c]) continue;
+                const float2 v = *reinterpret_cast<const float2*>(&hs[c][(s + 1) & (RING - 1)][fl_u]);
+                const long long o = hbase[c] + (long long)tt * 256 + fl_u;
+                if (hout) *reinterpret_cast<float2*>(hout + o) = v;
+                if (hsp) {
+                    const f32x2 x = {v.x, v.y};
+                    const f16x2 hi = __builtin_convertvector(x, f16x2);
+                    const f16x2 lo = __builtin_convertvector((x - __builtin_convertvector(hi, f32x2)) * 2048.f, f16x2);
+                    *reinterpret_cast<f16x2*>(hsp + o) = hi;
+                    *reinterpret_cast<f16x2*>(hsp + hplane + o) = lo;
+                }
             }
         }
     };
 
-    float gq[PF];
+    float gq[NC][PF];
 #pragma unroll
-    for (int i = 0; i < PF; ++i) gq[i] = gload(i);
+    for (int c = 0; c < NC; ++c)
+#pragma unroll
+        for (int i = 0; i < PF; ++i) gq[c][i] = gload(c, i);
     __syncthreads();
 
     int s0 = 0;
     for (; s0 + BLK <= T; s0 += BLK) {
 #pragma unroll
         for (int i = 0; i < BLK; ++i) {
-            const float gcur = gq[i % PF];
-            gq[i % PF] = gload(s0 + i + PF);
+            float gcur[NC];
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                gcur[c] = gq[c][i % PF];
+                gq[c][i % PF] = gload(c, s0 + i + PF);
+            }
             step(s0 + i, gcur);
         }
         flush(s0, BLK);
     }
     for (int s = s0; s < T; ++s) {
-        const float gcur = gq[0];
+        float gcur[NC];
 #pragma unroll
-        for (int i = 0; i + 1 < PF; ++i) gq[i] = gq[i + 1];
-        gq[PF - 1] = gload(s + PF);
+        for (int c = 0; c < NC; ++c) {
+            gcur[c] = gq[c][0];
+#pragma unroll
+            for (int i = 0; i + 1 < PF; ++i) gq[c][i] = gq[c][i + 1];
+            gq[c][PF - 1] = gload(c, s + PF);
+        }
         step(s, gcur);
     }
     flush(s0, T - s0);
@@ -173,14 +223,29 @@ __global__ __launch_bounds__(512) void lstm_rec_kernel(const float* __restrict__
 
 int dz_launch_lstm(const float* gx, const float* whh, float* hout, void* hsplit, long long hplane,
                    int B, int T, int unit_major, hipStream_t st) {
-    dim3 grid(B, 2);
     unsigned short* hsp = reinterpret_cast<unsigned short*>(hsplit);
     DZ_REQUIRE(hout || hsp, "lstm: no output");
     DZ_REQUIRE(hplane % 2 == 0, "lstm: odd plane distance");
-    if (unit_major)
-        DZ_LAUNCH(lstm_rec_kernel<true>, grid, dim3(512), 0, st, gx, whh, hout, hsp, hplane, B, T);
-    else
-        DZ_LAUNCH(lstm_rec_kernel<false>, grid, dim3(512), 0, st, gx, whh, hout, hsp, hplane, B, T);
+    // chains per workgroup: DZ_LSTM_NC=1|2, default 2 once one chain per CU would take more than half the
+    // chip (2 B > 128 CUs), 1 below (the latency regime: a step of one chain is the shortest)
+    static const int forced = [] {
+        const char* e = getenv("DZ_LSTM_NC");
+        return e ? atoi(e) : 0;
+    }();
+    const int nc = forced == 1 || forced == 2 ? forced : (2 * B > 128 ? 2 : 1);
+    if (nc == 2) {
+        dim3 grid((B + 1) / 2, 2);
+        if (unit_major)
+            DZ_LAUNCH((lstm_rec_kernel<true, 2>), grid, dim3(512), 0, st, gx, whh, hout, hsp, hplane, B, T);
+        else
+            DZ_LAUNCH((lstm_rec_kernel<false, 2>), grid, dim3(512), 0, st, gx, whh, hout, hsp, hplane, B, T);
+    } else {
+        dim3 grid(B, 2);
+        if (unit_major)
+            DZ_LAUNCH((lstm_rec_kernel<true, 1>), grid, dim3(512), 0, st, gx, whh, hout, hsp, hplane, B, T);
+        else
+            DZ_LAUNCH((lstm_rec_kernel<false, 1>), grid, dim3(512), 0, st, gx, whh, hout, hsp, hplane, B, T);
+    }
     DZ_HIP(hipGetLastError());
     return 0;
 }

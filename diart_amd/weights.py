@@ -116,6 +116,18 @@ SPLIT_REPORT: list = []
 SPLIT_LIMIT = 2.0 ** -20
 
 
+def dft_matrices(n_fft: int = 400) -> torch.Tensor:
+    """The windowed DFT of ECAPA's Fbank as ONE real GEMM operand, (2 * (n_fft // 2 + 1), n_fft) f64: rows
+    0 .. 200 = cos(2 pi k n / N) * w[n], rows 201 .. 401 = sin(...) * w[n] (periodic Hamming window, like
+    torch.stft's callers): frame @ rows.T = (Re, -Im) of rfft(frame * w); the power spectrum squares and adds
+    the halves (tests/test_oracle_dsp_pins.py checks it against numpy.fft)."""
+    n = torch.arange(n_fft, dtype=torch.float64)
+    win = torch.hamming_window(n_fft, dtype=torch.float64)
+    k = torch.arange(n_fft // 2 + 1, dtype=torch.float64)[:, None]
+    ang = 2.0 * math.pi * k * n[None, :] / n_fft
+    return torch.cat([torch.cos(ang) * win, torch.sin(ang) * win], 0)
+
+
 def lstm_whh_planes(whh: torch.Tensor, variant: int) -> torch.Tensor:
     """W_hh ``[2 dir][512][128]`` (PyTorch row order gate*128 + unit) -> int16 ``[2 dir][2 planes][512][128]``
     of f16 bit patterns for the matrix-core recurrence (``k_lstm_mfma.hip``).
@@ -332,12 +344,7 @@ class PackedEcapa:
                 dst.s, dst.h = pk.put(sc), pk.put(sh)
 
         # ---- features ------------------------------------------------------------------
-        n = torch.arange(400, dtype=torch.float64)
-        win = torch.hamming_window(400, dtype=torch.float64)          # periodic, like torch.stft callers
-        k = torch.arange(201, dtype=torch.float64)[:, None]
-        ang = 2.0 * math.pi * k * n[None, :] / 400.0
-        dft = torch.cat([torch.cos(ang) * win, torch.sin(ang) * win], 0)   # (402, 400)
-        w.dft = pk.put(_pad2(dft.float(), 448, 416))
+        w.dft = pk.put(_pad2(dft_matrices().float(), 448, 416))
         w.mel = pk.put(_pad2(ecapa_mel_filterbank().t().contiguous(), 128, 224))
         # ---- network -------------------------------------------------------------------
         layer(w.block0, "blocks.0.conv", 80, 1024, 416)
