@@ -101,10 +101,9 @@ STREAMS_PER_GPU = [64]
 
 
 def lstm_chains_per_wg():
-    """k_lstm.hip: DZ_LSTM_NC, else two chunks per workgroup once one chain per CU would take more than
-    half the chip."""
+    """k_lstm.hip: one chain per workgroup unless DZ_LSTM_NC=2 (experiment)."""
     e = os.environ.get("DZ_LSTM_NC", "")
-    return int(e) if e in ("1", "2") else (2 if 2 * STREAMS_PER_GPU[0] > 128 else 1)
+    return 2 if e == "2" else 1
 
 
 def device_kernel(tag, precision):

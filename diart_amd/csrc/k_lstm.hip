@@ -226,13 +226,16 @@ int dz_launch_lstm(const float* gx, const float* whh, float* hout, void* hsplit,
     unsigned short* hsp = reinterpret_cast<unsigned short*>(hsplit);
     DZ_REQUIRE(hout || hsp, "lstm: no output");
     DZ_REQUIRE(hplane % 2 == 0, "lstm: odd plane distance");
-    // chains per workgroup: DZ_LSTM_NC=1|2, default 2 once one chain per CU would take more than half the
-    // chip (2 B > 128 CUs), 1 below (the latency regime: a step of one chain is the shortest)
+    // chains per workgroup: DZ_LSTM_NC=2 selects the two-chunk form (EXPERIMENT).  Measured on MI355X, 64
+    // chunks (gpurun_out/visit_r3k.log): alone 273.8 us per layer on 64 CUs against 169.7 us on 128 (0.81x the
+    // CU-time, 1.61x the latency), and in the 64-stream pipeline 1.265 / 1.279 ms per step against 1.239 /
+    // 1.229 in the same visit: the longer dependent chain of a lane costs more than the freed CUs return
+    // (at 196 registers the two-chunk workgroup also keeps every GEMM workgroup off its CU).  Default: 1.
     static const int forced = [] {
         const char* e = getenv("DZ_LSTM_NC");
         return e ? atoi(e) : 0;
     }();
-    const int nc = forced == 1 || forced == 2 ? forced : (2 * B > 128 ? 2 : 1);
+    const int nc = forced == 2 ? 2 : 1;
     if (nc == 2) {
         dim3 grid((B + 1) / 2, 2);
         if (unit_major)

@@ -643,7 +643,7 @@ def test_split_gemm_dynamic_range(gpu, kernel):
     assert err < 1e-6, err        # an f32 GEMM of this depth lands at 1e-7 .. 3e-7 by the same measure
 
 
-def test_f16x3_dynamic_range_map(gpu):
+def test_f16x3_dynamic_range_map(gpu, monkeypatch):
     """VERDICT r2 next #6c: where does the split-f16 arithmetic stop being fp32-grade?  Uniform operand
     scales 2^-24 .. 2^15 (activations) and 2^-24 .. 2^8 (weights), one operand at a time, error against
     an f64 reference next to the exact-f32 MFMA kernel's on the same inputs.  The map is printed and
@@ -652,7 +652,10 @@ def test_f16x3_dynamic_range_map(gpu):
     kernel's error; below, the ABSOLUTE error floor 2^-36 |w| shows as a relative error that grows with
     1 / scale (never silent garbage)."""
     import json
+    import warnings
     from pathlib import Path
+    monkeypatch.setenv("DZ_SPLIT_STRICT", "0")       # the map goes below what split_f16 accepts for a real layer
+    warnings.simplefilter("ignore")
     g = torch.Generator().manual_seed(11)
     M, K, N = 256, 512, 128
     X0 = torch.randn(M, K, generator=g)
