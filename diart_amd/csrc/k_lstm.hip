@@ -231,11 +231,8 @@ int dz_launch_lstm(const float* gx, const float* whh, float* hout, void* hsplit,
     // CU-time, 1.61x the latency), and in the 64-stream pipeline 1.265 / 1.279 ms per step against 1.239 /
     // 1.229 in the same visit: the longer dependent chain of a lane costs more than the freed CUs return
     // (at 196 registers the two-chunk workgroup also keeps every GEMM workgroup off its CU).  Default: 1.
-    static const int forced = [] {
-        const char* e = getenv("DZ_LSTM_NC");
-        return e ? atoi(e) : 0;
-    }();
-    const int nc = forced == 2 ? 2 : 1;
+    const char* e_nc = getenv("DZ_LSTM_NC");            // (read per launch: the tests switch it in-process)
+    const int nc = e_nc && e_nc[0] == '2' ? 2 : 1;
     if (nc == 2) {
         dim3 grid((B + 1) / 2, 2);
         if (unit_major)
