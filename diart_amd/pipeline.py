@@ -182,10 +182,12 @@ class StreamBatch:
         # x-projection GEMM of one sub-batch runs under the latency-bound recurrence of another
         self.seg_split = max(1, min(int(os.environ.get("DZ_SEG_SPLIT", "1") if seg_split is None else seg_split), num_streams))
         self.emb_split = max(1, min(int(os.environ.get("DZ_EMB_SPLIT", "1") if emb_split is None else emb_split), num_streams))
-        # HIP stream priorities (0 normal, -1 high) were measured: raising the segmentation chain
-        # changes the step time by < 3 % (noise level) while it stretches the embedding kernels'
-        # wall durations 2x, so both stay at the default; the knobs remain for experiments
-        pa, pb = int(os.environ.get("DZ_PRIO_A", "0")), int(os.environ.get("DZ_PRIO_B", "0"))
+        # HIP stream priorities (0 normal, -1 high).  The segmentation chain is the long dependent one
+        # (4 recurrences + their projections: ~2.2 ms in the pipeline, two lanes): its streams get the
+        # high priority — round 3, two same-visit pairs: 1.215 vs 1.233 and 1.159 vs 1.180 ms per step
+        # (gpurun_out/visit_r3l.log; in round 2, with longer small kernels in that chain, the effect was
+        # inside the noise).  The embedding chain waits for the segmentation anyway and stays normal.
+        pa, pb = int(os.environ.get("DZ_PRIO_A", "-1")), int(os.environ.get("DZ_PRIO_B", "0"))
         # `depth` lanes, each with its own HIP streams and scratch arenas: step t runs on lane
         # t % depth, so a caller that keeps `depth` tickets between launch() and finish() has that
         # many steps on the GPU at once (the latency-bound recurrence of one step under the GEMMs
