@@ -338,13 +338,19 @@ class StreamBatch:
         slot["busy"] = True
         lib, esz = self._lib, 4
         cur = torch.cuda.current_stream(self.device)
+        slot["ev_in"].record(cur)                       # inputs produced on the caller's stream
         # InstanceNorm1d(1) statistics of the windows ONCE for both networks (each SincNet would
-        # otherwise make its own pass over the same 20 MB): on the caller's stream, ahead of `ev_in`
+        # otherwise make its own pass over the same 20 MB).  They go first on the lane's first
+        # segmentation stream — the high-priority one: on the caller's (normal-priority) stream this 14 us
+        # kernel sat 60 - 130 us in the queue in front of BOTH chains — and every other stream of the
+        # step waits for `ev_in` re-recorded behind it.
         stats = slot["stats"] if self.shared_stats else None
         if stats is not None:
-            _lib.check(lib.dz_wave_stats(self._ctx, base, stride, N, S, stats.data_ptr(), cur.cuda_stream),
+            a0 = lane["a"][0]
+            a0.wait_event(slot["ev_in"])
+            _lib.check(lib.dz_wave_stats(self._ctx, base, stride, N, S, stats.data_ptr(), a0.cuda_stream),
                        "dz_wave_stats")
-        slot["ev_in"].record(cur)                       # inputs produced on the caller's stream
+            slot["ev_in"].record(a0)
         for (i0, i1), h, a, ev in zip(sa, hsegs, lane["a"], slot["ev_seg"]):
             a.wait_event(slot["ev_in"])
             if i1 == i0:                                 # fewer rows than sub-batches
