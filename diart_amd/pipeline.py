@@ -323,6 +323,15 @@ class StreamBatch:
         decide that)."""
         assert 1 <= N <= self.n
         F, K, D = self.seg.num_frames(S), None, self.emb.dimension
+        if (S, 0) not in self._sub:
+            # The scratch arenas of EVERY lane before the first kernel of this window size is enqueued
+            # (~0.85 GB of hipMalloc + hipMemset per lane).  Created lazily, lane 1's allocation ran while
+            # step 0's kernels were on the GPU and whatever kernel was resident then sat 21 - 29 ms in the
+            # trace (round 2: a stats_pool launch; round 3, profiles/r03_a_stall_report.json: a TDNN GEMM
+            # and the split-K linear, dispatch index 106 / 117 = the second step) — device memory
+            # allocation stalls the running queues.
+            for ln in range(self.depth):
+                self._handles(S, ln)
         lane = self.lanes[self._t % self.depth]
         hsegs, hembs, _, _ = self._handles(S, self._t % self.depth)
         # sub-batch ranges of THIS step's rows (each at most the capacity its handle was built for)
