@@ -120,7 +120,7 @@ def dft_matrices(n_fft: int = 400) -> torch.Tensor:
     """The windowed DFT of ECAPA's Fbank as ONE real GEMM operand, (2 * (n_fft // 2 + 1), n_fft) f64: rows
     0 .. 200 = cos(2 pi k n / N) * w[n], rows 201 .. 401 = sin(...) * w[n] (periodic Hamming window, like
     torch.stft's callers): frame @ rows.T = (Re, -Im) of rfft(frame * w); the power spectrum squares and adds
-    the halves (tests/test_oracle_dsp_pins.py checks it against numpy.fft)."""
+    the halves (pinned against numpy.fft by the DSP pin tests under tests/)."""
     n = torch.arange(n_fft, dtype=torch.float64)
     win = torch.hamming_window(n_fft, dtype=torch.float64)
     k = torch.arange(n_fft // 2 + 1, dtype=torch.float64)[:, None]
