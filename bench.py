@@ -47,8 +47,8 @@ F_SEG, F_E1, F_E2, F_E3 = 293, 289, 285, 279
 # (the layer's input + output read / written once, f32) and weight bytes per LAUNCH.
 KERNELS = {
     "wave_stats": dict(mac=0, io=320_000, w=0, bound="hbm"),
-    # InstanceNorm + LeakyReLU of the last SincNet stage -> f16 planes (k_front.hip norm_split_kernel), once per network
-    "finalize_norm": dict(mac=0, io=F_SEG * 64 * 4 * 2, w=0, bound="hbm"),
+    # tile partials -> InstanceNorm scale / shift (exact-f32 path and DZ_FUSED_NORM=0 only: launch-bound)
+    "finalize_norm": dict(mac=0, io=(10 * 64 * 2 + 2 * 64) * 4, w=0, bound="hbm"),
     "sinc_conv0": dict(mac=160_138_000, io=320_000 + 2658 * 80 * 4, w=128 * 96 * 4, bound="mfma_f32"),
     "conv1_pool": dict(mac=63_696_000, io=(2658 * 80 + 884 * 64) * 4, w=64 * 416 * 4, bound="gemm"),
     "conv2_pool": dict(mac=15_840_000, io=(884 * 64 + 293 * 64) * 4, w=64 * 320 * 4, bound="gemm"),
@@ -79,7 +79,7 @@ def kernels_for(precision):
     tile in LDS and writes per-tile weighted moments (k_gemm_pre.hip pooled epilogue), and the `stats_pool`
     tag is the small kernel that merges them (pool_combine)."""
     k = {n: dict(v) for n, v in KERNELS.items()}
-    if precision == "f16x3" and os.environ.get("DZ_POOL_FUSE", "1") != "0" and os.environ.get("DZ_GEMM_PRE", "1") != "0":
+    if precision == "f16x3" and os.environ.get("DZ_POOL_FUSE", "1") != "0":
         moments = POOL_PIECES * 3 * 1536 * 2 * 4
         k["tdnn5"]["io"] = F_SEG * 512 * 4 + moments + 3 * F_SEG * 4
         k["stats_pool"]["io"] = moments + 3 * 3008 * 4
@@ -110,12 +110,12 @@ def device_kernel(tag, precision):
     """bench tag -> (rocprofv3 kernel symbol, bound, chip peak, unit): the roofline is reported per
     DEVICE kernel, so the layers that share one instantiation are one entry."""
     split = precision == "f16x3"
-    pre = split and os.environ.get("DZ_GEMM_PRE", "1") != "0"     # wide layers on k_gemm_pre.hip
+    pre = split                                                       # wide layers on k_gemm_pre.hip
     lstm = os.environ.get("DZ_LSTM", "valu")                          # weights.default_lstm_variant
     k = KERNELS[tag]
     fused_pool = split and pre and os.environ.get("DZ_POOL_FUSE", "1") != "0"
     if k["bound"] == "hbm":
-        return {"wave_stats": "wave_stats_kernel", "finalize_norm": "norm_split_kernel",
+        return {"wave_stats": "wave_stats_kernel", "finalize_norm": "finalize_norm_kernel",
                 "stats_pool": "pool_combine_kernel" if fused_pool else "stats_pool_reg_kernel<3, 72>",
                 "seg_classifier": "seg_head_kernel"}[tag], "hbm", PEAK_HBM_GBPS, "GB/s"
     if k["bound"] == "rec":
@@ -593,8 +593,8 @@ def main():
     sampled = [0]
 
     def run(t_first, count, pipe=None, profiled=False):
-        # pipe.depth steps are kept on the GPU (one per lane) while the host runs the clustering +
-        # output tail of the oldest one
+        # pipe.max_inflight steps are launched ahead (pipe.depth of them run concurrently, one per lane; the
+        # others wait in their lane's streams) while the host runs the clustering + output tail of the oldest
         pipe = pipe or main_pipe[0]
         inflight = []
         for t in range(t_first, t_first + count):
@@ -605,7 +605,7 @@ def main():
             h0 = time.perf_counter()
             inflight.append(pipe.launch(window(t)))
             h1 = time.perf_counter()
-            if len(inflight) > pipe.depth:
+            if len(inflight) >= pipe.max_inflight:
                 pipe.finish(inflight.pop(0), want_scores=True)
             host["launch"] += h1 - h0
             host["finish"] += time.perf_counter() - h1
@@ -685,7 +685,7 @@ def main():
     host_fed = None
     if not args.no_host_pass:
         from diart_amd.pipeline import AudioRing
-        ring = AudioRing(n, S, hop, slack_blocks=2 * pipe.depth + 2, device=device)   # >= steps in flight (depth + lag + 1)
+        ring = AudioRing(n, S, hop, slack_blocks=2 * pipe.max_inflight + 2, device=device)   # >= steps in flight
         blocks = audio_cpu.unfold(1, hop, hop)                     # (n, nblocks, hop) view
         pinned = [blocks[:, i].contiguous().pin_memory() for i in range(S // hop + total_steps)]
         for i in range(S // hop - 1):
@@ -704,7 +704,7 @@ def main():
                     h1 = time.perf_counter()
                     inflight.append(pipe.launch(ring))
                 h2 = time.perf_counter()
-                if len(inflight) > pipe.depth:
+                if len(inflight) >= pipe.max_inflight:
                     pipe.finish(inflight.pop(0), want_scores=True)
                 hf["push"] += h1 - h0
                 hf["launch"] += h2 - h1
@@ -758,7 +758,7 @@ def main():
                        "streams_per_gpu": n, "chunks_per_step": world * n, "parallelism": f"streams x{world}",
                        "dist_backend": torch.distributed.get_backend() if world > 1 else None,
                        "weights_abs_sum_per_rank": wsums, "host_threads_per_rank": host_threads,
-                       "steps_in_flight": pipe.depth, "seg_sub_batches": pipe.seg_split,
+                       "steps_in_flight": pipe.max_inflight, "lanes": pipe.depth, "seg_sub_batches": pipe.seg_split,
                        "hip_streams": pipe.num_hip_streams,
                        "exact_f32_value": exact["value"] if exact else None,
                        "host_fed_value": host_fed["value"] if host_fed else None},

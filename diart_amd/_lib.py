@@ -71,6 +71,8 @@ SIGNATURES = {
     "dz_emb_forward_multi": (C.c_int, [vp, vp, C.c_longlong, vp, C.c_int, C.c_int, C.c_int,
                                        C.c_int, vp, vp]),
     "dz_emb_frames": (C.c_int, [vp, vp, C.c_longlong, C.c_int, vp]),
+    "dz_seg_front": (C.c_int, [vp, vp, C.c_longlong, C.c_int, vp]),
+    "dz_seg_back": (C.c_int, [vp, C.c_int, vp, C.c_float, C.c_float, C.c_int, vp, vp]),
     "dz_wave_stats_floats": (C.c_int, []),
     "dz_wave_stats": (C.c_int, [vp, vp, C.c_longlong, C.c_int, C.c_int, vp, vp]),
     "dz_seg_use_wave_stats": (C.c_int, [vp, vp]),

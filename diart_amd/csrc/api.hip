@@ -156,14 +156,24 @@ extern "C" int dz_prof_pause(int paused) {
 extern "C" int dz_prof_collect(void) {
     DZ_HIP(hipDeviceSynchronize());
     std::lock_guard<std::mutex> lk(g_prof_mu);
+    // DZ_PROF_TIMELINE=<file>: additionally append "tag chunks start_us duration_us" of every bracketed launch
+    // (start relative to the first one of this drain; the dispatches' own timestamps, whatever stream they
+    // ran on) — the step's schedule without a tracer slowing the host down (tools/timeline.py)
+    const char* tl_path = getenv("DZ_PROF_TIMELINE");
+    FILE* tl = tl_path && tl_path[0] && g_prof.used > 0 ? fopen(tl_path, "a") : nullptr;
+    if (tl) fprintf(tl, "# drain of %d launches\n", g_prof.used);
     for (int i = 0; i < g_prof.used; ++i) {
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, g_prof.ev[i].start, g_prof.ev[i].stop) == hipSuccess) {
             g_prof.ms[g_prof.tag[i]] += ms;
             g_prof.n[g_prof.tag[i]] += 1;
             g_prof.chunks[g_prof.tag[i]] += g_prof.units[i];
+            float t0 = 0.f;
+            if (tl && hipEventElapsedTime(&t0, g_prof.ev[0].start, g_prof.ev[i].start) == hipSuccess)
+                fprintf(tl, "%s %d %.1f %.1f\n", kProfNames[g_prof.tag[i]], g_prof.units[i], t0 * 1e3, ms * 1e3);
         }
     }
+    if (tl) fclose(tl);
     g_prof.used = 0;
     // an event pair whose bracket never launched (a ProfScope around a path that returned early) fails
     // in hipEventElapsedTime: it is skipped above, and the runtime's sticky "last error" must not be left
@@ -213,13 +223,6 @@ extern "C" int dz_emb_frames_for(int num_samples) {
     return f > 0 ? f : 0;
 }
 
-// DZ_GEMM_PRE=0 keeps the f32-activation split kernel for every layer (k_gemm_split.hip); the
-// default routes the wide layers through k_gemm_pre.hip (activations as f16 hi/lo planes)
-static bool pre_split_enabled() {
-    const char* v = getenv("DZ_GEMM_PRE");
-    return !(v && v[0] == '0');
-}
-
 // DZ_FUSED_NORM=0 keeps the three finalize_norm launches of a SincNet; by default (split-f16 path)
 // every consumer derives its InstanceNorm scale / shift from the producer's tile partials itself
 static bool fused_norm_enabled() {
@@ -230,16 +233,6 @@ static bool fused_norm_enabled() {
 static bool pool_fuse_enabled() {
     const char* v = getenv("DZ_POOL_FUSE");
     return !(v && v[0] == '0');
-}
-// DZ_NORM_SPLIT=1 (EXPERIMENT, off by default): one norm_split launch applies the last SincNet norm into f16
-// planes and the first LSTM projection / tdnn1 run on the pre-split kernel instead of normalising and
-// splitting on load (k_gemm_split.hip).  Measured in a same-visit A/B (gpurun_out/visit_r3j.log): the two
-// launches get shorter in the pipeline (proj0 157 -> ~150 us as part of gemm_pre<0>, tdnn1 190 -> ~170) and now
-// fit beside a recurrence workgroup — and the STEP gets 2 % slower (1.225 - 1.232 vs 1.201 ms): what they
-// gain is taken from the recurrence and the other GEMMs on the same CUs.
-static bool norm_split_enabled() {
-    const char* v = getenv("DZ_NORM_SPLIT");
-    return v && v[0] == '1';
 }
 static bool conv_pool_enabled() {
     const char* v = getenv("DZ_CONV_POOL");
@@ -257,7 +250,7 @@ static int run_gemm(DzConvGemm& p, const void* split, hipStream_t st) {
 }
 
 struct SincScratch {
-    float *stats, *y0, *part0, *sc0, *sh0, *y1, *part1, *sc1, *sh1, *y2, *part2, *sc2, *sh2, *xn;
+    float *stats, *y0, *part0, *sc0, *sh0, *y1, *part1, *sc1, *sh1, *y2, *part2, *sc2, *sh2;
     void carve(Arena& a, const SincGeom& g, int Bm) {
         stats = a.take((size_t)Bm * 2 * DZ_WS_G);   // slice moments of the waveform
         y0 = a.take((size_t)Bm * g.P0 * 80);
@@ -272,7 +265,6 @@ struct SincScratch {
         part2 = a.take((size_t)Bm * g.nt2 * 64 * 2);
         sc2 = a.take((size_t)Bm * 64);
         sh2 = a.take((size_t)Bm * 64);
-        xn = a.take((size_t)Bm * g.P2 * 64);       // normalised output as f16 planes [2][Bm * P2][64]
     }
 };
 
@@ -368,13 +360,16 @@ struct dz_seg {
     const float* ext_stats;   // dz_seg_use_wave_stats: consumed (and cleared) by the next forward
     char* arena;
     SincScratch ss;
-    float *gx, *h0, *h1, *m0, *m1, *logit;
+    float *gx, *gx0, *h0, *h1, *m0, *m1, *logit;
+    int front_B;              // dz_seg_front ran for this many chunks and dz_seg_back has not consumed it yet
+    hipEvent_t ev_gx0_free;   // recorded behind the layer-0 recurrence: the next dz_seg_front may overwrite gx0
 };
 
 static void seg_carve(dz_seg* s, Arena& a) {
     const size_t rows = (size_t)s->Bm * s->g.P2;
     s->ss.carve(a, s->g, s->Bm);
     s->gx = a.take(rows * 1024);
+    s->gx0 = a.take(rows * 1024);      // layer 0's x-projection: written by the front half, one step ahead
     s->h0 = a.take(rows * 256);
     s->h1 = a.take(rows * 256);
     s->m0 = a.take(rows * 128);
@@ -404,7 +399,9 @@ extern "C" int dz_seg_create(dz_ctx* ctx, const dz_seg_weights* w, int max_batch
     dz_seg* s = new (std::nothrow) dz_seg;
     DZ_REQUIRE(s != nullptr, "dz_seg_create: out of memory");
     s->ctx = ctx; s->w = *w; s->g = g; s->Bm = max_batch; s->arena = nullptr; s->ext_stats = nullptr;
-    s->pre = pre_split_enabled() && w->wih_split[1] && w->wih_split[2] && w->wih_split[3] &&
+    s->front_B = 0; s->ev_gx0_free = nullptr;
+    DZ_HIP(hipEventCreateWithFlags(&s->ev_gx0_free, hipEventDisableTiming));
+    s->pre = w->wih_split[1] && w->wih_split[2] && w->wih_split[3] &&
              w->lin0_split && w->lin1_split;
     Arena measure;
     seg_carve(s, measure);
@@ -425,13 +422,16 @@ extern "C" int dz_seg_create(dz_ctx* ctx, const dz_seg_weights* w, int max_batch
 extern "C" int dz_seg_destroy(dz_seg* seg) {
     if (seg) {
         if (seg->arena) (void)hipFree(seg->arena);
+        if (seg->ev_gx0_free) (void)hipEventDestroy(seg->ev_gx0_free);
         delete seg;
     }
     return 0;
 }
 
+// phase 0: the whole network on one stream; 1: front half (SincNet + the first x-projection into gx0);
+// 2: back half (4 recurrences, projections 1..3, MLP head) of the chunks the last front half left
 static int seg_forward(dz_seg* s, const float* d_wave, long long wave_stride, int B, float* d_out,
-                       float* d_osp, float gamma, float beta, int normalize, void* stream);
+                       float* d_osp, float gamma, float beta, int normalize, void* stream, int phase = 0);
 static bool mlp_head_enabled() {
     static const bool on = [] {
         const char* e = getenv("DZ_MLP_HEAD");
@@ -449,19 +449,37 @@ extern "C" int dz_seg_forward_osp(dz_seg* s, const float* d_wave, long long wave
     DZ_REQUIRE(d_weights != nullptr, "dz_seg_forward_osp: d_weights is NULL");
     return seg_forward(s, d_wave, wave_stride, B, d_out, d_weights, gamma, beta, normalize, stream);
 }
+// The two halves of dz_seg_forward_osp for a caller that keeps the stateless front end of the NEXT step
+// off the long dependent chain of this one (StreamBatch): dz_seg_front(t + 2) — SincNet and the first
+// x-projection, on a stream of its own — runs under the recurrences of dz_seg_back(t) on the same handle.
+// The only buffer both halves touch is gx0; the front half waits (on the GPU) for the event the back half
+// records behind the layer-0 recurrence that reads it.
+extern "C" int dz_seg_front(dz_seg* s, const float* d_wave, long long wave_stride, int B, void* stream) {
+    DZ_REQUIRE(s != nullptr, "dz_seg_front: NULL handle");
+    return seg_forward(s, d_wave, wave_stride, B, nullptr, nullptr, 0.f, 0.f, 0, stream, 1);
+}
+extern "C" int dz_seg_back(dz_seg* s, int B, float* d_out, float gamma, float beta, int normalize,
+                           float* d_weights, void* stream) {
+    DZ_REQUIRE(s != nullptr, "dz_seg_back: NULL handle");
+    DZ_REQUIRE(B == s->front_B, "dz_seg_back: %d chunks, but dz_seg_front prepared %d", B, s->front_B);
+    return seg_forward(s, nullptr, 0, B, d_out, d_weights, gamma, beta, normalize, stream, 2);
+}
 static int seg_forward(dz_seg* s, const float* d_wave, long long wave_stride, int B, float* d_out,
-                       float* d_osp, float gamma, float beta, int normalize, void* stream) {
-    DZ_REQUIRE(s && d_out, "dz_seg_forward: NULL argument");
+                       float* d_osp, float gamma, float beta, int normalize, void* stream, int phase) {
+    DZ_REQUIRE(s && (d_out || phase == 1), "dz_seg_forward: NULL argument");
     DZ_REQUIRE(B >= 1 && B <= s->Bm, "dz_seg_forward: batch %d outside [1, %d]", B, s->Bm);
     int rc;
-    if ((rc = check_wave("dz_seg_forward", d_wave, wave_stride, s->g.S))) return rc;
+    if (phase != 2 && (rc = check_wave("dz_seg_forward", d_wave, wave_stride, s->g.S))) return rc;
     DZ_HIP(hipSetDevice(s->ctx->device));
     DzRangeScope range_scope(s->ctx->oflag_dev);
     hipStream_t st = (hipStream_t)stream;
     const int F = s->g.P2;
-    const float* ext = s->ext_stats;
-    s->ext_stats = nullptr;
-    if ((rc = run_sincnet(s->w.sinc, s->g, s->ss, d_wave, wave_stride, B, st, ext))) return rc;
+    if (phase != 2) {
+        if (phase == 1) DZ_HIP(hipStreamWaitEvent(st, s->ev_gx0_free, 0));   // (never recorded yet: no-op)
+        const float* ext = s->ext_stats;
+        s->ext_stats = nullptr;
+        if ((rc = run_sincnet(s->w.sinc, s->g, s->ss, d_wave, wave_stride, B, st, ext))) return rc;
+    }
 
     // 4 x { x-projection of both directions as one GEMM (N = 1024); persistent recurrence }.
     // With s->pre the hidden states travel as f16 (hi, lo) planes (same bytes as f32, same buffers)
@@ -471,8 +489,11 @@ static int seg_forward(dz_seg* s, const float* d_wave, long long wave_stride, in
     for (int layer = 0; layer < 4; ++layer) {
         DzConvGemm p;
         memset(&p, 0, sizeof(p));
-        p.W = s->w.wih[layer]; p.bias = s->w.bih[layer]; p.Y = s->gx;
+        float* const gxl = layer == 0 ? s->gx0 : s->gx;
+        p.W = s->w.wih[layer]; p.bias = s->w.bih[layer]; p.Y = gxl;
         p.taps = 1; p.dil = 1; p.Npad = 1024; p.Nstore = 1024; p.ldy = 1024; p.epi = DZ_EPI_BIAS;
+        const bool do_proj = layer == 0 ? phase != 2 : phase != 1;
+        const bool do_rec = phase != 1;
         if (layer == 0) {
             p.X = s->ss.y2;
             sinc_out_norm(p, s->w.sinc, s->g, s->ss, s->w.wih_split[0] != nullptr);
@@ -483,20 +504,7 @@ static int seg_forward(dz_seg* s, const float* d_wave, long long wave_stride, in
             p.B = 1; p.Tin = p.Tout = p.Tstore = B * F; p.Cin = 256; p.K = 256; p.Kpad = 256;
             p.ldx = 256;
         }
-        if (layer == 0 && s->pre && s->w.wih_split[0] && sinc_fused_norm(s->w.sinc) && norm_split_enabled()) {
-            { ProfScope ps(T_FIN, B);
-              if ((rc = dz_launch_norm_split(s->ss.y2, B, F, s->ss.part2, s->g.nt2, s->w.sinc.in2_g, s->w.sinc.in2_b,
-                                             s->ss.xn, rows * 64, st)))
-                  return rc; }
-            DzConvGemm q;
-            memset(&q, 0, sizeof(q));
-            q.W = s->w.wih[0]; q.bias = s->w.bih[0]; q.Y = s->gx; q.Wsplit = s->w.wih_split[0];
-            q.Xsplit = s->ss.xn; q.xplane = rows * 64;
-            q.B = 1; q.Tin = q.Tout = q.Tstore = B * F; q.Cin = 64; q.taps = 1; q.dil = 1; q.K = 64; q.Kpad = 64;
-            q.Npad = 1024; q.Nstore = 1024; q.ldx = 64; q.ldy = 1024; q.epi = DZ_EPI_BIAS;
-            ProfScope ps(T_PROJ0, B);
-            if ((rc = dz_launch_gemm_pre(q, st))) return rc;
-        } else
+        if (do_proj)
         { ProfScope ps(layer == 0 ? T_PROJ0 : T_PROJ, B);
           if (layer > 0 && s->pre) {
               p.X = nullptr; p.Xsplit = lin; p.xplane = rows * 256; p.Wsplit = s->w.wih_split[layer];
@@ -505,6 +513,10 @@ static int seg_forward(dz_seg* s, const float* d_wave, long long wave_stride, in
               rc = run_gemm(p, s->w.wih_split[layer], st);
           }
           if (rc) return rc; }
+        if (!do_rec) {               // front half: SincNet + the first projection are enqueued, that is all
+            s->front_B = B;
+            return 0;
+        }
         float* hout = (layer & 1) ? s->h1 : s->h0;
         { ProfScope ps(T_REC, B);
           // gx columns are unit-major (weights.py permutes the rows of W_ih); 16 chains per
@@ -512,10 +524,14 @@ static int seg_forward(dz_seg* s, const float* d_wave, long long wave_stride, in
           float* hf = s->pre ? nullptr : hout;
           void* hs = s->pre ? (void*)hout : nullptr;
           rc = s->w.whh_split[layer]
-                   ? dz_launch_lstm_mfma(s->gx, s->w.whh_split[layer], hf, hs, rows * 256, B, F, 1,
+                   ? dz_launch_lstm_mfma(gxl, s->w.whh_split[layer], hf, hs, rows * 256, B, F, 1,
                                          s->w.lstm_variant, st)
-                   : dz_launch_lstm(s->gx, s->w.whh[layer], hf, hs, rows * 256, B, F, 1, st);
+                   : dz_launch_lstm(gxl, s->w.whh[layer], hf, hs, rows * 256, B, F, 1, st);
           if (rc) return rc; }
+        if (layer == 0) {            // gx0 has been read: the next front half may overwrite it
+            DZ_HIP(hipEventRecord(s->ev_gx0_free, st));
+            s->front_B = 0;
+        }
         lin = hout;
     }
     // Linear(256,128)+leaky, Linear(128,128)+leaky, classifier
@@ -613,7 +629,7 @@ extern "C" int dz_emb_create(dz_ctx* ctx, const dz_emb_weights* w, int max_batch
     DZ_REQUIRE(e != nullptr, "dz_emb_create: out of memory");
     e->ctx = ctx; e->w = *w; e->g = g; e->Bm = max_batch; e->arena = nullptr; e->ext_stats = nullptr;
     e->pending_B = 0; e->pending_in = nullptr;
-    e->pre = pre_split_enabled() && w->tw_split[0] && w->tw_split[1] && w->tw_split[2] &&
+    e->pre = w->tw_split[0] && w->tw_split[1] && w->tw_split[2] &&
              w->tw_split[3] && w->tw_split[4];
     int t = g.P2;
     for (int i = 0; i < 5; ++i) {
@@ -681,19 +697,6 @@ static int emb_frames(dz_emb* e, const float* d_wave, long long stride, int B, h
             if (e->pre) { p.Y = nullptr; p.Ysplit = outp; p.yplane = plane; }
         } else {
             p.B = 1; p.Tin = B * P; p.Tout = p.Tstore = B * P - span;
-        }
-        if (i == 0 && e->pre && sinc_fused_norm(e->w.sinc) && norm_split_enabled()) {
-            { ProfScope ps(T_FIN, B);
-              if ((rc = dz_launch_norm_split(e->ss.y2, B, P, e->ss.part2, e->g.nt2, e->w.sinc.in2_g, e->w.sinc.in2_b,
-                                             e->ss.xn, (long long)B * P * 64, st)))
-                  return rc; }
-            p.X = nullptr; p.Xsplit = e->ss.xn; p.xplane = (long long)B * P * 64; p.Wsplit = e->w.tw_split[0];
-            p.norm_on_load = 0; p.npart = nullptr; p.nscale = p.nshift = nullptr; p.nld = 0;
-            p.B = 1; p.Tin = B * P; p.Tout = p.Tstore = B * P - span; p.xbs = p.ybs = 0;
-            p.Y = nullptr; p.Ysplit = outp; p.yplane = plane;
-            { ProfScope ps(T_TDNN1, B); if ((rc = dz_launch_gemm_pre(p, st))) return rc; }
-            in = outp;
-            continue;
         }
         if (i == 4 && e->pre && pool_fuse_enabled() && dz_gemm_pre_pool_ok(p)) {
             // tdnn5 runs with the pooling in its epilogue, i.e. when the weights are known (emb_head)

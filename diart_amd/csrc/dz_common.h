@@ -95,13 +95,25 @@ __device__ __forceinline__ void dz_tile_map(int agroup, int& bx, int& by, int& b
 }
 
 // ---------------------------------------------------------------------------
+// "kb-major" f16 planes: the operand format of k_gemm_pre.hip and k_mlp_head.hip (activations written by
+// the producing kernel's epilogue, weights packed by weights.py kb_major()).  A plane of R rows x K columns
+// (K % 32 == 0) is stored as K / 32 blocks of [R][32]: the 32-wide k-tile of 16 consecutive rows — what
+// one LDS-DMA instruction moves — is 1 KiB of contiguous memory.  The lo plane follows the hi plane
+// R * K elements further, as before.  Element (row, col) of a plane of R rows:
+// ---------------------------------------------------------------------------
+__host__ __device__ __forceinline__ long long dz_kb(long long row, int col, long long R) {
+    return ((long long)(col >> 5) * R + row) * 32 + (col & 31);
+}
+
+// ---------------------------------------------------------------------------
 // Epilogue helper of the split-f16 GEMMs: write an f32 result as the two f16 planes the next
 // layer's k_gemm_pre.hip reads (hi = f16(v), lo = f16((v - hi) * 2^11), lo plane `yplane` elements
 // after the hi plane).  Lanes 2i and 2i+1 of a quad hold columns n and n+1 of the same row (MFMA C/D
 // layout: column = lane & 31): they exchange their (hi, lo) pair through one DPP move, the even
 // lane stores (hi[n], hi[n+1]) to the hi plane and the odd lane (lo[n-1], lo[n]) to the lo plane —
 // one 4-byte store per lane, like an f32 store.  Every lane of the quad must call it; `ypl` is
-// dz_split_base(Yhi, yplane, odd); `idx` = row * ldy + column; inputs are clamped to +-65504.
+// dz_split_base(Yhi, yplane, odd); `idx` = dz_kb(row, column, rows of the plane) (an even / odd column pair
+// shares a k-block row); inputs are clamped to +-65504.
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ unsigned short* dz_split_base(void* ysplit, long long yplane, bool odd) {
     unsigned short* y = reinterpret_cast<unsigned short*>(ysplit);
@@ -222,9 +234,6 @@ int dz_launch_sinc_conv0_split(const float* wave, long long stride, int B, int S
                                int stats_are_moments, float gamma, float beta, const void* filt_split,
                                float* y0, int P0, float* partials, int ntile, hipStream_t st);
 int dz_conv0_split_ntile(int F0);
-// y [B][T][64] + tile partials -> InstanceNorm + LeakyReLU -> f16 (hi, lo * 2^11) planes [2][B * T][64]
-int dz_launch_norm_split(const float* y, int B, int T, const float* partials, int ntile, const float* gamma,
-                         const float* beta, void* planes, long long plane, hipStream_t st);
 // partial (sum,sumsq) -> per (b,c) scale/shift of InstanceNorm1d(C, affine)
 int dz_launch_finalize_norm(const float* partials, int B, int ntile, int C, int T,
                             const float* gamma, const float* beta, float* scale, float* shift,

@@ -519,62 +519,6 @@ __global__ void finalize_norm_kernel(const float* __restrict__ partials, int B, 
     shift[idx] = (float)((double)beta[c] - mean * sc);
 }
 
-// ---------------------------------------------------------------------------
-// norm_split: the LAST SincNet stage's InstanceNorm1d(64, affine) + LeakyReLU, applied once, with the
-// result written as the two f16 planes a k_gemm_pre.hip consumer reads (round 3).  Round 2 let the
-// first LSTM projection / tdnn1 normalise and split on load (k_gemm_split.hip, 8-wave tiles, 240
-// registers: no room beside a recurrence workgroup, 5 - 9x longer in the pipeline than alone); with the
-// planes in place both layers run on the pre-split kernel like every other wide layer.
-// y [B][T][64] (pre-norm pooled conv output) + the producer's tile partials -> planes [2][B * T][64].
-// One workgroup = 64 frames of one chunk; the chunk's scale / shift are derived from the partials by
-// every workgroup (10 tiles x 64 channels: cheaper than a finalize launch in between).
-// ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void norm_split_kernel(const float* __restrict__ y, int T,
-                                                         const float* __restrict__ partials, int ntile,
-                                                         const float* __restrict__ gamma,
-                                                         const float* __restrict__ beta,
-                                                         unsigned short* __restrict__ planes, long long plane,
-                                                         int* __restrict__ oflag) {
-    typedef _Float16 h4 __attribute__((ext_vector_type(4)));
-    __shared__ float nrm[128];
-    __shared__ double scratch[2 * 4 * 64];
-    const int b = blockIdx.y, r0 = blockIdx.x * 64, tid = threadIdx.x;
-    dz_norm_from_partials(partials, b, ntile, 64, T, gamma, beta, nrm, tid, 256, scratch);
-    __syncthreads();
-    float amax = 0.f;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int idx = tid + 256 * i, r = r0 + (idx >> 4), c4 = idx & 15;
-        if (r < T) {
-            const long long o = ((long long)b * T + r) * 64 + 4 * c4;
-            f32x4 v = *reinterpret_cast<const f32x4*>(y + o);
-            const f32x4 sc = *reinterpret_cast<const f32x4*>(nrm + 4 * c4);
-            const f32x4 sh = *reinterpret_cast<const f32x4*>(nrm + 64 + 4 * c4);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                float x = v[e] * sc[e] + sh[e];
-                x = x > 0.f ? x : x * DZ_LEAKY_SLOPE;
-                amax = fmaxf(amax, fabsf(x));
-                v[e] = __builtin_amdgcn_fmed3f(x, -65504.f, 65504.f);
-            }
-            const h4 hi = __builtin_convertvector(v, h4);
-            const h4 lo = __builtin_convertvector((v - __builtin_convertvector(hi, f32x4)) * 2048.f, h4);
-            *reinterpret_cast<h4*>(planes + o) = hi;
-            *reinterpret_cast<h4*>(planes + plane + o) = lo;
-        }
-    }
-    dz_flag_range(oflag, amax);
-}
-
-int dz_launch_norm_split(const float* y, int B, int T, const float* partials, int ntile, const float* gamma,
-                         const float* beta, void* planes, long long plane, hipStream_t st) {
-    DZ_REQUIRE(y && partials && gamma && beta && planes && plane % 4 == 0, "norm_split: bad arguments");
-    DZ_LAUNCH(norm_split_kernel, dim3((T + 63) / 64, B), dim3(256), 0, st, y, T, partials, ntile, gamma, beta,
-              reinterpret_cast<unsigned short*>(planes), plane, dz_cur_oflag);
-    DZ_HIP(hipGetLastError());
-    return 0;
-}
-
 int dz_launch_finalize_norm(const float* partials, int B, int ntile, int C, int T,
                             const float* gamma, const float* beta, float* scale, float* shift,
                             hipStream_t st) {

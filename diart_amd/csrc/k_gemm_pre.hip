@@ -13,8 +13,9 @@
 //     ds_write_b128 per thread per k-tile — at 29 % matrix-core busy the loop was bound by exactly
 //     this traffic (profiles/r01_p_*).
 //   * here the PRODUCER's epilogue writes the two f16 planes (4 bytes per element, the same HBM
-//     bytes as the f32 it replaces; split once per element), so a k-tile of either operand is
-//     plain bytes: it goes global -> LDS by LDS-DMA (buffer_load_dwordx4 ... lds, 16 B per lane, no
+//     bytes as the f32 it replaces; split once per element) in the "kb-major" order of dz_kb()
+//     (dz_common.h: [K / 32][rows][32] — the weights are packed the same way by weights.py), so a
+//     k-tile of either operand is plain, CONTIGUOUS bytes: it goes global -> LDS by LDS-DMA (buffer_load_dwordx4 ... lds, 16 B per lane, no
 //     VGPR staging, no ds_write, no VALU; the k-tile / tap offset is the instruction's scalar
 //     offset, out-of-range rows read as zeros through the buffer bounds check).
 //
@@ -89,18 +90,24 @@ __device__ __forceinline__ void gemm_pre_tile(const DzConvGemm& p, const int t0,
     const int rank = isB ? w - NWA : w, group = isB ? NWAVE - NWA : NWA, npc = isB ? PB : PA;
     const unsigned short* src = isB ? reinterpret_cast<const unsigned short*>(p.Wsplit)
                                     : reinterpret_cast<const unsigned short*>(p.Xsplit);
+    // kb-major planes (dz_common.h, dz_kb): plane = [K / 32][rows][32], so the 32-wide k-tile of 16
+    // consecutive rows — one LDS-DMA piece — is 1 KiB of contiguous memory (8 full cache lines; row-major
+    // planes gave 16 half lines per piece and cost the loop 8 - 16 %, round 3).  A row beyond the plane's
+    // rows reads the start of the next k-block (finite values of other rows) or, in the last block, zeros
+    // through the buffer bounds check: such rows only feed outputs that are never stored.
+    const int prows = isB ? p.Npad : (int)((unsigned)p.xplane / (unsigned)p.ldx);        // rows of a plane
     const long long plane_el = isB ? (long long)p.Npad * p.Kpad : p.xplane;     // f16 elements between hi and lo
-    const int ld = isB ? p.Kpad : p.ldx;                                        // f16 elements per row
-    const unsigned nbytes = (unsigned)((isB ? (long long)p.Npad : (long long)p.Tin) * ld * 2);
+    const unsigned nbytes = (unsigned)((long long)prows * (isB ? p.Kpad : p.ldx) * 2);
     const __amdgpu_buffer_rsrc_t rs_hi = __builtin_amdgcn_make_buffer_rsrc((void*)src, 0, nbytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_lo = __builtin_amdgcn_make_buffer_rsrc((void*)(src + plane_el), 0, nbytes, 0x00020000);
-    const int voff0 = ((isB ? n0 : t0) + (l >> 2)) * ld * 2 + (((l & 3) ^ ((l >> 4) & 3)) << 4);
-    const int vstep = 16 * ld * 2;
+    const int voff0 = ((isB ? n0 : t0) + (l >> 2)) * 64 + (((l & 3) ^ ((l >> 4) & 3)) << 4);
+    constexpr int vstep = 16 * 64;
+    const int kb_bytes = prows * 64;                                            // one k-block of the plane
     const int dst0 = isB ? 2 * PLANE_A : 0, dplane = isB ? PLANE_B : PLANE_A;
     auto issue = [&](int kt, int stage) {
         int soff;
         if (isB) {
-            soff = kt * (KT * 2);
+            soff = kt * kb_bytes;
         } else {
             const int k = kt * KT;
             int tap = 0, c = k;
@@ -108,7 +115,7 @@ __device__ __forceinline__ void gemm_pre_tile(const DzConvGemm& p, const int t0,
                 tap = k / p.Cin;
                 c = k - tap * p.Cin;
             }
-            soff = (tap * p.dil * p.ldx + c) * 2;
+            soff = (c >> 5) * kb_bytes + tap * p.dil * 64;
         }
         char* dst = smem + stage * STAGE + dst0;
 #pragma unroll
@@ -200,29 +207,22 @@ __device__ __forceinline__ void gemm_pre_tile(const DzConvGemm& p, const int t0,
         // advances incrementally instead of by a division per tile).
         const int r2 = w & 1;                                       // rank inside the pair of waves of a side
         char* const dbase = smem + dst0 + r2 * 1024;
-        // flags & 1 (TIMING EXPERIMENT, wrong results): address the operands as if the planes were stored
-        // k-block-major ([k / 32][row][32]: a 16-row piece = 1 KiB contiguous = 8 full cache lines instead
-        // of 16 half lines)
-        const bool kbf = flags & 1;
-        const int vstep_e = kbf ? 1024 : vstep;
-        const int vofs = (kbf ? ((isB ? n0 : t0) + (l >> 2)) * 64 + (((l & 3) ^ ((l >> 4) & 3)) << 4) : voff0) + r2 * vstep_e;
-        const int kb_rows64 = (isB ? p.Npad : p.Tin) * 64;
-        int cpos = 0, tapo = 0;                                     // channel / tap offset (elements) of tile kt + 1
+        const int vofs = voff0 + r2 * vstep;
+        int cpos = 0, tapo = 0;                                     // channel / tap offset (bytes of a k-block row) of tile kt + 1
         auto advance = [&]() -> int {                               // -> soffset (bytes) of the NEXT tile
             cpos += KT;
-            if (!isB && p.taps > 1 && cpos >= p.Cin) { cpos -= p.Cin; tapo += p.dil * p.ldx; }
-            if (kbf) return (cpos >> 5) * kb_rows64 + (isB ? 0 : (tapo / p.ldx) * 64);
-            return isB ? cpos * 2 : (tapo + cpos) * 2;
+            if (!isB && p.taps > 1 && cpos >= p.Cin) { cpos -= p.Cin; tapo += p.dil * 64; }
+            return (cpos >> 5) * kb_bytes + tapo;
         };
         int soff_next = 0, stage_next = 0;
-        const bool no_dma = flags & 2, no_rd = flags & 4;           // TIMING EXPERIMENTS (wrong results)
+        const bool no_dma = flags & 2, no_rd = flags & 4;           // TIMING EXPERIMENTS (DZ_GP_DBG, wrong results)
         auto piece = [&](int j) {                                   // j = 0..7: pieces r2 + 2j of "8 hi, then 8 lo"
             const int lo = j >= 4, i = r2 + 2 * (j & 3);            // i-th 16-row block of the plane (r2 folded into bases)
             (void)i;
             if (no_dma) return;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(lo ? rs_lo : rs_hi,
                 (__attribute__((address_space(3))) void*)(dbase + stage_next * STAGE + lo * dplane + (j & 3) * 2048), 16,
-                vofs + (j & 3) * 2 * vstep_e, soff_next, 0, 0);
+                vofs + (j & 3) * 2 * vstep, soff_next, 0, 0);
         };
         const char* sa0 = smem + (wm * 64) * 64;
         const char* sb0 = smem + 2 * PLANE_A + (wn * 64) * 64;
@@ -320,6 +320,7 @@ __device__ __forceinline__ void gemm_pre_tile(const DzConvGemm& p, const int t0,
     // consumer) and not at all to the f32 output.
     typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
     unsigned short* Yhi = reinterpret_cast<unsigned short*>(p.Ysplit);
+    const long long yrows = Yhi ? (long long)((unsigned)p.yplane / (unsigned)p.ldy) : 0;   // rows of an output plane
     float amax = 0.f;
     float* yt = reinterpret_cast<float*>(smem);
     if (POOL) __syncthreads();        // every wave is done with the last k-tile: the tile buffer reuses the stages
@@ -370,14 +371,15 @@ __device__ __forceinline__ void gemm_pre_tile(const DzConvGemm& p, const int t0,
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         if (n + e >= p.Nstore) v[e] = 0.f;
-                        amax = fmaxf(amax, fabsf(v[e]));
+                        if (ok) amax = fmaxf(amax, fabsf(v[e]));
                         v[e] = __builtin_amdgcn_fmed3f(v[e], -65504.f, 65504.f);
                     }
                     const f16x4 hi = __builtin_convertvector(v, f16x4);
                     const f16x4 lo = __builtin_convertvector((v - __builtin_convertvector(hi, f32x4)) * 2048.f, f16x4);
                     if (ok) {
-                        *reinterpret_cast<f16x4*>(Yhi + idx) = hi;
-                        *reinterpret_cast<f16x4*>(Yhi + p.yplane + idx) = lo;
+                        const long long kidx = dz_kb(t, n, yrows);     // four columns of one k-block row
+                        *reinterpret_cast<f16x4*>(Yhi + kidx) = hi;
+                        *reinterpret_cast<f16x4*>(Yhi + p.yplane + kidx) = lo;
                     }
                 }
             }
@@ -646,13 +648,15 @@ int dz_launch_gemm_pre_pool(const DzConvGemm& p_in, const DzPoolFuse& q, hipStre
     DzConvGemm p = p_in;
     if (!p.oflag) p.oflag = dz_cur_oflag;
     DZ_REQUIRE(p.Wsplit && p.Xsplit && q.part && q.s0, "gemm_pre_pool: NULL operand");
-    DZ_REQUIRE(p.epi == DZ_EPI_TDNN && p.B == 1 && p.taps == 1 && p.K == p.Kpad && p.Cin % KT == 0 && p.ldx % 8 == 0 &&
+    DZ_REQUIRE(p.epi == DZ_EPI_TDNN && p.B == 1 && p.taps == 1 && p.K == p.Kpad && p.Cin % KT == 0 &&
                    p.Npad % BN == 0 && p.Tout == p.Tin,
                "gemm_pre_pool: built for the flattened 1 x 1 TDNN layer");
     DZ_REQUIRE(q.np == dz_pool_pieces(q.P), "gemm_pre_pool: np must be dz_pool_pieces(P)");
     DZ_REQUIRE(q.K >= 1 && q.K <= 4 && q.P >= BM && q.T >= 2 && q.T <= q.P && p.Tout % q.P == 0 && q.Fw >= 2,
                "gemm_pre_pool: 1..4 speakers, chunk pitch >= 128 rows (got K %d, P %d, T %d)", q.K, q.P, q.T);
-    DZ_REQUIRE((long long)p.Tin * p.ldx * 2 < (1ll << 31) && (long long)p.Npad * p.Kpad * 2 < (1ll << 31),
+    DZ_REQUIRE(p.ldx > 0 && p.ldx % KT == 0 && p.xplane % p.ldx == 0 && p.xplane / p.ldx >= p.Tin,
+               "gemm_pre_pool: kb-major input planes need ldx %% 32 == 0 and xplane = rows * ldx with rows >= Tin");
+    DZ_REQUIRE(p.xplane * 2 < (1ll << 31) && (long long)p.Npad * p.Kpad * 2 < (1ll << 31),
                "gemm_pre_pool: operand plane exceeds the 2 GiB buffer-offset range");
     static DzAttrOnce attr_once;
     DZ_HIP(attr_once.raise((const void*)gemm_pre_pool_kernel, (int)POOL_LDS));
@@ -669,16 +673,19 @@ int dz_launch_gemm_pre(const DzConvGemm& p_in, hipStream_t st) {
                "gemm_pre: Wsplit / Xsplit (f16 hi/lo planes of W and of the input) are NULL");
     DZ_REQUIRE(p.Y != nullptr || p.Ysplit != nullptr, "gemm_pre: no output");
     DZ_REQUIRE(p.B == 1, "gemm_pre: flattened layers only (B = 1)");
-    DZ_REQUIRE(p.K == p.Kpad && p.K == p.taps * p.Cin && p.Cin % KT == 0 && p.ldx % 8 == 0,
-               "gemm_pre: K = taps * Cin without padding, Cin a multiple of 32, ldx of 8");
+    DZ_REQUIRE(p.K == p.Kpad && p.K == p.taps * p.Cin && p.Cin % KT == 0,
+               "gemm_pre: K = taps * Cin without padding, Cin a multiple of 32");
     DZ_REQUIRE(p.Npad % BN == 0, "gemm_pre: Npad must be a multiple of 128");
     DZ_REQUIRE(p.Tout > 0 && p.Tout == p.Tin - (p.taps - 1) * p.dil, "gemm_pre: Tout mismatch");
     DZ_REQUIRE(p.pad == 0 && p.X2 == nullptr && p.rowbias == nullptr && p.ksplit <= 1 && !p.norm_on_load,
                "gemm_pre: padding / second input / row bias / split-K / norm-on-load are not built here");
-    DZ_REQUIRE((long long)p.Tin * p.ldx * 2 < (1ll << 31) && (long long)p.Npad * p.Kpad * 2 < (1ll << 31),
+    DZ_REQUIRE(p.ldx > 0 && p.ldx % KT == 0 && p.xplane % p.ldx == 0 && p.xplane / p.ldx >= p.Tin,
+               "gemm_pre: kb-major input planes need ldx %% 32 == 0 and xplane = rows * ldx with rows >= Tin");
+    DZ_REQUIRE(p.xplane * 2 < (1ll << 31) && (long long)p.Npad * p.Kpad * 2 < (1ll << 31),
                "gemm_pre: operand plane exceeds the 2 GiB buffer-offset range");
-    DZ_REQUIRE(p.Ysplit == nullptr || (p.ldy % 4 == 0 && p.yplane % 4 == 0 && p.Npad <= p.ldy),
-               "gemm_pre: plane output needs ldy / yplane multiples of 4 and Npad <= ldy");
+    DZ_REQUIRE(p.Ysplit == nullptr || (p.ldy > 0 && p.ldy % KT == 0 && p.yplane % p.ldy == 0 && p.yplane / p.ldy >= p.Tout &&
+                                       p.Npad <= p.ldy && p.yplane * 2 < (1ll << 31)),
+               "gemm_pre: kb-major output planes need ldy %% 32 == 0, yplane = rows * ldy with rows >= Tout, Npad <= ldy");
     DZ_REQUIRE(p.Y == nullptr || (p.ldy % 4 == 0 && ((uintptr_t)p.Y & 15) == 0),
                "gemm_pre: f32 output needs ldy a multiple of 4 and a 16-byte aligned base");
     switch (p.epi) {

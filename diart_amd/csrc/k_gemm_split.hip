@@ -264,7 +264,9 @@ __global__ __launch_bounds__(128 * WM) void gemm_split_kernel(DzConvGemm p) {
     }
     float* Yb = p.Y ? p.Y + (long long)b * p.ybs : nullptr;
     // optional (hi, lo) f16 plane output for a k_gemm_pre.hip consumer (dz_store_split)
-    unsigned short* Ypl = p.Ysplit ? dz_split_base(p.Ysplit, p.yplane, li & 1) + (long long)b * p.ybs : nullptr;
+    // in the kb-major order of dz_kb(): batch item b owns rows b * (ybs / ldy) .. of the planes
+    unsigned short* Ypl = p.Ysplit ? dz_split_base(p.Ysplit, p.yplane, li & 1) : nullptr;
+    const long long yrows = Ypl ? p.yplane / p.ldy : 0, yrow0 = Ypl ? (long long)b * (p.ybs / p.ldy) : 0;
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
         const int n = n0 + wn * 32 * NB + nb * 32 + li;
@@ -284,7 +286,7 @@ __global__ __launch_bounds__(128 * WM) void gemm_split_kernel(DzConvGemm p) {
             if (EPI == DZ_EPI_TDNN) v = leaky(v) * e0 + e1;
             if (EPI == DZ_EPI_RELU_BN) v = fmaxf(v, 0.f) * e0 + e1;
             if (Yb && ok && nok) Yb[(long long)t * p.ldy + n] = v;
-            if (Ypl) dz_store_split(Ypl, (long long)t * p.ldy + n, nok ? v : 0.f, ok, li & 1, amax);
+            if (Ypl) dz_store_split(Ypl, dz_kb(yrow0 + t, n, yrows), nok ? v : 0.f, ok, li & 1, amax);
         }
     }
     dz_flag_range(p.oflag, amax);
@@ -317,6 +319,8 @@ int dz_launch_gemm_split(const DzConvGemm& p_in, hipStream_t st) {
     DZ_REQUIRE(!p.norm_on_load || (p.nscale && p.nshift) ||
                    (p.npart && p.ngamma && p.nbeta && p.npart_tiles > 0 && p.npart_T > 0 && p.nld <= 128),
                "gemm_split: norm-on-load needs nscale / nshift or the producer's partials + affine (nld <= 128)");
+    DZ_REQUIRE(p.Ysplit == nullptr || (p.ldy > 0 && p.ldy % 32 == 0 && p.yplane % p.ldy == 0 && p.ybs % p.ldy == 0),
+               "gemm_split: kb-major plane output needs ldy %% 32 == 0 and yplane / ybs multiples of ldy");
     DZ_REQUIRE(p.Ysplit == nullptr || (p.epi != DZ_EPI_POOL3 && p.ldy % 2 == 0 && p.yplane % 2 == 0 &&
                                        p.ybs % 2 == 0 && p.Npad <= p.ldy),
                "gemm_split: plane output needs even ldy / yplane / ybs, Npad <= ldy and no pooling");

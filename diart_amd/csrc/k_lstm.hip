@@ -177,8 +177,10 @@ __global__ __launch_bounds__(512) void lstm_rec_kernel(const float* __restrict__
                     const f32x2 x = {v.x, v.y};
                     const f16x2 hi = __builtin_convertvector(x, f16x2);
                     const f16x2 lo = __builtin_convertvector((x - __builtin_convertvector(hi, f32x2)) * 2048.f, f16x2);
-                    *reinterpret_cast<f16x2*>(hsp + o) = hi;
-                    *reinterpret_cast<f16x2*>(hsp + hplane + o) = lo;
+                    // planes in the kb-major order of dz_kb(): [256 / 32][B * T rows][32]
+                    const long long ok = dz_kb((long long)bc[c] * T + tt, dir * 128 + fl_u, hplane >> 8);
+                    *reinterpret_cast<f16x2*>(hsp + ok) = hi;
+                    *reinterpret_cast<f16x2*>(hsp + hplane + ok) = lo;
                 }
             }
         }
@@ -225,7 +227,8 @@ int dz_launch_lstm(const float* gx, const float* whh, float* hout, void* hsplit,
                    int B, int T, int unit_major, hipStream_t st) {
     unsigned short* hsp = reinterpret_cast<unsigned short*>(hsplit);
     DZ_REQUIRE(hout || hsp, "lstm: no output");
-    DZ_REQUIRE(hplane % 2 == 0, "lstm: odd plane distance");
+    DZ_REQUIRE(hplane % 256 == 0 && (!hsplit || hplane >= (long long)B * T * 256),
+               "lstm: the kb-major planes need hplane = rows * 256 with rows >= B * T");
     // chains per workgroup: DZ_LSTM_NC=2 selects the two-chunk form (EXPERIMENT).  Measured on MI355X, 64
     // chunks (gpurun_out/visit_r3k.log): alone 273.8 us per layer on 64 CUs against 169.7 us on 128 (0.81x the
     // CU-time, 1.61x the latency), and in the 64-stream pipeline 1.265 / 1.279 ms per step against 1.239 /

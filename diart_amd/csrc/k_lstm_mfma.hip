@@ -142,9 +142,10 @@ __global__ __launch_bounds__(512) void lstm_mfma_kernel(const float* __restrict_
             // h_t already is that representation
             const long long o = hbase + (long long)s * hstep;
             if (hout) *reinterpret_cast<f32x4*>(hout + o) = hv;
-            if (hsp) {
-                *reinterpret_cast<f16x4*>(hsp + o) = hhi;
-                *reinterpret_cast<f16x4*>(hsp + hplane + o) = hlo;
+            if (hsp) {                                   // kb-major planes (dz_kb): row o / 256, column o % 256
+                const long long ok = dz_kb(o >> 8, (int)(o & 255), hplane >> 8);
+                *reinterpret_cast<f16x4*>(hsp + ok) = hhi;
+                *reinterpret_cast<f16x4*>(hsp + hplane + ok) = hlo;
             }
         }
         lds_barrier();
@@ -269,8 +270,9 @@ __global__ __launch_bounds__(512) void lstm_mfma1_kernel(const float* __restrict
             if (hout) *reinterpret_cast<f32x4*>(hout + o) = hv;
             if (hsp) {
                 const f16x4 ohi = __builtin_convertvector(hv, f16x4);
-                *reinterpret_cast<f16x4*>(hsp + o) = ohi;
-                *reinterpret_cast<f16x4*>(hsp + hplane + o) =
+                const long long ok = dz_kb(o >> 8, (int)(o & 255), hplane >> 8);
+                *reinterpret_cast<f16x4*>(hsp + ok) = ohi;
+                *reinterpret_cast<f16x4*>(hsp + hplane + ok) =
                     __builtin_convertvector((hv - __builtin_convertvector(ohi, f32x4)) * LO_SCALE, f16x4);
             }
         }
@@ -417,9 +419,10 @@ __global__ __launch_bounds__(512) void lstm_mfma_dma_kernel(const float* __restr
         if (valid) {
             const long long o = hbase + (long long)s * hstep;
             if (hout) *reinterpret_cast<f32x4*>(hout + o) = hv;
-            if (hsp) {
-                *reinterpret_cast<f16x4*>(hsp + o) = hhi;
-                *reinterpret_cast<f16x4*>(hsp + hplane + o) = hlo;
+            if (hsp) {                                   // kb-major planes (dz_kb): row o / 256, column o % 256
+                const long long ok = dz_kb(o >> 8, (int)(o & 255), hplane >> 8);
+                *reinterpret_cast<f16x4*>(hsp + ok) = hhi;
+                *reinterpret_cast<f16x4*>(hsp + hplane + ok) = hlo;
             }
         }
         // the pieces of step s+1 (issued >= 2 steps ago) must have landed before anybody passes the
@@ -442,7 +445,8 @@ int dz_launch_lstm_mfma(const float* gx, const void* whh_split, float* hout, voi
     DZ_REQUIRE(hout || hsp, "lstm_mfma: no output");
     DZ_REQUIRE(variant != 3 || (unit_major && (long long)B * T * 4096 < (1ll << 31)),
                "lstm_mfma: variant 3 (LDS-DMA of gx) needs unit-major gx below 2 GiB");
-    DZ_REQUIRE(hplane % 4 == 0, "lstm_mfma: plane distance must be a multiple of 4 elements");
+    DZ_REQUIRE(hplane % 256 == 0 && (!hsplit || hplane >= (long long)B * T * 256),
+               "lstm_mfma: the kb-major planes need hplane = rows * 256 with rows >= B * T");
 #define DZ_L(K) DZ_LAUNCH(K, grid, dim3(512), 0, st, gx, whs, hout, hsp, hplane, B, T)
     if (variant == 0) { if (unit_major) DZ_L(lstm_mfma_kernel<true>); else DZ_L(lstm_mfma_kernel<false>); }
     if (variant == 1) { if (unit_major) DZ_L((lstm_mfma1_kernel<true, 0>)); else DZ_L((lstm_mfma1_kernel<false, 0>)); }

@@ -64,25 +64,27 @@ __global__ __launch_bounds__(256) void mlp_head_kernel(DzMlpHead p) {
     const unsigned nbytes = (unsigned)((isB ? 128ll : (long long)p.rows) * 256 * 2);
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)src, 0, nbytes, 0x00020000);
     const int chunk = ((l & 3) ^ ((l >> 4) & 3)) << 4;
-    const int voff0 = ((isB ? 0 : t0) + (l >> 2)) * 512 + chunk;          // 256 f16 per row
+    // kb-major planes (dz_common.h dz_kb): [256 / 32][rows][32] — a 16-row piece of a k-tile is 1 KiB contiguous
+    const int voff0 = ((isB ? 0 : t0) + (l >> 2)) * 64 + chunk;
+    const int kb_bytes = (isB ? 128 : p.rows) * 64;
     auto issue0 = [&](int kt, int stage) {
         char* dst = smem + R0 + stage * 4 * PLANE + w * PLANE;
 #pragma unroll
         for (int i = 0; i < 8; ++i)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(
-                rsrc, (__attribute__((address_space(3))) void*)(dst + i * 1024), 16, voff0 + i * 16 * 512, kt * 64, 0, 0);
+                rsrc, (__attribute__((address_space(3))) void*)(dst + i * 1024), 16, voff0 + i * 1024, kt * kb_bytes, 0, 0);
     };
     // lin1's B operand: 4 k-tiles x 2 planes x 8 pieces = 64 pieces, 16 per wave (k-tile w)
     const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc((void*)W1, 0, 2u * 128 * 128 * 2, 0x00020000);
     auto issue1 = [&]() {
-        const int voff1 = (l >> 2) * 256 + chunk;                           // 128 f16 per row
+        const int voff1 = (l >> 2) * 64 + chunk;                            // [128 / 32][128][32] per plane
 #pragma unroll
         for (int pl = 0; pl < 2; ++pl)
 #pragma unroll
             for (int i = 0; i < 8; ++i)
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(
                     rs1, (__attribute__((address_space(3))) void*)(smem + R0 + w * 2 * PLANE + pl * PLANE + i * 1024), 16,
-                    voff1 + i * 16 * 256 + pl * (128 * 128 * 2), w * 64, 0, 0);
+                    voff1 + i * 1024 + pl * (128 * 128 * 2), w * (128 * 64), 0, 0);
     };
 
     // ---- MFMA coordinates (k_gemm_pre.hip: transposed product, a lane owns one row) ---------------
@@ -227,7 +229,8 @@ int dz_launch_mlp_head(const DzMlpHead& p_in, hipStream_t st) {
     DZ_REQUIRE(p.rows > 0 && p.F > 0 && p.rows % p.F == 0, "mlp_head: %d rows are not whole chunks of %d frames", p.rows, p.F);
     DZ_REQUIRE(p.classes >= 1 && p.classes <= 8 && p.K >= 1 && p.K <= 8 && (p.powerset || p.K == p.classes),
                "mlp_head: classes %d / speakers %d", p.classes, p.K);
-    DZ_REQUIRE((long long)p.rows * 256 * 2 < (1ll << 31) && p.xplane % 8 == 0, "mlp_head: plane exceeds the buffer range");
+    DZ_REQUIRE((long long)p.rows * 256 * 2 < (1ll << 31), "mlp_head: plane exceeds the buffer range");
+    DZ_REQUIRE(p.xplane == (long long)p.rows * 256, "mlp_head: kb-major input planes of exactly `rows` rows (xplane = rows * 256)");
     static DzAttrOnce attr_once;
     DZ_HIP(attr_once.raise((const void*)mlp_head_kernel, (int)LDS_BYTES));
     DZ_LAUNCH(mlp_head_kernel, dim3((p.rows + 127) / 128), dim3(256), LDS_BYTES, st, p);

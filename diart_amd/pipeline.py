@@ -193,6 +193,12 @@ class StreamBatch:
         # many steps on the GPU at once (the latency-bound recurrence of one step under the GEMMs
         # of the others).  A lane is reused in stream order, which also orders its arenas.
         self.depth = max(1, int(os.environ.get("DZ_DEPTH", "2") if depth is None else depth))
+        # How many launched-but-unfinished steps a throughput caller (bench.py, FileBatch) keeps: `depth` lanes
+        # run concurrently, the steps beyond that wait IN THE STREAMS of their lane, so that a lane's next
+        # step starts the moment the previous one ends instead of after the host has come back from
+        # finish() (clustering of an older step + launch overhead: ~0.5 ms per step, during which the
+        # lane's segmentation stream sat empty).  DZ_INFLIGHT overrides (>= depth).
+        self.max_inflight = max(self.depth, int(os.environ.get("DZ_INFLIGHT", str(self.depth + 1))))
         # DZ_SHARED_EMB=1: ONE set of embedding streams serves every lane in step order and the
         # pooling of step t is enqueued `lag` = depth - 1 launches later, behind the frame features
         # of the following steps (only the last two kernels of the embedding network wait for the
@@ -204,9 +210,17 @@ class StreamBatch:
         self.shared_stats = os.environ.get("DZ_SHARED_STATS", "1") != "0"
         self.shared_emb = os.environ.get("DZ_SHARED_EMB", "0") != "0"
         self.lag = self.depth - 1 if self.shared_emb else 0
+        # DZ_SEG_FRONT=1: the stateless front half of the segmentation network (SincNet + the first
+        # x-projection, dz_seg_front) gets a stream of its own per lane.  launch(t + depth) is called
+        # before finish(t), so on one stream the front half of step t + depth queues BEHIND the
+        # recurrences of step t; on its own stream it runs under them and the lane's dependent chain is
+        # the back half only (dz_seg_back: 4 recurrences, 3 projections, the MLP head).
+        self.seg_front = os.environ.get("DZ_SEG_FRONT", "0") != "0"
+        pf = int(os.environ.get("DZ_PRIO_F", "0"))
         mk = lambda prio, k: [torch.cuda.Stream(self.device, priority=prio) for _ in range(k)]
         shared_b = mk(pb, self.emb_split) if self.shared_emb else None
-        self.lanes = [dict(a=mk(pa, self.seg_split), b=shared_b or mk(pb, self.emb_split))
+        self.lanes = [dict(a=mk(pa, self.seg_split), b=shared_b or mk(pb, self.emb_split),
+                           f=mk(pf, self.seg_split) if self.seg_front else None)
                       for _ in range(self.depth)]
         self.streams_a, self.streams_b = self.lanes[0]["a"], self.lanes[0]["b"]
         self.stream_a, self.stream_b = self.streams_a[0], self.streams_b[0]
@@ -254,6 +268,7 @@ class StreamBatch:
                  seg_h=torch.empty((n, F, K), dtype=torch.float32).pin_memory(),
                  emb_h=torch.empty((n, K, D), dtype=torch.float32).pin_memory(),
                  ev_seg=[torch.cuda.Event() for _ in range(self.seg_split)],
+                 ev_front=[torch.cuda.Event() for _ in range(self.seg_split)],
                  ev_emb=[torch.cuda.Event() for _ in range(self.emb_split - 1)],
                  ev_frames=[torch.cuda.Event() for _ in range(self.emb_split)],
                  ev_in=torch.cuda.Event(), done=torch.cuda.Event())
@@ -325,11 +340,9 @@ class StreamBatch:
         F, K, D = self.seg.num_frames(S), None, self.emb.dimension
         if (S, 0) not in self._sub:
             # The scratch arenas of EVERY lane before the first kernel of this window size is enqueued
-            # (~0.85 GB of hipMalloc + hipMemset per lane).  Created lazily, lane 1's allocation ran while
-            # step 0's kernels were on the GPU and whatever kernel was resident then sat 21 - 29 ms in the
-            # trace (round 2: a stats_pool launch; round 3, profiles/r03_a_stall_report.json: a TDNN GEMM
-            # and the split-K linear, dispatch index 106 / 117 = the second step) — device memory
-            # allocation stalls the running queues.
+            # (~0.85 GB of hipMalloc + hipMemset per lane): no device allocation while kernels run.  (This
+            # did NOT remove the 21 - 39 ms start-up stall some runs show in their third step — it persisted
+            # with the arenas allocated up front; profiles/README.md)
             for ln in range(self.depth):
                 self._handles(S, ln)
         lane = self.lanes[self._t % self.depth]
@@ -341,7 +354,7 @@ class StreamBatch:
             # every in-flight slot up front: a pinned-memory allocation made while kernels are
             # running stalls the queues for tens of milliseconds (seen as one 40 ms "kernel" in the
             # rocprofv3 trace of the second step)
-            for _ in range(self.depth + self.lag + 1):
+            for _ in range(self.max_inflight + self.lag):
                 self._new_slot(F, K, D)
         slot = self._slot(F, K, D)
         slot["busy"] = True
@@ -354,19 +367,32 @@ class StreamBatch:
         # kernel sat 60 - 130 us in the queue in front of BOTH chains — and every other stream of the
         # step waits for `ev_in` re-recorded behind it.
         stats = slot["stats"] if self.shared_stats else None
+        front = lane["f"]                               # None: both halves on the `a` streams
         if stats is not None:
-            a0 = lane["a"][0]
+            a0 = (front or lane["a"])[0]
             a0.wait_event(slot["ev_in"])
             _lib.check(lib.dz_wave_stats(self._ctx, base, stride, N, S, stats.data_ptr(), a0.cuda_stream),
                        "dz_wave_stats")
             slot["ev_in"].record(a0)
-        for (i0, i1), h, a, ev in zip(sa, hsegs, lane["a"], slot["ev_seg"]):
+        for j, ((i0, i1), h, a, ev) in enumerate(zip(sa, hsegs, lane["a"], slot["ev_seg"])):
             a.wait_event(slot["ev_in"])
             if i1 == i0:                                 # fewer rows than sub-batches
                 ev.record(a)
                 continue
             if stats is not None:
                 _lib.check(lib.dz_seg_use_wave_stats(h, stats[i0:].data_ptr()), "dz_seg_use_wave_stats")
+            if front is not None:
+                f = front[j]
+                f.wait_event(slot["ev_in"])
+                _lib.check(lib.dz_seg_front(h, base + i0 * stride * esz, stride, i1 - i0, f.cuda_stream),
+                           "dz_seg_front")
+                slot["ev_front"][j].record(f)
+                a.wait_event(slot["ev_front"][j])
+                _lib.check(lib.dz_seg_back(h, i1 - i0, slot["seg"][i0:i1].data_ptr(), self.gamma, self.beta,
+                                           int(self.norm_w), slot["w"][i0:i1].data_ptr(), a.cuda_stream),
+                           "dz_seg_back")
+                ev.record(a)
+                continue
             # segmentation + the OSP weights of its output (one launch sequence, no dz_osp of its own)
             _lib.check(lib.dz_seg_forward_osp(h, base + i0 * stride * esz, stride, i1 - i0,
                                               slot["seg"][i0:i1].data_ptr(), self.gamma, self.beta,
@@ -385,7 +411,7 @@ class StreamBatch:
         slot["keep"] = keep                              # keep the view alive until the GPU is done
         slot["pool"] = (lane, hembs, sa, sb, N, K, F)     # what _enqueue_pool needs
         if ring is not None:                             # pushes `slack` steps from now wait for these
-            ring._read_by(list(lane["a"]) + list(lane["b"]))
+            ring._read_by(list(lane["a"]) + list(lane["b"]) + list(front or []))
         self._pending.append(slot)
         while len(self._pending) > self.lag:
             self._enqueue_pool(self._pending.pop(0))
@@ -534,7 +560,7 @@ class FileBatch:
                                         num_threads=self.threads)
         self._F = F
         self._max_turns = self._tails.max_turns
-        n = self.engine.depth + 2
+        n = self.engine.max_inflight + 1
         self._stage = [torch.empty((self.rows, self.S), dtype=torch.float32, device=self.device) for _ in range(n)]
         self._turns = [np.empty((self.rows, self._max_turns, 3), dtype=np.float64) for _ in range(2)]
         self._nturns = [np.empty(self.rows, dtype=np.int32) for _ in range(2)]
@@ -725,7 +751,7 @@ class FileBatch:
 
         admit()
         while True:
-            while len(inflight) <= self.engine.depth and launch_step():
+            while len(inflight) < self.engine.max_inflight and launch_step():
                 pass
             if not inflight:
                 admit()

@@ -109,6 +109,21 @@ def split_f16(w: torch.Tensor, name: Optional[str] = None) -> torch.Tensor:
     return torch.stack([hi, lo]).view(torch.int16).contiguous()
 
 
+def kb_major(planes: torch.Tensor) -> torch.Tensor:
+    """``[2][R][K]`` planes (``split_f16``) -> the same elements in the "kb-major" order the LDS-DMA kernels
+    read (``k_gemm_pre.hip``, ``k_mlp_head.hip``; ``dz_kb`` in ``csrc/dz_common.h``): ``[2][K / 32][R][32]``,
+    i.e. the 32-wide k-tile of consecutive rows is contiguous (16 rows = one 1 KiB LDS-DMA piece = 8 full
+    cache lines; row-major planes made every piece 16 half lines).  ``K`` must be a multiple of 32."""
+    two, rows, k = planes.shape
+    assert two == 2 and k % 32 == 0, planes.shape
+    return planes.reshape(2, rows, k // 32, 32).permute(0, 2, 1, 3).contiguous()
+
+
+def from_kb(planes: torch.Tensor, rows: int, k: int) -> torch.Tensor:
+    """Inverse of ``kb_major``: any tensor holding ``2 * rows * k`` kb-major elements -> ``[2][rows][k]``."""
+    return planes.reshape(2, k // 32, rows, 32).permute(0, 2, 1, 3).reshape(2, rows, k).contiguous()
+
+
 # (name, shape, relative RMS representation error) of every matrix split so far in this process, and
 # the error above which a layer is refused: 2^-20 = 9.5e-7 is ~30x an f32 rounding and about where the
 # whole-network gates of this package (segmentation 1e-4 abs, embedding 1e-4 rel) would start to notice
@@ -190,9 +205,11 @@ class _Packed:
         self.tensors.append(d)
         return d.data_ptr()
 
-    def put_split(self, t: torch.Tensor, name: Optional[str] = None) -> int:
-        """The matrix as two f16 planes (hi, lo * 2^11) for the split-f16 GEMM path."""
-        d = split_f16(t, name).to(self.device)
+    def put_split(self, t: torch.Tensor, name: Optional[str] = None, kb: bool = False) -> int:
+        """The matrix as two f16 planes (hi, lo * 2^11) for the split-f16 GEMM path; ``kb``: in the kb-major
+        order of the layers that run on ``k_gemm_pre.hip`` / ``k_mlp_head.hip`` (``kb_major``)."""
+        d = split_f16(t, name)
+        d = (kb_major(d) if kb else d).to(self.device)
         self.tensors.append(d)
         return d.data_ptr()
 
@@ -248,7 +265,8 @@ class PackedSegmentation:
             kpad = 64 if layer == 0 else 256
             w.wih[layer] = pk.put(_pad2(wih, 1024, kpad))
             if split:
-                w.wih_split[layer] = pk.put_split(_pad2(wih, 1024, kpad), f"lstm.weight_ih_l{layer}")
+                # layer 0 runs on k_gemm_split.hip (row-major planes), layers 1..3 on k_gemm_pre.hip (kb-major)
+                w.wih_split[layer] = pk.put_split(_pad2(wih, 1024, kpad), f"lstm.weight_ih_l{layer}", kb=layer > 0)
             bias = torch.cat([g(f"lstm.bias_ih_l{layer}") + g(f"lstm.bias_hh_l{layer}"),
                               g(f"lstm.bias_ih_l{layer}_reverse") + g(f"lstm.bias_hh_l{layer}_reverse")], 0)
             w.bih[layer] = pk.put(um(bias))
@@ -263,8 +281,8 @@ class PackedSegmentation:
         w.lin0_w, w.lin0_b = pk.put(g("linear.0.weight")), pk.put(g("linear.0.bias"))
         w.lin1_w, w.lin1_b = pk.put(g("linear.1.weight")), pk.put(g("linear.1.bias"))
         if split:
-            w.lin0_split = pk.put_split(g("linear.0.weight"), "linear.0")
-            w.lin1_split = pk.put_split(g("linear.1.weight"), "linear.1")
+            w.lin0_split = pk.put_split(g("linear.0.weight"), "linear.0", kb=True)
+            w.lin1_split = pk.put_split(g("linear.1.weight"), "linear.1", kb=True)
         cls_w, cls_b = g("classifier.weight"), g("classifier.bias")
         ncls = cls_w.shape[0]
         w.cls_w, w.cls_b = pk.put(_pad2(cls_w, 64, 128)), pk.put(_pad1(cls_b, 64))
@@ -298,7 +316,8 @@ class PackedEmbedding:
             k = cw.shape[2] * cin_pad
             w.tw[i] = pk.put(_conv_pack(cw, cin_pad, npad, (k + 31) // 32 * 32))
             if split:
-                w.tw_split[i] = pk.put_split(_conv_pack(cw, cin_pad, npad, (k + 31) // 32 * 32), f"tdnn{i + 1}")
+                # tdnn1 runs on k_gemm_split.hip (row-major planes), tdnn2..5 on k_gemm_pre.hip (kb-major)
+                w.tw_split[i] = pk.put_split(_conv_pack(cw, cin_pad, npad, (k + 31) // 32 * 32), f"tdnn{i + 1}", kb=i > 0)
             w.tb[i] = pk.put(_pad1(g(f"tdnns.{3 * i}.bias"), npad))
             bn = f"tdnns.{3 * i + 2}."
             scale = g(bn + "weight") / torch.sqrt(g(bn + "running_var") + BN_EPS)

@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define DZ_VERSION 220   /* 2.2: dz_file_step_batch, dz_wave_stats shared by both networks */
+#define DZ_VERSION 230   /* 2.3: kb-major f16 planes for the LDS-DMA kernels; dz_seg_front / dz_seg_back */
 
 typedef struct dz_ctx dz_ctx;
 typedef struct dz_seg dz_seg;
@@ -84,7 +84,10 @@ typedef struct {
     int powerset;                /* 1: log-softmax -> hard multilabel (models.py:29-39) */
     int num_speakers;            /* speakers of the multilabel output (3)            */
     /* split-f16 matrix path (optional; NULL = exact-f32 MFMA for that layer): the same matrices
-     * as two f16 planes [2][Npad][Kpad], hi = f16(W), lo = f16((W - hi) * 2^11) (weights.py split_f16) */
+     * as two f16 planes [2][Npad][Kpad], hi = f16(W), lo = f16((W - hi) * 2^11) (weights.py split_f16).
+     * wih_split[0] row-major; wih_split[1..3], lin0_split and lin1_split — the layers whose operands go
+     * global -> LDS by LDS-DMA — in the "kb-major" order [2][Kpad / 32][Npad][32] (weights.py kb_major):
+     * element (n, k) of a plane at ((k / 32) * Npad + n) * 32 + k % 32                                  */
     const void* wih_split[4];
     const void* lin0_split;
     const void* lin1_split;
@@ -105,7 +108,8 @@ typedef struct {
     const float* emb_w;          /* [512][3008]  Linear(3000, D), zero padded        */
     const float* emb_b;          /* [512] */
     int dimension;               /* D = 512 */
-    const void* tw_split[5];     /* split-f16 planes of tw[i] (optional, NULL = exact f32)     */
+    const void* tw_split[5];     /* split-f16 planes of tw[i] (optional, NULL = exact f32): tw_split[0] row-major
+                                    [2][Npad][Kpad], tw_split[1..4] kb-major (see dz_seg_weights)  */
 } dz_emb_weights;
 
 /* ---- segmentation: replaces the callable behind SegmentationModel.__call__ --
@@ -138,6 +142,15 @@ int dz_emb_forward(dz_emb* emb, const float* d_wave, long long wave_stride,
 int dz_emb_forward_multi(dz_emb* emb, const float* d_wave, long long wave_stride,
                          const float* d_weights, int batch, int num_speakers,
                          int weight_frames, int normalize, float* d_out, void* stream);
+/* dz_seg_forward_osp in two halves, for a caller that keeps the stateless front end of its NEXT step off
+ * the dependent chain of the current one: dz_seg_front — SincNet + the first LSTM x-projection — may be
+ * enqueued (on any stream) while dz_seg_back of the previous step on the SAME handle is still running its
+ * recurrences; the handle orders the one buffer they share on the GPU.  dz_seg_back consumes what the last
+ * dz_seg_front left (same batch) and must be ordered behind it by the caller (stream order or an event).   */
+int dz_seg_front(dz_seg* seg, const float* d_wave, long long wave_stride, int batch, void* stream);
+int dz_seg_back(dz_seg* seg, int batch, float* d_out, float gamma, float beta, int normalize,
+                float* d_weights /* may be NULL: no OSP weights */, void* stream);
+
 /* InstanceNorm1d(1) statistics of `batch` windows (the first op of BOTH networks' SincNet: the
  * reference computes them once per model, models.py:133 and :262 each run their own front end) as
  * dz_wave_stats_floats() floats per window (slice means and M2s, merged by the consumer).  A handle
@@ -251,10 +264,14 @@ typedef struct {
     const float* rowbias; /* optional [B][Npad] per-batch-item bias added to `bias`   */
     const void* Wsplit;   /* split-f16 path: W as two f16 planes [2][Npad][Kpad], hi = f16(W),
                              lo = f16((W - hi) * 2^11) (weights.py split_f16); NULL on the f32 path   */
-    /* pre-split activations (k_gemm_pre.hip): the input as two f16 planes [Tin][ldx], hi at Xsplit,
-     * lo (scaled by 2^11) xplane ELEMENTS further; the output, when Ysplit is set, in the same form
-     * ([Tstore][ldy] f16, lo plane yplane elements further) so that the next layer reads plain
-     * bytes.  Y (f32) and Ysplit may both be set.                                               */
+    /* pre-split activations (k_gemm_pre.hip): the input as two f16 planes of R = xplane / ldx >= Tin rows
+     * x ldx columns, hi at Xsplit, lo (scaled by 2^11) xplane ELEMENTS further, each plane in kb-major
+     * order: [ldx / 32][R][32], element (t, c) at ((c / 32) * R + t) * 32 + c % 32 — the 32-wide k-tile
+     * of consecutive rows is contiguous.  dz_k_gemm_pre also expects Wsplit in that order
+     * ([Kpad / 32][Npad][32] per plane).  The output, when Ysplit is set (dz_k_gemm_pre, dz_k_gemm_split),
+     * is written in the same form (yplane / ldy rows x ldy columns, lo plane yplane elements further; batch
+     * item b of dz_k_gemm_split owns rows b * ybs / ldy ..) so that the next layer reads plain bytes.
+     * Y (f32, row-major) and Ysplit may both be set.                                            */
     const void* Xsplit;
     long long xplane;
     void* Ysplit;
@@ -282,7 +299,8 @@ int dz_k_gemm_pre(dz_ctx* ctx, const dz_convgemm_desc* desc, void* stream);
  * descriptor, outputs and partials as the POOL3 call of dz_k_gemm_split                       */
 /* Tail of the segmentation network in one launch (csrc/k_mlp_head.hip: linear[0] -> linear[1] ->
  * classifier -> activation -> OSP weights without min-max) and the stand-alone classifier + activation
- * + OSP kernel it is checked against; inputs as the internal layers pass them (f16 hi/lo planes).  */
+ * + OSP kernel it is checked against; inputs as the internal layers pass them (kb-major f16 hi/lo planes:
+ * xsplit of exactly `rows` rows x 256, w0split [2][8][128][32], w1split [2][4][128][32]).                */
 int dz_k_mlp_head(dz_ctx* ctx, const void* xsplit, long long xplane, const void* w0split, const void* w1split,
                   const float* b0, const float* b1, const float* cw, const float* cb, int rows, int frames,
                   int classes, int speakers, int powerset, float gamma, float beta, float* d_seg,
@@ -323,8 +341,9 @@ int dz_k_lstm(dz_ctx* ctx, const float* d_gx, const float* d_whh, float* d_hout,
 int dz_k_lstm_mfma(dz_ctx* ctx, const float* d_gx, const void* d_whh_split, float* d_hout,
                    int batch, int frames, int unit_major, int variant, void* stream);
 /* either recurrence kernel (d_whh_split NULL: the f32 vector kernel on d_whh) writing h as the two
- * f16 planes (B,T,256) a dz_k_gemm_pre consumer reads: hi = f16(h) at d_hsplit, lo = f16((h - hi) *
- * 2^11) hplane elements further; gx in PyTorch column order                                      */
+ * f16 planes of hplane / 256 >= B*T rows x 256 columns a dz_k_gemm_pre consumer reads, in kb-major order
+ * (see dz_convgemm_desc.Xsplit): hi = f16(h) at d_hsplit, lo = f16((h - hi) * 2^11) hplane elements
+ * further; gx in PyTorch column order                                                            */
 int dz_k_lstm_planes(dz_ctx* ctx, const float* d_gx, const float* d_whh, const void* d_whh_split,
                      int variant, void* d_hsplit, long long hplane, int batch, int frames, void* stream);
 int dz_k_stats_pool(dz_ctx* ctx, const float* d_x, int frames, int channels, int ldx,

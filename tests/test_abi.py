@@ -30,7 +30,7 @@ def test_every_declared_symbol_is_exported_and_bound():
 
 def test_geometry_and_version():
     lib = _lib.load()
-    assert lib.dz_version() == 220
+    assert lib.dz_version() == 230
     assert lib.dz_seg_frames_for(80000) == 293 and lib.dz_seg_frames_for(160000) == 589
     assert lib.dz_emb_frames_for(80000) == 279
     assert lib.dz_seg_frames_for(200) == 0

@@ -424,6 +424,18 @@ def _unplanes(p):
     return h[0] + h[1] / 2048.0
 
 
+def _kb(x):
+    """f32 (rows, cols) -> the kb-major planes (2, cols / 32, rows, 32) k_gemm_pre.hip / k_mlp_head.hip read."""
+    from diart_amd.weights import kb_major
+    return kb_major(_planes(x))
+
+
+def _unkb(p, rows, cols):
+    """kb-major plane buffer (any shape) -> row-major (2, rows, cols)."""
+    from diart_amd.weights import from_kb
+    return from_kb(p, rows, cols)
+
+
 @pytest.mark.parametrize("M,Cin,taps,dil,N,Nstore,epi,outs", [
     (300, 512, 3, 2, 512, 512, "tdnn", "planes"),
     (1000, 256, 1, 1, 1024, 1024, "bias", "f32"),
@@ -448,7 +460,7 @@ def test_gemm_pre(gpu, M, Cin, taps, dil, N, Nstore, epi, outs):
     bias[:Nstore] = torch.randn(Nstore, generator=g) * 0.2
     e0, e1 = torch.rand(N, generator=g) + 0.5, torch.randn(N, generator=g) * 0.1
     code = {"bias": _lib.EPI_BIAS, "leaky": _lib.EPI_BIAS_LEAKY, "tdnn": _lib.EPI_TDNN}[epi]
-    dX, dW = _planes(X).to(gpu), _planes(W).to(gpu)
+    dX, dW = _kb(X).to(gpu), _kb(W).to(gpu)
     db, de0, de1 = bias.to(gpu), e0.to(gpu), e1.to(gpu)
     Y = torch.full((M, N), float("nan"), device=gpu) if outs in ("f32", "both") else None
     Yp = torch.full((2, M, N), 0x7e00, dtype=torch.int16, device=gpu) if outs in ("planes", "both") else None
@@ -477,7 +489,7 @@ def test_gemm_pre(gpu, M, Cin, taps, dil, N, Nstore, epi, outs):
         assert not torch.isnan(got).any()
         assert (got - ref[:, :Nstore]).abs().max().item() < 4e-6 * scale
     if Yp is not None:
-        P = Yp.cpu()
+        P = _unkb(Yp.cpu(), M, N)
         got = _unplanes(P)[:Tout]
         assert (got[:, :Nstore] - ref[:, :Nstore]).abs().max().item() < 4e-6 * scale
         assert (P[:, :Tout, Nstore:] == 0).all()                          # padding columns are zeros
@@ -502,7 +514,7 @@ def test_mlp_head(gpu, powerset, B, F):
     cw[:classes] = torch.randn(classes, 128, generator=g) / 8
     cb = torch.zeros(64)
     cb[:classes] = torch.randn(classes, generator=g) * 0.2
-    dh, dW0, dW1 = _planes(h).to(gpu), _planes(W0).to(gpu), _planes(W1).to(gpu)
+    dh, dW0, dW1 = _kb(h).to(gpu), _kb(W0).to(gpu), _kb(W1).to(gpu)
     db0, db1, dcw, dcb = b0.to(gpu), b1.to(gpu), cw.to(gpu), cb.to(gpu)
     lib, ctx = _lib.load(), _ctx(gpu)
     # --- three launches
@@ -576,7 +588,7 @@ def test_gemm_split_plane_output(gpu):
         _lib.check(lib.dz_k_gemm_split(_ctx(gpu), C.byref(d), None), "dz_k_gemm_split")
     _sync()
     want = Yf.cpu()[:, :Tout].double()
-    got = _unplanes(Yp.cpu().view(2, B * T, N)).view(B, T, N)[:, :Tout]
+    got = _unplanes(_unkb(Yp.cpu(), B * T, N)).view(B, T, N)[:, :Tout]        # kb-major planes of B * T rows
     assert want.abs().max() > 0.5
     assert (got - want).abs().max().item() < 2.0 ** -21 * want.abs().max().item()
 
@@ -605,7 +617,7 @@ def test_lstm_plane_output(gpu, kernel):
                                         B * T * 256, B, T, None))
     _sync()
     want = hf.cpu().double()
-    got = _unplanes(hp.cpu().view(2, B * T, 256)).view(B, T, 256)
+    got = _unplanes(_unkb(hp.cpu(), B * T, 256)).view(B, T, 256)
     assert want.abs().max() > 0.3
     assert (got - want).abs().max().item() < 2.0 ** -21
 
@@ -623,13 +635,13 @@ def test_split_gemm_dynamic_range(gpu, kernel):
     W = torch.randn(N, K, generator=g) / math.sqrt(K)
     bias = torch.zeros(N)
     Y = torch.full((M, N), float("nan"), device=gpu)
-    dW, db = _planes(W).to(gpu), bias.to(gpu)
+    dW, db = (_kb(W) if kernel == "pre" else _planes(W)).to(gpu), bias.to(gpu)
     d = _lib.ConvGemmDesc()
     d.Wsplit, d.bias, d.Y = dW.data_ptr(), db.data_ptr(), Y.data_ptr()
     d.B, d.Tin, d.Tout, d.Tstore, d.Cin, d.taps, d.dil = 1, M, M, M, K, 1, 1
     d.K, d.Kpad, d.Npad, d.Nstore, d.ldx, d.ldy, d.epi = K, K, N, N, K, N, _lib.EPI_BIAS
     if kernel == "pre":
-        dX = _planes(X).to(gpu)
+        dX = _kb(X).to(gpu)
         d.Xsplit, d.xplane = dX.data_ptr(), M * K
         _lib.check(_lib.load().dz_k_gemm_pre(_ctx(gpu), C.byref(d), None))
     else:
@@ -675,7 +687,7 @@ def test_f16x3_dynamic_range_map(gpu, monkeypatch):
             d.K, d.Kpad, d.Npad, d.Nstore, d.ldx, d.ldy, d.epi = K, K, N, N, K, N, _lib.EPI_BIAS
             keep = []
             if kernel == "f16x3":
-                dW, dX = _planes(W).to(gpu), _planes(X).to(gpu)
+                dW, dX = _kb(W).to(gpu), _kb(X).to(gpu)
                 d.Wsplit, d.Xsplit, d.xplane = dW.data_ptr(), dX.data_ptr(), M * K
                 keep += [dW, dX]
                 _lib.check(lib.dz_k_gemm_pre(_ctx(gpu), C.byref(d), None))

@@ -351,3 +351,54 @@ def test_websocket_front_end_streams_rttm_from_the_gpu(gpu):
         assert got == want
     finally:
         fe.stop()
+
+
+def test_front_half_on_its_own_stream_is_the_same_arithmetic(gpu, monkeypatch):
+    """DZ_SEG_FRONT=1: SincNet + the first x-projection of step t + depth on their own stream under the
+    recurrences of step t (dz_seg_front / dz_seg_back).  Same kernels, same operands: bit-identical
+    outputs, with depth + 1 steps in flight (the front half of a lane's next step overlaps its current
+    back half; the handle's event guards the one buffer they share)."""
+    n, W, hop, steps = 8, 80000, 8000, 9
+    audio = torch.from_numpy(synth_streams(n, (W + hop * steps) / 16000.0, seed0=910)).to(gpu)
+    seg_sd, emb_sd = synth_segmentation_state(), synth_embedding_state()
+
+    def run(front, split=1):
+        monkeypatch.setenv("DZ_SEG_FRONT", "1" if front else "0")
+        sb = StreamBatch(M.HipSegmentation(seg_sd, max_batch=n), M.HipEmbedding(emb_sd, max_batch=n), n,
+                         device=gpu, seg_split=split, emb_split=1)
+        assert sb.seg_front == front
+        inflight, out = [], []
+        for t in range(steps):
+            inflight.append(sb.launch(audio[:, t * hop:t * hop + W]))
+            if len(inflight) > sb.depth:
+                out.append([np.array(x) for x in sb.finish(inflight.pop(0))])
+        while inflight:
+            out.append([np.array(x) for x in sb.finish(inflight.pop(0))])
+        return out
+
+    want = run(False)
+    for split in (1, 2):
+        got = run(True, split)
+        for t in range(steps):
+            for a, b in zip(want[t], got[t]):
+                assert np.array_equal(a, b), (split, t)
+
+
+def test_back_half_refuses_a_batch_the_front_half_did_not_prepare(gpu):
+    from diart_amd import _lib
+    lib = _lib.load()
+    seg = M.HipSegmentation(synth_segmentation_state(), max_batch=4).to(gpu)
+    h = seg._create(80000, 4)
+    try:
+        x = torch.from_numpy(synth_streams(4, 5.0, seed0=5)).to(gpu)
+        out = torch.empty((4, 293, 3), device=gpu)
+        st = torch.cuda.current_stream(gpu).cuda_stream
+        assert lib.dz_seg_back(h, 4, out.data_ptr(), 3.0, 10.0, 0, None, st) != 0     # nothing prepared
+        assert b"dz_seg_front prepared 0" in lib.dz_last_error()
+        assert lib.dz_seg_front(h, x.data_ptr(), x.stride(0), 3, st) == 0
+        assert lib.dz_seg_back(h, 4, out.data_ptr(), 3.0, 10.0, 0, None, st) != 0
+        assert lib.dz_seg_back(h, 3, out.data_ptr(), 3.0, 10.0, 0, None, st) == 0
+        torch.cuda.synchronize()
+        assert torch.equal(out[:3], seg(x[:3, None, :]))
+    finally:
+        seg._destroy(h)

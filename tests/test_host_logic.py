@@ -339,3 +339,26 @@ def test_split_f16_measures_how_well_a_layer_is_represented():
     assert W.SPLIT_REPORT[-1][0] == "tiny layer" and W.SPLIT_REPORT[-1][2] > W.SPLIT_LIMIT
     split_f16(torch.randn(64, 256) * 2.0 ** -12, "small but fine")      # 2^-12: still 22-bit grade
     assert W.SPLIT_REPORT[-1][2] < 2.0 ** -21
+
+
+def test_kb_major_is_the_index_map_the_kernels_use():
+    """``weights.kb_major``: [2][R][K] planes -> [2][K / 32][R][32], element (r, c) of a plane at
+    ((c // 32) * R + r) * 32 + c % 32 (``dz_kb`` in csrc/dz_common.h — what the producing epilogues write and
+    the LDS-DMA loads of k_gemm_pre.hip / k_mlp_head.hip read); ``from_kb`` is its inverse."""
+    from diart_amd.weights import from_kb, kb_major, split_f16
+    g = torch.Generator().manual_seed(3)
+    R, K = 37, 96
+    planes = split_f16(torch.randn(R, K, generator=g))
+    kb = kb_major(planes)
+    assert kb.shape == (2, K // 32, R, 32) and kb.is_contiguous()
+    flat = kb.reshape(2, -1)
+    for r, c in ((0, 0), (5, 31), (5, 32), (36, 95), (17, 64)):
+        assert flat[0, ((c // 32) * R + r) * 32 + c % 32] == planes[0, r, c]
+        assert flat[1, ((c // 32) * R + r) * 32 + c % 32] == planes[1, r, c]
+    assert torch.equal(from_kb(kb, R, K), planes)
+    assert torch.equal(from_kb(flat.reshape(-1), R, K), planes)          # any shape holding the same elements
+    # a 16-row piece of one k-tile is 1 KiB of contiguous memory
+    piece = flat[0, (1 * R + 16) * 32:(1 * R + 32) * 32].reshape(16, 32)
+    assert torch.equal(piece, planes[0, 16:32, 32:64])
+    with pytest.raises(AssertionError):
+        kb_major(split_f16(torch.randn(4, 40)))

@@ -20,7 +20,7 @@ i=0
 for cfg in $GRID; do
   i=$((i+1))
   echo "=== bench $cfg" >> $OUT
-  env $(echo $cfg | tr ',' ' ') timeout 300 python bench.py --steps ${STEPS:-200} --warmup 10 --no-cpu-baseline --no-exact-f32 --pmc off ${BENCH_ARGS:---no-host-pass} \
+  env $(echo $cfg | tr ',' ' ') timeout ${BENCH_TIMEOUT:-90} python bench.py --steps ${STEPS:-200} --warmup 10 --no-cpu-baseline --no-exact-f32 --pmc off ${BENCH_ARGS:---no-host-pass} \
       > gpurun_out/bench_${TAG}_$i.json 2>gpurun_out/bench_${TAG}_$i.err
   python - <<PY >> $OUT
 import json

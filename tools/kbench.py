@@ -108,10 +108,10 @@ def convgemm(name, Bn, Tin, Cin, N, taps, dil, epi, Npad=None, pro=False, pool=F
             print(f"    {name}_convpool vs f32 kernel: rel L2 {err:.2e}", flush=True)
     if not ksplit and not pro and not pool and Cin % 32 == 0 and Npad % 128 == 0 and (not only or name + "_pre" in only or name in only):
         # k_gemm_pre.hip: flattened rows, both operands as f16 planes, f32 and plane output
-        from diart_amd.weights import split_f16
+        from diart_amd.weights import kb_major, split_f16
         M = Bn * Tin
-        xs = split_f16(X.reshape(M, Cin).cpu()).to(dev)
-        ws = split_f16(W.cpu()).to(dev)
+        xs = kb_major(split_f16(X.reshape(M, Cin).cpu())).to(dev)
+        ws = kb_major(split_f16(W.cpu())).to(dev)
         Yf = torch.zeros(M, Npad, device=dev)
         Yp = torch.zeros(2, M, Npad, dtype=torch.int16, device=dev)
         d2 = _lib.ConvGemmDesc()
@@ -198,10 +198,10 @@ timeit("stats_pool", lambda: _lib.check(lib.dz_k_stats_pool(ctx, x5.data_ptr(), 
        bytes_=B * 279 * 1536 * 4.0)
 # ---- segmentation tail: two MLP GEMMs + head (three launches) vs k_mlp_head.hip (one) --------
 if not only or "mlp_head" in only:
-    from diart_amd.weights import split_f16
+    from diart_amd.weights import kb_major, split_f16
     rows = B * F
-    hs = split_f16(torch.tanh(torch.randn(rows, 256))).to(dev)
-    w0s, w1s = split_f16(torch.randn(128, 256) / 16).to(dev), split_f16(torch.randn(128, 128) / 11).to(dev)
+    hs = kb_major(split_f16(torch.tanh(torch.randn(rows, 256)))).to(dev)
+    w0s, w1s = kb_major(split_f16(torch.randn(128, 256) / 16)).to(dev), kb_major(split_f16(torch.randn(128, 128) / 11)).to(dev)
     b0, b1 = torch.zeros(128, device=dev), torch.zeros(128, device=dev)
     cw, cb = torch.randn(64, 128, device=dev) / 8, torch.zeros(64, device=dev)
     segb, wb = torch.empty(B, F, 3, device=dev), torch.empty(B, 3, F, device=dev)
