@@ -49,7 +49,8 @@ class SeRes2Net(C.Structure):
 
 class EcapaWeights(C.Structure):
     _fields_ = [("dft", vp), ("mel", vp), ("block0", Layer), ("ser", SeRes2Net * 3), ("mfa", Layer),
-                ("asp_tdnn", Layer), ("asp_wms", vp), ("asp_conv", Layer), ("fc", Layer), ("zeros", vp)]
+                ("asp_tdnn", Layer), ("asp_wms", vp), ("asp_conv", Layer), ("fc", Layer), ("zeros", vp),
+                ("dft_split", vp)]
 
 
 # name -> (restype, argtypes); must list every function of include/diart_amd.h

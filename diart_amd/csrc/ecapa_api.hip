@@ -8,7 +8,7 @@
 
 namespace {
 
-enum { MIN_NUM_SAMPLES = 640, HOP = 160, NFFT = 400, C1 = 1024, C3 = 3072, EMB = 192, FC_SPLIT = 16 };
+enum { MIN_NUM_SAMPLES = 640, HOP = 160, NFFT = 400, C1 = 1024, C3 = 3072, EMB = 192, FC_SPLIT = 16, SE_SPLIT = 8 };
 
 struct Carve {
     char* base = nullptr;
@@ -122,11 +122,12 @@ static int gemm(hipStream_t st, const float* X, int ldx, long long xbs, int B, i
     p.Cin = Cin; p.taps = taps; p.dil = dil; p.pad = pad; p.K = taps * Cin; p.Kpad = Kpad;
     p.Npad = Npad; p.Nstore = Nstore; p.ldx = ldx; p.ldy = ldy; p.xbs = xbs; p.ybs = ybs;
     p.epi = epi; p.X2 = X2; p.rowbias = rowbias; p.ksplit = ksplit; p.ysplit = ysplit;
-    // the wide 1x1 layers (87 % of the network's FLOPs) come with split-f16 planes in the default
-    // precision: same contraction on the f16 matrix cores (k_gemm_split.hip)
-    if (L.wsplit && epi == DZ_EPI_RELU_BN && taps == 1 && pad == 0 && !X2 && !rowbias && ksplit <= 1 &&
-        Npad % 128 == 0 && Cin % 8 == 0) {
+    // every layer that comes with split-f16 planes (default precision: block 0, the wide 1x1 layers, the
+    // Res2Net convolutions with their reflect padding and second input, the attention's output
+    // convolution, the DFT) runs the same contraction on the f16 matrix cores (k_gemm_split.hip)
+    if (L.wsplit && (epi == DZ_EPI_RELU_BN || epi == DZ_EPI_BIAS) && !rowbias && ksplit <= 1 && Cin % 8 == 0) {
         p.Wsplit = L.wsplit;
+        p.Npad = (Npad + 127) / 128 * 128;       // (the DFT's planes are packed with 512 rows)
         return dz_launch_gemm_split(p, st);
     }
     return dz_launch_convgemm(p, st);
@@ -185,7 +186,7 @@ extern "C" int dz_ecapa_forward(dz_ecapa* e, const float* d_wave, long long wave
     const long long NT = (long long)N * T;
 
     // ---- 2. Fbank: STFT as one GEMM over overlapping rows (hop 160 < window 400) ---------------
-    dz_layer dft = {w.dft, w.zeros, nullptr, nullptr, nullptr};
+    dz_layer dft = {w.dft, w.zeros, nullptr, nullptr, w.dft_split};
     if ((rc = gemm(st, e->sig, HOP, e->lstride, N, T, NFFT, 1, 1, 0, dft, nullptr, 416, 448, 402, e->spec,
                    404, (long long)T * 404, DZ_EPI_BIAS)))
         return rc;
@@ -226,9 +227,12 @@ extern "C" int dz_ecapa_forward(dz_ecapa* e, const float* d_wave, long long wave
             return rc;
         // squeeze-excitation + residual, written straight into its slice of the concatenation
         if ((rc = dz_launch_se_mean(e->t2, T, C1, C1, N, e->nmask, e->smean, st))) return rc;
-        if ((rc = gemm(st, e->smean, C1, 0, 1, N, C1, 1, 1, 0, b.se1, nullptr, C1, 128, 128, e->sfc1, 128, 0,
-                       DZ_EPI_BIAS_RELU)))
+        // squeeze (N rows x 1024 -> 128): one output tile, so the K loop is split 8 ways (a lone workgroup
+        // walking 32 k-tiles took 90 us); the ReLU follows the fixed-order reduce
+        if ((rc = gemm(st, e->smean, C1, 0, 1, N, C1, 1, 1, 0, b.se1, nullptr, C1, 128, 128, e->parts, 128, 0,
+                       DZ_EPI_BIAS, nullptr, nullptr, SE_SPLIT, (long long)N * 128)))
             return rc;
+        if ((rc = dz_launch_splitk_finish(e->parts, SE_SPLIT, (long long)N * 128, N, 128, 2, e->sfc1, st))) return rc;
         if ((rc = gemm(st, e->sfc1, 128, 0, 1, N, 128, 1, 1, 0, b.se2, nullptr, 128, C1, C1, e->gate, C1, 0,
                        DZ_EPI_BIAS_SIGMOID)))
             return rc;
@@ -242,9 +246,11 @@ extern "C" int dz_ecapa_forward(dz_ecapa* e, const float* d_wave, long long wave
     // attentive statistics pooling with global context: W [x; mean; std] = Wx x + Wms [mean; std]
     if ((rc = dz_launch_asp_gstats(e->mfa, T, C3, N, e->nmask, e->gstat, st))) return rc;
     dz_layer wms = {w.asp_wms, w.zeros, nullptr, nullptr};
-    if ((rc = gemm(st, e->gstat, 2 * C3, 0, 1, N, 2 * C3, 1, 1, 0, wms, nullptr, 2 * C3, 128, 128, e->rb, 128, 0,
-                   DZ_EPI_BIAS)))
+    // (N rows x 6144 -> 128: one output tile and 192 k-tiles — 0.5 ms for a lone workgroup; split-K like fc)
+    if ((rc = gemm(st, e->gstat, 2 * C3, 0, 1, N, 2 * C3, 1, 1, 0, wms, nullptr, 2 * C3, 128, 128, e->parts, 128, 0,
+                   DZ_EPI_BIAS, nullptr, nullptr, FC_SPLIT, (long long)N * 128)))
         return rc;
+    if ((rc = dz_launch_splitk_finish(e->parts, FC_SPLIT, (long long)N * 128, N, 128, 0, e->rb, st))) return rc;
     if ((rc = gemm(st, e->mfa, C3, (long long)T * C3, N, T, C3, 1, 1, 0, w.asp_tdnn, nullptr, C3, 128, 128, e->a1,
                    128, (long long)T * 128, DZ_EPI_RELU_BN_TANH, nullptr, e->rb)))
         return rc;

@@ -91,6 +91,7 @@ __global__ __launch_bounds__(128 * WM) void gemm_split_kernel(DzConvGemm p) {
     const int crow = tid >> 2, cidx = tid & 3;
     const bool has_b = tid < BN * 4;
     const float* Xb = p.X + (long long)b * p.xbs;
+    const float* X2b = !PRO && p.X2 ? p.X2 + (long long)b * p.xbs : nullptr;
     const float* nsc = PRO ? p.nscale + (long long)b * p.nld : nullptr;
     const float* nsh = PRO ? p.nshift + (long long)b * p.nld : nullptr;
     __shared__ __attribute__((aligned(16))) float nrm_s[PRO ? 256 : 4];   // scale[nld] | shift[nld], nld <= 128
@@ -120,13 +121,24 @@ __global__ __launch_bounds__(128 * WM) void gemm_split_kernel(DzConvGemm p) {
             tap = k / p.Cin;
             c = k - tap * p.Cin;
         }
-        const int toff = tap * p.dil;
+        const int toff = tap * p.dil - (PRO ? 0 : p.pad);
         {
             f32x4 v0 = {0.f, 0.f, 0.f, 0.f}, v1 = {0.f, 0.f, 0.f, 0.f};
             if (kvalid) {
-                const float* src = Xb + (long long)(trow + toff) * p.ldx + c;
-                v0 = *reinterpret_cast<const f32x4*>(src);
-                v1 = *reinterpret_cast<const f32x4*>(src + 4);
+                int tt = trow + toff;
+                if (!PRO && p.pad) {   // "same" convolution with reflect padding (ECAPA TDNN blocks; k_convgemm.hip)
+                    tt = tt < 0 ? -tt : tt;
+                    tt = tt >= p.Tin ? 2 * (p.Tin - 1) - tt : tt;
+                }
+                const long long xo = (long long)tt * p.ldx + c;
+                v0 = *reinterpret_cast<const f32x4*>(Xb + xo);
+                v1 = *reinterpret_cast<const f32x4*>(Xb + xo + 4);
+                if (!PRO && X2b) {     // Res2Net: the convolution input is x_i + y_{i-1}
+                    const f32x4 u0 = *reinterpret_cast<const f32x4*>(X2b + xo);
+                    const f32x4 u1 = *reinterpret_cast<const f32x4*>(X2b + xo + 4);
+                    v0 += u0;
+                    v1 += u1;
+                }
                 if (PRO) {
                     const f32x4 s0 = *reinterpret_cast<const f32x4*>(nsc + c);
                     const f32x4 s1 = *reinterpret_cast<const f32x4*>(nsc + c + 4);
@@ -312,9 +324,13 @@ int dz_launch_gemm_split(const DzConvGemm& p_in, hipStream_t st) {
     DZ_REQUIRE(p.Kpad % KT == 0 && p.Cin % 8 == 0 && p.ldx % 4 == 0 && p.K % 8 == 0,
                "gemm_split: bad K/Cin/ldx (Cin and K must be multiples of 8)");
     DZ_REQUIRE(p.K <= p.Kpad && p.K == p.taps * p.Cin, "gemm_split: K mismatch");
-    DZ_REQUIRE(p.pad == 0 && p.X2 == nullptr && p.rowbias == nullptr && p.ksplit <= 1,
-               "gemm_split: padding / second input / row bias / split-K are f32-path features");
-    DZ_REQUIRE(p.Tout > 0 && p.Tout == p.Tin - (p.taps - 1) * p.dil, "gemm_split: Tout mismatch");
+    DZ_REQUIRE(p.rowbias == nullptr && p.ksplit <= 1, "gemm_split: row bias / split-K are f32-path features");
+    DZ_REQUIRE((p.pad == 0 && p.X2 == nullptr) || !p.norm_on_load,
+               "gemm_split: padding / a second input are not built together with norm-on-load");
+    DZ_REQUIRE(p.pad >= 0 && p.Tout > 0 && p.Tout == (p.pad ? p.Tin : p.Tin - (p.taps - 1) * p.dil),
+               "gemm_split: Tout mismatch");
+    DZ_REQUIRE(p.pad == 0 || (2 * p.pad == (p.taps - 1) * p.dil && p.pad < p.Tin),
+               "gemm_split: reflect 'same' padding needs 2*pad == (taps-1)*dil and pad < Tin");
     DZ_REQUIRE(p.Y != nullptr || p.Ysplit != nullptr, "gemm_split: no output");
     DZ_REQUIRE(!p.norm_on_load || (p.nscale && p.nshift) ||
                    (p.npart && p.ngamma && p.nbeta && p.npart_tiles > 0 && p.npart_T > 0 && p.nld <= 128),

@@ -315,7 +315,8 @@ __global__ __launch_bounds__(256) void l2norm_kernel(float* __restrict__ x, int 
 
 // ---------------------------------------------------------------------------
 // splitk_finish: out[r][:] = sum_z parts[z][r][:] in fixed order (deterministic, unlike
-// atomics), optionally followed by x <- x / ||x||_2.  One workgroup per row, thread = column
+// atomics), optionally followed by x <- x / ||x||_2 (normalize = 1) or x <- max(x, 0) (normalize = 2: the
+// ReLU of a split-K layer, which cannot be applied to partial sums).  One workgroup per row, thread = column
 // (dim <= 512); the partials of a column are fetched four at a time (the one-wave-per-row version
 // walked 8 x nsplit dependent L2 round trips per lane: 45 us for 192 rows).  The sum of squares is
 // formed in the order of that version (columns l, l+64, ... per lane, then the butterfly).
@@ -341,7 +342,8 @@ __global__ __launch_bounds__(512) void splitk_finish_kernel(const float* __restr
         }
         for (; z < nsplit; ++z) a += p[(long long)z * stride];
     }
-    if (normalize) {
+    if (normalize == 2) a = fmaxf(a, 0.f);
+    if (normalize == 1) {
         sq[w][l] = a * a;
         __syncthreads();
         if (w == 0) {

@@ -355,8 +355,8 @@ class PackedEcapa:
         def layer(dst, prefix, cin_pad, npad, kpad, norm=True, weight=None, wide=False):
             cw = g(prefix + ".conv.weight") if weight is None else weight
             dst.w = pk.put(_conv_pack(cw, cin_pad, npad, kpad))
-            if wide and split:   # 1x1, >= 1024 channels: also as split-f16 planes
-                dst.wsplit = pk.put_split(_conv_pack(cw, cin_pad, npad, kpad))
+            if wide and split:   # also as split-f16 planes: the layer runs on k_gemm_split.hip
+                dst.wsplit = pk.put_split(_conv_pack(cw, cin_pad, npad, kpad), prefix)
             dst.b = pk.put(_pad1(g(prefix + ".conv.bias"), npad))
             if norm:
                 sc, sh = bn(prefix.rsplit(".conv", 1)[0] + ".norm", npad)
@@ -364,14 +364,16 @@ class PackedEcapa:
 
         # ---- features ------------------------------------------------------------------
         w.dft = pk.put(_pad2(dft_matrices().float(), 448, 416))
+        if split:
+            w.dft_split = pk.put_split(_pad2(dft_matrices().float(), 512, 416), "windowed DFT")
         w.mel = pk.put(_pad2(ecapa_mel_filterbank().t().contiguous(), 128, 224))
         # ---- network -------------------------------------------------------------------
-        layer(w.block0, "blocks.0.conv", 80, 1024, 416)
+        layer(w.block0, "blocks.0.conv", 80, 1024, 416, wide=True)
         for i in range(3):
             p, b = f"blocks.{i + 1}", w.ser[i]
             layer(b.tdnn1, p + ".tdnn1.conv", 1024, 1024, 1024, wide=True)
             for j in range(7):
-                layer(b.res[j], p + f".res2net_block.blocks.{j}.conv", 128, 128, 384)
+                layer(b.res[j], p + f".res2net_block.blocks.{j}.conv", 128, 128, 384, wide=True)
             layer(b.tdnn2, p + ".tdnn2.conv", 1024, 1024, 1024, wide=True)
             layer(b.se1, p + ".se_block.conv1", 1024, 128, 1024, norm=False)
             layer(b.se2, p + ".se_block.conv2", 128, 1024, 128, norm=False)
@@ -379,7 +381,7 @@ class PackedEcapa:
         aw = g("asp.tdnn.conv.conv.weight")                           # (128, 9216, 1)
         layer(w.asp_tdnn, "asp.tdnn.conv", 3072, 128, 3072, weight=aw[:, :3072])
         w.asp_wms = pk.put(aw[:, 3072:, 0].contiguous())             # (128, 6144)
-        layer(w.asp_conv, "asp.conv", 128, 3072, 128, norm=False)
+        layer(w.asp_conv, "asp.conv", 128, 3072, 128, norm=False, wide=True)
         sc, sh = bn("asp_bn", 6144)
         fw, fb = g("fc.conv.weight")[:, :, 0], g("fc.conv.bias")     # (192, 6144)
         w.fc.w = pk.put((fw * sc[None, :]).contiguous())

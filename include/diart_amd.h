@@ -186,7 +186,8 @@ typedef struct {
     const float* b;   /* [Npad] bias                                                          */
     const float* s;   /* [Npad] folded BatchNorm scale (NULL if the layer has no norm)        */
     const float* h;   /* [Npad] folded BatchNorm shift                                        */
-    const void* wsplit; /* optional split-f16 planes of w (the wide 1x1 layers: tdnn1, tdnn2, mfa)   */
+    const void* wsplit; /* optional split-f16 planes of w, row-major [2][Npad][Kpad] (block0, tdnn1, Res2Net,
+                           tdnn2, mfa, asp_conv): the layer then runs on the f16 matrix cores        */
 } dz_layer;
 typedef struct {
     dz_layer tdnn1;    /* 1x1, 1024 -> 1024                                                   */
@@ -206,6 +207,7 @@ typedef struct {
     dz_layer asp_conv;     /* [3072][128]                                                      */
     dz_layer fc;           /* [192][6144] with asp_bn folded in                                */
     const float* zeros;    /* [6144] zeros                                                     */
+    const void* dft_split; /* optional split-f16 planes [2][512][416] of dft (zero padded rows)        */
 } dz_ecapa_weights;
 typedef struct dz_ecapa dz_ecapa;
 int dz_ecapa_frames_for(int num_samples);   /* 1 + S / 160 */
