@@ -718,3 +718,43 @@ def test_f16x3_dynamic_range_map(gpu, monkeypatch):
     out = Path(__file__).resolve().parent.parent / "gpurun_out"
     out.mkdir(exist_ok=True)
     (out / "f16x3_range.json").write_text(json.dumps(rows, indent=1))
+
+
+@pytest.mark.parametrize("kernel", ["f32", "f16x3"])
+@pytest.mark.parametrize("taps,dil,Cin,N,T", [(3, 2, 128, 128, 77), (3, 4, 128, 128, 301), (5, 1, 80, 1024, 150)])
+def test_same_convolution_with_reflect_padding_and_second_input(gpu, kernel, taps, dil, Cin, N, T):
+    """ECAPA-TDNN's "same" convolutions (reflect padding, speechbrain Conv1d) with the Res2Net second input
+    (conv(x_i + y_{i-1})) -> ReLU -> folded BatchNorm, on the exact-f32 kernel and (round 3) on the
+    split-f16 kernel, against torch's own reflect-padded conv1d in f64."""
+    g = torch.Generator().manual_seed(taps * 100 + dil)
+    B, pad = 3, (taps - 1) * dil // 2
+    x = torch.randn(B, T, Cin, generator=g)
+    x2 = torch.randn(B, T, Cin, generator=g) if Cin == 128 else None
+    w = torch.randn(N, Cin, taps, generator=g) / math.sqrt(Cin * taps)
+    bias, e0, e1 = torch.randn(N, generator=g) * 0.1, torch.rand(N, generator=g) + 0.5, torch.randn(N, generator=g) * 0.1
+    kpad = (taps * Cin + 31) // 32 * 32
+    Wp = _pack(w, Cin, N, kpad)
+    from diart_amd.weights import split_f16
+    keep = [t.to(gpu) for t in (x, Wp, split_f16(Wp), bias, e0, e1)]
+    Y = torch.full((B, T, N), float("nan"), device=gpu)
+    d = _lib.ConvGemmDesc()
+    d.X, d.W, d.bias, d.e0, d.e1, d.Y = keep[0].data_ptr(), keep[1].data_ptr(), keep[3].data_ptr(), keep[4].data_ptr(), keep[5].data_ptr(), Y.data_ptr()
+    if x2 is not None:
+        dx2 = x2.to(gpu)
+        d.X2 = dx2.data_ptr()
+    d.B, d.Tin, d.Tout, d.Tstore, d.Cin, d.taps, d.dil, d.pad = B, T, T, T, Cin, taps, dil, pad
+    d.K, d.Kpad, d.Npad, d.Nstore, d.ldx, d.ldy = taps * Cin, kpad, N, N, Cin, N
+    d.xbs, d.ybs, d.epi = T * Cin, T * N, _lib.EPI_RELU_BN
+    lib = _lib.load()
+    if kernel == "f16x3":
+        d.Wsplit = keep[2].data_ptr()
+        _lib.check(lib.dz_k_gemm_split(_ctx(gpu), C.byref(d), None), "dz_k_gemm_split")
+    else:
+        _lib.check(lib.dz_k_convgemm(_ctx(gpu), C.byref(d), None), "dz_k_convgemm")
+    _sync()
+    xin = (x if x2 is None else x + x2).double().permute(0, 2, 1)
+    ref = F.conv1d(F.pad(xin, (pad, pad), mode="reflect"), w.double(), bias.double(), dilation=dil)
+    ref = (F.relu(ref) * e0.double()[None, :, None] + e1.double()[None, :, None]).permute(0, 2, 1)
+    got = Y.cpu().double()
+    assert not torch.isnan(got).any()
+    assert (got - ref).abs().max().item() < 3e-5 * max(1.0, ref.abs().max().item())
