@@ -105,18 +105,19 @@ __device__ __forceinline__ void gemm_pre_tile(const DzConvGemm& p, const int t0,
     const int kb_bytes = prows * 64;                                            // one k-block of the plane
     const int dst0 = isB ? 2 * PLANE_A : 0, dplane = isB ? PLANE_B : PLANE_A;
     auto issue = [&](int kt, int stage) {
-        int soff;
-        if (isB) {
-            soff = kt * kb_bytes;
-        } else {
-            const int k = kt * KT;
-            int tap = 0, c = k;
-            if (p.taps > 1) {
-                tap = k / p.Cin;
-                c = k - tap * p.Cin;
-            }
-            soff = (c >> 5) * kb_bytes + tap * p.dil * 64;
+        // k-tile kt of the loop = (channel block kt / taps, tap kt % taps): the taps of one channel block are
+        // consecutive, so the three reads of (almost) the same activation lines — rows t, t + dil, t + 2 dil of
+        // one k-block — follow each other while the lines are still in the L2.  In the tap-major order of the
+        // weight matrix's K axis they were a third of the loop apart, and with 16 row tiles in flight per XCD
+        // (4.3 MB of activations beside 3 MB of weights in a 4 MB L2) each sweep fetched them from HBM again:
+        // FETCH_SIZE of tdnn2 - 4 was 2.05x the algorithmic bytes.  (The weights keep their layout: k-block
+        // tap * Cin / 32 + channel block.)
+        int cblk = kt, tap = 0;
+        if (p.taps > 1) {
+            cblk = kt / p.taps;
+            tap = kt - cblk * p.taps;
         }
+        const int soff = isB ? (tap * (p.Cin >> 5) + cblk) * kb_bytes : cblk * kb_bytes + tap * p.dil * 64;
         char* dst = smem + stage * STAGE + dst0;
 #pragma unroll
         for (int j = 0; j < JMAX; ++j) {
@@ -208,11 +209,11 @@ __device__ __forceinline__ void gemm_pre_tile(const DzConvGemm& p, const int t0,
         const int r2 = w & 1;                                       // rank inside the pair of waves of a side
         char* const dbase = smem + dst0 + r2 * 1024;
         const int vofs = voff0 + r2 * vstep;
-        int cpos = 0, tapo = 0;                                     // channel / tap offset (bytes of a k-block row) of tile kt + 1
+        int cblk = 0, tap = 0;                                      // (channel block, tap) of tile kt + 1, see issue()
+        const int tap_step = isB ? (p.Cin >> 5) * kb_bytes : p.dil * 64;
         auto advance = [&]() -> int {                               // -> soffset (bytes) of the NEXT tile
-            cpos += KT;
-            if (!isB && p.taps > 1 && cpos >= p.Cin) { cpos -= p.Cin; tapo += p.dil * 64; }
-            return (cpos >> 5) * kb_bytes + tapo;
+            if (++tap == p.taps) { tap = 0; ++cblk; }
+            return cblk * kb_bytes + tap * tap_step;
         };
         int soff_next = 0, stage_next = 0;
         const bool no_dma = flags & 2, no_rd = flags & 4;           // TIMING EXPERIMENTS (DZ_GP_DBG, wrong results)
@@ -658,6 +659,15 @@ int dz_launch_gemm_pre_pool(const DzConvGemm& p_in, const DzPoolFuse& q, hipStre
                "gemm_pre_pool: kb-major input planes need ldx %% 32 == 0 and xplane = rows * ldx with rows >= Tin");
     DZ_REQUIRE(p.xplane * 2 < (1ll << 31) && (long long)p.Npad * p.Kpad * 2 < (1ll << 31),
                "gemm_pre_pool: operand plane exceeds the 2 GiB buffer-offset range");
+    // Row tiles swept together per XCD (dz_tile_map_lin).  ONE: the 12 column tiles of a row tile are then
+    // consecutive workgroups of their XCD and share the activation tile while it is in the L2 (live PMC,
+    // per launch: 157 MB with groups of 4, 145 with 2, 135 with 1; the weights — 3 MB — stay resident
+    // either way).  DZ_POOL_AG overrides.
+    static const int pool_ag = [] {
+        const char* e = getenv("DZ_POOL_AG");
+        return e && atoi(e) > 0 ? atoi(e) : 1;
+    }();
+    if (!p.agroup) p.agroup = pool_ag;
     static DzAttrOnce attr_once;
     DZ_HIP(attr_once.raise((const void*)gemm_pre_pool_kernel, (int)POOL_LDS));
     const int gx = (p.Tout + BM - 1) / BM, gy = p.Npad / BN;
