@@ -64,14 +64,26 @@ __global__ __launch_bounds__(256) void convgemm_kernel(DzConvGemm p) {
     const float* Wt = p.W + (long long)(n0 + lrow) * p.Kpad + lkq * 4;
 
     f32x4 ra[C::A_F4], rb[C::B_F4];
+    // Wide multi-tap layers (x-vector tdnn2 - 4: Cin = 512) walk K with the taps of one 32-channel block
+    // consecutive — loop tile kt = (channel block kt / taps, tap kt % taps) — so that the three reads of
+    // (almost) the same activation lines follow each other; in the tap-major order of W's K axis they were a
+    // third of the loop apart and the L2 (16+ row tiles in flight per XCD beside the weights) had dropped
+    // them in between: FETCH_SIZE 2x the algorithmic bytes.  Same products, different summation order.
+    const bool tap_minor = p.taps > 1 && p.Cin % KT == 0 && p.K == p.Kpad;
     auto load_tile = [&](int kt) {
-        const int k = kt * KT + lkq * 4;
-        const bool kvalid = k < p.K;
-        int tap = 0, c = k;
-        if (p.taps > 1) {
-            tap = k / p.Cin;
-            c = k - tap * p.Cin;
+        int kw = kt * KT;                     // first column of this tile in W's K axis
+        int tap = 0, c = kw + lkq * 4;
+        if (tap_minor) {
+            const int cblk = kt / p.taps;
+            tap = kt - cblk * p.taps;
+            c = cblk * KT + lkq * 4;
+            kw = tap * p.Cin + cblk * KT;
+        } else if (p.taps > 1) {
+            tap = c / p.Cin;
+            c -= tap * p.Cin;
         }
+        const int k = kw + lkq * 4;
+        const bool kvalid = k < p.K;
         f32x4 sc = {0.f, 0.f, 0.f, 0.f}, sh = {0.f, 0.f, 0.f, 0.f};
         if (PRO && kvalid) {
             sc = *reinterpret_cast<const f32x4*>(nsc + c);
@@ -103,7 +115,7 @@ __global__ __launch_bounds__(256) void convgemm_kernel(DzConvGemm p) {
         }
 #pragma unroll
         for (int a = 0; a < C::B_F4; ++a)
-            rb[a] = *reinterpret_cast<const f32x4*>(Wt + (long long)(32 * a) * p.Kpad + kt * KT);
+            rb[a] = *reinterpret_cast<const f32x4*>(Wt + (long long)(32 * a) * p.Kpad + kw);
     };
     auto store_tile = [&](int buf) {
         float* As = smem + buf * C::TILE;
