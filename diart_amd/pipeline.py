@@ -229,6 +229,8 @@ class StreamBatch:
         # where finish() spends its time: waiting for the GPU vs clustering + output tail on the host
         self.host_seconds = {"wait": 0.0, "work": 0.0}
         self._sub: dict = {}
+        self._warmed: set = set()
+        self._warming, self._real_steps = False, 0       # (see _warm_up)
         self._slots: List[dict] = []
         self._lib = _lib.load()
         self._ctx = _lib.context(self.device.index)
@@ -345,6 +347,17 @@ class StreamBatch:
             # with the arenas allocated up front; profiles/README.md)
             for ln in range(self.depth):
                 self._handles(S, ln)
+            # ... and the output tail's host state NOW, while the GPU is idle: built lazily in the first
+            # finish() — 64 aggregation states (30 MB of fresh host memory, mapped and first touched) + 7.5 MB
+            # of result buffers while two steps were on the GPU — it froze every resident kernel for 20 - 40 ms
+            # (tools/stall_probe.py: gone when only this is moved; the first clustering call, which starts the
+            # worker threads, is not the trigger).  This was the start-up stall of rounds 1 - 3.
+            if self.with_tail and self.tail is None:
+                self.tail = BatchedOutputTail(self.n, F, self.max_speakers, self.step, self.latency,
+                                              self.tau_active, num_threads=self.cluster_threads)
+        if S not in self._warmed:
+            self._warmed.add(S)
+            self._warm_up(S)
         lane = self.lanes[self._t % self.depth]
         hsegs, hembs, _, _ = self._handles(S, self._t % self.depth)
         # sub-batch ranges of THIS step's rows (each at most the capacity its handle was built for)
@@ -418,6 +431,50 @@ class StreamBatch:
         self._t += 1
         return slot
 
+    def _warm_up(self, S: int) -> None:
+        """A few overlapped steps on silence before the first real one of this window size.  Besides the
+        start-up stall proper (the output tail's host buffers, now allocated before the first launch: see
+        `_launch_rows`), a fresh process shows two 7 - 12 ms intervals within its first ~8 steps
+        (tools/stall_probe.py, no tracer; profiles/r03_f_stall_probe.txt): one-time set-up for the first
+        launches of each kernel on each queue — gone after warm steps, while warming the streams, the copy
+        path and the events alone did not move them.  Complete steps (GPU + host half: the worker pool's
+        threads start here too) while no stream has any state yet, GPU-only steps for a second window size
+        later on; ~0.1 s of construction time instead of latency spikes in a live stream.  DZ_WARMUP=<steps>
+        (0 = off)."""
+        steps = int(os.environ.get("DZ_WARMUP", "10"))
+        if steps <= 0:
+            return
+        zeros = torch.zeros((self.n, S), dtype=torch.float32, device=self.device)
+        saved = dict(self.host_seconds)
+        inflight: List[dict] = []
+        if self._real_steps == 0:                        # complete steps, then forget them
+            self._warming = True
+            try:
+                for _ in range(steps):
+                    inflight.append(self.launch(zeros))
+                    if len(inflight) >= self.max_inflight:
+                        self.finish(inflight.pop(0))
+                while inflight:
+                    self.finish(inflight.pop(0))
+            finally:
+                self._warming = False
+            torch.cuda.synchronize(self.device)
+            self.reset()
+        else:
+            base, stride = zeros.data_ptr(), zeros.stride(0)
+            for _ in range(steps):
+                inflight.append(self._launch_rows(base, stride, self.n, S, zeros))
+                if len(inflight) >= self.max_inflight:
+                    t = inflight.pop(0)
+                    self._wait(t)
+                    t["busy"], t["keep"] = False, None
+            for t in inflight:
+                self._wait(t)
+                t["busy"], t["keep"] = False, None
+            torch.cuda.synchronize(self.device)
+        self._t = 0
+        self.host_seconds.update(saved)
+
     def _enqueue_pool(self, slot: dict):
         """Statistics pooling + Linear + normalisation of a launched step (they consume the OSP
         weights, i.e. wait for its segmentation), the copy of its results to pinned memory and its
@@ -450,6 +507,8 @@ class StreamBatch:
         reuses: copy what has to outlive the next step."""
         import time as _time
         self._wait(ticket)
+        if not self._warming:
+            self._real_steps += 1
         t1 = _time.perf_counter()
         # The ticket's slot is ALWAYS handed back (ADVICE r2): an exception between here and the end
         # used to leak it, and every later launch then allocated a new pinned slot while kernels were
