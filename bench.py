@@ -622,6 +622,13 @@ def main():
     # steps the contract asks for
     run(0, min(total_steps, 10))
     torch.cuda.synchronize()
+    # Everything allocated so far (torch, numpy, the pipeline's Python objects) lives for the whole run: take it
+    # out of the cyclic collector's generations, or a full collection stops the launching thread for 5 - 8 ms
+    # once per few hundred steps (seen as a GPU idle gap of that length in the dispatch timestamps; the steps
+    # themselves create no cycles).  What a service loop does after start-up; nothing is skipped.
+    import gc
+    gc.collect()
+    gc.freeze()
     # ---- size the host threads from what the second batch of settling steps measures -----------
     n_settle = min(total_steps, 10)
     host["launch"] = host["finish"] = 0.0

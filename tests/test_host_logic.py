@@ -362,3 +362,47 @@ def test_kb_major_is_the_index_map_the_kernels_use():
     assert torch.equal(piece, planes[0, 16:32, 32:64])
     with pytest.raises(AssertionError):
         kb_major(split_f16(torch.randn(4, 40)))
+
+
+def test_timeline_tool_splits_a_drain_into_steps(tmp_path):
+    """tools/timeline.py on a hand-made DZ_PROF_TIMELINE file (csrc/api.hip dz_prof_collect: one line per
+    bracketed launch, host enqueue order): steps are cut at `wave_stats`, the first SincNet of a step is
+    the segmentation's, the second the embedding's, everything from tdnn5 on is the part behind the
+    segmentation."""
+    import importlib.util
+    import json
+    root = __import__("pathlib").Path(__file__).resolve().parent.parent
+    spec = importlib.util.spec_from_file_location("dz_timeline", root / "tools" / "timeline.py")
+    tl = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(tl)
+    seg = ["sinc_conv0", "conv1_pool", "conv2_pool", "lstm_proj0", "lstm_rec", "lstm_proj", "lstm_rec", "seg_mlp"]
+    emb = ["sinc_conv0", "conv1_pool", "conv2_pool", "tdnn1", "tdnn2", "tdnn3", "tdnn4"]
+    tail = ["tdnn5", "stats_pool", "emb_linear"]
+    lines = ["# drain of %d launches" % (3 * (1 + len(seg) + len(emb) + len(tail)))]
+    for step in range(3):
+        z = 1000.0 * step
+        lines.append(f"wave_stats 64 {z:.1f} 10.0")
+        for i, k in enumerate(seg):
+            lines.append(f"{k} 64 {z + 20 + 100 * i:.1f} 90.0")          # 10 us gaps
+        for i, k in enumerate(emb):
+            lines.append(f"{k} 64 {z + 50 + 60 * i:.1f} 50.0")
+        for i, k in enumerate(tail):
+            lines.append(f"{k} 64 {z + 830 + 40 * i:.1f} 30.0")
+    f = tmp_path / "tl.txt"
+    f.write_text("\n".join(lines) + "\n")
+    st = tl.steps_of(tl.read(str(f))[0])
+    assert len(st) == 3
+    assert [k["tag"] for k in st[1]["seg"]] == seg and [k["tag"] for k in st[1]["emb"]] == emb
+    assert [k["tag"] for k in st[1]["tail"]] == tail
+    assert st[2]["stats"] == 2000.0 and st[2]["seg"][0]["t0"] == 2020.0 and st[2]["tail"][-1]["t1"] == 2940.0
+    out = tmp_path / "tl.json"
+    import sys
+    argv = sys.argv
+    sys.argv = ["timeline.py", str(f), "--steps", "1:3", "--json", str(out)]
+    try:
+        tl.main()
+    finally:
+        sys.argv = argv
+    summary = json.loads(out.read_text())
+    assert abs(summary["mean_period_us"] - 1000.0) < 1e-6
+    assert abs(summary["steps"][0]["seg_span_us"] - 790.0) < 1e-6 and abs(summary["steps"][0]["seg_busy_us"] - 720.0) < 1e-6
