@@ -402,3 +402,34 @@ def test_back_half_refuses_a_batch_the_front_half_did_not_prepare(gpu):
         assert torch.equal(out[:3], seg(x[:3, None, :]))
     finally:
         seg._destroy(h)
+
+
+def test_warm_steps_leave_no_trace(gpu, monkeypatch):
+    """StreamBatch runs warm steps on silence before the first real one (pipeline.py _warm_up: the output
+    tail is built and the first-launch set-up absorbed while no stream is live).  They must leave nothing
+    behind: identical segmentation / embeddings / clustering / speech turns with DZ_WARMUP=0, stream clocks
+    at zero, lanes starting at 0."""
+    n, W, hop, steps = 4, 80000, 8000, 6
+    audio = torch.from_numpy(synth_streams(n, (W + hop * steps) / 16000.0, seed0=77)).to(gpu)
+    seg_sd, emb_sd = synth_segmentation_state(), synth_embedding_state()
+
+    def run(warm):
+        monkeypatch.setenv("DZ_WARMUP", str(warm))
+        sb = StreamBatch(M.HipSegmentation(seg_sd, max_batch=n), M.HipEmbedding(emb_sd, max_batch=n), n,
+                         device=gpu, tail=True, latency=1.0)
+        out = []
+        for t in range(steps):
+            ticket = sb.launch(audio[:, t * hop:t * hop + W])
+            if t == 0:
+                assert sb._real_steps == 0 and sb._t == 1 and (sb._steps == 1).all() and sb.tail is not None
+            res = [np.array(x) for x in sb.finish(ticket)]
+            agg, rows, t0, r, turns, nturns = ticket["tail"]
+            out.append(res + [np.array(rows), np.array(t0), np.array(nturns),
+                              np.concatenate([turns[i, :nturns[i]].ravel() for i in range(n)])])
+        assert sb._real_steps == steps
+        return out
+
+    cold, warm = run(0), run(10)
+    for a, b in zip(cold, warm):
+        for x, y in zip(a, b):
+            assert np.array_equal(x, y, equal_nan=True)
