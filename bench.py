@@ -106,6 +106,11 @@ def lstm_chains_per_wg():
     return 2 if e == "2" else 1
 
 
+def gemm_generation():
+    """k_gemm_pre.hip dispatches its launches to k_gemm_g2.hip with DZ_GEMM_GEN=2 (dz_gemm_gen())."""
+    return 2 if os.environ.get("DZ_GEMM_GEN", "1") == "2" else 1
+
+
 def device_kernel(tag, precision):
     """bench tag -> (rocprofv3 kernel symbol, bound, chip peak, unit): the roofline is reported per
     DEVICE kernel, so the layers that share one instantiation are one entry."""
@@ -138,10 +143,11 @@ def device_kernel(tag, precision):
     nsplit = pre and os.environ.get("DZ_NORM_SPLIT", "0") == "1" and os.environ.get("DZ_CONV_POOL", "1") != "0"
     if pre and (tag in ("tdnn2", "tdnn3", "tdnn4", "tdnn5", "lstm_proj", "seg_mlp") or (nsplit and tag in ("lstm_proj0", "tdnn1"))):
         ilv = "true" if os.environ.get("DZ_GP_LOOP", "1") != "0" else "false"
-        sym = {"lstm_proj": f"gemm_pre_kernel<0, {ilv}>", "lstm_proj0": f"gemm_pre_kernel<0, {ilv}>",
-               "seg_mlp": f"gemm_pre_kernel<1, {ilv}>",
-               "tdnn5": "gemm_pre_pool_kernel" if fused_pool else f"gemm_pre_kernel<3, {ilv}>"}.get(
-                   tag, f"gemm_pre_kernel<3, {ilv}>")
+        kern = lambda epi: f"gemm_pre_kernel<{epi}, {ilv}>"
+        if gemm_generation() == 2:                                    # k_gemm_g2.hip
+            kern = lambda epi: f"gemm_g2_kernel<{epi}, {os.environ.get('DZ_G2_MT', '2')}>"
+        sym = {"lstm_proj": kern(0), "lstm_proj0": kern(0), "seg_mlp": kern(1),
+               "tdnn5": "gemm_pre_pool_kernel" if fused_pool else kern(3)}.get(tag, kern(3))
         return sym, "mfma", PEAK_F16_MATRIX_TFLOPS / SPLIT_PRODUCTS, "TFLOP/s"
     if tag in ("conv1_pool", "conv2_pool") and os.environ.get("DZ_CONV_POOL", "1") != "0":
         return ("conv_pool_h_kernel<80>" if tag == "conv1_pool" else "conv_pool_h_kernel<64>"), "mfma", \

@@ -909,6 +909,19 @@ extern "C" int dz_k_gemm_pre(dz_ctx* ctx, const dz_convgemm_desc* d, void* strea
     DzRangeScope range_scope(ctx->oflag_dev);
     return dz_launch_gemm_pre(*d, (hipStream_t)stream);
 }
+extern "C" int dz_k_gemm_g2(dz_ctx* ctx, const dz_convgemm_desc* d, int row_fragments, void* stream) {
+    DZ_REQUIRE(ctx && d, "dz_k_gemm_g2: NULL argument");
+    DZ_REQUIRE(d->Wsplit && d->Xsplit && (d->Y || d->Ysplit) && d->B == 1 && d->K == d->Kpad && d->K == d->taps * d->Cin &&
+                   d->Cin % 32 == 0 && d->Npad % 128 == 0 && d->pad == 0 && !d->X2 && !d->rowbias && d->ksplit <= 1 &&
+                   !d->norm_on_load && d->Tout > 0 && d->Tout == d->Tin - (d->taps - 1) * d->dil && d->ldx % 32 == 0 &&
+                   d->xplane % d->ldx == 0 && d->xplane / d->ldx >= d->Tin,
+               "dz_k_gemm_g2: the requirements of dz_k_gemm_pre apply");
+    DZ_HIP(hipSetDevice(ctx->device));
+    DzRangeScope range_scope(ctx->oflag_dev);
+    DzConvGemm p = *d;
+    if (!p.oflag) p.oflag = ctx->oflag_dev;
+    return dz_launch_gemm_g2(p, row_fragments, (hipStream_t)stream);
+}
 extern "C" int dz_k_mlp_head(dz_ctx* ctx, const void* xsplit, long long xplane, const void* w0split,
                              const void* w1split, const float* b0, const float* b1, const float* cw,
                              const float* cb, int rows, int frames, int classes, int speakers, int powerset,

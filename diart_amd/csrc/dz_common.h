@@ -250,6 +250,11 @@ int dz_launch_gemm_split(const DzConvGemm& p, hipStream_t st);
 int dz_launch_conv_pool(const DzConvGemm& p, hipStream_t st);
 // k_gemm_pre.hip: both operands pre-split into f16 planes, tiles loaded by LDS-DMA
 int dz_launch_gemm_pre(const DzConvGemm& p, hipStream_t st);
+// k_gemm_g2.hip: generation 2 of the same layer (single accumulator, three LDS stages, counted vmcnt);
+// mt = row fragments per wave (2, 3, 4 -> 128 / 192 / 256 x 128 tiles), 0 = DZ_G2_MT / default
+int dz_launch_gemm_g2(const DzConvGemm& p, int mt, hipStream_t st);
+int dz_g2_default_mt();
+int dz_gemm_gen();
 // The same launch with the weighted statistics pooling (paper Eq. 1) fused into the epilogue of the LAST
 // x-vector layer (tdnn5): the 128 x 128 output tile is parked in LDS instead of HBM and reduced there
 // to per-(tile, chunk, speaker, channel) weighted means and centred second moments — exact two-pass

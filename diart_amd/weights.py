@@ -129,6 +129,8 @@ def from_kb(planes: torch.Tensor, rows: int, k: int) -> torch.Tensor:
 # whole-network gates of this package (segmentation 1e-4 abs, embedding 1e-4 rel) would start to notice
 SPLIT_REPORT: list = []
 SPLIT_LIMIT = 2.0 ** -20
+# largest |w| of a kb-major weight matrix (the layers on k_gemm_pre.hip / k_gemm_g2.hip): 2^11 |w| must stay an f16
+KB_WEIGHT_LIMIT = 31.98
 
 
 def dft_matrices(n_fft: int = 400) -> torch.Tensor:
@@ -209,6 +211,12 @@ class _Packed:
         """The matrix as two f16 planes (hi, lo * 2^11) for the split-f16 GEMM path; ``kb``: in the kb-major
         order of the layers that run on ``k_gemm_pre.hip`` / ``k_mlp_head.hip`` (``kb_major``)."""
         d = split_f16(t, name)
+        if kb and t.numel() and float(t.detach().abs().max()) >= KB_WEIGHT_LIMIT:
+            # k_gemm_g2.hip multiplies the hi plane of a weight fragment by 2^11 in f16 (one accumulator per
+            # fragment): exact while |w| < 32, infinite beyond
+            raise ValueError(f"{name or 'matrix'}: |weight| up to {float(t.detach().abs().max()):g} >= {KB_WEIGHT_LIMIT:g} "
+                             "cannot be scaled by 2^11 inside the f16 range (k_gemm_g2.hip); load the model with "
+                             "precision=\"f32\"")
         d = (kb_major(d) if kb else d).to(self.device)
         self.tensors.append(d)
         return d.data_ptr()

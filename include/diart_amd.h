@@ -296,6 +296,10 @@ int dz_k_gemm_split(dz_ctx* ctx, const dz_convgemm_desc* desc, void* stream);
 /* ... with the activations pre-split as well (desc->Wsplit and desc->Xsplit set; B = 1, K = taps*Cin
  * unpadded, Cin % 32 == 0): operand tiles go global -> LDS by LDS-DMA                            */
 int dz_k_gemm_pre(dz_ctx* ctx, const dz_convgemm_desc* desc, void* stream);
+/* generation 2 of the same layer (k_gemm_g2.hip: one accumulator per fragment, three LDS stages, counted
+ * vmcnt); row_fragments = 2, 3, 4 -> 128 / 192 / 256 x 128 tiles, 0 = default.  dz_k_gemm_pre dispatches to it
+ * with DZ_GEMM_GEN=2 outside the single-chunk latency regime.                                        */
+int dz_k_gemm_g2(dz_ctx* ctx, const dz_convgemm_desc* desc, int row_fragments, void* stream);
 /* SincNet stages 1 / 2 (DZ_EPI_POOL3, k = 5, 64 output columns, Cin 80 or 64, norm-on-load, dense
  * rows) on the dedicated kernel: input tile resident in LDS, weights in registers; same
  * descriptor, outputs and partials as the POOL3 call of dz_k_gemm_split                       */

@@ -445,8 +445,11 @@ def _unkb(p, rows, cols):
     (5, 256, 1, 1, 128, 128, "leaky", "f32"),
     (5157, 256, 3, 1, 512, 512, "tdnn", "both"),     # 128 x 128 tiles with a ragged last row tile
 ])
-def test_gemm_pre(gpu, M, Cin, taps, dil, N, Nstore, epi, outs):
-    """k_gemm_pre.hip (both operands as f16 hi/lo planes, tiles by LDS-DMA) against an f64 torch
+@pytest.mark.parametrize("kern", ["pre", "g2_mt2", "g2_mt3", "g2_mt4"])
+def test_gemm_pre(gpu, M, Cin, taps, dil, N, Nstore, epi, outs, kern):
+    """k_gemm_pre.hip and the three tile sizes of its generation 2, k_gemm_g2.hip (one accumulator per
+    fragment, three LDS stages, counted vmcnt), against an f64 torch restatement.
+    k_gemm_pre.hip (both operands as f16 hi/lo planes, tiles by LDS-DMA) against an f64 torch
     restatement: implicit-GEMM convolution over the flattened rows, every epilogue, f32 and / or
     plane output (whose hi + lo * 2^-11 must reproduce the f32 result to 2^-21), zeroed padding
     columns, ragged last tile."""
@@ -473,7 +476,10 @@ def test_gemm_pre(gpu, M, Cin, taps, dil, N, Nstore, epi, outs):
         d.Ysplit, d.yplane = Yp.data_ptr(), M * N
     d.B, d.Tin, d.Tout, d.Tstore, d.Cin, d.taps, d.dil = 1, M, Tout, Tout, Cin, taps, dil
     d.K, d.Kpad, d.Npad, d.Nstore, d.ldx, d.ldy, d.epi = K, K, N, Nstore, Cin, N, code
-    _lib.check(_lib.load().dz_k_gemm_pre(_ctx(gpu), C.byref(d), None), "dz_k_gemm_pre")
+    if kern == "pre":
+        _lib.check(_lib.load().dz_k_gemm_pre(_ctx(gpu), C.byref(d), None), "dz_k_gemm_pre")
+    else:
+        _lib.check(_lib.load().dz_k_gemm_g2(_ctx(gpu), C.byref(d), int(kern[-1]), None), "dz_k_gemm_g2")
     _sync()
     # reference on the operands the kernel saw (22-bit planes), f64
     Xq, Wq = _unplanes(_planes(X)), _unplanes(_planes(W))
