@@ -698,7 +698,9 @@ static int emb_frames(dz_emb* e, const float* d_wave, long long stride, int B, h
         } else {
             p.B = 1; p.Tin = B * P; p.Tout = p.Tstore = B * P - span;
         }
-        if (i == 4 && e->pre && pool_fuse_enabled() && dz_gemm_pre_pool_ok(p)) {
+        // (the pooled epilogue walks at most two chunks per 128-row tile: chunk pitch >= 128 rows, i.e. windows of
+        // ~2.3 s and longer; shorter windows keep the unfused tdnn5 + stats_pool)
+        if (i == 4 && e->pre && pool_fuse_enabled() && e->g.P2 >= 128 && e->T[4] >= 2 && dz_gemm_pre_pool_ok(p)) {
             // tdnn5 runs with the pooling in its epilogue, i.e. when the weights are known (emb_head)
             e->pending_B = B;
             e->pending_in = in;
@@ -737,7 +739,8 @@ static int emb_head(dz_emb* e, const float* d_weights, int Fw, int rows, int row
             q.w = d_weights; q.Fw = Fw; q.K = rows_per_x; q.P = P; q.T = e->T[4]; q.np = dz_pool_pieces(P);
             q.part = e->ppart; q.s0 = e->ps0;
             { ProfScope ps(T_TDNN5, B); if ((rc = dz_launch_gemm_pre_pool(p, q, st))) return rc; }
-            e->pending_B = 0;
+            // the frames stay pending: tdnn4's planes are intact until the next dz_emb_frames, so a second
+            // dz_emb_pool on the same frames (other weights) runs the pooled tdnn5 again
             { ProfScope ps(T_POOL, B);
               if ((rc = dz_launch_pool_combine(e->ppart, e->ps0, B, rows_per_x, dz_pool_pieces(P), P, e->T[4], 1500, 1536, e->pooled,
                                                kPoolLd, st)))

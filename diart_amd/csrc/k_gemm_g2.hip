@@ -53,7 +53,9 @@ __device__ __forceinline__ float leaky(float v) { return v > 0.f ? v : v * DZ_LE
 
 #define G2_PIN() __builtin_amdgcn_sched_barrier(0)
 
-template <int EPI, int MT>
+// DBG (timing experiments, results are wrong): 1 = no LDS-DMA inside the loop, 2 = no MFMAs, 4 = no fragment
+// reads inside the loop, 8 = no barrier (waits only)
+template <int EPI, int MT, int DBG = 0>
 __device__ __forceinline__ void g2_tile(const DzConvGemm& p, const int t0, const int n0, char* smem) {
     constexpr int PLANE_A = plane_a(MT), STAGE = stage_bytes(MT);
     constexpr int NPA = 2 * MT, NPB = 4, PPW = NPA + NPB;     // LDS-DMA pieces per wave and k-tile
@@ -96,7 +98,9 @@ __device__ __forceinline__ void g2_tile(const DzConvGemm& p, const int t0, const
     };
     char* const dA = smem + w * 1024;
     char* const dB = smem + 2 * PLANE_A + w * 1024;
+    bool in_loop = false;
     auto piece = [&](const int j) {          // j = 0 .. PPW-1 (compile-time after unrolling)
+        if ((DBG & 1) && in_loop) return;
         char* const st = (j < NPA ? dA : dB) + f_stage * STAGE;
         if (j < NPA) {
             const int lo = j >= MT, i = j - lo * MT;
@@ -141,36 +145,57 @@ __device__ __forceinline__ void g2_tile(const DzConvGemm& p, const int t0, const
         f16x8 ah[MT], al[MT], bh[2], bl[2];
     };
     Frags S0, S1;
-    auto read_frags = [&](Frags& S, const int stage, const int foff) {
+    // fragment r of a set (compile-time r): the order in which a k-step's MFMAs first need them
+    //   r = 0, 1: bh[0], bh[1]   2 .. MT+1: ah[.]   MT+2 .. 2MT+1: al[.]   2MT+2, 2MT+3: bl[0], bl[1]
+    constexpr int NR = 4 + 2 * MT;
+    auto read_one = [&](Frags& S, const int stage, const int foff, const int r) {
+        if ((DBG & 4) && in_loop) return;
         const char* a = fa + stage * STAGE + foff;
         const char* b = fb + stage * STAGE + foff;
+        if (r < 2)
+            S.bh[r] = *reinterpret_cast<const f16x8*>(b + r * 2048);
+        else if (r < 2 + MT)
+            S.ah[r - 2] = *reinterpret_cast<const f16x8*>(a + (r - 2) * 2048);
+        else if (r < 2 + 2 * MT)
+            S.al[r - 2 - MT] = *reinterpret_cast<const f16x8*>(a + PLANE_A + (r - 2 - MT) * 2048);
+        else
+            S.bl[r - 2 - 2 * MT] = *reinterpret_cast<const f16x8*>(b + PLANE_B + (r - 2 - 2 * MT) * 2048);
+    };
+    auto read_frags = [&](Frags& S, const int stage, const int foff) {
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            S.bh[t] = *reinterpret_cast<const f16x8*>(b + t * 2048);
-            S.bl[t] = *reinterpret_cast<const f16x8*>(b + PLANE_B + t * 2048);
-        }
-#pragma unroll
-        for (int t = 0; t < MT; ++t) {
-            S.ah[t] = *reinterpret_cast<const f16x8*>(a + t * 2048);
-            S.al[t] = *reinterpret_cast<const f16x8*>(a + PLANE_A + t * 2048);
-        }
+        for (int r = 0; r < NR; ++r) read_one(S, stage, foff, r);
     };
     // One 16-wide k-step: 6 MT MFMAs ordered (product, mt, nt) so that two MFMAs on one accumulator are 2 MT
-    // instructions apart; after every GAP-th MFMA one LDS-DMA piece of the tile being fetched (pieces
-    // [p0, p0 + np)).  TRANSPOSED product as in k_gemm_pre.hip: the weight fragment is the MFMA's row operand,
-    // so a lane ends with one output row (lane & 31) and groups of four consecutive output columns.
-    auto kstep = [&](const Frags& S, const int p0, const int np) {
+    // instructions apart.  Between them, one at a time: the NR fragment reads of the NEXT k-step into the other
+    // register set (all at once they are a burst of 4 waves x 8 KB that the LDS serves at its full rate while no
+    // wave issues an MFMA — measured: +12 us on a 30 us tile, tools/g2ablate.py) and one LDS-DMA piece of the
+    // tile being fetched after every GAP-th MFMA (pieces [p0, p0 + np)).  TRANSPOSED product as in
+    // k_gemm_pre.hip: the weight fragment is the MFMA's row operand, so a lane ends with one output row (lane &
+    // 31) and groups of four consecutive output columns.
+    auto kstep = [&](const Frags& S, Frags& Sn, const bool rd, const int rstage, const int rfoff, const int p0,
+                     const int np) {
         f16x8 b2[2];
 #pragma unroll
         for (int t = 0; t < 2; ++t) b2[t] = S.bh[t] * (_Float16)2048.f;
         const int gap = np > 0 ? NM / np : NM + 1;
-        int issued = 0;
+        constexpr int rgap = NM / NR;
+        int issued = 0, nread = 0;
 #pragma unroll
         for (int m = 0; m < NM; ++m) {
             const int ty = m / (2 * MT), r = m - ty * 2 * MT, mt = r >> 1, nt = r & 1;
             const f16x8 bo = ty == 0 ? b2[nt] : ty == 1 ? S.bh[nt] : S.bl[nt];
             const f16x8 ao = ty == 1 ? S.al[mt] : S.ah[mt];
-            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bo, ao, acc[mt][nt], 0, 0, 0);
+            if (DBG & 2) {
+                asm volatile("" ::"v"(bo), "v"(ao));
+            } else {
+                acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bo, ao, acc[mt][nt], 0, 0, 0);
+            }
+            if (rd && nread < NR && (m + 1) % rgap == 0) {
+                G2_PIN();
+                read_one(Sn, rstage, rfoff, nread);
+                G2_PIN();
+                ++nread;
+            }
             if (issued < np && (m + 1) % gap == 0) {
                 G2_PIN();
                 piece(p0 + issued);
@@ -180,6 +205,10 @@ __device__ __forceinline__ void g2_tile(const DzConvGemm& p, const int t0, const
         }
 #pragma unroll
         for (; issued < np; ++issued) piece(p0 + issued);
+        if (rd) {
+#pragma unroll
+            for (; nread < NR; ++nread) read_one(Sn, rstage, rfoff, nread);
+        }
     };
 
     const int nk = p.Kpad / KT;
@@ -206,22 +235,26 @@ __device__ __forceinline__ void g2_tile(const DzConvGemm& p, const int t0, const
     //           tile kt + 2 issued above may still fly), barrier -> tile kt + 1 is visible to everybody
     //   bottom: S0 <- (kt + 1, k-step 0); MFMAs of k-step 1 with the other pieces of tile kt + 2
     int s = 0;
+    in_loop = true;
     auto body = [&](auto more_c, auto next_c) {
         constexpr bool more = decltype(more_c)::value;      // tile kt + 2 exists
         constexpr bool next = decltype(next_c)::value;      // tile kt + 1 exists
         if (more) f_advance();
-        read_frags(S1, s, foff1);
-        kstep(S0, 0, more ? H : 0);
+        kstep(S0, S1, true, s, foff1, 0, more ? H : 0);
         const int s1 = s == NST - 1 ? 0 : s + 1;
         if (next) {
-            if (more)
+            if (DBG & 8) {
+                if (more)
+                    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(H) : "memory");
+                else
+                    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            } else if (more)
                 asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(H) : "memory");
             else
                 asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
             G2_PIN();
-            read_frags(S0, s1, foff0);
         }
-        kstep(S1, H, more ? PPW - H : 0);
+        kstep(S1, S0, next, s1, foff0, H, more ? PPW - H : 0);
         s = s1;
     };
     int kt = 0;
@@ -297,13 +330,13 @@ __device__ __forceinline__ void g2_tile(const DzConvGemm& p, const int t0, const
     dz_flag_range(p.oflag, amax);
 }
 
-template <int EPI, int MT>
+template <int EPI, int MT, int DBG = 0>
 __global__ __launch_bounds__(256) void gemm_g2_kernel(DzConvGemm p, int gx) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int gy = p.Npad / BN;
     int bx, by, bz;
     dz_tile_map_lin(blockIdx.x, gx, gy, 1, p.agroup, bx, by, bz);
-    g2_tile<EPI, MT>(p, bx * 64 * MT, by * BN, smem);
+    g2_tile<EPI, MT, DBG>(p, bx * 64 * MT, by * BN, smem);
 }
 
 template <int EPI, int MT>
@@ -312,6 +345,17 @@ int launch_mt(const DzConvGemm& p, hipStream_t st) {
     DZ_HIP(attr_once.raise((const void*)gemm_g2_kernel<EPI, MT>, (int)lds_bytes(MT)));
     const int gx = (p.Tout + 64 * MT - 1) / (64 * MT), gy = p.Npad / BN;
     DZ_LAUNCH((gemm_g2_kernel<EPI, MT>), dim3(gx * gy), dim3(256), lds_bytes(MT), st, p, gx);
+    DZ_HIP(hipGetLastError());
+    return 0;
+}
+
+// timing experiments (dz_k_gemm_g2 with row_fragments = 2 + 16 * DBG, TDNN epilogue only)
+template <int DBG>
+int launch_dbg(const DzConvGemm& p, hipStream_t st) {
+    static DzAttrOnce attr_once;
+    DZ_HIP(attr_once.raise((const void*)gemm_g2_kernel<DZ_EPI_TDNN, 2, DBG>, (int)lds_bytes(2)));
+    const int gx = (p.Tout + 127) / 128, gy = p.Npad / BN;
+    DZ_LAUNCH((gemm_g2_kernel<DZ_EPI_TDNN, 2, DBG>), dim3(gx * gy), dim3(256), lds_bytes(2), st, p, gx);
     DZ_HIP(hipGetLastError());
     return 0;
 }
@@ -343,6 +387,20 @@ int dz_g2_default_mt() {
 // requirements are those of dz_launch_gemm_pre (k_gemm_pre.hip), which checks them and dispatches here
 int dz_launch_gemm_g2(const DzConvGemm& p, int mt, hipStream_t st) {
     if (mt <= 0) mt = dz_g2_default_mt();
+    if (mt >= 16) {
+        switch (mt >> 4) {
+            case 1: return launch_dbg<1>(p, st);
+            case 2: return launch_dbg<2>(p, st);
+            case 3: return launch_dbg<3>(p, st);
+            case 5: return launch_dbg<5>(p, st);
+            case 6: return launch_dbg<6>(p, st);
+            case 7: return launch_dbg<7>(p, st);
+            case 13: return launch_dbg<13>(p, st);
+            case 15: return launch_dbg<15>(p, st);
+        }
+        dz_set_error("gemm_g2: timing experiment %d is not instantiated", mt >> 4);
+        return 2;
+    }
     switch (p.epi) {
         case DZ_EPI_BIAS: return launch<DZ_EPI_BIAS>(p, mt, st);
         case DZ_EPI_BIAS_LEAKY: return launch<DZ_EPI_BIAS_LEAKY>(p, mt, st);

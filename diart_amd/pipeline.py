@@ -207,6 +207,9 @@ class StreamBatch:
         # fewer streams than lanes x 2, the runtime multiplexes streams onto GPU_MAX_HW_QUEUES hardware
         # queues).  With the default recurrence kernel two full lanes measured 8 % faster (24.7 k vs
         # 22.8 k xRT), so the default is one embedding stream per lane.
+        # DZ_ABLATE=noemb | noseg: TIMING EXPERIMENT (results are wrong): one of the two networks is not launched,
+        # to see what the step costs when the other one has the chip to itself
+        self._ablate = os.environ.get("DZ_ABLATE", "")
         self.shared_stats = os.environ.get("DZ_SHARED_STATS", "1") != "0"
         self.shared_emb = os.environ.get("DZ_SHARED_EMB", "0") != "0"
         self.lag = self.depth - 1 if self.shared_emb else 0
@@ -231,6 +234,7 @@ class StreamBatch:
         self._sub: dict = {}
         self._warmed: set = set()
         self._warming, self._real_steps = False, 0       # (see _warm_up)
+        self._real_launches = 0                          # launches issued for a caller (not by _warm_up)
         self._slots: List[dict] = []
         self._lib = _lib.load()
         self._ctx = _lib.context(self.device.index)
@@ -358,6 +362,8 @@ class StreamBatch:
         if S not in self._warmed:
             self._warmed.add(S)
             self._warm_up(S)
+        if not self._warming:
+            self._real_launches += 1
         lane = self.lanes[self._t % self.depth]
         hsegs, hembs, _, _ = self._handles(S, self._t % self.depth)
         # sub-batch ranges of THIS step's rows (each at most the capacity its handle was built for)
@@ -406,6 +412,9 @@ class StreamBatch:
                            "dz_seg_back")
                 ev.record(a)
                 continue
+            if self._ablate == "noseg":
+                ev.record(a)
+                continue
             # segmentation + the OSP weights of its output (one launch sequence, no dz_osp of its own)
             _lib.check(lib.dz_seg_forward_osp(h, base + i0 * stride * esz, stride, i1 - i0,
                                               slot["seg"][i0:i1].data_ptr(), self.gamma, self.beta,
@@ -414,7 +423,7 @@ class StreamBatch:
             ev.record(a)
         for (i0, i1), h, b, ev in zip(sb, hembs, lane["b"], slot["ev_frames"]):
             b.wait_event(slot["ev_in"])
-            if i1 > i0:
+            if i1 > i0 and self._ablate != "noemb":
                 if stats is not None:
                     _lib.check(lib.dz_emb_use_wave_stats(h, stats[i0:].data_ptr()), "dz_emb_use_wave_stats")
                 _lib.check(lib.dz_emb_frames(h, base + i0 * stride * esz, stride, i1 - i0, b.cuda_stream),
@@ -447,7 +456,11 @@ class StreamBatch:
         zeros = torch.zeros((self.n, S), dtype=torch.float32, device=self.device)
         saved = dict(self.host_seconds)
         inflight: List[dict] = []
-        if self._real_steps == 0:                        # complete steps, then forget them
+        # Complete steps (and the reset() that forgets them) only while NO launch has been issued for a caller:
+        # counting finished steps instead (round 3) let a second window size, or a first finish() that comes
+        # after several launches (FileBatch never calls finish), wipe the clustering / tail state and the
+        # step counters under tickets that were still in flight.
+        if self._real_launches == 0:                     # complete steps, then forget them
             self._warming = True
             try:
                 for _ in range(steps):
@@ -460,19 +473,25 @@ class StreamBatch:
                 self._warming = False
             torch.cuda.synchronize(self.device)
             self.reset()
-        else:
+            self._t = 0
+        else:                                            # GPU-only steps: no stream state is touched
             base, stride = zeros.data_ptr(), zeros.stride(0)
-            for _ in range(steps):
-                inflight.append(self._launch_rows(base, stride, self.n, S, zeros))
-                if len(inflight) >= self.max_inflight:
-                    t = inflight.pop(0)
+            t_saved = self._t
+            self._warming = True
+            try:
+                for _ in range(steps):
+                    inflight.append(self._launch_rows(base, stride, self.n, S, zeros))
+                    if len(inflight) >= self.max_inflight:
+                        t = inflight.pop(0)
+                        self._wait(t)
+                        t["busy"], t["keep"] = False, None
+                for t in inflight:
                     self._wait(t)
                     t["busy"], t["keep"] = False, None
-            for t in inflight:
-                self._wait(t)
-                t["busy"], t["keep"] = False, None
+            finally:
+                self._warming = False
+                self._t = t_saved
             torch.cuda.synchronize(self.device)
-        self._t = 0
         self.host_seconds.update(saved)
 
     def _enqueue_pool(self, slot: dict):
@@ -487,6 +506,12 @@ class StreamBatch:
             for (j0, j1), ev in zip(sa, slot["ev_seg"]):
                 if j0 < i1 and i0 < j1:
                     b.wait_event(ev)
+            if self._ablate == "noemb":
+                if not slot.get("_filled"):       # something the clustering accepts
+                    with torch.cuda.stream(b):
+                        slot["emb"].fill_(0.04)
+                    slot["_filled"] = True
+                continue
             _lib.check(lib.dz_emb_pool(h, slot["w"][i0:i1].data_ptr(), i1 - i0, K, F, 1,
                                        slot["emb"][i0:i1].data_ptr(), b.cuda_stream), "dz_emb_pool")
         b0 = lane["b"][0]
@@ -673,7 +698,18 @@ class FileBatch:
             import threading
             self.q: "queue.Queue" = queue.Queue(maxsize=depth)
             self.done = False
+            self.stop = False               # set by close(): the thread stops producing and hands its buffer back
             self._END = object()
+            self._owner = owner
+
+            def put(item) -> bool:          # q.put that gives up when the consumer has gone away
+                while not self.stop:
+                    try:
+                        self.q.put(item, timeout=0.05)
+                        return True
+                    except queue.Full:
+                        continue
+                return False
 
             def work():
                 try:
@@ -687,12 +723,28 @@ class FileBatch:
                             wav = np.ascontiguousarray(wav, dtype=np.float32).reshape(-1)
                             t = owner._pool.acquire(len(wav))
                             t[:len(wav)].copy_(torch.from_numpy(wav))
-                        self.q.put((uri, t, len(wav), shift))
-                    self.q.put(self._END)
+                        if not put((uri, t, len(wav), shift)):
+                            owner._pool.release(t)
+                            return
+                    put(self._END)
                 except BaseException as exc:       # surfaces in the consumer
-                    self.q.put(exc)
+                    put(exc)
 
             threading.Thread(target=work, name="dz-file-loader", daemon=True).start()
+
+        def close(self) -> None:
+            """Stop the loader thread and give the pinned buffers of files that were read but never admitted
+            back to the pool (the consumer is leaving early: an exception in a step)."""
+            import queue
+            self.stop = True
+            while True:
+                try:
+                    item = self.q.get(timeout=0.1)
+                except queue.Empty:
+                    break
+                if isinstance(item, tuple):
+                    self._owner._pool.release(item[1])
+            self.done = True
 
         def get(self, block: bool):
             import queue
@@ -737,11 +789,15 @@ class FileBatch:
                     if item is None:
                         return
                     uri, pinned, nsamp, shift = item
+                    if uri in done or any(f is not None and f["uri"] == uri for f in open_files):
+                        self._pool.release(pinned)
+                        raise ValueError(f"FileBatch.run: two files share the uri {uri!r}; the results are keyed by it")
                     nwin = (nsamp - self.S) // self.hop + 1 if nsamp >= self.S else 0
                     _lib.check(self._lib.dz_clu_reset(self._clu[slot]), "dz_clu_reset")
                     self._tails.reset(slot)
                     if nwin <= 0:
                         done[uri] = []
+                        self._pool.release(pinned)      # shorter than one window: nothing to upload
                         return admit()
                     open_files[slot] = dict(uri=uri, shift=float(shift), nwin=nwin, sent=0, got=0, turns=[], start=0,
                                             audio=pinned[:nsamp].to(self.device, non_blocking=True), host=pinned)
@@ -808,17 +864,32 @@ class FileBatch:
                     open_files[slot] = None
                     self._pool.release(f["host"])     # its upload finished long ago (results depend on it)
 
-        admit()
-        while True:
-            while len(inflight) < self.engine.max_inflight and launch_step():
-                pass
-            if not inflight:
-                admit()
-                if not any(f is not None for f in open_files):
-                    break
-                continue
-            finish_step()
+        try:
             admit()
+            while True:
+                while len(inflight) < self.engine.max_inflight and launch_step():
+                    pass
+                if not inflight:
+                    admit()
+                    if not any(f is not None for f in open_files):
+                        break
+                    continue
+                finish_step()
+                admit()
+        except BaseException:
+            # leave nothing behind: tickets still on the GPU are waited for and handed back (a busy
+            # ticket makes every later launch allocate pinned memory under running kernels), the open files'
+            # and the loader's pinned buffers return to the pool, the loader thread stops
+            for ticket, _, _ in inflight:
+                try:
+                    self.engine._wait(ticket)
+                finally:
+                    ticket["busy"], ticket["keep"] = False, None
+            for f in open_files:
+                if f is not None:
+                    self._pool.release(f["host"])
+            files.close()
+            raise
         out = {}
         for uri, rec in done.items():
             ann = Annotation(uri=uri, modality="speech")

@@ -254,7 +254,11 @@ class StreamServer:
         but whose engine run failed is lost for that stream (recorded in ``step_errors``)."""
         with self._lock:
             for st, blocks, consumed, chunk, start in undo:
-                taken = len(blocks) - len(st.blocks)          # push() may have appended meanwhile
+                # blocks this step popped: both take functions count every pop in `consumed`.  (NOT len(blocks)
+                # - len(st.blocks): a push() that lands while the engine runs — the lock is released then —
+                # makes that short, and taken blocks would be dropped; ADVICE r3.)  st.blocks now holds the
+                # untaken blocks followed by whatever was pushed meanwhile.
+                taken = st.consumed - consumed
                 keep = pushed.get(st.slot, 0) if self.rings is not None else 0
                 keep = min(keep, taken)
                 st.blocks = blocks[keep:taken] + st.blocks

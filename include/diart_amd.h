@@ -166,7 +166,10 @@ int dz_emb_use_wave_stats(dz_emb* emb, const float* d_moments);
 /* The two halves of dz_emb_forward_multi.  dz_emb_frames (SincNet + TDNN stack, 99.5 % of the
  * embedding FLOPs) does not depend on the segmentation, so it can run on a second stream while
  * dz_seg_forward's latency-bound LSTM occupies a handful of CUs; dz_emb_pool then consumes the
- * OSP weights.  The frame features stay in the handle's scratch between the two calls.        */
+ * OSP weights.  The frame features stay in the handle's scratch between the two calls, and until the
+ * next dz_emb_frames: dz_emb_pool may be called again on the same frames with other weights (on the
+ * split-f16 path with windows of >= 128 frames the last TDNN layer runs inside dz_emb_pool, with the
+ * pooling in its epilogue, so every call pays for that layer again).                               */
 int dz_emb_frames(dz_emb* emb, const float* d_wave, long long wave_stride, int batch, void* stream);
 int dz_emb_pool(dz_emb* emb, const float* d_weights, int batch, int num_speakers,
                 int weight_frames, int normalize, float* d_out, void* stream);

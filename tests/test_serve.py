@@ -311,6 +311,40 @@ def test_failed_step_in_host_window_mode_can_be_retried_without_losing_a_window(
         assert srv.close(k).to_rttm() == ref.close(k).to_rttm()
 
 
+def test_push_during_a_failing_step_does_not_lose_taken_blocks():
+    """ADVICE r3 (serve.py _roll_back): the lock is released while the engine runs, so the I/O thread may
+    push() then; if that step fails, the blocks it took go back IN FRONT of the newly pushed one, none lost."""
+    srv = None
+
+    class PushThenFail(Recorder):
+        def __init__(self):
+            super().__init__()
+            self.calls = 0
+
+        def __call__(self, windows, starts, slots):
+            self.calls += 1
+            if self.calls == 1:
+                srv.push("a", np.full(8000, 9.0, dtype=np.float32))     # lands mid-step
+                raise RuntimeError("engine down")
+            return super().__call__(windows, starts, slots)
+
+    eng = PushThenFail()
+    srv = StreamServer(None, None, max_streams=1, engine=eng)
+    srv.open("a")
+    blocks = [np.full(8000, float(i + 1), dtype=np.float32) for i in range(11)]
+    for b in blocks:
+        srv.push("a", b)
+    with pytest.raises(RuntimeError):
+        srv.step()                       # takes 10 blocks (one window), the engine pushes block "9.0" and raises
+    st = srv._streams["a"]
+    assert st.consumed == 0
+    assert [float(b[0]) for b in st.blocks] == [float(i + 1) for i in range(11)] + [9.0]
+    srv.drain()
+    # windows of the retried run: blocks 1..10, 2..11, 3..11+9
+    assert [float(w[0][0]) for w, _, _ in eng.batches] == [1.0, 2.0, 3.0]
+    assert float(eng.batches[-1][0][0][-1]) == 9.0
+
+
 def test_failed_step_in_ring_mode_keeps_host_block_count_equal_to_the_ring():
     """Ring mode: blocks that reached the ring before the failure stay consumed (the ring cannot be
     rewound), blocks that did not go back to the queue — the stream's later windows and start times

@@ -119,8 +119,8 @@ def layer(name, rows_in, Cin, N, taps, dil, epi, plane_out):
     set_out(False)
     outs = {}
     for tag, gen, mt in (("g1", 1, 0), ("g2_mt2", 2, 2), ("g2_mt3", 2, 3), ("g2_mt4", 2, 4)):
-        Yf.zero_()
         with torch.cuda.stream(s_main):
+            Yf.zero_()
             run(gen, mt)(s_main.cuda_stream)
         torch.cuda.synchronize()
         got = Yf[:Tout].double()
@@ -133,8 +133,8 @@ def layer(name, rows_in, Cin, N, taps, dil, epi, plane_out):
     set_out(True)
     planes = {}
     for tag, gen, mt in (("g1", 1, 0), ("g2_mt2", 2, 2), ("g2_mt3", 2, 3)):
-        Yp.zero_()
         with torch.cuda.stream(s_main):
+            Yp.zero_()
             run(gen, mt)(s_main.cuda_stream)
         torch.cuda.synchronize()
         v = Yp.view(torch.float16).float()
