@@ -130,6 +130,7 @@ SIGNATURES = {
     "dz_k_gemm_split": (C.c_int, [vp, vp, vp]),
     "dz_k_gemm_pre": (C.c_int, [vp, vp, vp]),
     "dz_k_gemm_g2": (C.c_int, [vp, vp, C.c_int, vp]),
+    "dz_k_gemm_g3": (C.c_int, [vp, vp, C.c_int, vp]),
     "dz_k_mlp_head": (C.c_int, [vp, vp, C.c_longlong, vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int,
                                 C.c_int, C.c_float, C.c_float, vp, vp, vp]),
     "dz_k_seg_head": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_float,

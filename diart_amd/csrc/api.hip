@@ -81,6 +81,12 @@ extern "C" int dz_range_check(dz_ctx* ctx, int reset) {
                      "the result differs from an f32 reference; use precision=\"f32\" for such inputs");
         return 6;
     }
+    DZ_HIP(hipSetDevice(ctx->device));
+    if (dz_g3_error(reset)) {
+        dz_set_error("k_gemm_g3.hip: a workgroup gave up waiting for the partial sums of a neighbour (the results of "
+                     "that launch are wrong); DZ_GEMM_GEN=1 selects the non-persistent kernel");
+        return 7;
+    }
     return 0;
 }
 
@@ -924,6 +930,19 @@ extern "C" int dz_k_gemm_g2(dz_ctx* ctx, const dz_convgemm_desc* d, int row_frag
     DzConvGemm p = *d;
     if (!p.oflag) p.oflag = ctx->oflag_dev;
     return dz_launch_gemm_g2(p, row_fragments, (hipStream_t)stream);
+}
+extern "C" int dz_k_gemm_g3(dz_ctx* ctx, const dz_convgemm_desc* d, int row_fragments, void* stream) {
+    DZ_REQUIRE(ctx && d, "dz_k_gemm_g3: NULL argument");
+    DZ_REQUIRE(d->Wsplit && d->Xsplit && (d->Y || d->Ysplit) && d->B == 1 && d->K == d->Kpad && d->K == d->taps * d->Cin &&
+                   d->Cin % 32 == 0 && d->Npad % 128 == 0 && d->pad == 0 && !d->X2 && !d->rowbias && d->ksplit <= 1 &&
+                   !d->norm_on_load && d->Tout > 0 && d->Tout == d->Tin - (d->taps - 1) * d->dil && d->ldx % 32 == 0 &&
+                   d->xplane % d->ldx == 0 && d->xplane / d->ldx >= d->Tin,
+               "dz_k_gemm_g3: the requirements of dz_k_gemm_pre apply");
+    DZ_HIP(hipSetDevice(ctx->device));
+    DzRangeScope range_scope(ctx->oflag_dev);
+    DzConvGemm p = *d;
+    if (!p.oflag) p.oflag = ctx->oflag_dev;
+    return dz_launch_gemm_g3(p, row_fragments, (hipStream_t)stream);
 }
 extern "C" int dz_k_mlp_head(dz_ctx* ctx, const void* xsplit, long long xplane, const void* w0split,
                              const void* w1split, const float* b0, const float* b1, const float* cw,

@@ -255,6 +255,10 @@ int dz_launch_gemm_pre(const DzConvGemm& p, hipStream_t st);
 int dz_launch_gemm_g2(const DzConvGemm& p, int mt, hipStream_t st);
 int dz_g2_default_mt();
 int dz_gemm_gen();
+// k_gemm_g3.hip: generation 2's loop as a persistent kernel over a balanced (Stream-K) split of the iteration
+// space, one workgroup per CU; mt as above (0 = DZ_G3_MT / default 4).  dz_g3_error: a wait timed out.
+int dz_launch_gemm_g3(const DzConvGemm& p, int mt, hipStream_t st);
+int dz_g3_error(int reset);
 // The same launch with the weighted statistics pooling (paper Eq. 1) fused into the epilogue of the LAST
 // x-vector layer (tdnn5): the 128 x 128 output tile is parked in LDS instead of HBM and reduced there
 // to per-(tile, chunk, speaker, channel) weighted means and centred second moments — exact two-pass

@@ -640,11 +640,12 @@ int launch(const DzConvGemm& p, hipStream_t st) {
 
 }  // namespace
 
-// DZ_GEMM_GEN: 1 = k_gemm_pre.hip's loop, 2 = k_gemm_g2.hip
+// DZ_GEMM_GEN: 1 = k_gemm_pre.hip's loop, 2 = k_gemm_g2.hip, 3 = k_gemm_g3.hip (persistent, Stream-K)
 int dz_gemm_gen() {
     static const int gen = [] {
         const char* e = getenv("DZ_GEMM_GEN");
-        return e && atoi(e) == 2 ? 2 : 1;
+        const int v = e ? atoi(e) : 1;
+        return v == 2 || v == 3 ? v : 1;
     }();
     return gen;
 }
@@ -708,7 +709,8 @@ int dz_launch_gemm_pre(const DzConvGemm& p_in, hipStream_t st) {
     DZ_REQUIRE(p.Y == nullptr || (p.ldy % 4 == 0 && ((uintptr_t)p.Y & 15) == 0),
                "gemm_pre: f32 output needs ldy a multiple of 4 and a 16-byte aligned base");
     // generation 2 (k_gemm_g2.hip) for every launch outside the latency regime (there: 64 x 64 tiles below)
-    if (dz_gemm_gen() == 2 && 4 * ((p.Tout + BM - 1) / BM) * (p.Npad / BN) >= wg_slots()) return dz_launch_gemm_g2(p, 0, st);
+    if (dz_gemm_gen() >= 2 && 4 * ((p.Tout + BM - 1) / BM) * (p.Npad / BN) >= wg_slots())
+        return dz_gemm_gen() == 3 ? dz_launch_gemm_g3(p, 0, st) : dz_launch_gemm_g2(p, 0, st);
     switch (p.epi) {
         case DZ_EPI_BIAS: return launch<DZ_EPI_BIAS>(p, st);
         case DZ_EPI_BIAS_LEAKY: return launch<DZ_EPI_BIAS_LEAKY>(p, st);

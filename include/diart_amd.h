@@ -303,6 +303,11 @@ int dz_k_gemm_pre(dz_ctx* ctx, const dz_convgemm_desc* desc, void* stream);
  * vmcnt); row_fragments = 2, 3, 4 -> 128 / 192 / 256 x 128 tiles, 0 = default.  dz_k_gemm_pre dispatches to it
  * with DZ_GEMM_GEN=2 outside the single-chunk latency regime.                                        */
 int dz_k_gemm_g2(dz_ctx* ctx, const dz_convgemm_desc* desc, int row_fragments, void* stream);
+/* generation 3 (k_gemm_g3.hip): the same loop as a persistent kernel, one workgroup per CU, every workgroup the
+ * same number of k-tile iterations (a tile shared by two workgroups is finished by the one that holds its end);
+ * row_fragments as above, 0 = default (4).  DZ_GEMM_GEN=3.  A timed-out hand-over is reported by dz_range_check
+ * (error 7).                                                                                          */
+int dz_k_gemm_g3(dz_ctx* ctx, const dz_convgemm_desc* desc, int row_fragments, void* stream);
 /* SincNet stages 1 / 2 (DZ_EPI_POOL3, k = 5, 64 output columns, Cin 80 or 64, norm-on-load, dense
  * rows) on the dedicated kernel: input tile resident in LDS, weights in registers; same
  * descriptor, outputs and partials as the POOL3 call of dz_k_gemm_split                       */

@@ -445,10 +445,11 @@ def _unkb(p, rows, cols):
     (5, 256, 1, 1, 128, 128, "leaky", "f32"),
     (5157, 256, 3, 1, 512, 512, "tdnn", "both"),     # 128 x 128 tiles with a ragged last row tile
 ])
-@pytest.mark.parametrize("kern", ["pre", "g2_mt2", "g2_mt3", "g2_mt4"])
+@pytest.mark.parametrize("kern", ["pre", "g2_mt2", "g2_mt3", "g2_mt4", "g3_mt2", "g3_mt3", "g3_mt4"])
 def test_gemm_pre(gpu, M, Cin, taps, dil, N, Nstore, epi, outs, kern):
     """k_gemm_pre.hip and the three tile sizes of its generation 2, k_gemm_g2.hip (one accumulator per
-    fragment, three LDS stages, counted vmcnt), against an f64 torch restatement.
+    fragment, three LDS stages, counted vmcnt) and of generation 3, k_gemm_g3.hip (the same loop, persistent,
+    Stream-K), against an f64 torch restatement.
     k_gemm_pre.hip (both operands as f16 hi/lo planes, tiles by LDS-DMA) against an f64 torch
     restatement: implicit-GEMM convolution over the flattened rows, every epilogue, f32 and / or
     plane output (whose hi + lo * 2^-11 must reproduce the f32 result to 2^-21), zeroed padding
@@ -478,9 +479,12 @@ def test_gemm_pre(gpu, M, Cin, taps, dil, N, Nstore, epi, outs, kern):
     d.K, d.Kpad, d.Npad, d.Nstore, d.ldx, d.ldy, d.epi = K, K, N, Nstore, Cin, N, code
     if kern == "pre":
         _lib.check(_lib.load().dz_k_gemm_pre(_ctx(gpu), C.byref(d), None), "dz_k_gemm_pre")
-    else:
+    elif kern.startswith("g2"):
         _lib.check(_lib.load().dz_k_gemm_g2(_ctx(gpu), C.byref(d), int(kern[-1]), None), "dz_k_gemm_g2")
+    else:       # persistent, balanced split of the (tile, k-tile) space: tiles shared by two workgroups
+        _lib.check(_lib.load().dz_k_gemm_g3(_ctx(gpu), C.byref(d), int(kern[-1]), None), "dz_k_gemm_g3")
     _sync()
+    _lib.range_check(gpu.index or 0)
     # reference on the operands the kernel saw (22-bit planes), f64
     Xq, Wq = _unplanes(_planes(X)), _unplanes(_planes(W))
     cols = torch.cat([Xq[j * dil: j * dil + Tout] for j in range(taps)], dim=1)   # (Tout, taps*Cin)

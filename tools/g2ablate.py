@@ -25,9 +25,13 @@ ncu = torch.cuda.get_device_properties(0).multi_processor_count
 res = {"cus": ncu}
 
 
-def desc(M, Cin, N, taps, dil, plane):
+def desc(M, Cin, N, taps, dil, plane, fill="random"):
     K = taps * Cin
     X, W = torch.randn(M, Cin) * 0.7, torch.randn(N, K) / K ** 0.5
+    if fill == "zeros":
+        X, W = torch.zeros(M, Cin), torch.zeros(N, K)
+    elif fill == "const":        # hi planes constant, lo planes zero
+        X, W = torch.full((M, Cin), 0.5), torch.full((N, K), 0.25)
     keep = [kb_major(split_f16(X)).to(dev), kb_major(split_f16(W)).to(dev), torch.zeros(N, device=dev), torch.ones(N, device=dev),
             torch.zeros(M, N, device=dev), torch.zeros(2, M * N, dtype=torch.int16, device=dev)]
     d = _lib.ConvGemmDesc()
@@ -76,4 +80,31 @@ for label, M in (("one tile per CU", 128 * (ncu // 4)), ("tdnn2 (2.2 tiles per C
 ideal = 48 * 24 * 32 / 2.4e3
 res["ideal_us_per_tile_at_2.4GHz"] = round(ideal, 1)
 Path(args.out).parent.mkdir(exist_ok=True)
+Path(args.out).write_text(json.dumps(res, indent=1))
+
+# ---- generation 3 on shapes without / with shared tiles (256 x 128 tiles) ----------------------------------------
+for label, M in (("g3: one 256x128 tile per CU (no sharing)", 256 * (ncu // 4)), ("g3: tdnn2", 64 * 289),
+                 ("g3: 1.5 tiles per CU", 384 * (ncu // 4))):
+    d, keep = desc(M + 4, 512, 512, 3, 2, True)
+    row = {}
+    for nm, fn in (("g2 mt4", lambda: lib.dz_k_gemm_g2(ctx, C.byref(d), 4, None)),
+                   ("g3 mt4", lambda: lib.dz_k_gemm_g3(ctx, C.byref(d), 4, None)),
+                   ("g3 mt2", lambda: lib.dz_k_gemm_g3(ctx, C.byref(d), 2, None)),
+                   ("g1", lambda: lib.dz_k_gemm_pre(ctx, C.byref(d), None))):
+        row[nm] = timeit(lambda: _lib.check(fn(), nm))
+    res[label] = row
+    print(label, json.dumps(row), flush=True)
+Path(args.out).write_text(json.dumps(res, indent=1))
+
+# ---- is the ~40 % wall the power budget?  the same launches on zero / constant operands (DVFS give-back) ----------
+M = 128 * (ncu // 4) * 2
+for fill in ("random", "const", "zeros"):
+    d, keep = desc(M + 4, 512, 512, 3, 2, True, fill)
+    row = {}
+    for nm, fn in (("g1", lambda: lib.dz_k_gemm_pre(ctx, C.byref(d), None)),
+                   ("g2 mt4", lambda: lib.dz_k_gemm_g2(ctx, C.byref(d), 4, None)),
+                   ("g3 mt4", lambda: lib.dz_k_gemm_g3(ctx, C.byref(d), 4, None))):
+        row[nm] = timeit(lambda: _lib.check(fn(), nm))
+    res["fill " + fill] = row
+    print("two 128x128 tiles per CU, operands", fill, json.dumps(row), flush=True)
 Path(args.out).write_text(json.dumps(res, indent=1))

@@ -103,6 +103,8 @@ def layer(name, rows_in, Cin, N, taps, dil, epi, plane_out):
     def run(gen, mt):
         if gen == 1:
             return lambda st: _lib.check(lib.dz_k_gemm_pre(ctx, C.byref(d), st), name)
+        if gen == 3:
+            return lambda st: _lib.check(lib.dz_k_gemm_g3(ctx, C.byref(d), mt, st), name)
         return lambda st: _lib.check(lib.dz_k_gemm_g2(ctx, C.byref(d), mt, st), name)
 
     # ---- results: f32 output of every variant against the f64 product of the operands' f32 values ----
@@ -118,7 +120,8 @@ def layer(name, rows_in, Cin, N, taps, dil, epi, plane_out):
     row = {"shape": [M, K, N], "gflop": round(flop / 1e9, 2)}
     set_out(False)
     outs = {}
-    for tag, gen, mt in (("g1", 1, 0), ("g2_mt2", 2, 2), ("g2_mt3", 2, 3), ("g2_mt4", 2, 4)):
+    ALL = (("g1", 1, 0), ("g2_mt2", 2, 2), ("g2_mt3", 2, 3), ("g2_mt4", 2, 4), ("g3_mt2", 3, 2), ("g3_mt3", 3, 3), ("g3_mt4", 3, 4))
+    for tag, gen, mt in ALL:
         with torch.cuda.stream(s_main):
             Yf.zero_()
             run(gen, mt)(s_main.cuda_stream)
@@ -127,24 +130,24 @@ def layer(name, rows_in, Cin, N, taps, dil, epi, plane_out):
         outs[tag] = Yf[:Tout].clone()
         row[tag + "_rel_l2_vs_f64"] = float(((got - acc).norm() / acc.norm()).item())
         row[tag + "_max_abs_vs_f64"] = float((got - acc).abs().max().item())
-    for tag in ("g2_mt2", "g2_mt3", "g2_mt4"):
+    for tag in [t for t, _, _ in ALL[1:]]:
         row[tag + "_max_abs_vs_g1"] = float((outs[tag] - outs["g1"]).abs().max().item())
     # plane output: gen 2 planes against gen 1 planes (hi must agree except at rounding ties of different sums)
     set_out(True)
     planes = {}
-    for tag, gen, mt in (("g1", 1, 0), ("g2_mt2", 2, 2), ("g2_mt3", 2, 3)):
+    for tag, gen, mt in (("g1", 1, 0), ("g2_mt2", 2, 2), ("g3_mt4", 3, 4)):
         with torch.cuda.stream(s_main):
             Yp.zero_()
             run(gen, mt)(s_main.cuda_stream)
         torch.cuda.synchronize()
         v = Yp.view(torch.float16).float()
         planes[tag] = v[0] + v[1] / 2048.0
-    for tag in ("g2_mt2", "g2_mt3"):
+    for tag in ("g2_mt2", "g3_mt4"):
         row[tag + "_planes_max_abs_vs_g1"] = float((planes[tag] - planes["g1"]).abs().max().item())
     _lib.check(lib.dz_range_check(ctx, 1), "range")
     # ---- time ----
     set_out(plane_out)
-    for tag, gen, mt in (("g1", 1, 0), ("g2_mt2", 2, 2), ("g2_mt3", 2, 3), ("g2_mt4", 2, 4)):
+    for tag, gen, mt in ALL:
         for nrec in ((0,) if args.no_rec else (0, 1, 2)):
             us = timeit(run(gen, mt), nrec)
             row[f"{tag}_us_rec{nrec}"] = round(us, 1)
