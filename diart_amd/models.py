@@ -49,15 +49,14 @@ def default_precision() -> str:
 
 
 def _read_state(src: StateSource) -> Dict[str, torch.Tensor]:
-    """A state dict, or a file holding one (plain, or a Lightning checkpoint's 'state_dict')."""
+    """A state dict, or a file holding one: ``.safetensors``, a plain ``torch.save`` of a state dict (speechbrain's
+    ``embedding_model.ckpt``) or a PyTorch-Lightning checkpoint (``pyannote/segmentation``, ``pyannote/embedding``:
+    what the reference loads through pyannote.audio, /root/reference/src/diart/models.py:50, :59).  Files are read
+    by ``checkpoint.read_state``: tensors only, no foreign class is imported and no pickle code runs."""
     if isinstance(src, dict):
         return src
-    obj = torch.load(str(src), map_location="cpu", weights_only=False)
-    if isinstance(obj, dict) and "state_dict" in obj and isinstance(obj["state_dict"], dict):
-        obj = obj["state_dict"]
-    if not isinstance(obj, dict):
-        raise ValueError(f"{src}: expected a state dict")
-    return obj
+    from .checkpoint import read_state
+    return read_state(src)
 
 
 def _device_index(device: torch.device) -> int:
