@@ -176,7 +176,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-tail", action="store_true",
                     help="stop after clustering (skip the C++ aggregation + binarisation tail)")
-    ap.add_argument("--cpu-chunks", type=int, default=8, help="chunks in the bounded CPU sample")
+    ap.add_argument("--cpu-chunks", type=int, default=32, help="windows per batch of the bounded CPU sample (Benchmark's batch_size, inference.py:275)")
     ap.add_argument("--cpu-worker", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--cpu-threads", type=int, default=8, help=argparse.SUPPRESS)
     ap.add_argument("--kernel-table", type=str, default="", help="write the per-kernel table here")
@@ -229,58 +229,81 @@ def _usable_cores():
 
 
 def cpu_baseline_worker(n_chunks, threads, budget_s):
-    """Runs in a CHILD process that never touches the GPU (``bench.py --cpu-worker``): the oracle
-    ("port" of the reference CPU path) on the host cores, reference-style — the embedding network
-    run on K repeated waveforms per chunk (blocks/embedding.py:57), clustering per chunk."""
+    """Runs in a CHILD process that never touches the GPU (``bench.py --cpu-worker``): the CPU restatement of the
+    reference path (oracle/: "port") on the host cores, shaped like the reference's own ``Benchmark``
+    (/root/reference/src/diart/inference.py:275, :392-432): batches of ``n_chunks`` = 32 CONSECUTIVE windows of one
+    file through segmentation -> OverlappedSpeechPenalty -> the embedding network on K = 3 repeated waveforms per
+    chunk (blocks/embedding.py:57-61) -> normalisation, then per chunk, in order: incremental clustering,
+    DelayedAggregation and Binarize (blocks/diarization.py:193-232).  The reference's own classes cannot be loaded
+    here (/root/reference does not exist on the GPU box); tools/cpu_reference_baseline.py times THEM around the same
+    restated networks in the build container (profiles/r04_cpu_reference_baseline_buildbox.json)."""
     torch.set_num_threads(threads)
     from oracle.models_ref import PyanNetRef, XVectorSincNetRef
     from oracle.functional_ref import overlapped_speech_penalty_ref, normalize_embeddings_ref
     from oracle.clustering_ref import OnlineSpeakerClusteringRef
-    from diart_amd.synth import synth_embedding_state, synth_segmentation_state, synth_streams
+    from oracle.pyannote_stub import SlidingWindow as SW, SlidingWindowFeature as SWF
+    from oracle.tail_ref import TailRef
+    from diart_amd.synth import sliding_chunks, synth_embedding_state, synth_segmentation_state, synth_stream
     seg_m, emb_m = PyanNetRef().eval(), XVectorSincNetRef().eval()
     seg_m.load_state_dict(synth_segmentation_state())
     emb_m.load_state_dict(synth_embedding_state())
-    x = torch.from_numpy(synth_streams(n_chunks, 5.0, seed0=0))[:, None, :80000].contiguous()
-    clus = [OnlineSpeakerClusteringRef(0.6, 0.3, 1.0, "cosine", 20) for _ in range(n_chunks)]
+    B = n_chunks
+    stream = synth_stream(0, 5.0 + 0.5 * (4 * B - 1))                 # 4 batches of B consecutive windows
+    windows = torch.from_numpy(np.ascontiguousarray(sliding_chunks(stream)))[:, None, :]
+    nb = windows.shape[0] // B
+    state = {"clu": None, "tail": None, "pos": 0}
 
-    def one():
+    def reset():
+        state["clu"], state["tail"], state["pos"] = OnlineSpeakerClusteringRef(0.6, 0.3, 1.0, "cosine", 20), TailRef(0.5, 0.5, 0.6), 0
+
+    def one(dedup=False):
+        if state["pos"] >= nb:
+            reset()
+        i0 = state["pos"] * B
+        x = windows[i0:i0 + B]
         with torch.no_grad():
             seg = seg_m(x)
             w = overlapped_speech_penalty_ref(seg)
-            rows = x.repeat(1, 3, 1).reshape(n_chunks * 3, 1, -1)
-            emb = emb_m(rows, w.permute(0, 2, 1).reshape(n_chunks * 3, -1)).view(n_chunks, 3, -1)
+            if dedup:
+                emb = emb_m.forward_multi(x, w)
+            else:
+                rows = x.repeat(1, 3, 1).reshape(B * 3, 1, -1)
+                emb = emb_m(rows, w.permute(0, 2, 1).reshape(B * 3, -1)).view(B, 3, -1)
             emb = normalize_embeddings_ref(emb)
-        for i in range(n_chunks):
-            clus[i](seg[i].numpy(), emb[i].numpy())
+        res = 5.0 / seg.shape[1]
+        for j in range(B):
+            scores, _ = state["clu"](seg[j].numpy(), emb[j].numpy())
+            state["tail"](SWF(scores, SW(start=(i0 + j) * 0.5, duration=res, step=res)))
+        state["pos"] += 1
 
-    def dedup():
-        with torch.no_grad():
-            seg = seg_m(x)
-            emb_m.forward_multi(x, overlapped_speech_penalty_ref(seg))
-
+    reset()
     t0 = time.monotonic()
     one()  # warm-up
     warm = time.monotonic() - t0
     t0 = time.monotonic()
     reps = 0
-    while reps < 1 or (time.monotonic() - t0 < budget_s and reps < 200):
+    while reps < 1 or (time.monotonic() - t0 < budget_s and reps < 400):
         one()
         reps += 1
         if warm > budget_s:
             break
     dt = time.monotonic() - t0
-    cps = reps * n_chunks / dt
+    cps = reps * B / dt
+    reset()
     t1 = time.monotonic()
-    dedup()
-    cps_dedup = n_chunks / (time.monotonic() - t1)
+    nd = 0
+    while nd < 1 or (time.monotonic() - t1 < budget_s / 3 and nd < 100):
+        one(dedup=True)
+        nd += 1
+    cps_dedup = nd * B / (time.monotonic() - t1)
     print(json.dumps({
         "value": round(cps / 2, 3), "unit": "xRT 16 kHz streams (chunks/s / 2)", "cores": threads,
-        "kind": "port",
-        "sample": f"{reps} passes over {n_chunks} chunks (5 s each) of the same synthetic stream "
-                  f"generator, torch-CPU fp32 restatement (oracle/) with the same seeded weights, "
-                  f"embedding run on 3 repeated waveforms per chunk as the reference does "
-                  f"(blocks/embedding.py:57) + clustering, {dt:.1f} s of CPU work after a {warm:.1f} s "
-                  f"warm-up pass; de-duplicated CPU variant: {cps_dedup / 2:.3f} xRT"}), flush=True)
+        "kind": "port", "batch": B, "repeats": reps, "dedup_value": round(cps_dedup / 2, 3), "dedup_repeats": nd,
+        "sample": f"{reps} Benchmark-shaped batches of {B} consecutive windows (5 s window, 0.5 s step) of one synthetic "
+                  f"file: torch-CPU fp32 restatement (oracle/) with the same seeded weights, embedding network on 3 "
+                  f"repeated waveforms per chunk as the reference does (blocks/embedding.py:57), then clustering + "
+                  f"aggregation + binarisation chunk by chunk; {dt:.1f} s of CPU work after a {warm:.1f} s warm-up "
+                  f"batch; de-duplicated embedding (one pass per chunk, {nd} batches): {cps_dedup / 2:.3f} xRT"}), flush=True)
 
 
 def cpu_baseline(n_chunks):
@@ -512,7 +535,7 @@ def config3(args):
 def main():
     args = parse()
     if args.cpu_worker:
-        return cpu_baseline_worker(args.cpu_chunks, args.cpu_threads, 12.0)
+        return cpu_baseline_worker(args.cpu_chunks, args.cpu_threads, 20.0)
     if args.config == 3:
         return config3(args)
     from diart_amd import distributed as D

@@ -157,3 +157,21 @@ class ToyEmbedding:
             w = weights.to(e.dtype)
             pooled = (e * w[..., None]).sum(1) / w.sum(1, keepdim=True)
         return torch.tanh(8.0 * pooled) @ self.proj                           # (N, D)
+
+
+# ---- long-horizon parity (tests/test_gpu_long_horizon.py, make_long_horizon.py) -------------------------------------
+LONG_SECONDS = 600.0
+LONG_STREAMS = ((7001, 3), (7002, 4), (7003, 5), (7004, 3))          # (seed, speakers taking turns)
+LONG_LATENCIES = (0.5, 5.0)
+LONG_CENTER_STEPS = (50, 150, 400, 800, 1190)                       # chunk indices at which centroids are kept
+
+
+def long_horizon_audio(i: int):
+    """Stream i of the long-horizon scenario as a 16-bit WAV holds it (write_wav -> read_wav of
+    diart_amd/inference.py): float32 samples k / 32768."""
+    import numpy as np
+    from diart_amd.synth import synth_stream
+    seed, nspk = LONG_STREAMS[i]
+    x = synth_stream(seed, LONG_SECONDS, num_speakers=nspk)
+    pcm = np.clip(np.rint(np.asarray(x, dtype=np.float64) * 32768.0), -32768, 32767).astype("<i2")
+    return pcm.astype(np.float32) / 32768.0

@@ -1,0 +1,154 @@
+"""Long-horizon parity.  The reference's clustering is a running-sum state machine
+(/root/reference/src/diart/blocks/clustering.py:197-208): a numeric difference that is invisible per chunk could drive
+the centroids apart — or flip an assignment and cascade — over many steps; 30 s streams (51 chunks) cannot show it.
+
+4 streams x 600 s (1 191 chunks each, 3 - 5 synthetic speakers taking turns) against tests/golden/long_horizon.npz:
+the output of the REFERENCE'S OWN ``SpeakerDiarization`` pipeline class (its blocks, clustering, aggregation, loaded by
+path) around the restated networks with the same seeded weights (tests/golden/make_long_horizon.py), latency 0.5 s and
+5 s.  Paths under test, both arithmetic modes:
+
+* ``StreamBatch`` at batch 64 — the 4 streams in scattered slots among 60 FILLER streams whose content changes every
+  step, so the batch composition (which rows share a 128-row GEMM tile, which chunks meet in a pooled tdnn5 tile)
+  differs from any per-stream run;
+* ``Benchmark`` -> ``FileBatch`` over the 4 WAV files (consecutive windows of all files per GPU step).
+
+Gates: DER of every hypothesis against the golden turns <= 0.5 % (north-star tolerance); reported, and held to the
+numbers seen: the first chunk at which a local -> global assignment differs, and the centroid deviation at the golden's
+checkpoints."""
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+
+from diart_amd import models as M
+from diart_amd.blocks import SpeakerDiarization, SpeakerDiarizationConfig
+from diart_amd.blocks.aggregation import BatchedOutputTail
+from diart_amd.features import Annotation, Segment
+from diart_amd.metrics import DiarizationErrorRate
+from diart_amd.pipeline import StreamBatch
+from diart_amd.synth import synth_embedding_state, synth_segmentation_state, synth_streams
+
+GOLD = Path(__file__).resolve().parent / "golden"
+sys.path.insert(0, str(GOLD))
+import scenarios  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+SR, S, H = 16000, 80000, 8000
+SLOTS = (3, 17, 40, 62)                      # where the four real streams sit in the batch of 64
+
+
+@pytest.fixture(scope="module")
+def gold():
+    return np.load(GOLD / "long_horizon.npz")
+
+
+@pytest.fixture(scope="module")
+def audio():
+    return [scenarios.long_horizon_audio(i) for i in range(len(scenarios.LONG_STREAMS))]
+
+
+def _annotation(rows, uri) -> Annotation:
+    """PredictionAccumulator semantics (sinks.py:59-88): every chunk's turns, then support(0.05)."""
+    ann = Annotation(uri=uri)
+    for n, (i, s, e, g) in enumerate(rows):
+        ann[Segment(float(s), float(e)), (int(i), n)] = f"speaker{int(g)}"
+    return ann.support(0.05)
+
+
+def _report(tag, gold, si, assign, centers):
+    """First chunk whose assignment differs from the reference pipeline's, centroid deviation at the checkpoints."""
+    want = gold[f"assign_{si}"]
+    diff = np.where((assign != want).any(axis=1))[0]
+    first = int(diff[0]) if len(diff) else None
+    devs = []
+    for k, step in enumerate(scenarios.LONG_CENTER_STEPS):
+        act = gold[f"active_{si}"][k]
+        ref = gold[f"centers_{si}"][k][act].astype(np.float64)
+        got = centers[step][act]
+        devs.append(float(np.linalg.norm(got - ref) / max(np.linalg.norm(ref), 1e-30)))
+    print(f"{tag} stream {si}: assignments differ at {len(diff)} of {len(want)} chunks (first: {first}); "
+          f"relative centroid deviation at chunks {scenarios.LONG_CENTER_STEPS}: " + " ".join(f"{d:.1e}" for d in devs))
+    return first, len(diff), devs
+
+
+@pytest.mark.parametrize("precision", ["f16x3", "f32"])
+def test_stream_batch_of_64_over_600_s_matches_the_reference_pipeline(gpu, gold, audio, precision):
+    n = int(gold["num_chunks"])
+    assert n == 1191
+    seg = M.HipSegmentation(synth_segmentation_state(), max_batch=64, precision=precision)
+    emb = M.HipEmbedding(synth_embedding_state(), max_batch=64, precision=precision)
+    real = [torch.from_numpy(a).to(gpu) for a in audio]
+    fill = torch.from_numpy(synth_streams(60, 61.0, seed0=9100)).to(gpu)          # 60 x 61 s, walked cyclically
+    nfill = (fill.shape[1] - S) // H + 1
+    others = [i for i in range(64) if i not in SLOTS]
+    ders = {}
+    for latency in scenarios.LONG_LATENCIES:
+        sb = StreamBatch(seg, emb, 64, device=gpu, tail=True, latency=latency)
+        rows = [[] for _ in SLOTS]
+        assign = np.zeros((len(SLOTS), n, 3), dtype=np.int64)
+        centers = [dict() for _ in SLOTS]
+        waves = torch.empty((64, S), dtype=torch.float32, device=gpu)
+        starts = np.zeros(64)
+        tickets = []
+
+        def drain(ticket, i):
+            _, _, _, a = sb.finish(ticket, want_scores=False)
+            _, _, _, _, turns, nturns = ticket["tail"]
+            for k, slot in enumerate(SLOTS):
+                assign[k, i] = a[slot]
+                for s_, e_, g_ in turns[slot][:int(nturns[slot])]:
+                    rows[k].append((i, s_, e_, g_))
+                if i in scenarios.LONG_CENTER_STEPS:
+                    centers[k][i] = sb.clustering.streams[slot].centers.copy()
+
+        for i in range(n):
+            for k, slot in enumerate(SLOTS):
+                waves[slot] = real[k][i * H:i * H + S]
+            j = (i * 7) % nfill                                   # the fillers move through their audio at another pace
+            waves[others] = fill[:, j * H:j * H + S]
+            starts[:] = i * 0.5
+            tickets.append((sb.launch(waves.clone(), starts.copy()), i))
+            if len(tickets) >= 2:
+                drain(*tickets.pop(0))
+        while tickets:
+            drain(*tickets.pop(0))
+        for k in range(len(SLOTS)):
+            hyp = _annotation(rows[k], f"s{k}")
+            ref = _annotation(gold[f"turns_{k}_{latency}"], f"s{k}")
+            d = DiarizationErrorRate()(ref, hyp, detailed=True)
+            first, ndiff, devs = _report(f"StreamBatch {precision} latency {latency}", gold, k, assign[k], centers[k])
+            print(f"    DER vs the reference pipeline = {100 * d['diarization error rate']:.4f} % of {d['total']:.0f} s "
+                  f"({len(hyp)} vs {len(ref)} turns)")
+            ders[(latency, k)] = d["diarization error rate"]
+            assert d["total"] > 60.0 and d["diarization error rate"] <= 0.005
+            # what was measured (profiles/r04_*_long_horizon.txt): no assignment ever differs and the centroids stay
+            # within f32 rounding of the reference's after 1 190 updates
+            assert ndiff == 0, f"stream {k}: assignment differs first at chunk {first}"
+            assert max(devs) < 1e-4
+        del sb
+    assert max(ders.values()) <= 0.005
+
+
+@pytest.mark.parametrize("latency", scenarios.LONG_LATENCIES)
+def test_benchmark_over_four_600_s_files_matches_the_reference_pipeline(gpu, gold, audio, tmp_path, latency):
+    from diart_amd.features import load_rttm
+    from diart_amd.inference import Benchmark, write_wav
+    speech = tmp_path / "wav"
+    speech.mkdir()
+    for i, a in enumerate(audio):
+        write_wav(speech / f"s{i}.wav", a, SR)
+    seg = M.SegmentationModel.from_state(synth_segmentation_state(), max_batch=64)
+    emb = M.EmbeddingModel.from_state(synth_embedding_state(), max_batch=64)
+    cfg = SpeakerDiarizationConfig(segmentation=seg, embedding=emb, latency=latency, device=gpu)
+    b = Benchmark(speech, None, tmp_path / "out", show_report=False, batch_size=32)
+    b(SpeakerDiarization, cfg)
+    assert b.last_path == "file_batch"
+    for i in range(len(audio)):
+        hyp = load_rttm(tmp_path / "out" / f"s{i}.rttm")[f"s{i}"]
+        ref = _annotation(gold[f"turns_{i}_{latency}"], f"s{i}")
+        d = DiarizationErrorRate()(ref, hyp, detailed=True)
+        print(f"Benchmark latency {latency} file s{i}: DER vs the reference pipeline = "
+              f"{100 * d['diarization error rate']:.4f} % of {d['total']:.0f} s")
+        assert d["total"] > 60.0 and d["diarization error rate"] <= 0.005
