@@ -174,6 +174,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--streams", type=int, default=64, help="concurrent streams per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-rehearsal", action="store_true", help="skip the 8-rank host-contention rehearsal (N = 1 only)")
     ap.add_argument("--no-tail", action="store_true",
                     help="stop after clustering (skip the C++ aggregation + binarisation tail)")
     ap.add_argument("--cpu-chunks", type=int, default=32, help="windows per batch of the bounded CPU sample (Benchmark's batch_size, inference.py:275)")
@@ -330,6 +331,41 @@ def cpu_baseline(n_chunks):
     return json.loads(lines[-1])
 
 
+def host_rehearsal(args, precision, usable, ranks=8):
+    """What 8 ranks on this node's host cores would leave each rank: the same job (short, headline pass only) as
+    a child process pinned to usable / 8 cores, and unpinned for comparison — the 1 -> 8 GPU target is decided by
+    16 host cores shared by 8 ranks as much as by the GPUs, and a one-GPU box cannot show it any other way."""
+    import subprocess
+    allowed = sorted(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else list(range(os.cpu_count() or 1))
+    share = max(1, min(len(allowed), usable) // ranks)
+    cores = allowed[:share]
+    steps = max(args.steps, 100)
+    cmd = [sys.executable, str(ROOT / "bench.py"), "--steps", str(steps), "--warmup", "5", "--no-cpu-baseline", "--no-exact-f32",
+           "--no-host-pass", "--pmc", "off", "--no-rehearsal", "--precision", precision, "--streams", str(args.streams)]
+    res = {}
+    for tag, pin in (("unpinned", None), ("pinned", cores)):
+        env = dict(os.environ)
+        if pin is not None:
+            env["DZ_POOL_SPIN_US"] = os.environ.get("DZ_POOL_SPIN_US", "0")      # no core to spare for spinning
+        try:
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=120, env=env,
+                               preexec_fn=(lambda c=pin: os.sched_setaffinity(0, c)) if pin is not None else None)
+            lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+            if not lines:
+                raise RuntimeError("no bench line; stderr: " + r.stderr[-300:])
+            line = lines[-1]
+            d = json.loads(line)
+            res[tag] = {"value": d["value"], "ms_per_step": d["ms_per_step"], "host": d.get("host")}
+        except Exception as exc:          # noqa: BLE001 — the bench line must appear whatever happens here
+            res[tag] = {"value": None, "error": repr(exc)[:200]}
+    ok = res["pinned"].get("value") and res["unpinned"].get("value")
+    return {"ranks_emulated": ranks, "cores_per_rank": share, "cores": cores, "steps": steps,
+            "pinned": res["pinned"], "unpinned": res["unpinned"],
+            "pinned_over_unpinned": round(res["pinned"]["value"] / res["unpinned"]["value"], 4) if ok else None,
+            "note": "child runs of this command (headline pass only, no per-kernel brackets): `pinned` may use "
+                    "usable_cores / 8 cores (sched_setaffinity), as one of 8 ranks on this node would; target >= 0.95"}
+
+
 def _match_pmc(files, groups, key):
     """{device kernel symbol -> value} from a per-kernel PMC summary ({"kernels": {full name: {...}}})."""
     got = {}
@@ -356,7 +392,7 @@ def pmc_live(precision):
     t_start, budget = time.monotonic(), float(os.environ.get("DZ_PMC_BUDGET_S", "200"))
     work = Path(tempfile.mkdtemp(prefix="dz_pmc_"))
     cmd = [sys.executable, str(ROOT / "bench.py"), "--steps", "3", "--warmup", "1", "--no-cpu-baseline",
-           "--no-exact-f32", "--no-host-pass", "--pmc", "off", "--precision", precision]
+           "--no-exact-f32", "--no-host-pass", "--pmc", "off", "--no-rehearsal", "--precision", precision]
     env = dict(os.environ, PYTHONDONTWRITEBYTECODE="1", TMPDIR="/tmp")
     passes = {"FETCH_SIZE": ["FETCH_SIZE"], "WRITE_SIZE": ["WRITE_SIZE"],
               "MFMA": ["SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CYCLES", "GRBM_GUI_ACTIVE"]}
@@ -412,6 +448,7 @@ def build_roofline(table, precision, n_sampled, pmc):
     if pmc is not None:
         traffic_of = _match_pmc(pmc["traffic"], groups, "hbm_bytes_per_launch")
         mfma_util_of = _match_pmc(pmc["mfma"], groups, "mfma_util")
+        busy_of, busy_n = _match_pmc(pmc["mfma"], groups, "mfma_busy_cycles"), _match_pmc(pmc["mfma"], groups, "launches")
         source = pmc["source"]
     else:
         # fall-back: the committed passes of the same command (profiles/, named per round in README.md)
@@ -419,6 +456,8 @@ def build_roofline(table, precision, n_sampled, pmc):
         tfile, mfile = ROOT / "profiles" / f"traffic{suffix}.json", ROOT / "profiles" / f"mfma_util{suffix}.json"
         traffic_of = _match_pmc(json.loads(tfile.read_text()), groups, "hbm_bytes_per_launch") if tfile.exists() else {}
         mfma_util_of = _match_pmc(json.loads(mfile.read_text()), groups, "mfma_util") if mfile.exists() else {}
+        busy_of = _match_pmc(json.loads(mfile.read_text()), groups, "mfma_busy_cycles") if mfile.exists() else {}
+        busy_n = _match_pmc(json.loads(mfile.read_text()), groups, "launches") if mfile.exists() else {}
         source = (f"committed: profiles/{tfile.name} / {mfile.name} (rocprofv3 --pmc passes of `bench.py --steps 3` from an "
                   "earlier visit; NOT measured in this run)") if traffic_of else None
     total_ms = sum(v["ms"] for v in groups.values()) or 1.0
@@ -436,7 +475,9 @@ def build_roofline(table, precision, n_sampled, pmc):
              "share_of_kernel_time": round(v["ms"] / total_ms, 4),
              "alg_gflop_per_launch": round(v["gflop"] / v["launches"], 3),
              "alg_bytes_per_launch": int(v["bytes"] / v["launches"]),
-             "traffic": traffic_of.get(g), "mfma_util_pmc": mfma_util_of.get(g)}
+             "traffic": traffic_of.get(g), "mfma_util_pmc": mfma_util_of.get(g),
+             # SQ_VALU_MFMA_BUSY_CYCLES of one launch, summed over the chip's SIMDs (PMC pass)
+             "mfma_busy_cycles_per_launch": (round(busy_of[g] / busy_n[g]) if busy_of.get(g) is not None and busy_n.get(g) else None)}
         if e["traffic"]:
             e["traffic_over_alg_bytes"] = round(e["traffic"] / max(1, e["alg_bytes_per_launch"]), 2)
         if g.startswith("lstm_rec_kernel"):
@@ -458,6 +499,38 @@ def build_roofline(table, precision, n_sampled, pmc):
         "hbm": "HBM3E peak"}[roof["bound"]]
     roof["traffic_source"] = source
     return roof, per_kernel
+
+
+def step_level(per_kernel, ms_per_step, precision, source):
+    """What the north-star asks for the STEP: matrix-core utilisation and HBM GB/s against the gfx950 peaks —
+    (mfma_util_step, hbm_gbps_step, the dominant MATRIX kernel's roofline entry).  Matrix-core busy time and HBM
+    bytes per launch come from the rocprofv3 --pmc passes (`source`), launches per step and durations from this
+    run's own brackets."""
+    step_us = 1e3 * ms_per_step
+    # matrix-pipe busy SIMD-cycles of a step (PMC, per launch x launches per step) over the SIMD-cycles the step
+    # offers at the nominal 2.4 GHz (256 CUs x 4 SIMDs): a LOWER bound of the utilisation when the chip clocks down
+    busy = sum((k.get("mfma_busy_cycles_per_launch") or 0) * k["launches_per_step"] for k in per_kernel)
+    have_util = any(k.get("mfma_busy_cycles_per_launch") for k in per_kernel)
+    busy_us = busy / (1024 * 2400.0)                 # -> microseconds of ALL SIMDs busy
+    gflop = sum(k["alg_gflop_per_launch"] * k["launches_per_step"] for k in per_kernel if k["bound"] == "mfma")
+    products = 1 if precision == "f32" else SPLIT_PRODUCTS
+    peak = PEAK_F32_MATRIX_TFLOPS if precision == "f32" else PEAK_F16_MATRIX_TFLOPS
+    mfma = {"busy_frac_pmc": round(busy_us / step_us, 4) if have_util else None,
+            "issued_tflops": round(products * gflop / ms_per_step, 1),       # GFLOP / ms = TFLOP/s
+            "peak_tflops": peak, "frac_of_peak": round(products * gflop / ms_per_step / peak, 4),
+            "busy_simd_cycles_per_step": int(busy) if have_util else None,
+            "note": ("busy_frac_pmc = SQ_VALU_MFMA_BUSY_CYCLES of the step's launches (PMC pass, per launch x launches per "
+                     "step) / (1024 SIMDs x 2.4 GHz x step time); issued_tflops = matrix FLOPs the step issues (%d MFMA product%s per "
+                     "algorithmic product) / step time, against the dense %s matrix peak" %
+                     (products, "" if products == 1 else "s", "f32" if precision == "f32" else "f16")),
+            "source": source}
+    byts = sum((k["traffic"] or 0) * k["launches_per_step"] for k in per_kernel)
+    alg = sum(k["alg_bytes_per_launch"] * k["launches_per_step"] for k in per_kernel)
+    hbm = {"gbps": round(byts / step_us / 1e3, 1) if byts else None, "bytes_per_step": int(byts) if byts else None,
+           "peak_gbps": PEAK_HBM_GBPS, "frac_of_peak": round(byts / step_us / 1e3 / PEAK_HBM_GBPS, 4) if byts else None,
+           "alg_bytes_per_step": int(alg), "source": source}
+    mk = next((dict(k) for k in per_kernel if k["bound"] == "mfma"), None)
+    return mfma, hbm, mk
 
 
 # ---- BASELINE.json configs[2]: segmentation-3.0 (powerset) + speechbrain ECAPA-TDNN -------------------
@@ -690,7 +763,10 @@ def main():
         sampled[0] = 0
         host["launch"] = host["finish"] = 0.0
         p.host_seconds["wait"] = p.host_seconds["work"] = 0.0
+        cpu0 = time.process_time()                     # CPU time of every thread of this process
         el = D.timed_max_over_ranks(lambda: run(args.warmup, args.steps, p, profiled=prof), device)
+        host["cpu_ms_per_step"] = 1e3 * (time.process_time() - cpu0) / args.steps
+        host["launch_ms_per_step"], host["work_ms_per_step"] = 1e3 * host["launch"] / args.steps, 1e3 * p.host_seconds["work"] / args.steps
         hs = p.host_seconds
         log(f"{label}: {el:.3f}s for {args.steps} steps; host time per step: launch "
             f"{1e3 * host['launch'] / args.steps:.3f} ms, finish {1e3 * host['finish'] / args.steps:.3f} ms = waiting for "
@@ -701,6 +777,10 @@ def main():
         return el, tab, sampled[0]
 
     elapsed, table, n_sampled = timed_pass(pipe, f"timed region ({precision})")
+    host_line = {"cpu_ms_per_step": round(host["cpu_ms_per_step"], 3), "launch_ms_per_step": round(host["launch_ms_per_step"], 3),
+                 "clustering_tail_wall_ms_per_step": round(host["work_ms_per_step"], 3), "threads": host_threads,
+                 "usable_cores": usable,
+                 "note": "CPU time of all threads of the rank per step (launching thread + worker pool) in the timed region"}
 
     # ---- the same job on the exact-f32 MFMA path: the number at the reference's own arithmetic,
     # measured the same way (own per-kernel brackets, own roofline), not `value` ----------------------
@@ -772,6 +852,10 @@ def main():
             r32, pk32 = build_roofline(exact.pop("_table"), "f32", exact.pop("_sampled"), pmc32)
             r32["whole_path_tflops"] = round(2 * exact["value"] / world * ALG_GFLOP_PER_CHUNK / 1e3, 2)
             exact["roofline"], exact["roofline_kernels"] = r32, pk32
+        mfma_step, hbm_step, roof_mfma = step_level(per_kernel, 1e3 * elapsed / args.steps, precision, roof.get("traffic_source"))
+        if exact is not None:
+            exact["mfma_util_step"], exact["hbm_gbps_step"], exact["roofline_mfma"] = step_level(
+                exact["roofline_kernels"], exact["ms_per_step"], "f32", exact["roofline"].get("traffic_source"))
         out = {
             "metric": "real-time-factor xRT streams/GPU @500ms step", "value": round(cps / 2, 2),
             "unit": "xRT 16 kHz streams (chunks/s / 2)", "n_gpus": world, "steps": args.steps,
@@ -798,12 +882,16 @@ def main():
                        "hip_streams": pipe.num_hip_streams,
                        "exact_f32_value": exact["value"] if exact else None,
                        "host_fed_value": host_fed["value"] if host_fed else None},
-            "roofline": roof, "roofline_kernels": per_kernel,
+            "roofline": roof, "roofline_mfma": roof_mfma, "mfma_util_step": mfma_step, "hbm_gbps_step": hbm_step,
+            "roofline_kernels": per_kernel,
             "roofline_sampling": f"{n_sampled} of the {args.steps} timed steps (every {PROF_EVERY}th) carried the "
                                  "per-kernel event pairs; instrumenting every launch costs ~15 % of throughput",
             "exact_f32": exact,
             "host_fed": host_fed,
+            "host": host_line,
         }
+        if world == 1 and not args.no_rehearsal:
+            out["host_rehearsal"] = host_rehearsal(args, precision, usable)
         if args.kernel_table:
             Path(args.kernel_table).parent.mkdir(parents=True, exist_ok=True)
             Path(args.kernel_table).write_text(json.dumps(table, indent=1))

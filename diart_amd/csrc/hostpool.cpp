@@ -1,5 +1,6 @@
 #include "hostpool.h"
 
+#include <stdlib.h>
 #include <unistd.h>
 
 #include <atomic>
@@ -12,8 +13,18 @@
 namespace {
 
 constexpr int MAX_WORKERS = 63;
-constexpr int SPIN_US = 40;      // a worker polls this long for the next job before it sleeps: the two
-                                 // stages of one step arrive back to back, the next step ~1 ms later
+// A worker polls this long for the next job before it sleeps: the two stages of one step arrive back to back, the
+// next step ~1 ms later.  DZ_POOL_SPIN_US overrides (0 = sleep at once): with 8 ranks on a node's 16 usable cores a
+// rank has two cores for its launching thread and its pool, and a spinning worker takes one of them from the thread
+// that feeds the GPU (bench.py's host rehearsal sets it from the cores a rank really has).
+int spin_us() {
+    static const int us = [] {
+        const char* e = getenv("DZ_POOL_SPIN_US");
+        const int v = e ? atoi(e) : 40;
+        return v < 0 ? 0 : v;
+    }();
+    return us;
+}
 
 struct Pool {
     std::mutex callers;                       // one parallel-for at a time
@@ -49,7 +60,7 @@ void worker_main(Pool* p, int id, unsigned long long seen) {
         // wait for a job newer than the last one this worker looked at: spin briefly, then sleep
         const auto t0 = std::chrono::steady_clock::now();
         while (p->gen.load(std::memory_order_acquire) == seen) {
-            if (std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(SPIN_US)) {
+            if (std::chrono::steady_clock::now() - t0 >= std::chrono::microseconds(spin_us())) {
                 std::unique_lock<std::mutex> lk(p->mu);
                 p->wake.wait(lk, [&] { return p->gen.load(std::memory_order_acquire) != seen; });
                 break;
@@ -101,6 +112,13 @@ void dz_host_parallel(int n, int threads, const std::function<void(int, int)>& f
     }
     p->wake.notify_all();
     drain(p, 0);
-    while (p->left.load(std::memory_order_acquire) > 0) __builtin_ia32_pause();
+    // wait for the acknowledgements: a short spin, then give the core away — on an oversubscribed rank the worker
+    // that has not acknowledged yet may be waiting for exactly this core
+    for (int spins = 0; p->left.load(std::memory_order_acquire) > 0; ++spins) {
+        if (spins < 2000)
+            __builtin_ia32_pause();
+        else
+            std::this_thread::yield();
+    }
     p->fn = nullptr;
 }

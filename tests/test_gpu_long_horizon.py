@@ -49,12 +49,22 @@ def audio():
     return [scenarios.long_horizon_audio(i) for i in range(len(scenarios.LONG_STREAMS))]
 
 
-def _annotation(rows, uri) -> Annotation:
-    """PredictionAccumulator semantics (sinks.py:59-88): every chunk's turns, then support(0.05)."""
+def _annotation(rows, uri, max_chunk=None, rttm_precision=False) -> Annotation:
+    """PredictionAccumulator semantics (sinks.py:59-88): every chunk's turns, then support(0.05).  ``max_chunk``:
+    only the turns of chunks below it (the golden's rows beyond ``num_chunks`` are the windows a FILE's right padding
+    adds).  ``rttm_precision``: segments as an RTTM file holds them (start and duration with 3 decimals)."""
     ann = Annotation(uri=uri)
     for n, (i, s, e, g) in enumerate(rows):
-        ann[Segment(float(s), float(e)), (int(i), n)] = f"speaker{int(g)}"
-    return ann.support(0.05)
+        if max_chunk is None or i < max_chunk:
+            ann[Segment(float(s), float(e)), (int(i), n)] = f"speaker{int(g)}"
+    ann = ann.support(0.05)
+    if rttm_precision:
+        out = Annotation(uri=uri)
+        for n, (seg, _, label) in enumerate(ann.itertracks(yield_label=True)):
+            start, dur = float(f"{seg.start:.3f}"), float(f"{seg.duration:.3f}")
+            out[Segment(start, start + dur), n] = label
+        ann = out
+    return ann
 
 
 def _report(tag, gold, si, assign, centers):
@@ -116,7 +126,7 @@ def test_stream_batch_of_64_over_600_s_matches_the_reference_pipeline(gpu, gold,
             drain(*tickets.pop(0))
         for k in range(len(SLOTS)):
             hyp = _annotation(rows[k], f"s{k}")
-            ref = _annotation(gold[f"turns_{k}_{latency}"], f"s{k}")
+            ref = _annotation(gold[f"turns_{k}_{latency}"], f"s{k}", max_chunk=n)
             d = DiarizationErrorRate()(ref, hyp, detailed=True)
             first, ndiff, devs = _report(f"StreamBatch {precision} latency {latency}", gold, k, assign[k], centers[k])
             print(f"    DER vs the reference pipeline = {100 * d['diarization error rate']:.4f} % of {d['total']:.0f} s "
@@ -147,7 +157,9 @@ def test_benchmark_over_four_600_s_files_matches_the_reference_pipeline(gpu, gol
     assert b.last_path == "file_batch"
     for i in range(len(audio)):
         hyp = load_rttm(tmp_path / "out" / f"s{i}.rttm")[f"s{i}"]
-        ref = _annotation(gold[f"turns_{i}_{latency}"], f"s{i}")
+        # the golden's turns include the windows of the file's right padding (latency - step seconds of zeros,
+        # blocks/base.py:81-85), and an RTTM file keeps 3 decimals
+        ref = _annotation(gold[f"turns_{i}_{latency}"], f"s{i}", rttm_precision=True)
         d = DiarizationErrorRate()(ref, hyp, detailed=True)
         print(f"Benchmark latency {latency} file s{i}: DER vs the reference pipeline = "
               f"{100 * d['diarization error rate']:.4f} % of {d['total']:.0f} s")

@@ -87,7 +87,8 @@ def test_committed_goldens_regenerate_from_the_reference(tmp_path):
     r = subprocess.run([sys.executable, str(gold / "make_golden.py"), "--out", str(tmp_path)],
                        capture_output=True, text=True, env=dict(__import__("os").environ, PYTHONDONTWRITEBYTECODE="1"))
     assert r.returncode == 0, r.stderr[-2000:]
-    names = sorted(p.name for p in gold.glob("*.npz"))
+    # (long_horizon.npz has its own generator, make_long_horizon.py: ~6 min of CPU; held by tests/test_gpu_long_horizon.py)
+    names = sorted(p.name for p in gold.glob("*.npz") if p.name != "long_horizon.npz")
     assert names == sorted(p.name for p in tmp_path.glob("*.npz")) and len(names) == 8
     for name in names:
         a, b = np.load(gold / name), np.load(tmp_path / name)
