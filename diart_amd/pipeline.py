@@ -210,6 +210,20 @@ class StreamBatch:
         # DZ_ABLATE=noemb | noseg: TIMING EXPERIMENT (results are wrong): one of the two networks is not launched,
         # to see what the step costs when the other one has the chip to itself
         self._ablate = os.environ.get("DZ_ABLATE", "")
+        # How the host waits.  With cores to spare the launching thread spins on the step's `done` event (lowest
+        # latency) and the pool's workers poll 40 us for the next job; a rank that has ~2 cores for itself (8 ranks
+        # on a node's 16 usable cores) cannot afford either: the event is then a blocking one (the thread sleeps in
+        # the driver until the GPU signals) and the workers sleep at once.  DZ_WAIT=spin | block, DZ_POOL_SPIN_US.
+        from .hostinfo import usable_cores
+        try:
+            ranks_here = max(1, int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1"))))
+        except ValueError:
+            ranks_here = 1
+        self.cores_per_rank = usable_cores() / ranks_here
+        mode = os.environ.get("DZ_WAIT", "auto")
+        self.blocking_wait = mode == "block" or (mode == "auto" and self.cores_per_rank < 4)
+        if self.cores_per_rank < 4:
+            os.environ.setdefault("DZ_POOL_SPIN_US", "0")          # read once by hostpool.cpp, at its first job
         self.shared_stats = os.environ.get("DZ_SHARED_STATS", "1") != "0"
         self.shared_emb = os.environ.get("DZ_SHARED_EMB", "0") != "0"
         self.lag = self.depth - 1 if self.shared_emb else 0
@@ -277,7 +291,7 @@ class StreamBatch:
                  ev_front=[torch.cuda.Event() for _ in range(self.seg_split)],
                  ev_emb=[torch.cuda.Event() for _ in range(self.emb_split - 1)],
                  ev_frames=[torch.cuda.Event() for _ in range(self.emb_split)],
-                 ev_in=torch.cuda.Event(), done=torch.cuda.Event())
+                 ev_in=torch.cuda.Event(), done=torch.cuda.Event(blocking=self.blocking_wait))
         self._slots.append(s)
         return s
 
