@@ -203,8 +203,9 @@ def kernel_table(lib, precision="f16x3"):
     counts 32), hence algorithmic FLOP and HBM bytes PER LAUNCH at the launch's real batch."""
     rows = []
     name, ms, n, ch = C.c_char_p(), C.c_double(), C.c_longlong(), C.c_longlong()
-    for tag in range(24):
-        lib.dz_prof_get(tag, C.byref(name), C.byref(ms), C.byref(n), C.byref(ch))
+    for tag in range(32):
+        if lib.dz_prof_get(tag, C.byref(name), C.byref(ms), C.byref(n), C.byref(ch)) != 0:
+            continue
         if n.value == 0:
             continue
         nm = name.value.decode()
@@ -574,6 +575,8 @@ def config3(args):
     chunks = [SlidingWindowFeature(stream[i * H:i * H + S, None], SlidingWindow(start=i * 0.5, duration=1 / 16000, step=1 / 16000))
               for i in range(B * total)]
     log(f"config 3: {len(chunks)} windows of one {len(stream) / 16000:.0f} s stream, batches of {B}, precision {precision}")
+    from diart_amd import _lib
+    lib = _lib.load()
     for i in range(args.warmup):
         pipe(chunks[i * B:(i + 1) * B])
     torch.cuda.synchronize()
@@ -585,6 +588,45 @@ def config3(args):
     elapsed = time.perf_counter() - t0
     cps = B * args.steps / elapsed
     gflop_chunk = 2.0 * (656_230_928 + 3 * ECAPA_MAC_PER_ROW) / 1e9
+    # ---- per-kernel brackets (the dispatches' own timestamps), on a few extra steps after the timed region ------
+    nprof = min(4, args.steps)
+    lib.dz_prof_enable(1)
+    for i in range(nprof):
+        pipe(chunks[(args.warmup + i) * B:(args.warmup + i + 1) * B])
+    lib.dz_prof_collect()
+    name, ms, n_, ch = C.c_char_p(), C.c_double(), C.c_longlong(), C.c_longlong()
+    split = precision != "f32"
+    T_ROW = 498                                          # frames of a full 5 s mask
+    mac_row = {                                          # algorithmic MACs per ECAPA row, by bracket
+        "ecapa_fbank": T_ROW * (400 * 402 + 201 * 80), "ecapa_block0": T_ROW * 80 * 5 * 1024,
+        "ecapa_wide1x1": T_ROW * (6 * 1024 * 1024 + 3072 * 3072), "ecapa_res2net": 3 * T_ROW * 7 * 128 * 128 * 3,
+        "ecapa_se": 3 * 2 * 1024 * 128, "ecapa_asp": 6144 * 128 + T_ROW * (3072 * 128 + 128 * 3072), "ecapa_fc": 6144 * 192}
+    groups = []
+    for tag in range(32):
+        if lib.dz_prof_get(tag, C.byref(name), C.byref(ms), C.byref(n_), C.byref(ch)) != 0 or n_.value == 0:
+            continue
+        nm = name.value.decode()
+        per_step_ms = ms.value / nprof
+        g = {"kernel": nm, "launches_per_step": round(n_.value / nprof, 2), "ms_per_step": round(per_step_ms, 3),
+             "avg_launch_us": round(1e3 * ms.value / n_.value, 1)}
+        if nm in mac_row:
+            gf = 2.0 * mac_row[nm] * 3 * B / 1e9                # 3 rows per chunk, B chunks per step
+            on_f16 = split and nm in ("ecapa_wide1x1", "ecapa_block0", "ecapa_fbank", "ecapa_res2net", "ecapa_asp")
+            peak = PEAK_F16_MATRIX_TFLOPS / SPLIT_PRODUCTS if on_f16 else PEAK_F32_MATRIX_TFLOPS
+            g.update({"bound": "mfma", "alg_gflop_per_step": round(gf, 1), "achieved": round(gf / per_step_ms, 2),
+                      "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(gf / per_step_ms / peak, 4)})
+        else:
+            k = kernels_for(precision).get(nm)
+            if k and k["mac"]:
+                gf = 2.0 * k["mac"] * B / 1e9
+                g.update({"alg_gflop_per_step": round(gf, 2), "achieved": round(gf / per_step_ms, 2), "unit": "TFLOP/s"})
+        groups.append(g)
+    lib.dz_prof_enable(0)
+    tot = sum(g["ms_per_step"] for g in groups) or 1.0
+    for g in groups:
+        g["share_of_kernel_time"] = round(g["ms_per_step"] / tot, 4)
+    groups.sort(key=lambda g: -g["ms_per_step"])
+    dom = next((g for g in groups if g.get("bound") == "mfma"), groups[0] if groups else {})
     out = {
         "metric": "real-time-factor xRT streams/GPU @500ms step", "value": round(cps / 2, 2),
         "unit": "xRT 16 kHz streams (chunks/s / 2)", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
@@ -594,12 +636,12 @@ def config3(args):
                                "architectures (random-init weights), 5 s window / 500 ms step, one synthetic stream through "
                                "the blocks pipeline in batches of 32 consecutive windows (96 embedding rows per step)",
                    "chunks_per_step": B, "speech_turns_emitted": turns},
-        "roofline": {"kernel": "whole path (no per-kernel brackets on the ECAPA launches)", "bound": "mfma",
-                     "achieved": round(cps * gflop_chunk / 1e3, 2), "peak": round(PEAK_F16_MATRIX_TFLOPS / SPLIT_PRODUCTS, 1),
-                     "unit": "TFLOP/s", "frac": round(cps * gflop_chunk / 1e3 / (PEAK_F16_MATRIX_TFLOPS / SPLIT_PRODUCTS), 4),
-                     "traffic": None, "alg_gflop_per_chunk": round(gflop_chunk, 2),
-                     "peak_note": "f16 matrix peak / 3 (the wide 1 x 1 layers run split-f16; block 0, the Res2Net 128-channel "
-                                  "convolutions, SE and attentive pooling are exact f32 — priced against the faster pipe)"},
+        "roofline": dict(dom, traffic=None, whole_path_tflops=round(cps * gflop_chunk / 1e3, 2),
+                         alg_gflop_per_chunk=round(gflop_chunk, 2), kernel_time_ms_per_step=round(tot, 3),
+                         peak_note="f16 matrix peak / 3 for the layers on the split-f16 kernels (three MFMAs per "
+                                   "algorithmic product), exact-f32 matrix peak for the others; brackets = the "
+                                   "dispatches' own timestamps over %d steps after the timed region" % nprof),
+        "roofline_kernels": groups,
         "cpu_baseline": None,
     }
     print(json.dumps(out), flush=True)

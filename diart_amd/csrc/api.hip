@@ -97,11 +97,14 @@ extern "C" int dz_range_check(dz_ctx* ctx, int reset) {
 // whatever stream it ran, no marker packets between kernels.  dz_prof_collect() synchronises and
 // accumulates.
 // ---------------------------------------------------------------------------
-enum { PROF_POOL = 8192, PROF_TAGS = 24 };
+enum { PROF_POOL = 8192, PROF_TAGS = 32 };
 static const char* kProfNames[PROF_TAGS] = {
     "wave_stats", "sinc_conv0", "finalize_norm", "conv1_pool", "conv2_pool", "lstm_proj",
     "lstm_rec", "seg_mlp", "seg_classifier", "tdnn1", "tdnn2", "tdnn3", "tdnn4", "tdnn5",
-    "stats_pool", "emb_linear", "l2norm", "osp", "powerset", "cdist", "lstm_proj0", "", "", ""};
+    "stats_pool", "emb_linear", "l2norm", "osp", "powerset", "cdist", "lstm_proj0",
+    // config 3 (ecapa_api.hip; DZ_T_ECAPA_* in dz_common.h)
+    "ecapa_fbank", "ecapa_block0", "ecapa_wide1x1", "ecapa_res2net", "ecapa_se", "ecapa_asp", "ecapa_fc",
+    "", "", "", ""};
 enum { T_WAVE = 0, T_CONV0, T_FIN, T_CONV1, T_CONV2, T_PROJ, T_REC, T_MLP, T_CLS, T_TDNN1, T_TDNN2,
        T_TDNN3, T_TDNN4, T_TDNN5, T_POOL, T_EMBLIN, T_L2, T_OSP, T_PSET, T_CDIST, T_PROJ0 };
 thread_local DzLaunchProf* dz_launch_prof = nullptr;
@@ -122,20 +125,19 @@ struct Prof {
 // "consumed by the next DZ_LAUNCH" hand-off itself is thread local.
 static Prof g_prof;
 static std::mutex g_prof_mu;
-struct ProfScope {
-    // `chunks`: how many 5 s chunks this launch processes (the unit bench.py's roofline counts in)
-    ProfScope(int tag, int chunks) {
-        if (!g_prof.on) return;
-        std::lock_guard<std::mutex> lk(g_prof_mu);
-        if (g_prof.on && g_prof.used < PROF_POOL) {
-            const int slot = g_prof.used++;
-            g_prof.tag[slot] = tag;
-            g_prof.units[slot] = chunks;
-            dz_launch_prof = &g_prof.ev[slot];   // consumed by the next DZ_LAUNCH
-        }
+// `chunks`: how many 5 s chunks (ECAPA: embedding rows) this launch processes — the unit bench.py's roofline counts in
+DzProfScope::DzProfScope(int tag, int chunks) {
+    if (!g_prof.on) return;
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    if (g_prof.on && g_prof.used < PROF_POOL && tag >= 0 && tag < PROF_TAGS) {
+        const int slot = g_prof.used++;
+        g_prof.tag[slot] = tag;
+        g_prof.units[slot] = chunks;
+        dz_launch_prof = &g_prof.ev[slot];   // consumed by the next DZ_LAUNCH
     }
-    ~ProfScope() { dz_launch_prof = nullptr; }
-};
+}
+DzProfScope::~DzProfScope() { dz_launch_prof = nullptr; }
+typedef DzProfScope ProfScope;
 extern "C" int dz_prof_enable(int on) {
     std::lock_guard<std::mutex> lk(g_prof_mu);
     if (on && !g_prof.made) {

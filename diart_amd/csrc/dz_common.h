@@ -41,6 +41,13 @@ struct DzAttrOnce {
 struct DzLaunchProf {
     hipEvent_t start, stop;
 };
+// Bracket for bench.py's per-kernel table (api.hip): the NEXT DZ_LAUNCH on this thread carries the event pair.
+struct DzProfScope {
+    DzProfScope(int tag, int units);
+    ~DzProfScope();
+};
+enum { DZ_T_ECAPA_FBANK = 21, DZ_T_ECAPA_BLOCK0, DZ_T_ECAPA_WIDE, DZ_T_ECAPA_RES2, DZ_T_ECAPA_SE, DZ_T_ECAPA_ASP,
+       DZ_T_ECAPA_FC };
 // range flag (dz_ctx::oflag_dev) of the context whose forward pass is being enqueued on this host
 // thread: picked up by the split-f16 launchers when the descriptor does not name one
 extern thread_local int* dz_cur_oflag;

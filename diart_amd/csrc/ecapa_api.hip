@@ -111,7 +111,7 @@ extern "C" int dz_ecapa_destroy(dz_ecapa* e) {
 }
 
 // one convgemm launch; X is [B][Tin][ldx] with Cin channels used, Y [B][Tin or flat][ldy]
-static int gemm(hipStream_t st, const float* X, int ldx, long long xbs, int B, int T, int Cin, int taps,
+static int gemm(int tag, int rows_n, hipStream_t st, const float* X, int ldx, long long xbs, int B, int T, int Cin, int taps,
                 int dil, int pad, const dz_layer& L, const float* bias, int Kpad, int Npad, int Nstore,
                 float* Y, int ldy, long long ybs, int epi, const float* X2 = nullptr,
                 const float* rowbias = nullptr, int ksplit = 0, long long ysplit = 0) {
@@ -128,8 +128,10 @@ static int gemm(hipStream_t st, const float* X, int ldx, long long xbs, int B, i
     if (L.wsplit && (epi == DZ_EPI_RELU_BN || epi == DZ_EPI_BIAS) && !rowbias && ksplit <= 1 && Cin % 8 == 0) {
         p.Wsplit = L.wsplit;
         p.Npad = (Npad + 127) / 128 * 128;       // (the DFT's planes are packed with 512 rows)
+        DzProfScope ps(tag, rows_n);
         return dz_launch_gemm_split(p, st);
     }
+    DzProfScope ps(tag, rows_n);
     return dz_launch_convgemm(p, st);
 }
 
@@ -148,9 +150,10 @@ extern "C" int dz_ecapa_forward(dz_ecapa* e, const float* d_wave, long long wave
 
     // ---- 1. mask -> kept samples, zero padded rows (200 leading zeros = centred STFT) ---------
     DZ_HIP(hipMemsetAsync(e->sig, 0, sizeof(float) * (size_t)N * e->lstride, st));
-    if ((rc = dz_launch_mask_compact(d_wave, wave_stride, e->S, d_masks, mask_frames, N, e->sig,
-                                     e->lstride, e->lens, st)))
-        return rc;
+    { DzProfScope ps(DZ_T_ECAPA_FBANK, N);
+      if ((rc = dz_launch_mask_compact(d_wave, wave_stride, e->S, d_masks, mask_frames, N, e->sig,
+                                       e->lstride, e->lens, st)))
+          return rc; }
     int* h_lens = e->h_pin;
     int* h_nvalid = h_lens + e->Nm;
     int* h_nmask = h_nvalid + e->Nm;
@@ -187,19 +190,19 @@ extern "C" int dz_ecapa_forward(dz_ecapa* e, const float* d_wave, long long wave
 
     // ---- 2. Fbank: STFT as one GEMM over overlapping rows (hop 160 < window 400) ---------------
     dz_layer dft = {w.dft, w.zeros, nullptr, nullptr, w.dft_split};
-    if ((rc = gemm(st, e->sig, HOP, e->lstride, N, T, NFFT, 1, 1, 0, dft, nullptr, 416, 448, 402, e->spec,
+    if ((rc = gemm(DZ_T_ECAPA_FBANK, N, st, e->sig, HOP, e->lstride, N, T, NFFT, 1, 1, 0, dft, nullptr, 416, 448, 402, e->spec,
                    404, (long long)T * 404, DZ_EPI_BIAS)))
         return rc;
-    if ((rc = dz_launch_power(e->spec, 404, NT, e->pw, st))) return rc;
+    { DzProfScope ps(DZ_T_ECAPA_FBANK, N); if ((rc = dz_launch_power(e->spec, 404, NT, e->pw, st))) return rc; }
     dz_layer mel = {w.mel, w.zeros, nullptr, nullptr, nullptr};
-    if ((rc = gemm(st, e->pw, 204, 0, 1, (int)NT, 204, 1, 1, 0, mel, nullptr, 224, 128, 80, e->melp, 80, 0,
+    if ((rc = gemm(DZ_T_ECAPA_FBANK, N, st, e->pw, 204, 0, 1, (int)NT, 204, 1, 1, 0, mel, nullptr, 224, 128, 80, e->melp, 80, 0,
                    DZ_EPI_BIAS)))
         return rc;
-    if ((rc = dz_launch_fbank_post(e->melp, T, N, e->nvalid, e->feats, st))) return rc;
+    { DzProfScope ps(DZ_T_ECAPA_FBANK, N); if ((rc = dz_launch_fbank_post(e->melp, T, N, e->nvalid, e->feats, st))) return rc; }
 
     // ---- 3. ECAPA-TDNN -------------------------------------------------------------------------
     // block 0: Conv1d(80 -> 1024, k5) -> ReLU -> BN
-    if ((rc = gemm(st, e->feats, 80, (long long)T * 80, N, T, 80, 5, 1, 2, w.block0, nullptr, 416, C1, C1,
+    if ((rc = gemm(DZ_T_ECAPA_BLOCK0, N, st, e->feats, 80, (long long)T * 80, N, T, 80, 5, 1, 2, w.block0, nullptr, 416, C1, C1,
                    e->b0, C1, (long long)T * C1, DZ_EPI_RELU_BN)))
         return rc;
     const int dil[3] = {2, 3, 4};
@@ -208,7 +211,7 @@ extern "C" int dz_ecapa_forward(dz_ecapa* e, const float* d_wave, long long wave
         const float* xin = i == 0 ? e->b0 : e->cat + (size_t)(i - 1) * C1;
         const int ldin = i == 0 ? C1 : C3;
         // tdnn1 (1x1)
-        if ((rc = gemm(st, xin, ldin, 0, 1, (int)NT, C1, 1, 1, 0, b.tdnn1, nullptr, C1, C1, C1, e->t1, C1, 0,
+        if ((rc = gemm(DZ_T_ECAPA_WIDE, N, st, xin, ldin, 0, 1, (int)NT, C1, 1, 1, 0, b.tdnn1, nullptr, C1, C1, C1, e->t1, C1, 0,
                        DZ_EPI_RELU_BN)))
             return rc;
         // Res2Net: y0 = x0; y1 = f1(x1); yi = fi(xi + y(i-1))
@@ -216,55 +219,56 @@ extern "C" int dz_ecapa_forward(dz_ecapa* e, const float* d_wave, long long wave
                                 (size_t)NT, hipMemcpyDeviceToDevice, st));
         for (int j = 1; j < 8; ++j) {
             const float* x2 = j >= 2 ? e->res + (j - 1) * 128 : nullptr;
-            if ((rc = gemm(st, e->t1 + j * 128, C1, (long long)T * C1, N, T, 128, 3, dil[i], dil[i], b.res[j - 1],
+            if ((rc = gemm(DZ_T_ECAPA_RES2, N, st, e->t1 + j * 128, C1, (long long)T * C1, N, T, 128, 3, dil[i], dil[i], b.res[j - 1],
                            nullptr, 384, 128, 128, e->res + j * 128, C1, (long long)T * C1, DZ_EPI_RELU_BN,
                            x2)))
                 return rc;
         }
         // tdnn2 (1x1)
-        if ((rc = gemm(st, e->res, C1, 0, 1, (int)NT, C1, 1, 1, 0, b.tdnn2, nullptr, C1, C1, C1, e->t2, C1, 0,
+        if ((rc = gemm(DZ_T_ECAPA_WIDE, N, st, e->res, C1, 0, 1, (int)NT, C1, 1, 1, 0, b.tdnn2, nullptr, C1, C1, C1, e->t2, C1, 0,
                        DZ_EPI_RELU_BN)))
             return rc;
         // squeeze-excitation + residual, written straight into its slice of the concatenation
-        if ((rc = dz_launch_se_mean(e->t2, T, C1, C1, N, e->nmask, e->smean, st))) return rc;
+        { DzProfScope ps(DZ_T_ECAPA_SE, N); if ((rc = dz_launch_se_mean(e->t2, T, C1, C1, N, e->nmask, e->smean, st))) return rc; }
         // squeeze (N rows x 1024 -> 128): one output tile, so the K loop is split 8 ways (a lone workgroup
         // walking 32 k-tiles took 90 us); the ReLU follows the fixed-order reduce
-        if ((rc = gemm(st, e->smean, C1, 0, 1, N, C1, 1, 1, 0, b.se1, nullptr, C1, 128, 128, e->parts, 128, 0,
+        if ((rc = gemm(DZ_T_ECAPA_SE, N, st, e->smean, C1, 0, 1, N, C1, 1, 1, 0, b.se1, nullptr, C1, 128, 128, e->parts, 128, 0,
                        DZ_EPI_BIAS, nullptr, nullptr, SE_SPLIT, (long long)N * 128)))
             return rc;
-        if ((rc = dz_launch_splitk_finish(e->parts, SE_SPLIT, (long long)N * 128, N, 128, 2, e->sfc1, st))) return rc;
-        if ((rc = gemm(st, e->sfc1, 128, 0, 1, N, 128, 1, 1, 0, b.se2, nullptr, 128, C1, C1, e->gate, C1, 0,
+        { DzProfScope ps(DZ_T_ECAPA_SE, N); if ((rc = dz_launch_splitk_finish(e->parts, SE_SPLIT, (long long)N * 128, N, 128, 2, e->sfc1, st))) return rc; }
+        if ((rc = gemm(DZ_T_ECAPA_SE, N, st, e->sfc1, 128, 0, 1, N, 128, 1, 1, 0, b.se2, nullptr, 128, C1, C1, e->gate, C1, 0,
                        DZ_EPI_BIAS_SIGMOID)))
             return rc;
-        if ((rc = dz_launch_se_apply(e->t2, C1, e->gate, xin, ldin, e->cat + (size_t)i * C1, C3, N, T, C1, st)))
-            return rc;
+        { DzProfScope ps(DZ_T_ECAPA_SE, N);
+          if ((rc = dz_launch_se_apply(e->t2, C1, e->gate, xin, ldin, e->cat + (size_t)i * C1, C3, N, T, C1, st)))
+              return rc; }
     }
     // multi-layer feature aggregation
-    if ((rc = gemm(st, e->cat, C3, 0, 1, (int)NT, C3, 1, 1, 0, w.mfa, nullptr, C3, C3, C3, e->mfa, C3, 0,
+    if ((rc = gemm(DZ_T_ECAPA_WIDE, N, st, e->cat, C3, 0, 1, (int)NT, C3, 1, 1, 0, w.mfa, nullptr, C3, C3, C3, e->mfa, C3, 0,
                    DZ_EPI_RELU_BN)))
         return rc;
     // attentive statistics pooling with global context: W [x; mean; std] = Wx x + Wms [mean; std]
-    if ((rc = dz_launch_asp_gstats(e->mfa, T, C3, N, e->nmask, e->gstat, st))) return rc;
+    { DzProfScope ps(DZ_T_ECAPA_ASP, N); if ((rc = dz_launch_asp_gstats(e->mfa, T, C3, N, e->nmask, e->gstat, st))) return rc; }
     dz_layer wms = {w.asp_wms, w.zeros, nullptr, nullptr};
     // (N rows x 6144 -> 128: one output tile and 192 k-tiles — 0.5 ms for a lone workgroup; split-K like fc)
-    if ((rc = gemm(st, e->gstat, 2 * C3, 0, 1, N, 2 * C3, 1, 1, 0, wms, nullptr, 2 * C3, 128, 128, e->parts, 128, 0,
+    if ((rc = gemm(DZ_T_ECAPA_ASP, N, st, e->gstat, 2 * C3, 0, 1, N, 2 * C3, 1, 1, 0, wms, nullptr, 2 * C3, 128, 128, e->parts, 128, 0,
                    DZ_EPI_BIAS, nullptr, nullptr, FC_SPLIT, (long long)N * 128)))
         return rc;
-    if ((rc = dz_launch_splitk_finish(e->parts, FC_SPLIT, (long long)N * 128, N, 128, 0, e->rb, st))) return rc;
-    if ((rc = gemm(st, e->mfa, C3, (long long)T * C3, N, T, C3, 1, 1, 0, w.asp_tdnn, nullptr, C3, 128, 128, e->a1,
+    { DzProfScope ps(DZ_T_ECAPA_ASP, N); if ((rc = dz_launch_splitk_finish(e->parts, FC_SPLIT, (long long)N * 128, N, 128, 0, e->rb, st))) return rc; }
+    if ((rc = gemm(DZ_T_ECAPA_ASP, N, st, e->mfa, C3, (long long)T * C3, N, T, C3, 1, 1, 0, w.asp_tdnn, nullptr, C3, 128, 128, e->a1,
                    128, (long long)T * 128, DZ_EPI_RELU_BN_TANH, nullptr, e->rb)))
         return rc;
     float* logits = e->cat;   // the concatenation is dead once the MFA layer has consumed it
-    if ((rc = gemm(st, e->a1, 128, 0, 1, (int)NT, 128, 1, 1, 0, w.asp_conv, nullptr, 128, C3, C3, logits, C3, 0,
+    if ((rc = gemm(DZ_T_ECAPA_ASP, N, st, e->a1, 128, 0, 1, (int)NT, 128, 1, 1, 0, w.asp_conv, nullptr, 128, C3, C3, logits, C3, 0,
                    DZ_EPI_BIAS)))
         return rc;
-    if ((rc = dz_launch_asp_pool(e->mfa, logits, T, C3, N, e->nmask, e->pooled, st))) return rc;
+    { DzProfScope ps(DZ_T_ECAPA_ASP, N); if ((rc = dz_launch_asp_pool(e->mfa, logits, T, C3, N, e->nmask, e->pooled, st))) return rc; }
     // asp_bn (folded) + fc, split-K with a fixed-order reduce
     const long long ysplit = (long long)N * EMB;
-    if ((rc = gemm(st, e->pooled, 2 * C3, 0, 1, N, 2 * C3, 1, 1, 0, w.fc, nullptr, 2 * C3, EMB, EMB, e->parts, EMB,
+    if ((rc = gemm(DZ_T_ECAPA_FC, N, st, e->pooled, 2 * C3, 0, 1, N, 2 * C3, 1, 1, 0, w.fc, nullptr, 2 * C3, EMB, EMB, e->parts, EMB,
                    0, DZ_EPI_BIAS, nullptr, nullptr, FC_SPLIT, ysplit)))
         return rc;
-    if ((rc = dz_launch_splitk_finish(e->parts, FC_SPLIT, ysplit, N, EMB, 0, d_out, st))) return rc;
+    { DzProfScope ps(DZ_T_ECAPA_FC, N); if ((rc = dz_launch_splitk_finish(e->parts, FC_SPLIT, ysplit, N, EMB, 0, d_out, st))) return rc; }
     return dz_launch_nan_rows(d_out, N, EMB, e->tooshort, st);
 }
 

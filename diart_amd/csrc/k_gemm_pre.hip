@@ -709,8 +709,19 @@ int dz_launch_gemm_pre(const DzConvGemm& p_in, hipStream_t st) {
     DZ_REQUIRE(p.Y == nullptr || (p.ldy % 4 == 0 && ((uintptr_t)p.Y & 15) == 0),
                "gemm_pre: f32 output needs ldy a multiple of 4 and a 16-byte aligned base");
     // generation 2 (k_gemm_g2.hip) for every launch outside the latency regime (there: 64 x 64 tiles below)
-    if (dz_gemm_gen() >= 2 && 4 * ((p.Tout + BM - 1) / BM) * (p.Npad / BN) >= wg_slots())
-        return dz_gemm_gen() == 3 ? dz_launch_gemm_g3(p, 0, st) : dz_launch_gemm_g2(p, 0, st);
+    if (dz_gemm_gen() >= 2 && 4 * ((p.Tout + BM - 1) / BM) * (p.Npad / BN) >= wg_slots()) {
+        // generation 3 pays a hand-over of the accumulators per workgroup: only worth it for long k-loops
+        // (DZ_G3_MINK, default 1024: tdnn2 / tdnn3 of the x-vector network; the others stay on generation 1)
+        static const int g3_min_k = [] {
+            const char* e = getenv("DZ_G3_MINK");
+            return e ? atoi(e) : 1024;
+        }();
+        if (dz_gemm_gen() == 3) {
+            if (p.K >= g3_min_k) return dz_launch_gemm_g3(p, 0, st);
+        } else {
+            return dz_launch_gemm_g2(p, 0, st);
+        }
+    }
     switch (p.epi) {
         case DZ_EPI_BIAS: return launch<DZ_EPI_BIAS>(p, st);
         case DZ_EPI_BIAS_LEAKY: return launch<DZ_EPI_BIAS_LEAKY>(p, st);

@@ -1,5 +1,5 @@
 #!/bin/bash
-# Run LOCALLY after a tools/gpu_final_r3.sh visit: gpurun merges only gpurun_out/ back, so the judged
+# Run LOCALLY after a tools/gpu_final_r3.sh / gpu_final_r4.sh visit: gpurun merges only gpurun_out/ back, so the judged
 # copies under profiles/ are made here from the merged files.   usage: tools/collect_profiles.sh <tag>
 TAG=${1:-r03_a}
 for P in f16x3 f32; do
@@ -18,4 +18,7 @@ cp gpurun_out/bench_${TAG}_two_ranks.json profiles/${TAG}_bench_two_ranks_rehear
 cat gpurun_out/bf_${TAG}_config1.json gpurun_out/bf_${TAG}_config4.json gpurun_out/bf_${TAG}_config4_loop.json > profiles/${TAG}_file_benchmark.jsonl
 [ -f gpurun_out/f16x3_range.json ] && cp gpurun_out/f16x3_range.json profiles/${TAG}_f16x3_range_map.json
 [ -f gpurun_out/latency.json ] && cp gpurun_out/latency.json profiles/${TAG}_latency_config5.json
+[ -f gpurun_out/g2bench_${TAG}.json ] && cp gpurun_out/g2bench_${TAG}.json profiles/${TAG}_gemm_generations_isolated.json
+[ -f gpurun_out/long_horizon_${TAG}.txt ] && cp gpurun_out/long_horizon_${TAG}.txt profiles/${TAG}_long_horizon.txt
+[ -f gpurun_out/pytest_gpu_${TAG}.txt ] && tail -3 gpurun_out/pytest_gpu_${TAG}.txt > profiles/${TAG}_pytest_gpu_tail.txt
 ls profiles | grep ${TAG}
