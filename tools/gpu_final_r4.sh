@@ -51,7 +51,8 @@ DZ_CONCURRENT_FILES=0 timeout -s KILL 300 python tools/benchmark_files.py --file
 for f in gpurun_out/bf16/rttm_w1/*.rttm; do cmp -s $f gpurun_out/bf16l/rttm_w1/$(basename $f) || echo "RTTM DIFF $f"; done; echo "rttm files compared"
 rm -rf gpurun_out/bf1 gpurun_out/bf16 gpurun_out/bf16l
 echo "=== config 3"
-timeout -s KILL 300 python bench.py --config 3 --steps 20 --warmup 3 2> /dev/null | tail -1 | cut -c1-600 | tee gpurun_out/bench_${TAG}_config3.json
+timeout -s KILL 300 python bench.py --config 3 --steps 20 --warmup 3 2> /dev/null | grep '^{"metric"' | tail -1 > gpurun_out/bench_${TAG}_config3.json
+cut -c1-300 gpurun_out/bench_${TAG}_config3.json
 echo "=== bench.py --gpus 2 as one process (rehearsal on this box's GPU count)"
 NG=$(python -c "import torch;print(torch.cuda.device_count())")
 if [ "$NG" -ge 2 ]; then ENVX=""; else ENVX="DZ_FORCE_DEVICE=0 DZ_DIST_BACKEND=gloo"; fi
