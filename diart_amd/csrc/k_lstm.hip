@@ -61,7 +61,12 @@ constexpr int PF = 4;      // x-projection prefetch distance in steps
 // one barrier serves both; a 64-chunk batch then occupies 64 CUs instead of 128 for ~1.25x the layer
 // time, i.e. 0.63x the CU-time, and leaves the other CUs ENTIRELY to the GEMM / convolution workgroups
 // (which at 240 - 256 registers cannot sit beside a recurrence workgroup at all).
-template <bool UM, int NC>
+// PK: the contraction as 64 v_pk_fma_f32 per step (true) or 128 plain v_fma_f32 (false).  Alone the packed form
+// is faster; BESIDE A WAVE THAT ISSUES MFMAs — where this kernel spends most of its life in the 64-stream pipeline —
+// packed f32 VALU is the slow one (MI355X_MICROARCH.md, "price of one filler beside MFMAs"; measured here, round 4,
+// tools/rec_contention.py: 187 us alone -> 320 - 355 us beside MFMA-issuing waves, while LDS-DMA, fragment reads and
+// barriers of a neighbour cost it nothing).
+template <bool UM, int NC, bool PK = true>
 __global__ __launch_bounds__(512) void lstm_rec_kernel(const float* __restrict__ gx,
                                                        const float* __restrict__ whh,
                                                        float* __restrict__ hout,
@@ -140,8 +145,19 @@ __global__ __launch_bounds__(512) void lstm_rec_kernel(const float* __restrict__
                 const f32x2 h01 = {hv[c][0], hv[c][1]}, h23 = {hv[c][2], hv[c][3]};
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    acc[c][j] = __builtin_elementwise_fma(wreg[j][2 * jj + 0], h01, acc[c][j]);
-                    acc[c][j] = __builtin_elementwise_fma(wreg[j][2 * jj + 1], h23, acc[c][j]);
+                    if (PK) {
+                        acc[c][j] = __builtin_elementwise_fma(wreg[j][2 * jj + 0], h01, acc[c][j]);
+                        acc[c][j] = __builtin_elementwise_fma(wreg[j][2 * jj + 1], h23, acc[c][j]);
+                    } else {
+                        // inline asm: hipcc's SLP vectoriser packs adjacent scalar FMAs right back into v_pk_fma_f32
+                        float a0 = acc[c][j][0], a1 = acc[c][j][1];
+                        asm("v_fma_f32 %0, %1, %2, %0" : "+v"(a0) : "v"(wreg[j][2 * jj + 0][0]), "v"(hv[c][0]));
+                        asm("v_fma_f32 %0, %1, %2, %0" : "+v"(a1) : "v"(wreg[j][2 * jj + 0][1]), "v"(hv[c][1]));
+                        asm("v_fma_f32 %0, %1, %2, %0" : "+v"(a0) : "v"(wreg[j][2 * jj + 1][0]), "v"(hv[c][2]));
+                        asm("v_fma_f32 %0, %1, %2, %0" : "+v"(a1) : "v"(wreg[j][2 * jj + 1][1]), "v"(hv[c][3]));
+                        acc[c][j][0] = a0;
+                        acc[c][j][1] = a1;
+                    }
                 }
             }
         }
@@ -244,10 +260,17 @@ int dz_launch_lstm(const float* gx, const float* whh, float* hout, void* hsplit,
             DZ_LAUNCH((lstm_rec_kernel<false, 2>), grid, dim3(512), 0, st, gx, whh, hout, hsp, hplane, B, T);
     } else {
         dim3 grid(B, 2);
-        if (unit_major)
+        // DZ_LSTM_PK=0: plain v_fma_f32 in the contraction (see the PK template parameter)
+        const char* e_pk = getenv("DZ_LSTM_PK");
+        const bool pk = !(e_pk && e_pk[0] == '0');
+        if (unit_major && pk)
             DZ_LAUNCH((lstm_rec_kernel<true, 1>), grid, dim3(512), 0, st, gx, whh, hout, hsp, hplane, B, T);
-        else
+        else if (unit_major)
+            DZ_LAUNCH((lstm_rec_kernel<true, 1, false>), grid, dim3(512), 0, st, gx, whh, hout, hsp, hplane, B, T);
+        else if (pk)
             DZ_LAUNCH((lstm_rec_kernel<false, 1>), grid, dim3(512), 0, st, gx, whh, hout, hsp, hplane, B, T);
+        else
+            DZ_LAUNCH((lstm_rec_kernel<false, 1, false>), grid, dim3(512), 0, st, gx, whh, hout, hsp, hplane, B, T);
     }
     DZ_HIP(hipGetLastError());
     return 0;
