@@ -314,6 +314,9 @@ __device__ __forceinline__ int ch_pi(int i) { return ((i & 3) << 2) | ((i >> 2) 
 // Persistent: the grid is at most two workgroups per CU, each walks a contiguous range of (chunk,
 // tile) pairs with its B fragments resident; the samples of tile t+1 are fetched into registers
 // before the MFMA loop of tile t and parked in the other LDS buffer after it (one barrier per tile).
+// DBG (timing experiments, DZ_CONV0_DBG; results are wrong): 1 = no parking of the next tile's samples, 2 = no
+// MFMAs, 4 = no fragment reads inside the tile loop, 8 = no result stores / partials
+template <int DBG = 0>
 __global__ __launch_bounds__(192, 2) void sinc_conv0_h_kernel(
     const float* __restrict__ wave, long long stride, int S, const float* __restrict__ stats,
     int stats_are_moments, float gamma, float beta, const unsigned short* __restrict__ fsp,
@@ -430,11 +433,15 @@ __global__ __launch_bounds__(192, 2) void sinc_conv0_h_kernel(
             for (int r = 0; r < 16; ++r) accm[r] = accx[r] = 0.f;
 #pragma unroll
             for (int ks = 0; ks < 16; ++ks) {
-                const ch_f16x8 ah = *reinterpret_cast<const ch_f16x8*>(ap + 32 * ks);
-                const ch_f16x8 al = *reinterpret_cast<const ch_f16x8*>(ap + CH_PL + 32 * ks);
-                accx = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[ks], accx, 0, 0, 0);
-                accm = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[ks], accm, 0, 0, 0);
-                accx = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[ks], accx, 0, 0, 0);
+                const ch_f16x8 ah = *reinterpret_cast<const ch_f16x8*>((DBG & 4) ? xs + 16 * l : ap + 32 * ks);
+                const ch_f16x8 al = *reinterpret_cast<const ch_f16x8*>((DBG & 4) ? xs + 16 * l + 1024 : ap + CH_PL + 32 * ks);
+                if (DBG & 2) {
+                    asm volatile("" ::"v"(ah), "v"(al), "v"(bh[ks]), "v"(bl[ks]));
+                } else {
+                    accx = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[ks], accx, 0, 0, 0);
+                    accm = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[ks], accm, 0, 0, 0);
+                    accx = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[ks], accx, 0, 0, 0);
+                }
                 // keep the fragment reads at most four k-steps ahead of their MFMAs: hoisting all 32
                 // reads of a block (128 registers) spills the resident filter fragments
                 if ((ks & 3) == 3) asm volatile("" ::: "memory");
@@ -447,11 +454,14 @@ __global__ __launch_bounds__(192, 2) void sinc_conv0_h_kernel(
         }
         // the next tile's samples first: parking waits for this wave's LDS-DMA (vmcnt), which must
         // not also wait for the result stores below
-        if (t + 1 < t_end) park(t + 1, xs2[(t + 1 - t_begin) & 1]);
+        if (t + 1 < t_end && !(DBG & 1)) park(t + 1, xs2[(t + 1 - t_begin) & 1]);
+        if (DBG & 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         // pooled rows + InstanceNorm partials: C/D column = lane & 31 = filter, row rho <-> m = pi(rho)
         const int bb = t / ntile, tile = t - bb * ntile;
         float sum = 0.f, ssq = 0.f;
-        if (ch < 80) {
+        if (DBG & 8) {
+            asm volatile("" ::"v"(pmax));
+        } else if (ch < 80) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int rho = (r & 3) + 8 * (r >> 2) + 4 * g;
@@ -466,7 +476,7 @@ __global__ __launch_bounds__(192, 2) void sinc_conv0_h_kernel(
         }
         sum += __shfl_xor(sum, 32, 64);
         ssq += __shfl_xor(ssq, 32, 64);
-        if (ch < 80 && g == 0) {
+        if (ch < 80 && g == 0 && !(DBG & 8)) {
             float* pp = partials + (((long long)bb * ntile + tile) * 80 + ch) * 2;
             pp[0] = sum;
             pp[1] = ssq;
@@ -486,9 +496,24 @@ int dz_launch_sinc_conv0_split(const float* wave, long long stride, int B, int S
                                float* y0, int P0, float* partials, int ntile, hipStream_t st) {
     const int total = ntile * B;
     const int grid = total < 512 ? total : 512;    // two resident workgroups per CU
-    DZ_LAUNCH(sinc_conv0_h_kernel, dim3(grid), dim3(192), 0, st, wave, stride, S, stats,
-              stats_are_moments, gamma, beta, reinterpret_cast<const unsigned short*>(fsp), y0, P0,
-              partials, ntile, total, dz_cur_oflag);
+    const char* e_dbg = getenv("DZ_CONV0_DBG");
+    const int dbg = e_dbg ? atoi(e_dbg) : 0;
+#define DZ_C0(D)                                                                                          \
+    DZ_LAUNCH(sinc_conv0_h_kernel<D>, dim3(grid), dim3(192), 0, st, wave, stride, S, stats,                \
+              stats_are_moments, gamma, beta, reinterpret_cast<const unsigned short*>(fsp), y0, P0,        \
+              partials, ntile, total, dz_cur_oflag)
+    switch (dbg) {
+        case 1: DZ_C0(1); break;
+        case 2: DZ_C0(2); break;
+        case 4: DZ_C0(4); break;
+        case 8: DZ_C0(8); break;
+        case 9: DZ_C0(9); break;
+        case 13: DZ_C0(13); break;
+        case 15: DZ_C0(15); break;
+        case 6: DZ_C0(6); break;
+        default: DZ_C0(0); break;
+    }
+#undef DZ_C0
     DZ_HIP(hipGetLastError());
     return 0;
 }
