@@ -14,7 +14,7 @@ cp gpurun_out/kernels_${TAG}_f32_same_run.json profiles/${TAG}_kernels_events_ro
 cp gpurun_out/stall_${TAG}.json profiles/${TAG}_stall_report.json
 cp gpurun_out/kbench_${TAG}.json profiles/${TAG}_kbench_isolated.json
 cp gpurun_out/bench_${TAG}_config3.json profiles/${TAG}_bench_config3.json
-cp gpurun_out/bench_${TAG}_two_ranks.json profiles/${TAG}_bench_two_ranks_rehearsal.json
+grep "^{\"metric\"" gpurun_out/bench_${TAG}_two_ranks.json | tail -1 > profiles/${TAG}_bench_two_ranks_rehearsal.json
 cat gpurun_out/bf_${TAG}_config1.json gpurun_out/bf_${TAG}_config4.json gpurun_out/bf_${TAG}_config4_loop.json > profiles/${TAG}_file_benchmark.jsonl
 [ -f gpurun_out/f16x3_range.json ] && cp gpurun_out/f16x3_range.json profiles/${TAG}_f16x3_range_map.json
 [ -f gpurun_out/latency.json ] && cp gpurun_out/latency.json profiles/${TAG}_latency_config5.json
