@@ -128,7 +128,8 @@ def device_kernel(tag, precision):
             sym = {"0": "lstm_mfma_kernel<true>", "3": "lstm_mfma_dma_kernel"}.get(
                 lstm, "lstm_mfma1_kernel<true, %d>" % (0 if lstm == "1" else 8))
             return sym, "mfma", PEAK_F16_MATRIX_TFLOPS / SPLIT_PRODUCTS, "TFLOP/s"
-        return f"lstm_rec_kernel<true, {lstm_chains_per_wg()}>", "valu", PEAK_F32_VECTOR_TFLOPS, "TFLOP/s"
+        pk = "false" if os.environ.get("DZ_LSTM_PK", "1") == "0" else "true"      # packed-FMA template argument
+        return f"lstm_rec_kernel<true, {lstm_chains_per_wg()}, {pk}>", "valu", PEAK_F32_VECTOR_TFLOPS, "TFLOP/s"
     if tag == "sinc_conv0" and split and os.environ.get("DZ_CONV0_SPLIT", "1") != "0":
         return "sinc_conv0_h_kernel", "mfma", PEAK_F16_MATRIX_TFLOPS / SPLIT_PRODUCTS, "TFLOP/s"
     if k["bound"] == "mfma_f32" or not split:
@@ -527,7 +528,11 @@ def step_level(per_kernel, ms_per_step, precision, source):
             "source": source}
     byts = sum((k["traffic"] or 0) * k["launches_per_step"] for k in per_kernel)
     alg = sum(k["alg_bytes_per_launch"] * k["launches_per_step"] for k in per_kernel)
+    # a kernel whose PMC row was not found would silently drop its bytes: name it, and count its algorithmic bytes
+    missing = [k["kernel"] for k in per_kernel if byts and not k["traffic"]]
+    byts += sum(k["alg_bytes_per_launch"] * k["launches_per_step"] for k in per_kernel if byts and not k["traffic"])
     hbm = {"gbps": round(byts / step_us / 1e3, 1) if byts else None, "bytes_per_step": int(byts) if byts else None,
+           "kernels_without_pmc_row_counted_at_algorithmic_bytes": missing,
            "peak_gbps": PEAK_HBM_GBPS, "frac_of_peak": round(byts / step_us / 1e3 / PEAK_HBM_GBPS, 4) if byts else None,
            "alg_bytes_per_step": int(alg), "source": source}
     mk = next((dict(k) for k in per_kernel if k["bound"] == "mfma"), None)
