@@ -108,7 +108,8 @@ def lstm_chains_per_wg():
 
 def gemm_generation():
     """k_gemm_pre.hip dispatches its launches to k_gemm_g2.hip with DZ_GEMM_GEN=2 (dz_gemm_gen())."""
-    return 2 if os.environ.get("DZ_GEMM_GEN", "1") == "2" else 1
+    g = os.environ.get("DZ_GEMM_GEN", "1")
+    return int(g) if g in ("2", "3") else 1
 
 
 def device_kernel(tag, precision):
@@ -146,7 +147,9 @@ def device_kernel(tag, precision):
         ilv = "true" if os.environ.get("DZ_GP_LOOP", "1") != "0" else "false"
         kern = lambda epi: f"gemm_pre_kernel<{epi}, {ilv}>"
         if gemm_generation() == 2:                                    # k_gemm_g2.hip
-            kern = lambda epi: f"gemm_g2_kernel<{epi}, {os.environ.get('DZ_G2_MT', '2')}>"
+            kern = lambda epi: f"gemm_g2_kernel<{epi}, {os.environ.get('DZ_G2_MT', '2')}, 0>"
+        if gemm_generation() == 3 and tag in ("tdnn2", "tdnn3"):      # k_gemm_g3.hip: layers with K >= DZ_G3_MINK (1024)
+            kern = lambda epi: f"gemm_g3_kernel<{epi}, {os.environ.get('DZ_G3_MT', '4')}>"
         sym = {"lstm_proj": kern(0), "lstm_proj0": kern(0), "seg_mlp": kern(1),
                "tdnn5": "gemm_pre_pool_kernel" if fused_pool else kern(3)}.get(tag, kern(3))
         return sym, "mfma", PEAK_F16_MATRIX_TFLOPS / SPLIT_PRODUCTS, "TFLOP/s"

@@ -103,3 +103,36 @@ int main(void) {
     assert r.returncode == 0, r.stderr
     r = subprocess.run([str(exe)], capture_output=True, text=True)
     assert r.returncode == 0 and "abi ok" in r.stdout, (r.returncode, r.stdout, r.stderr)
+
+
+def test_every_device_kernel_bench_names_is_in_the_library(monkeypatch):
+    """bench.py joins its per-launch brackets with the rocprofv3 / PMC rows by DEVICE KERNEL SYMBOL.  A template
+    parameter added to a kernel (round 4: the recurrence's packed-FMA switch) silently un-joins it — `traffic` of the
+    headline kernel came out null.  Every symbol bench.py can name must be a kernel of the built library."""
+    import importlib.util
+    import shutil
+    import subprocess
+    from diart_amd import _lib
+    if shutil.which("nm") is None:
+        import pytest
+        pytest.skip("nm not available")
+    spec = importlib.util.spec_from_file_location("bench_for_symbols", ROOT / "bench.py")
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    syms = subprocess.run(["nm", "-C", str(_lib.lib_path())], capture_output=True, text=True, check=True).stdout
+    variants = [{}, {"DZ_LSTM_NC": "2"}, {"DZ_LSTM_PK": "0"}, {"DZ_LSTM": "0"}, {"DZ_LSTM": "1"}, {"DZ_LSTM": "2"},
+                {"DZ_LSTM": "3"}, {"DZ_GEMM_GEN": "2"}, {"DZ_GEMM_GEN": "3"}, {"DZ_POOL_FUSE": "0"}, {"DZ_SPLIT_WM": "2"}, {"DZ_CONV_POOL": "0"},
+                {"DZ_MLP_HEAD": "0"}, {"DZ_CONV0_SPLIT": "0"}, {"DZ_GP_LOOP": "0"}]
+    missing = []
+    for env in variants:
+        for k in ("DZ_LSTM_NC", "DZ_LSTM_PK", "DZ_LSTM", "DZ_GEMM_GEN", "DZ_POOL_FUSE", "DZ_SPLIT_WM", "DZ_CONV_POOL",
+                  "DZ_MLP_HEAD", "DZ_CONV0_SPLIT", "DZ_GP_LOOP", "DZ_G2_MT", "DZ_G3_MT", "DZ_NORM_SPLIT"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        for precision in ("f16x3", "f32"):
+            for tag in bench.kernels_for(precision):
+                sym = bench.device_kernel(tag, precision)[0].split(" (")[0]
+                if sym + "(" not in syms and sym + "<" not in syms:       # (a template whose arguments bench leaves out)
+                    missing.append((env, precision, tag, sym))
+    assert not missing, missing
