@@ -743,18 +743,20 @@ def main():
     # every 10th step of the timed region carries the per-kernel event pairs (DZ_PROF_EVERY=1: all)
     PROF_EVERY = max(1, int(os.environ.get("DZ_PROF_EVERY", "10")))
     sampled = [0]
+    stamps = []                    # host clock at every launch (the timed passes report the spread of the step period)
 
-    def run(t_first, count, pipe=None, profiled=False):
+    def run(t_first, count, pipe=None, profiled=False, every=None):
         # pipe.max_inflight steps are launched ahead (pipe.depth of them run concurrently, one per lane; the
         # others wait in their lane's streams) while the host runs the clustering + output tail of the oldest
         pipe = pipe or main_pipe[0]
         inflight = []
         for t in range(t_first, t_first + count):
             if profiled:
-                on = (t - t_first) % PROF_EVERY == 0
+                on = (t - t_first) % (every or PROF_EVERY) == 0
                 lib.dz_prof_pause(0 if on else 1)
                 sampled[0] += int(on)
             h0 = time.perf_counter()
+            stamps.append(h0)
             inflight.append(pipe.launch(window(t)))
             h1 = time.perf_counter()
             if len(inflight) >= pipe.max_inflight:
@@ -802,6 +804,17 @@ def main():
         f"{step_ms0:.2f} ms step; {usable} usable cores, {world} rank(s): {host_threads_used} host threads per rank "
         f"(node-wide demand ~{world * cpu_ms / max(1e-3, step_ms0):.1f} cores)")
     host_threads = host_threads_used
+    # The timed region brackets every PROF_EVERY-th step's launches with timing events.  The FIRST dispatches of a
+    # stream that carry such events are a start-up cost of the runtime (seen once as a ~11 ms launch call inside a
+    # 25 ms timed region: 17 718 xRT on a box whose untouched passes of the same run gave 24 400 - 27 200): pay it here
+    def prof_warm(p):
+        if not os.environ.get("DZ_NO_PROF"):
+            lib.dz_prof_enable(1)
+            run(0, min(total_steps, 2 * p.max_inflight), p, profiled=True, every=1)      # every lane's streams
+            lib.dz_prof_collect()
+            lib.dz_prof_enable(0)
+
+    prof_warm(pipe)
     run(0, args.warmup)
     torch.cuda.synchronize()
     log("warm-up done")
@@ -814,7 +827,12 @@ def main():
         host["launch"] = host["finish"] = 0.0
         p.host_seconds["wait"] = p.host_seconds["work"] = 0.0
         cpu0 = time.process_time()                     # CPU time of every thread of this process
+        del stamps[:]
         el = D.timed_max_over_ranks(lambda: run(args.warmup, args.steps, p, profiled=prof), device)
+        gaps = np.diff(np.asarray(stamps)) * 1e3 if len(stamps) > 2 else np.zeros(1)
+        # launch-to-launch period of the host loop inside the timed region: a one-off stall (runtime, OS) shows up as
+        # max >> p50 — `value` is still total / K, as the contract says
+        host["step_period_ms"] = {"p50": round(float(np.median(gaps)), 3), "max": round(float(gaps.max()), 3)}
         host["cpu_ms_per_step"] = 1e3 * (time.process_time() - cpu0) / args.steps
         host["launch_ms_per_step"], host["work_ms_per_step"] = 1e3 * host["launch"] / args.steps, 1e3 * p.host_seconds["work"] / args.steps
         hs = p.host_seconds
@@ -828,6 +846,7 @@ def main():
 
     elapsed, table, n_sampled = timed_pass(pipe, f"timed region ({precision})")
     host_line = {"cpu_ms_per_step": round(host["cpu_ms_per_step"], 3), "launch_ms_per_step": round(host["launch_ms_per_step"], 3),
+                 "step_period_ms_in_timed_region": host["step_period_ms"],
                  "clustering_tail_wall_ms_per_step": round(host["work_ms_per_step"], 3), "threads": host_threads,
                  "usable_cores": usable,
                  "note": "CPU time of all threads of the rank per step (launching thread + worker pool) in the timed region"}
@@ -837,6 +856,7 @@ def main():
     exact = None
     if precision != "f32" and not args.no_exact_f32:
         p32 = make_pipe("f32")
+        prof_warm(p32)
         run(0, args.warmup, p32)
         torch.cuda.synchronize()
         e32, table32, n_sampled32 = timed_pass(p32, "exact-f32 pass")

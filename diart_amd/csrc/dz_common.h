@@ -101,6 +101,16 @@ __device__ __forceinline__ void dz_tile_map(int agroup, int& bx, int& by, int& b
     dz_tile_map_lin(blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z), gx, gy, gridDim.z, agroup, bx, by, bz);
 }
 
+// Persistent kernels that give workgroup L the contiguous range [L * total / grid, (L + 1) * total / grid) of a
+// (chunk, tile) list: hardware workgroup b runs on XCD b % 8, so with L = b eight NEIGHBOURING ranges — the tiles of
+// one chunk — sit on eight different XCDs and everything they share (the chunk's normalisation partials, the halo
+// rows between two ranges) is fetched into eight L2s (TCC counters, tools/tcc_probe.sh: conv_pool_h<80> reads
+// exactly its input alone and 29 MB more in the pipeline = 64 chunks x 8 XCDs x 54 KB of partials).  With this map
+// XCD x owns the contiguous eighth [x * grid / 8, (x + 1) * grid / 8) of the ranges.
+__device__ __forceinline__ int dz_xcd_contiguous(int b, int grid) {
+    return (grid & 7) == 0 ? (b & 7) * (grid >> 3) + (b >> 3) : b;
+}
+
 // ---------------------------------------------------------------------------
 // "kb-major" f16 planes: the operand format of k_gemm_pre.hip and k_mlp_head.hip (activations written by
 // the producing kernel's epilogue, weights packed by weights.py kb_major()).  A plane of R rows x K columns

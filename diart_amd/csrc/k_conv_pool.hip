@@ -68,8 +68,9 @@ __global__ __launch_bounds__(256, 2) void conv_pool_h_kernel(
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6), l = tid & 63, li = l & 31, g = l >> 5;
     const int nt = w & 1, kh = w >> 1;                                // channel block, k-half
     const int ks_lo = kh ? G::KS0 : 0, ks_n = kh ? G::KS - G::KS0 : G::KS0;
-    const int t_begin = (int)((long long)blockIdx.x * total / gridDim.x);
-    const int t_end = (int)((long long)(blockIdx.x + 1) * total / gridDim.x);
+    const int wg = dz_xcd_contiguous(blockIdx.x, gridDim.x);         // neighbouring tile ranges on ONE XCD
+    const int t_begin = (int)((long long)wg * total / gridDim.x);
+    const int t_end = (int)((long long)(wg + 1) * total / gridDim.x);
     if (t_begin >= t_end) return;
 
     // ---- weight fragments of this wave: channels 32 nt + li, k = 16 ks + 8 g .. +7 -------------

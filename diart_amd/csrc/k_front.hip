@@ -330,8 +330,9 @@ __global__ __launch_bounds__(192, 2) void sinc_conv0_h_kernel(
     float (*stat_s)[2] = reinterpret_cast<float (*)[2]>(lds_all + 2 * CH_LDS + 1536 * 4);
     const int tid = threadIdx.x;
     const int w = tid >> 6, l = tid & 63, li = l & 31, g = l >> 5;
-    const int t_begin = (int)((long long)blockIdx.x * total / gridDim.x);
-    const int t_end = (int)((long long)(blockIdx.x + 1) * total / gridDim.x);
+    const int wg = dz_xcd_contiguous(blockIdx.x, gridDim.x);         // neighbouring tile ranges on ONE XCD
+    const int t_begin = (int)((long long)wg * total / gridDim.x);
+    const int t_end = (int)((long long)(wg + 1) * total / gridDim.x);
     if (t_begin >= t_end) return;
     const int b_first = t_begin / ntile;
 
