@@ -139,6 +139,9 @@ def device_kernel(tag, precision):
                "lstm_proj0": "convgemm_kernel<128, true, 0>", "seg_mlp": "convgemm_kernel<128, false, 1>",
                "tdnn1": "convgemm_kernel<128, true, 3>",
                "emb_linear": "convgemm_kernel<128, false, 0> (split-K)", "seg_head": "seg_head_kernel"}
+        if os.environ.get("DZ_F32_GEMM", "1") != "0":                  # wide layers without a prologue: k_gemm_f32.hip
+            sym.update({"lstm_proj": "gemm_f32_kernel<0>", "seg_mlp": "gemm_f32_kernel<1>", "tdnn2": "gemm_f32_kernel<3>",
+                        "tdnn3": "gemm_f32_kernel<3>", "tdnn4": "gemm_f32_kernel<3>", "tdnn5": "gemm_f32_kernel<3>"})
         return sym.get(tag, "convgemm_kernel<128, false, 3>"), "mfma", PEAK_F32_MATRIX_TFLOPS, "TFLOP/s"
     if pre and tag == "seg_mlp" and os.environ.get("DZ_MLP_HEAD", "1") != "0":
         return "mlp_head_kernel", "mfma", PEAK_F16_MATRIX_TFLOPS / SPLIT_PRODUCTS, "TFLOP/s"

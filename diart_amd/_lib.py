@@ -127,6 +127,7 @@ SIGNATURES = {
                                      C.c_int, vp, C.c_double, vp, C.c_int, vp, vp, C.c_int]),
     # kernel-level entry points
     "dz_k_convgemm": (C.c_int, [vp, vp, vp]),
+    "dz_k_gemm_f32": (C.c_int, [vp, vp, vp]),
     "dz_k_gemm_split": (C.c_int, [vp, vp, vp]),
     "dz_k_gemm_pre": (C.c_int, [vp, vp, vp]),
     "dz_k_gemm_g2": (C.c_int, [vp, vp, C.c_int, vp]),

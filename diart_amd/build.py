@@ -15,7 +15,7 @@ from pathlib import Path
 HERE = Path(__file__).resolve().parent
 CSRC = HERE / "csrc"
 LIB = HERE / "libdiart_amd.so"
-SOURCES = ["api.hip", "ecapa_api.hip", "k_front.hip", "k_convgemm.hip", "k_gemm_split.hip", "k_gemm_pre.hip", "k_gemm_g2.hip", "k_gemm_g3.hip", "k_mlp_head.hip", "k_conv_pool.hip", "k_lstm.hip", "k_lstm_mfma.hip", "k_pool.hip",
+SOURCES = ["api.hip", "ecapa_api.hip", "k_front.hip", "k_convgemm.hip", "k_gemm_f32.hip", "k_gemm_split.hip", "k_gemm_pre.hip", "k_gemm_g2.hip", "k_gemm_g3.hip", "k_mlp_head.hip", "k_conv_pool.hip", "k_lstm.hip", "k_lstm_mfma.hip", "k_pool.hip",
            "k_ecapa.hip", "ring.hip", "cluster.cpp", "tail.cpp", "hostpool.cpp", "filebatch.cpp"]
 ARCH = "gfx950"
 

@@ -908,6 +908,11 @@ extern "C" int dz_k_convgemm(dz_ctx* ctx, const dz_convgemm_desc* d, void* strea
     DzRangeScope range_scope(ctx->oflag_dev);
     return dz_launch_convgemm(*d, (hipStream_t)stream);
 }
+extern "C" int dz_k_gemm_f32(dz_ctx* ctx, const dz_convgemm_desc* d, void* stream) {
+    DZ_REQUIRE(ctx && d, "dz_k_gemm_f32: NULL argument");
+    DZ_HIP(hipSetDevice(ctx->device));
+    return dz_launch_gemm_f32(*d, (hipStream_t)stream);
+}
 extern "C" int dz_k_gemm_split(dz_ctx* ctx, const dz_convgemm_desc* d, void* stream) {
     DZ_REQUIRE(ctx && d, "dz_k_gemm_split: NULL argument");
     DZ_HIP(hipSetDevice(ctx->device));

@@ -259,6 +259,9 @@ int dz_launch_finalize_norm(const float* partials, int B, int ntile, int C, int 
 // k_convgemm.hip ------------------------------------------------------------
 typedef dz_convgemm_desc DzConvGemm;
 int dz_launch_convgemm(const DzConvGemm& p, hipStream_t st);
+// k_gemm_f32.hip: the exact-f32 kernel of the wide layers (dz_launch_convgemm routes to it when dz_gemm_f32_ok)
+bool dz_gemm_f32_ok(const DzConvGemm& p);
+int dz_launch_gemm_f32(const DzConvGemm& p, hipStream_t st);
 // k_gemm_split.hip: the same contraction on the f16 matrix cores with both operands split into
 // (hi, lo) f16 pairs — 3 MFMAs per product, f32 accumulation
 int dz_launch_gemm_split(const DzConvGemm& p, hipStream_t st);

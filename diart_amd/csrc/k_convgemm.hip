@@ -262,6 +262,7 @@ int launch(const DzConvGemm& p, hipStream_t st) {
 int dz_convgemm_ntile(int Tout) { return (Tout + BM - 1) / BM; }
 
 int dz_launch_convgemm(const DzConvGemm& p, hipStream_t st) {
+    if (dz_gemm_f32_ok(p)) return dz_launch_gemm_f32(p, st);      // wide layers without a prologue: k_gemm_f32.hip
     DZ_REQUIRE(p.Kpad % KT == 0 && p.Cin % 4 == 0 && p.ldx % 4 == 0, "convgemm: bad K/Cin/ldx");
     DZ_REQUIRE(p.K <= p.Kpad && p.K == p.taps * p.Cin, "convgemm: K mismatch");
     DZ_REQUIRE(p.pad >= 0 && p.Tout > 0 &&

@@ -294,6 +294,11 @@ typedef struct {
                              with dz_range_check                                                 */
 } dz_convgemm_desc;
 int dz_k_convgemm(dz_ctx* ctx, const dz_convgemm_desc* desc, void* stream);
+/* the exact-f32 kernel of the wide layers alone (k_gemm_f32.hip; dz_k_convgemm routes to it by itself when the
+ * layer is in its domain: f32 operands, no prologue / padding / split-K, Npad % 128 == 0, K = taps * Cin unpadded
+ * with Cin % 32 == 0; DZ_F32_GEMM=0 keeps every layer on the round-1 kernel).  Same arithmetic per product (one
+ * exact f32 FMA), another order of the k sum.  Error if the layer is outside the domain.               */
+int dz_k_gemm_f32(dz_ctx* ctx, const dz_convgemm_desc* desc, void* stream);
 /* the same layer on the split-f16 matrix-core path (desc->Wsplit must be set)       */
 int dz_k_gemm_split(dz_ctx* ctx, const dz_convgemm_desc* desc, void* stream);
 /* ... with the activations pre-split as well (desc->Wsplit and desc->Xsplit set; B = 1, K = taps*Cin

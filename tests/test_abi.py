@@ -122,11 +122,11 @@ def test_every_device_kernel_bench_names_is_in_the_library(monkeypatch):
     syms = subprocess.run(["nm", "-C", str(_lib.lib_path())], capture_output=True, text=True, check=True).stdout
     variants = [{}, {"DZ_LSTM_NC": "2"}, {"DZ_LSTM_PK": "0"}, {"DZ_LSTM": "0"}, {"DZ_LSTM": "1"}, {"DZ_LSTM": "2"},
                 {"DZ_LSTM": "3"}, {"DZ_GEMM_GEN": "2"}, {"DZ_GEMM_GEN": "3"}, {"DZ_POOL_FUSE": "0"}, {"DZ_SPLIT_WM": "2"}, {"DZ_CONV_POOL": "0"},
-                {"DZ_MLP_HEAD": "0"}, {"DZ_CONV0_SPLIT": "0"}, {"DZ_GP_LOOP": "0"}]
+                {"DZ_MLP_HEAD": "0"}, {"DZ_CONV0_SPLIT": "0"}, {"DZ_GP_LOOP": "0"}, {"DZ_F32_GEMM": "0"}]
     missing = []
     for env in variants:
         for k in ("DZ_LSTM_NC", "DZ_LSTM_PK", "DZ_LSTM", "DZ_GEMM_GEN", "DZ_POOL_FUSE", "DZ_SPLIT_WM", "DZ_CONV_POOL",
-                  "DZ_MLP_HEAD", "DZ_CONV0_SPLIT", "DZ_GP_LOOP", "DZ_G2_MT", "DZ_G3_MT", "DZ_NORM_SPLIT"):
+                  "DZ_MLP_HEAD", "DZ_CONV0_SPLIT", "DZ_GP_LOOP", "DZ_G2_MT", "DZ_G3_MT", "DZ_NORM_SPLIT", "DZ_F32_GEMM"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)

@@ -286,6 +286,71 @@ def test_convgemm_pool3(gpu, Cin, Tin, split):
     assert torch.allclose(ps[..., 1], (ref ** 2).sum(2), rtol=1e-5, atol=1e-4)
 
 
+@pytest.mark.parametrize("B,Tin,Cin,taps,dil,N,Nstore,epi", [
+    (1, 64 * 289, 512, 3, 2, 512, 512, "tdnn"),          # config-2 tdnn2, flattened
+    (1, 1000, 512, 1, 1, 1536, 1500, "tdnn"),            # tdnn5: stored columns end inside a 4-column group
+    (1, 18752, 256, 1, 1, 1024, 1024, "bias"),           # LSTM projection
+    (3, 293, 256, 1, 1, 128, 128, "leaky"),              # MLP, batched, ragged last row tile
+    (2, 131, 128, 3, 3, 256, 255, "bias"),               # taps + dilation, batched, odd Nstore
+    (1, 97, 32, 1, 1, 128, 3, "sigmoid"),                # one k-tile, three stored columns
+    (1, 300, 1024, 1, 1, 384, 384, "relu"), (1, 300, 1024, 1, 1, 384, 384, "relu_bn"),
+    (1, 130, 96, 5, 1, 128, 128, "relu_bn_tanh")])
+def test_gemm_f32_wide_layers(gpu, monkeypatch, B, Tin, Cin, taps, dil, N, Nstore, epi):
+    """k_gemm_f32.hip (LDS-DMA operands, 128 x 128 tiles, v_mfma_f32_32x32x2_f32) against the f64 contraction and
+    against the round-1 kernel it replaces for these layers (k_convgemm.hip, DZ_F32_GEMM=0): the same products, one
+    exact f32 FMA each, in another order."""
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(Tin + Cin + N)
+    K = taps * Cin
+    Tout = Tin - (taps - 1) * dil
+    X = torch.randn(B, Tin, Cin, generator=g)
+    W = torch.zeros(N, K)
+    W[:Nstore] = torch.randn(Nstore, K, generator=g) / math.sqrt(K)
+    bias, e0, e1 = torch.zeros(N), torch.ones(N), torch.zeros(N)
+    bias[:Nstore] = torch.randn(Nstore, generator=g) * 0.1
+    e0[:Nstore] = torch.rand(Nstore, generator=g) + 0.5
+    e1[:Nstore] = torch.randn(Nstore, generator=g) * 0.1
+    code = {"bias": _lib.EPI_BIAS, "leaky": _lib.EPI_BIAS_LEAKY, "sigmoid": _lib.EPI_BIAS_SIGMOID, "tdnn": _lib.EPI_TDNN,
+            "relu": 5, "relu_bn": 6, "relu_bn_tanh": 7}[epi]
+    dX, dW, db, de0, de1 = (t.contiguous().to(gpu) for t in (X, W, bias, e0, e1))
+    outs = {}
+    for which in ("new", "old"):
+        Y = torch.full((B, Tout, Nstore), float("nan"), device=gpu)
+        d = _lib.ConvGemmDesc()
+        d.X, d.W, d.bias, d.Y, d.e0, d.e1 = dX.data_ptr(), dW.data_ptr(), db.data_ptr(), Y.data_ptr(), de0.data_ptr(), de1.data_ptr()
+        d.B, d.Tin, d.Tout, d.Tstore, d.Cin, d.taps, d.dil = B, Tin, Tout, Tout, Cin, taps, dil
+        d.K, d.Kpad, d.Npad, d.Nstore, d.ldx, d.ldy = K, K, N, Nstore, Cin, Nstore
+        d.xbs, d.ybs, d.epi = Tin * Cin, Tout * Nstore, code
+        if Nstore % 4:          # 16-byte stores need ldy % 4 == 0: such a layer stays on the round-1 kernel
+            d.ldy = (Nstore + 3) // 4 * 4
+            Y = torch.full((B, Tout, d.ldy), float("nan"), device=gpu)
+            d.Y, d.ybs = Y.data_ptr(), Tout * d.ldy
+        if which == "new":
+            _lib.check(lib.dz_k_gemm_f32(_ctx(gpu), C.byref(d), None), "dz_k_gemm_f32")
+        else:
+            monkeypatch.setenv("DZ_F32_GEMM", "0")
+            _lib.check(lib.dz_k_convgemm(_ctx(gpu), C.byref(d), None), "dz_k_convgemm")
+            monkeypatch.delenv("DZ_F32_GEMM")
+        _sync()
+        outs[which] = Y[:, :, :Nstore].cpu()
+        if d.ldy > Nstore:
+            assert torch.isnan(Y[:, :, Nstore:]).all()           # nothing is written beyond the stored columns
+    ref = torch.zeros(B, Tout, Nstore, dtype=torch.float64)
+    Wd = W[:Nstore].double()
+    for tp in range(taps):
+        ref += X[:, tp * dil: tp * dil + Tout].double() @ Wd[:, tp * Cin:(tp + 1) * Cin].t()
+    ref += bias[:Nstore].double()
+    aff = lambda v: v * e0[:Nstore].double() + e1[:Nstore].double()
+    ref = {"bias": lambda v: v, "leaky": lambda v: F.leaky_relu(v, 0.01), "sigmoid": torch.sigmoid,
+           "tdnn": lambda v: aff(F.leaky_relu(v, 0.01)), "relu": torch.relu, "relu_bn": lambda v: aff(torch.relu(v)),
+           "relu_bn_tanh": lambda v: torch.tanh(aff(torch.relu(v)))}[epi](ref)
+    scale = max(1.0, ref.abs().max().item())
+    for which, Y in outs.items():
+        assert not torch.isnan(Y).any(), which
+        assert (Y.double() - ref).abs().max().item() < 2e-5 * scale, which
+    assert (outs["new"] - outs["old"]).abs().max().item() < 1e-5 * scale
+
+
 # --------------------------------------------------------------------------- #
 @pytest.mark.parametrize("kernel", ["valu", "mfma0", "mfma0_um", "mfma1", "mfma1_um", "mfma2", "mfma2_um", "mfma3_um"])
 @pytest.mark.parametrize("B,T", [(1, 293), (3, 40), (17, 64), (32, 293)])

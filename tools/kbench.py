@@ -80,7 +80,19 @@ def convgemm(name, Bn, Tin, Cin, N, taps, dil, epi, Npad=None, pro=False, pool=F
     d.ksplit, d.ysplit = ksplit, Bn * Tstore * Npad
     d.agroup = args.agroup
     flop = 2.0 * Bn * Tout * K * N
+    os.environ["DZ_F32_GEMM"] = "0"                       # the round-1 exact-f32 kernel (k_convgemm.hip)
     timeit(name, lambda: _lib.check(lib.dz_k_convgemm(ctx, C.byref(d), st), name), flop=flop)
+    del os.environ["DZ_F32_GEMM"]
+    if not pro and not pool and not ksplit and Npad % 128 == 0 and Cin % 32 == 0 and (not only or name in only or name + "_f32g2" in only):
+        # k_gemm_f32.hip: what dz_k_convgemm routes these layers to by default
+        y_old = Y.clone()
+        Y.zero_()
+        only_saved = set(only)
+        only.clear()
+        timeit(name + "_f32g2", lambda: _lib.check(lib.dz_k_gemm_f32(ctx, C.byref(d), st), name), flop=flop)
+        only.update(only_saved)
+        torch.cuda.synchronize()
+        results[name + "_f32g2"]["max_abs_vs_round1_kernel"] = float((Y - y_old).abs().max().item())
     if not ksplit and (Npad % 128 == 0 or pool) and (not only or name + "_split" in only or name in only):
         from diart_amd.weights import split_f16
         ws = split_f16(W.cpu()).to(dev)
@@ -188,6 +200,9 @@ convgemm("tdnn2", B, 289, 512, 512, 3, 2, _lib.EPI_TDNN)
 convgemm("tdnn3", B, 285, 512, 512, 3, 3, _lib.EPI_TDNN)
 convgemm("tdnn4", B, 279, 512, 512, 1, 1, _lib.EPI_TDNN)
 convgemm("tdnn5", B, 279, 512, 1500, 1, 1, _lib.EPI_TDNN, Npad=1536)
+# the pipeline runs tdnn2..5 FLATTENED over all B * P rows (api.hip emb_frames): the form the exact-f32 kernels see
+convgemm("tdnn2_flat", 1, B * 293, 512, 512, 3, 2, _lib.EPI_TDNN)
+convgemm("tdnn5_flat", 1, B * 293, 512, 1500, 1, 1, _lib.EPI_TDNN, Npad=1536)
 convgemm("emb_linear", 1, B * 3, 3008, 512, 1, 1, _lib.EPI_BIAS, ksplit=16)
 # ---- stats pooling ----------------------------------------------------------------------------
 x5 = torch.randn(B, 279, 1536, device=dev)
