@@ -821,6 +821,8 @@ def main():
     run(0, args.warmup)
     torch.cuda.synchronize()
     log("warm-up done")
+    period = {}                    # per timed pass: launch-to-launch period p50 / max, host launch time per step
+
     def timed_pass(p, label):
         """K timed steps of pipeline `p` (barrier + synchronize on both sides, max over ranks) with the
         per-kernel event pairs on every PROF_EVERY-th step -> (elapsed s, kernel table, sampled steps)."""
@@ -845,6 +847,7 @@ def main():
         lib.dz_prof_collect()
         tab = kernel_table(lib, p.seg.precision)   # read before dz_prof_enable(0) clears the accumulators
         lib.dz_prof_enable(0)
+        period[label] = dict(host["step_period_ms"], launch_ms_per_step=round(host["launch_ms_per_step"], 3))
         return el, tab, sampled[0]
 
     elapsed, table, n_sampled = timed_pass(pipe, f"timed region ({precision})")
@@ -867,6 +870,7 @@ def main():
                  "ms_per_step": round(1e3 * e32 / args.steps, 3), "dtype": "f32",
                  "note": "same job with precision='f32' (v_mfma_f32_16x16x4_f32 everywhere): the reference's own "
                          "arithmetic; per-kernel brackets and roofline collected exactly like the headline pass",
+                 "host_step_period_ms": period.get("exact-f32 pass"),
                  "_table": table32, "_sampled": n_sampled32}
 
     # ---- the same job fed from HOST buffers: every step uploads the 500 ms of new audio of each

@@ -11,14 +11,14 @@
 // as the MFMAs), its 96-row tile leaves 1.5 rounds of 772 tiles on 512 slots, and the fragment loop has no
 // software pipeline.  This kernel is k_gemm_pre.hip's loop with f32 data:
 //
-//   * tile 128 x 128 x 32, 4 waves (2 x 2), wave tile 64 x 64 = 2 x 2 fragments of v_mfma_f32_32x32x2_f32
-//     (64 cycles each; 64 per wave per k-tile = 4096 cycles between two barriers);
-//   * both operands are plain row-major f32 ([rows][Cin] activations, [Npad][Kpad] weights): a 32-wide k-tile
-//     of 8 rows is 8 x 128 contiguous bytes and goes global -> LDS by ONE LDS-DMA instruction per wave
+//   * tile 128 x 128 x 16, 4 waves (2 x 2), wave tile 64 x 64 = 2 x 2 fragments of v_mfma_f32_32x32x2_f32
+//     (64 cycles each; 32 per wave per k-tile = 2048 cycles between two barriers);
+//   * both operands are plain row-major f32 ([rows][Cin] activations, [Npad][Kpad] weights): a 16-wide k-tile
+//     of 16 rows is 16 x 64 contiguous bytes and goes global -> LDS by ONE LDS-DMA instruction per wave
 //     (buffer_load_dwordx4 ... lds, 16 B per lane, no VGPR staging, no ds_write, no VALU); rows beyond the
 //     operand read as zeros through the buffer bounds check (the row — tap shift included — is in the
 //     per-lane offset, which the check always covers; the scalar offset only moves inside a row);
-//   * LDS stage = A [128][128 B] | B [128][128 B]; the 16-byte chunk c of row r sits in slot c ^ ((r >> 1) & 7),
+//   * LDS stage = A [128][64 B] | B [128][64 B]; the 16-byte chunk c of row r sits in slot c ^ ((r >> 2) & 3),
 //     so the 16 lanes of a ds_read_b128 group (16 consecutive rows, one chunk) cover all 64 banks once; the
 //     LDS-DMA destination is lane-linear, so the swizzle is applied to the per-lane SOURCE chunk;
 //   * a lane's ds_read_b128 = 4 consecutive k of its row = the operand of 4 MFMAs: lane (row, h) of MFMA u of
@@ -26,8 +26,10 @@
 //     consistently; each product is still one exact f32 FMA into the f32 accumulator);
 //   * TRANSPOSED product (weights = the MFMA's row operand): a lane ends with one output row and, per
 //     register group, four consecutive columns: 16-byte stores;
-//   * two stages (64 KiB) -> two workgroups per CU; per k-tile a wave issues its 8 LDS-DMA pieces between the
-//     MFMAs of the tile before (one every 8 MFMAs) and re-reads fragments one sub-step ahead.
+//   * FOUR stages (64 KiB, two workgroups per CU), counted vmcnt: the 4 pieces a wave fetches of tile kt + 3 are
+//     issued between the MFMAs of tile kt (one every 8 MFMAs), so a piece has three k-tiles (~6 000 cycles) to land
+//     before the top-of-loop wait needs it.  (The first version had two 32-wide stages and fetched tile kt + 1
+//     during tile kt: its last pieces were ~500 cycles old at the wait — 96 - 103 TFLOP/s on the TDNN layers.)
 #include "dz_common.h"
 #include <stdlib.h>
 #include <type_traits>
@@ -36,10 +38,11 @@ namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int BM = 128, BN = 128, KT = 32;
-constexpr int OPER = 128 * KT * 4;          // bytes of one operand tile of a stage
+constexpr int BM = 128, BN = 128, KT = 16;
+constexpr int NST = 4;                      // LDS stages: the pieces of tile kt + 3 are issued while tile kt is computed
+constexpr int OPER = 128 * KT * 4;          // bytes of one operand tile of a stage (8 KiB)
 constexpr int STAGE = 2 * OPER;             // A | B
-constexpr size_t LDS_BYTES = 2 * (size_t)STAGE + 3 * BN * sizeof(float);
+constexpr size_t LDS_BYTES = NST * (size_t)STAGE + 3 * BN * sizeof(float);
 
 __device__ __forceinline__ float leaky(float v) { return v > 0.f ? v : v * DZ_LEAKY_SLOPE; }
 
@@ -53,24 +56,23 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(DzConvGemm p) {
     const int t0 = bx * BM, n0 = by * BN, b = bz;
 
     // ---- staging: waves 0, 1 fetch the activation tile, waves 2, 3 the weight tile; wave of rank r takes the
-    // 8-row pieces r, r + 2, ... (8 per k-tile).  Lane -> (row l >> 3 of the piece, LDS slot l & 7); the slot
-    // holds source chunk slot ^ ((row >> 1) & 7), and for piece r + 2 j that is (4 r + (l >> 4)) & 7.
+    // 16-row pieces r, r + 2, ... (4 per k-tile).  Lane -> (row l >> 2 of the piece, LDS slot l & 3); the slot
+    // holds source chunk slot ^ ((row >> 2) & 3) = slot ^ ((l >> 4) & 3) for every piece.
     const bool isB = w >= 2;
     const int rank = w & 1;
     const float* base = isB ? p.W : p.X + (long long)b * p.xbs;
     const int ld = isB ? p.Kpad : p.ldx;                         // floats per operand row
     const int nrows = isB ? p.Npad : p.Tin;
-    const __amdgpu_buffer_rsrc_t rsrc =
-        __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (unsigned)((long long)nrows * ld * 4), 0x00020000);
-    const int swz = (rank << 2) | ((l >> 4) & 3);
-    const int voff0 = (((isB ? n0 : t0) + 8 * rank + (l >> 3)) * ld + (((l & 7) ^ swz) << 2)) * 4;   // bytes
-    const int vstep = 16 * ld * 4;                               // pieces i and i + 2 are 16 rows apart
+    const unsigned nbytes = (unsigned)((long long)nrows * ld * 4);
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, nbytes, 0x00020000);
+    const int voff0 = (((isB ? n0 : t0) + 16 * rank + (l >> 2)) * ld + (((l & 3) ^ ((l >> 4) & 3)) << 2)) * 4;   // bytes
+    const int vstep = 32 * ld * 4;                               // pieces i and i + 2 are 32 rows apart
     const int tap_v = isB ? 0 : p.dil * ld * 4;                  // per-lane byte offset of one tap (activations)
     const int tap_s = isB ? p.Cin * 4 : 0;                       // scalar byte offset of one tap (weights' K axis)
     char* const dbase = smem + (isB ? OPER : 0) + rank * 1024;
 
     // ---- epilogue parameters -> LDS (visible behind the first barrier of the loop) ----------------------
-    float* par = reinterpret_cast<float*>(smem + 2 * STAGE);
+    float* par = reinterpret_cast<float*>(smem + NST * STAGE);
     {
         constexpr bool AFF = EPI == DZ_EPI_TDNN || EPI == DZ_EPI_RELU_BN || EPI == DZ_EPI_RELU_BN_TANH;
         const int which = tid >> 5, c4 = (tid & 31) * 4;
@@ -85,9 +87,9 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(DzConvGemm p) {
     // ---- MFMA coordinates ---------------------------------------------------------------------------------
     const int li = l & 31, g = l >> 5;
     const int wm = w >> 1, wn = w & 1;
-    int foff[4];                                  // this lane's chunk of sub-step s inside a 32-row block
+    int foff[2];                                  // this lane's chunk of sub-step s inside a 32-row block
 #pragma unroll
-    for (int s = 0; s < 4; ++s) foff[s] = li * 128 + (((2 * s + g) ^ ((li >> 1) & 7)) << 4);
+    for (int s = 0; s < 2; ++s) foff[s] = li * 64 + (((2 * s + g) ^ ((li >> 2) & 3)) << 4);
     f32x16 acc[2][2];
 #pragma unroll
     for (int xb = 0; xb < 2; ++xb)
@@ -96,63 +98,89 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(DzConvGemm p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[xb][nb][r] = 0.f;
 
-    // k-tile kt of the loop = (channel block kt / taps, tap kt % taps): the taps of one channel block follow each
-    // other (the three reads of almost the same activation lines stay in the L2, see k_gemm_pre.hip)
+    // k-tile kt of the loop = (channel half-block kt / taps, tap kt % taps): the taps of one 16-channel block follow
+    // each other (the reads of almost the same activation lines stay in the L2, see k_gemm_pre.hip)
     const int nk = p.Kpad / KT;
-    int cblk = 0, tap = 0;
-    int voff_t = voff0, soff_t = 0, stage_next = 0;      // of the tile being fetched
-    auto piece = [&](int j) {
+    int cblk = 0, tap = 0, fetched = 0;                   // (block, tap) and index of the NEXT tile to fetch
+    int stage_f = 0;                                      // its stage
+    // Tiles beyond the last one are "fetched" with an out-of-range offset (zeros into a stage nobody reads): the
+    // loop body has no branch around its LDS-DMA instructions and its vmcnt is the same in every iteration
+    auto fetch_piece = [&](int j) {
+        const int in = fetched < nk;
+        const int voff = in ? voff0 + tap * tap_v + j * vstep : 0x7f000000;
+        const int soff = __builtin_amdgcn_readfirstlane(cblk * (KT * 4) + tap * tap_s);
         __builtin_amdgcn_raw_ptr_buffer_load_lds(
-            rsrc, (__attribute__((address_space(3))) void*)(dbase + stage_next * STAGE + j * 2048), 16,
-            voff_t + j * vstep, soff_t, 0, 0);
+            rsrc, (__attribute__((address_space(3))) void*)(dbase + stage_f * STAGE + j * 2048), 16, voff, soff, 0, 0);
     };
-    auto advance = [&]() {
+    auto fetched_one = [&]() {
+        ++fetched;
+        stage_f = (stage_f + 1) & (NST - 1);
         if (++tap == p.taps) { tap = 0; ++cblk; }
-        voff_t = voff0 + tap * tap_v;
-        soff_t = __builtin_amdgcn_readfirstlane(cblk * (KT * 4) + tap * tap_s);
     };
 #pragma unroll
-    for (int j = 0; j < 8; ++j) piece(j);                 // tile 0 -> stage 0
+    for (int t = 0; t < NST - 1; ++t) {                   // tiles 0 .. 2 -> stages 0 .. 2
+#pragma unroll
+        for (int j = 0; j < 4; ++j) fetch_piece(j);
+        fetched_one();
+    }
 
-    const char* const sa0 = smem + (wm * 64) * 128;       // activation rows of this wave
-    const char* const sb0 = smem + OPER + (wn * 64) * 128;
-#define DZ_RD(base, blk, s) (*reinterpret_cast<const f32x4*>((base) + (blk) * 4096 + foff[s]))
+    const char* const sa0 = smem + (wm * 64) * 64;        // activation rows of this wave
+    const char* const sb0 = smem + OPER + (wn * 64) * 64;
+#define DZ_RD(base, blk, s) (*reinterpret_cast<const f32x4*>((base) + (blk) * 2048 + foff[s]))
 #define DZ_PIN() __builtin_amdgcn_sched_barrier(0)
-    auto body = [&](const int kt, auto more_c) {
-        constexpr bool more = decltype(more_c)::value;
-        // own pieces of tile kt have landed + every wave is done with the fragment reads of tile kt - 1
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        if (more) advance();
-        stage_next = (kt + 1) & 1;
-        const char* sa = sa0 + (kt & 1) * STAGE;
-        const char* sb = sb0 + (kt & 1) * STAGE;
-        f32x4 wf[2][2], xf[2][2];                          // [buffer][32-row block]
-        wf[0][0] = DZ_RD(sb, 0, 0); xf[0][0] = DZ_RD(sa, 0, 0);
-        wf[0][1] = DZ_RD(sb, 1, 0); xf[0][1] = DZ_RD(sa, 1, 0);
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            const int cur = s & 1, nxt = cur ^ 1;
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                DZ_PIN();
-                if (u == 1 && s < 3) {                     // fragments of sub-step s + 1, behind the first MFMAs of s
-                    wf[nxt][0] = DZ_RD(sb, 0, s + 1); xf[nxt][0] = DZ_RD(sa, 0, s + 1);
-                    wf[nxt][1] = DZ_RD(sb, 1, s + 1); xf[nxt][1] = DZ_RD(sa, 1, s + 1);
-                    DZ_PIN();
-                }
-                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[cur][0][u], xf[cur][0][u], acc[0][0], 0, 0, 0);
-                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[cur][1][u], xf[cur][0][u], acc[0][1], 0, 0, 0);
-                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[cur][1][u], xf[cur][1][u], acc[1][1], 0, 0, 0);
-                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[cur][0][u], xf[cur][1][u], acc[1][0], 0, 0, 0);
-                if (more && (u & 1)) {                     // one LDS-DMA piece every 8 MFMAs
-                    DZ_PIN();
-                    piece(2 * s + (u >> 1));
-                }
-            }
-        }
-    };
-    for (int kt = 0; kt + 1 < nk; ++kt) body(kt, std::true_type{});
-    body(nk - 1, std::false_type{});
+#define DZ_MM4(buf, u)                                                                                          \
+    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[buf][0][u], xf[buf][0][u], acc[0][0], 0, 0, 0);         \
+    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[buf][1][u], xf[buf][0][u], acc[0][1], 0, 0, 0);         \
+    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[buf][1][u], xf[buf][1][u], acc[1][1], 0, 0, 0);         \
+    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[buf][0][u], xf[buf][1][u], acc[1][0], 0, 0, 0)
+    // The loop is software-pipelined ACROSS the k-tile boundary: the barrier of tile kt + 1 and the first fragment
+    // reads behind it sit in front of the LAST EIGHT MFMAs of tile kt (whose operands are in registers), so the
+    // matrix pipe has 512 cycles of work while the barrier settles and the LDS answers.  With the barrier at the top
+    // of a tile the pipe was 74 % busy (SQ_VALU_MFMA_BUSY_CYCLES / GRBM_GUI_ACTIVE, tools/visits/gpu_r4w.sh): two
+    // workgroups per CU that started together stall together.
+    f32x4 wf[2][2], xf[2][2];                              // [buffer][32-row block]; buffer 0 = sub-step 0
+    // tile 0 has landed (8 younger pieces may be in flight)
+    asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    wf[0][0] = DZ_RD(sb0, 0, 0); xf[0][0] = DZ_RD(sa0, 0, 0);
+    wf[0][1] = DZ_RD(sb0, 1, 0); xf[0][1] = DZ_RD(sa0, 1, 0);
+    for (int kt = 0; kt < nk; ++kt) {
+        const char* sa = sa0 + (kt & (NST - 1)) * STAGE;
+        const char* sb = sb0 + (kt & (NST - 1)) * STAGE;
+        const char* san = sa0 + ((kt + 1) & (NST - 1)) * STAGE;
+        const char* sbn = sb0 + ((kt + 1) & (NST - 1)) * STAGE;
+        DZ_PIN();
+        DZ_MM4(0, 0);
+        DZ_PIN();
+        wf[1][0] = DZ_RD(sb, 0, 1); xf[1][0] = DZ_RD(sa, 0, 1);     // sub-step 1 of this tile
+        wf[1][1] = DZ_RD(sb, 1, 1); xf[1][1] = DZ_RD(sa, 1, 1);
+        DZ_PIN();
+        DZ_MM4(0, 1);
+        DZ_PIN();
+        fetch_piece(0);                                    // tile kt + 3 -> the stage tile kt - 1 was read from
+        DZ_PIN();
+        DZ_MM4(0, 2);
+        DZ_MM4(0, 3);
+        DZ_PIN();
+        fetch_piece(1);
+        DZ_PIN();
+        DZ_MM4(1, 0);
+        DZ_MM4(1, 1);
+        DZ_PIN();
+        fetch_piece(2);
+        DZ_PIN();
+        // every fragment read of tile kt is complete (lgkmcnt) in every wave (barrier), and this wave's pieces of tile
+        // kt + 1 have landed: younger than those are the 4 of tile kt + 2 and the 3 of tile kt + 3 issued above
+        asm volatile("s_waitcnt vmcnt(7) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        wf[0][0] = DZ_RD(sbn, 0, 0); xf[0][0] = DZ_RD(san, 0, 0);   // sub-step 0 of tile kt + 1 (after the last tile: unused)
+        wf[0][1] = DZ_RD(sbn, 1, 0); xf[0][1] = DZ_RD(san, 1, 0);
+        DZ_PIN();
+        DZ_MM4(1, 2);
+        DZ_MM4(1, 3);
+        DZ_PIN();
+        fetch_piece(3);
+        fetched_one();
+    }
+#undef DZ_MM4
 #undef DZ_RD
 #undef DZ_PIN
 
@@ -218,7 +246,7 @@ bool dz_gemm_f32_ok(const DzConvGemm& p) {
     const char* e = getenv("DZ_F32_GEMM");                // (read per launch: the tests switch it in-process)
     const bool on = !(e && e[0] == '0');
     return on && p.X && p.W && p.Y && !p.Ysplit && !p.norm_on_load && p.pad == 0 && !p.X2 && !p.rowbias &&
-           p.ksplit <= 1 && !p.partials && p.Npad % BN == 0 && p.K == p.Kpad && p.Cin % KT == 0 && p.K == p.taps * p.Cin &&
+           p.ksplit <= 1 && !p.partials && p.Npad % BN == 0 && p.K == p.Kpad && p.Cin % KT == 0 && p.Kpad >= KT && p.K == p.taps * p.Cin &&
            p.ldx % 4 == 0 && p.ldy % 4 == 0 && p.Tout > 0 && p.Tout == p.Tin - (p.taps - 1) * p.dil &&
            p.epi != DZ_EPI_POOL3 && (long long)p.Tin * p.ldx * 4 < (1ll << 31) && (long long)p.Npad * p.Kpad * 4 < (1ll << 31);
 }
