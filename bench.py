@@ -174,6 +174,15 @@ def log(msg):
     print(f"[bench +{time.monotonic() - _T0:7.1f}s] {msg}", file=sys.stderr, flush=True)
 
 
+def emit(full, details_path):
+    """Full record -> side file + stderr; ONE compact line (<= 4000 characters) -> stdout, nothing after it."""
+    from diart_amd import benchline
+    where = benchline.write_details(full, details_path) if details_path else None
+    print("[bench details] " + json.dumps(full), file=sys.stderr, flush=True)
+    sys.stdout.write(benchline.line(full, where) + "\n")
+    sys.stdout.flush()
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -199,6 +208,9 @@ def parse():
                     help="BASELINE.json configs index + 1: 2 = 64 streams, pyannote/segmentation + pyannote/embedding "
                          "(the metric's config, default); 3 = segmentation-3.0 (powerset) + ECAPA-TDNN through the "
                          "blocks pipeline, batches of 32 consecutive windows")
+    ap.add_argument("--details", type=str, default=os.environ.get("DZ_BENCH_DETAILS", "gpurun_out/bench_details.json"),
+                    help="side file for the full record (per-kernel tables, exact-f32 tables, rehearsal, notes); "
+                         "stdout carries ONE compact JSON line (diart_amd/benchline.py)")
     ap.add_argument("--no-exact-f32", action="store_true",
                     help="skip the second, untimed-for-`value` pass on the exact-f32 MFMA path")
     return ap.parse_args()
@@ -655,7 +667,7 @@ def config3(args):
         "roofline_kernels": groups,
         "cpu_baseline": None,
     }
-    print(json.dumps(out), flush=True)
+    emit(out, args.details)
 
 
 def main():
@@ -694,6 +706,11 @@ def main():
     # DZ_DIST_BACKEND=gloo); the driver's real runs use one GPU per rank over RCCL
     device = torch.device("cuda", int(os.environ.get("DZ_FORCE_DEVICE", local)))
     torch.cuda.set_device(device)
+    from diart_amd.hostinfo import bind_rank
+    affinity = bind_rank(local, int(os.environ.get("LOCAL_WORLD_SIZE", world)),
+                         int(os.environ["DZ_FORCE_DEVICE"]) if "DZ_FORCE_DEVICE" in os.environ else None)
+    if world > 1:
+        log(f"rank {rank}: cpu affinity {affinity}")
     lib = _lib.load()
 
     # ---- weights: synthesised on rank 0, broadcast over RCCL ---------------------------
@@ -954,6 +971,8 @@ def main():
                                    "(random-init weights), %d concurrent synthetic 16 kHz streams per GPU" % n,
                        "streams_per_gpu": n, "chunks_per_step": world * n, "parallelism": f"streams x{world}",
                        "dist_backend": torch.distributed.get_backend() if world > 1 else None,
+                       "rccl_ranks": (torch.distributed.get_world_size() if world > 1 and torch.distributed.get_backend() == "nccl"
+                                      else 0), "cpu_affinity": affinity,
                        "weights_abs_sum_per_rank": wsums, "host_threads_per_rank": host_threads,
                        "steps_in_flight": pipe.max_inflight, "lanes": pipe.depth, "seg_sub_batches": pipe.seg_split,
                        "hip_streams": pipe.num_hip_streams,
@@ -973,11 +992,10 @@ def main():
             Path(args.kernel_table).parent.mkdir(parents=True, exist_ok=True)
             Path(args.kernel_table).write_text(json.dumps(table, indent=1))
         if not args.no_cpu_baseline and world == 1:
-            print(json.dumps(dict(out, cpu_baseline="pending")), file=sys.stderr, flush=True)
             out["cpu_baseline"] = cpu_baseline(args.cpu_chunks)
         elif not args.no_cpu_baseline:
             out["cpu_baseline"] = None
-        print(json.dumps(out), flush=True)
+        emit(out, args.details)
     if world > 1:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
