@@ -7,10 +7,14 @@ symbol is exported); creating a context does.
 from __future__ import annotations
 
 import ctypes as C
+import os
 from pathlib import Path
 from typing import Optional
 
-_LIB_PATH = Path(__file__).resolve().parent / "libdiart_amd.so"
+# DZ_EXPERIMENTS=1 loads the experiments build (`python -m diart_amd.build --experiments`: the never-default
+# kernel generations and the DZ_* switches that select them, include/diart_amd_experiments.h)
+EXPERIMENTS = os.environ.get("DZ_EXPERIMENTS", "0") not in ("", "0")
+_LIB_PATH = Path(__file__).resolve().parent / ("libdiart_amd_exp.so" if EXPERIMENTS else "libdiart_amd.so")
 _lib: Optional[C.CDLL] = None
 
 c_float_p = C.POINTER(C.c_float)
@@ -57,6 +61,10 @@ class EcapaWeights(C.Structure):
 SIGNATURES = {
     "dz_last_error": (C.c_char_p, []),
     "dz_version": (C.c_int, []),
+    "dz_set_option": (C.c_int, [C.c_char_p, C.c_int]),
+    "dz_get_option": (C.c_int, [C.c_char_p, c_int_p]),
+    "dz_has_experiments": (C.c_int, []),
+    "dz_host_pool_set_spin": (C.c_int, [C.c_int]),
     "dz_abi_struct_sizes": (C.c_int, [C.POINTER(C.c_int * 5)]),
     "dz_ctx_create": (C.c_int, [C.c_int, C.POINTER(vp)]),
     "dz_ctx_destroy": (C.c_int, [vp]),
@@ -130,15 +138,12 @@ SIGNATURES = {
     "dz_k_gemm_f32": (C.c_int, [vp, vp, vp]),
     "dz_k_gemm_split": (C.c_int, [vp, vp, vp]),
     "dz_k_gemm_pre": (C.c_int, [vp, vp, vp]),
-    "dz_k_gemm_g2": (C.c_int, [vp, vp, C.c_int, vp]),
-    "dz_k_gemm_g3": (C.c_int, [vp, vp, C.c_int, vp]),
     "dz_k_mlp_head": (C.c_int, [vp, vp, C.c_longlong, vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int,
                                 C.c_int, C.c_float, C.c_float, vp, vp, vp]),
     "dz_k_seg_head": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_float,
                                 C.c_float, C.c_int, vp, vp]),
     "dz_k_conv_pool": (C.c_int, [vp, vp, vp]),
     "dz_k_convgemm_ntile": (C.c_int, [C.c_int]),
-    "dz_k_conv_pool_debug": (C.c_int, [vp]),
     "dz_k_wave_stats": (C.c_int, [vp, vp, C.c_longlong, C.c_int, C.c_int, vp, vp]),
     "dz_k_sinc_conv0": (C.c_int, [vp, vp, C.c_longlong, C.c_int, C.c_int, vp, C.c_float,
                                   C.c_float, vp, vp, vp, vp]),
@@ -152,6 +157,14 @@ SIGNATURES = {
     "dz_k_stats_pool": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, vp, C.c_int, C.c_int,
                                   C.c_int, vp, C.c_int, vp]),
     "dz_k_powerset": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, vp, vp]),
+}
+
+
+# include/diart_amd_experiments.h: bound only when the loaded library is the experiments build
+EXPERIMENT_SIGNATURES = {
+    "dz_k_gemm_g2": (C.c_int, [vp, vp, C.c_int, vp]),
+    "dz_k_gemm_g3": (C.c_int, [vp, vp, C.c_int, vp]),
+    "dz_k_conv_pool_debug": (C.c_int, [vp]),
 }
 
 
@@ -191,6 +204,13 @@ def load() -> C.CDLL:
             fn = getattr(lib, name)  # AttributeError if a declared symbol is missing
             fn.restype = res
             fn.argtypes = args
+        if lib.dz_has_experiments():
+            for name, (res, args) in EXPERIMENT_SIGNATURES.items():
+                fn = getattr(lib, name)
+                fn.restype = res
+                fn.argtypes = args
+        elif EXPERIMENTS:
+            raise DiartAmdError(f"DZ_EXPERIMENTS=1 but {_LIB_PATH} is not an experiments build")
         sizes = (C.c_int * 5)()
         lib.dz_abi_struct_sizes(C.byref(sizes))
         mine = [C.sizeof(t) for t in (SincNetWeights, SegWeights, EmbWeights, EcapaWeights, ConvGemmDesc)]
@@ -199,6 +219,26 @@ def load() -> C.CDLL:
                                 f"{list(sizes)} (library) vs {mine} (this binding); rebuild it")
         _lib = lib
     return _lib
+
+
+def experiments() -> bool:
+    """Is the loaded library the experiments build?  (The shipped one ignores every kernel-selection switch.)"""
+    return bool(load().dz_has_experiments())
+
+
+def exp_env(name: str, default: str) -> str:
+    """A DZ_* switch that only the experiments build honours: `default` in the shipped configuration."""
+    return os.environ.get(name, default) if EXPERIMENTS else default
+
+
+def set_option(name: str, value: int) -> None:
+    check(load().dz_set_option(name.encode(), int(value)), "dz_set_option")
+
+
+def get_option(name: str) -> int:
+    v = C.c_int()
+    check(load().dz_get_option(name.encode(), C.byref(v)), "dz_get_option")
+    return v.value
 
 
 def check(rc: int, what: str = "") -> None:

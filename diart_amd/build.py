@@ -15,8 +15,12 @@ from pathlib import Path
 HERE = Path(__file__).resolve().parent
 CSRC = HERE / "csrc"
 LIB = HERE / "libdiart_amd.so"
-SOURCES = ["api.hip", "ecapa_api.hip", "k_front.hip", "k_convgemm.hip", "k_gemm_f32.hip", "k_gemm_split.hip", "k_gemm_pre.hip", "k_gemm_g2.hip", "k_gemm_g3.hip", "k_mlp_head.hip", "k_conv_pool.hip", "k_lstm.hip", "k_lstm_mfma.hip", "k_pool.hip",
+LIB_EXPERIMENTS = HERE / "libdiart_amd_exp.so"
+SOURCES = ["api.hip", "ecapa_api.hip", "k_front.hip", "k_convgemm.hip", "k_gemm_f32.hip", "k_gemm_split.hip", "k_gemm_pre.hip",
+           "k_mlp_head.hip", "k_conv_pool.hip", "k_lstm.hip", "k_lstm_mfma.hip", "k_pool.hip",
            "k_ecapa.hip", "ring.hip", "cluster.cpp", "tail.cpp", "hostpool.cpp", "filebatch.cpp"]
+# -DDZ_EXPERIMENTS only (csrc/dz_common.h "build flavours"): the never-default GEMM generations
+EXPERIMENT_SOURCES = ["experiments/k_gemm_g2.hip", "experiments/k_gemm_g3.hip"]
 ARCH = "gfx950"
 
 
@@ -34,12 +38,19 @@ def _stale(out: Path, deps) -> bool:
     return any(Path(d).stat().st_mtime > t for d in deps)
 
 
-def build(force: bool = False, verbose: bool = False) -> Path:
+def build(force: bool = False, verbose: bool = False, experiments: bool = False) -> Path:
+    """experiments=False: the shipped library (one configuration per layer, no kernel-selection switches).
+    experiments=True: libdiart_amd_exp.so with -DDZ_EXPERIMENTS (measurement builds; DZ_EXPERIMENTS=1 loads it)."""
     hipcc = _hipcc()
-    objdir = HERE / "build"
-    objdir.mkdir(exist_ok=True)
-    headers = [CSRC / "dz_common.h", CSRC / "hostpool.h", HERE.parent / "include" / "diart_amd.h"]
-    flags = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function"]
+    objdir = HERE / "build" / ("exp" if experiments else "ship")
+    objdir.mkdir(parents=True, exist_ok=True)
+    headers = [CSRC / "dz_common.h", CSRC / "hostpool.h", HERE.parent / "include" / "diart_amd.h",
+               HERE.parent / "include" / "diart_amd_experiments.h"]
+    flags = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function", f"-I{CSRC}"]
+    sources, lib = list(SOURCES), LIB
+    if experiments:
+        flags.append("-DDZ_EXPERIMENTS")
+        sources, lib = sources + EXPERIMENT_SOURCES, LIB_EXPERIMENTS
 
     def compile_one(src: str) -> Path:
         s = CSRC / src
@@ -53,15 +64,15 @@ def build(force: bool = False, verbose: bool = False) -> Path:
                 print(r.stderr, file=sys.stderr)
         return o
 
-    with ThreadPoolExecutor(max_workers=len(SOURCES)) as ex:
-        objs = list(ex.map(compile_one, SOURCES))
-    if force or _stale(LIB, objs):
-        cmd = [hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", *map(str, objs), "-o", str(LIB), "-lpthread"]
+    with ThreadPoolExecutor(max_workers=min(len(sources), os.cpu_count() or 4)) as ex:
+        objs = list(ex.map(compile_one, sources))
+    if force or _stale(lib, objs):
+        cmd = [hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", *map(str, objs), "-o", str(lib), "-lpthread"]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"link failed:\n{r.stderr}")
-    return LIB
+    return lib
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    print(build(force="--force" in sys.argv, verbose=True, experiments="--experiments" in sys.argv))

@@ -93,9 +93,14 @@ def _element_size(dtype: torch.dtype) -> int:
     return torch.empty((), dtype=dtype).element_size()
 
 
+class UnknownStorage(Stub):
+    """A tensor whose storage class is outside ``_STORAGE_DTYPES`` (UntypedStorage, quantised, ...): kept as a
+    marker so that ``read_state`` can name the entry instead of dropping it silently."""
+
+
 def _rebuild_tensor(storage, storage_offset, size, stride, *unused):
     if not isinstance(storage, _Storage):
-        return Stub()
+        return UnknownStorage()
     size, stride = tuple(int(s) for s in size), tuple(int(s) for s in stride)
     if len(storage.buf) == 0 or any(s == 0 for s in size):
         return torch.empty(size, dtype=storage.dtype)
@@ -263,9 +268,16 @@ def read_state(path: Union[str, Path]) -> Dict[str, torch.Tensor]:
                              f"found {type(obj).__name__}")
         state = {str(k): v for k, v in obj.items() if isinstance(v, torch.Tensor)}
         dropped = [str(k) for k, v in obj.items() if not isinstance(v, torch.Tensor)]
+        unknown = [str(k) for k, v in obj.items() if isinstance(v, UnknownStorage)]
+        if unknown:
+            raise ValueError(f"{path}: tensor(s) {unknown[:5]} use a storage class this reader does not know "
+                             f"(known: {sorted(_STORAGE_DTYPES)}); re-save the checkpoint as safetensors")
         if not state:
             raise ValueError(f"{path}: no tensors in the state dict (entries: {dropped[:5]} ...)")
-    if state and all(k.startswith("model.") for k in state):
-        state = {k[len("model."):]: v for k, v in state.items()}
+    # a Lightning module keeps its network under `model.`: strip the prefix PER KEY (one extra top-level entry —
+    # a loss weight, a metric buffer — must not keep the prefix on all the others), unless that would collide
+    stripped = {(k[len("model."):] if k.startswith("model.") else k): v for k, v in state.items()}
+    if len(stripped) == len(state) and any(k.startswith("model.") for k in state):
+        state = stripped
     # own the memory (frombuffer views keep whole storages alive) and drop aliasing between entries
     return {k: v.clone() for k, v in state.items()}

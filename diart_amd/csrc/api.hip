@@ -81,12 +81,14 @@ extern "C" int dz_range_check(dz_ctx* ctx, int reset) {
                      "the result differs from an f32 reference; use precision=\"f32\" for such inputs");
         return 6;
     }
+#ifdef DZ_EXPERIMENTS
     DZ_HIP(hipSetDevice(ctx->device));
     if (dz_g3_error(reset)) {
         dz_set_error("k_gemm_g3.hip: a workgroup gave up waiting for the partial sums of a neighbour (the results of "
                      "that launch are wrong); DZ_GEMM_GEN=1 selects the non-persistent kernel");
         return 7;
     }
+#endif
     return 0;
 }
 
@@ -231,19 +233,47 @@ extern "C" int dz_emb_frames_for(int num_samples) {
     return f > 0 ? f : 0;
 }
 
+// ---- run-time options (dz_common.h) ----------------------------------------------------------------
+static int g_options[DZ_OPT_COUNT] = {1, 1};
+static const char* const kOptionNames[DZ_OPT_COUNT] = {"f32_gemm", "pool_fuse"};
+int dz_option(int id) { return id >= 0 && id < DZ_OPT_COUNT ? __atomic_load_n(&g_options[id], __ATOMIC_RELAXED) : 0; }
+static int option_index(const char* name) {
+    for (int i = 0; name && i < DZ_OPT_COUNT; ++i)
+        if (strcmp(name, kOptionNames[i]) == 0) return i;
+    return -1;
+}
+extern "C" int dz_set_option(const char* name, int value) {
+    const int i = option_index(name);
+    DZ_REQUIRE(i >= 0, "dz_set_option: unknown option '%s' (f32_gemm, pool_fuse)", name ? name : "(null)");
+    __atomic_store_n(&g_options[i], value, __ATOMIC_RELAXED);
+    return 0;
+}
+extern "C" int dz_get_option(const char* name, int* value) {
+    const int i = option_index(name);
+    DZ_REQUIRE(i >= 0 && value, "dz_get_option: unknown option '%s' (f32_gemm, pool_fuse)", name ? name : "(null)");
+    *value = dz_option(i);
+    return 0;
+}
+extern "C" int dz_has_experiments(void) {
+#ifdef DZ_EXPERIMENTS
+    return 1;
+#else
+    return 0;
+#endif
+}
+
 // DZ_FUSED_NORM=0 keeps the three finalize_norm launches of a SincNet; by default (split-f16 path)
 // every consumer derives its InstanceNorm scale / shift from the producer's tile partials itself
 static bool fused_norm_enabled() {
-    const char* v = getenv("DZ_FUSED_NORM");
+    const char* v = dz_exp_env("DZ_FUSED_NORM");
     return !(v && v[0] == '0');
 }
 // DZ_POOL_FUSE=0: tdnn5 writes its f32 output and stats_pool reads it back (the round-2 path)
 static bool pool_fuse_enabled() {
-    const char* v = getenv("DZ_POOL_FUSE");
-    return !(v && v[0] == '0');
+    return dz_option(DZ_OPT_POOL_FUSE) != 0;
 }
 static bool conv_pool_enabled() {
-    const char* v = getenv("DZ_CONV_POOL");
+    const char* v = dz_exp_env("DZ_CONV_POOL");
     return !(v && v[0] == '0');
 }
 
@@ -442,7 +472,7 @@ static int seg_forward(dz_seg* s, const float* d_wave, long long wave_stride, in
                        float* d_osp, float gamma, float beta, int normalize, void* stream, int phase = 0);
 static bool mlp_head_enabled() {
     static const bool on = [] {
-        const char* e = getenv("DZ_MLP_HEAD");
+        const char* e = dz_exp_env("DZ_MLP_HEAD");
         return !(e && e[0] == '0');
     }();
     return on;
@@ -925,6 +955,7 @@ extern "C" int dz_k_gemm_pre(dz_ctx* ctx, const dz_convgemm_desc* d, void* strea
     DzRangeScope range_scope(ctx->oflag_dev);
     return dz_launch_gemm_pre(*d, (hipStream_t)stream);
 }
+#ifdef DZ_EXPERIMENTS
 extern "C" int dz_k_gemm_g2(dz_ctx* ctx, const dz_convgemm_desc* d, int row_fragments, void* stream) {
     DZ_REQUIRE(ctx && d, "dz_k_gemm_g2: NULL argument");
     DZ_REQUIRE(d->Wsplit && d->Xsplit && (d->Y || d->Ysplit) && d->B == 1 && d->K == d->Kpad && d->K == d->taps * d->Cin &&
@@ -951,6 +982,7 @@ extern "C" int dz_k_gemm_g3(dz_ctx* ctx, const dz_convgemm_desc* d, int row_frag
     if (!p.oflag) p.oflag = ctx->oflag_dev;
     return dz_launch_gemm_g3(p, row_fragments, (hipStream_t)stream);
 }
+#endif  // DZ_EXPERIMENTS
 extern "C" int dz_k_mlp_head(dz_ctx* ctx, const void* xsplit, long long xplane, const void* w0split,
                              const void* w1split, const float* b0, const float* b1, const float* cw,
                              const float* cb, int rows, int frames, int classes, int speakers, int powerset,
@@ -979,11 +1011,13 @@ extern "C" int dz_k_conv_pool(dz_ctx* ctx, const dz_convgemm_desc* d, void* stre
     DzRangeScope range_scope(ctx->oflag_dev);
     return dz_launch_conv_pool(*d, (hipStream_t)stream);
 }
+#ifdef DZ_EXPERIMENTS
 // phase time stamps of conv_pool_h (tools/kbench.py): 2 x 64 shader-clock stamps per workgroup
 extern "C" int dz_k_conv_pool_debug(long long* d_stamps) {
     dz_conv_pool_dbg = d_stamps;
     return 0;
 }
+#endif
 extern "C" int dz_k_convgemm_ntile(int t_out) { return dz_convgemm_ntile(t_out); }
 extern "C" int dz_k_wave_stats(dz_ctx* ctx, const float* d_wave, long long stride, int batch,
                                int samples, float* d_stats, void* stream) {

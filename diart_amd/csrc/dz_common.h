@@ -7,6 +7,26 @@
 #include <mutex>
 #include "../../include/diart_amd.h"
 
+// ---- build flavours ---------------------------------------------------------------------------------
+// The shipped library has ONE configuration of every layer.  Kernels and switches that only exist to measure
+// alternatives — k_gemm_g2.hip / k_gemm_g3.hip, the two-chunk and plain-FMA recurrences, lstm_mfma variants
+// 1 / 2, the old multi-launch paths, and the timing-only instantiations whose RESULTS ARE WRONG — are compiled
+// only with -DDZ_EXPERIMENTS (`python -m diart_amd.build --experiments` -> libdiart_amd_exp.so, loaded with
+// DZ_EXPERIMENTS=1), where DZ_* environment variables select them through dz_exp_env().  In the shipped
+// build dz_exp_env() is a null constant: the branches fold away and the variables are never read.
+#ifdef DZ_EXPERIMENTS
+#include <stdlib.h>
+static inline const char* dz_exp_env(const char* name) { return getenv(name); }
+#else
+#define dz_exp_env(name) ((const char*)nullptr)
+#endif
+// Run-time options of the shipped library (api.hip: dz_set_option / dz_get_option, by name).
+//   f32_gemm  (1): exact-f32 wide layers on k_gemm_f32.hip; 0 keeps them on k_convgemm.hip (the kernel the
+//                  prologue layers use anyway; tests compare the two)
+//   pool_fuse (1): statistics pooling inside tdnn5's epilogue; 0 = tdnn5 + stats_pool (the exact-f32 form)
+enum { DZ_OPT_F32_GEMM = 0, DZ_OPT_POOL_FUSE, DZ_OPT_COUNT };
+int dz_option(int id);
+
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
@@ -235,7 +255,9 @@ void dz_set_error(const char* fmt, ...);
 // wave statistics in two steps: slice moments, then (mean, rstd) merged by the consumer
 #define DZ_WS_G 8   /* slices per chunk in wave_stats */
 // slice moments of the raw waveform -> mom[B][DZ_WS_G][2] (mean_i, M2_i)
+#ifdef DZ_EXPERIMENTS
 extern long long* dz_conv_pool_dbg;
+#endif
 int dz_launch_wave_stats(const float* wave, long long stride, int B, int S, float* mom,
                          hipStream_t st);
 // slice moments -> stats[B][2] = (mean, rstd)
@@ -272,13 +294,17 @@ int dz_launch_conv_pool(const DzConvGemm& p, hipStream_t st);
 int dz_launch_gemm_pre(const DzConvGemm& p, hipStream_t st);
 // k_gemm_g2.hip: generation 2 of the same layer (single accumulator, three LDS stages, counted vmcnt);
 // mt = row fragments per wave (2, 3, 4 -> 128 / 192 / 256 x 128 tiles), 0 = DZ_G2_MT / default
+#ifdef DZ_EXPERIMENTS
 int dz_launch_gemm_g2(const DzConvGemm& p, int mt, hipStream_t st);
 int dz_g2_default_mt();
-int dz_gemm_gen();
+#endif
+int dz_gemm_gen();       // 1 in the shipped build
 // k_gemm_g3.hip: generation 2's loop as a persistent kernel over a balanced (Stream-K) split of the iteration
 // space, one workgroup per CU; mt as above (0 = DZ_G3_MT / default 4).  dz_g3_error: a wait timed out.
+#ifdef DZ_EXPERIMENTS
 int dz_launch_gemm_g3(const DzConvGemm& p, int mt, hipStream_t st);
 int dz_g3_error(int reset);
+#endif
 // The same launch with the weighted statistics pooling (paper Eq. 1) fused into the epilogue of the LAST
 // x-vector layer (tdnn5): the 128 x 128 output tile is parked in LDS instead of HBM and reduced there
 // to per-(tile, chunk, speaker, channel) weighted means and centred second moments — exact two-pass

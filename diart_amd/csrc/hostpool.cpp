@@ -14,17 +14,11 @@ namespace {
 
 constexpr int MAX_WORKERS = 63;
 // A worker polls this long for the next job before it sleeps: the two stages of one step arrive back to back, the
-// next step ~1 ms later.  DZ_POOL_SPIN_US overrides (0 = sleep at once): with 8 ranks on a node's 16 usable cores a
+// next step ~1 ms later.  dz_host_pool_set_spin() overrides (0 = sleep at once): with 8 ranks on a node's 16 usable cores a
 // rank has two cores for its launching thread and its pool, and a spinning worker takes one of them from the thread
-// that feeds the GPU (bench.py's host rehearsal sets it from the cores a rank really has).
-int spin_us() {
-    static const int us = [] {
-        const char* e = getenv("DZ_POOL_SPIN_US");
-        const int v = e ? atoi(e) : 40;
-        return v < 0 ? 0 : v;
-    }();
-    return us;
-}
+// that feeds the GPU (StreamBatch sets it from the cores a rank really has).
+std::atomic<int> g_spin_us{40};
+int spin_us() { return g_spin_us.load(std::memory_order_relaxed); }
 
 struct Pool {
     std::mutex callers;                       // one parallel-for at a time
@@ -121,4 +115,9 @@ void dz_host_parallel(int n, int threads, const std::function<void(int, int)>& f
             std::this_thread::yield();
     }
     p->fn = nullptr;
+}
+
+extern "C" int dz_host_pool_set_spin(int microseconds) {
+    g_spin_us.store(microseconds < 0 ? 0 : microseconds, std::memory_order_relaxed);
+    return 0;
 }

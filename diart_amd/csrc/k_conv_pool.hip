@@ -59,7 +59,11 @@ __global__ __launch_bounds__(256, 2) void conv_pool_h_kernel(
     if (dbg && (threadIdx.x & 63) == 0 && ((threadIdx.x >> 6) == 0 || (threadIdx.x >> 6) == 3))
         dq = dbg + ((long long)blockIdx.x * 2 + (threadIdx.x >> 7)) * 64;
     int dn = 0;
+#ifdef DZ_EXPERIMENTS       // phase stamps for tools/conv_pool_phases.py: experiments build only
 #define DZ_STAMP() do { if (dq && dn < 64) dq[dn++] = __builtin_readcyclecounter(); } while (0)
+#else
+#define DZ_STAMP() do { } while (0)
+#endif
     extern __shared__ __attribute__((aligned(256))) char lds[];
     char* xs = lds;                                                  // [2 planes][ROWS][PITCH]
     float* xch = reinterpret_cast<float*>(lds + 2 * G::PLANE);       // [2][3][16][64]
@@ -235,7 +239,11 @@ __global__ __launch_bounds__(256, 2) void conv_pool_h_kernel(
 }
 
 }  // namespace
+#ifdef DZ_EXPERIMENTS
 long long* dz_conv_pool_dbg = nullptr;      // set by dz_k_conv_pool_debug (phase stamps, kbench only)
+#else
+static long long* const dz_conv_pool_dbg = nullptr;
+#endif
 namespace {
 
 template <int CIN>

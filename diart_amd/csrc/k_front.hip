@@ -497,13 +497,13 @@ int dz_launch_sinc_conv0_split(const float* wave, long long stride, int B, int S
                                float* y0, int P0, float* partials, int ntile, hipStream_t st) {
     const int total = ntile * B;
     const int grid = total < 512 ? total : 512;    // two resident workgroups per CU
-    const char* e_dbg = getenv("DZ_CONV0_DBG");
-    const int dbg = e_dbg ? atoi(e_dbg) : 0;
 #define DZ_C0(D)                                                                                          \
     DZ_LAUNCH(sinc_conv0_h_kernel<D>, dim3(grid), dim3(192), 0, st, wave, stride, S, stats,                \
               stats_are_moments, gamma, beta, reinterpret_cast<const unsigned short*>(fsp), y0, P0,        \
               partials, ntile, total, dz_cur_oflag)
-    switch (dbg) {
+#ifdef DZ_EXPERIMENTS
+    const char* e_dbg = dz_exp_env("DZ_CONV0_DBG");     // timing-only instantiations: results are wrong
+    switch (e_dbg ? atoi(e_dbg) : 0) {
         case 1: DZ_C0(1); break;
         case 2: DZ_C0(2); break;
         case 4: DZ_C0(4); break;
@@ -514,6 +514,9 @@ int dz_launch_sinc_conv0_split(const float* wave, long long stride, int B, int S
         case 6: DZ_C0(6); break;
         default: DZ_C0(0); break;
     }
+#else
+    DZ_C0(0);
+#endif
 #undef DZ_C0
     DZ_HIP(hipGetLastError());
     return 0;

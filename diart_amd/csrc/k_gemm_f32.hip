@@ -243,12 +243,18 @@ int launch(const DzConvGemm& p, hipStream_t st) {
 // Layers this kernel serves: f32 operands without a prologue, K = taps * Cin with Cin a multiple of 32 (no K
 // padding), full 128-column tiles, f32 output.  DZ_F32_GEMM=0 keeps every layer on k_convgemm.hip.
 bool dz_gemm_f32_ok(const DzConvGemm& p) {
-    const char* e = getenv("DZ_F32_GEMM");                // (read per launch: the tests switch it in-process)
-    const bool on = !(e && e[0] == '0');
-    return on && p.X && p.W && p.Y && !p.Ysplit && !p.norm_on_load && p.pad == 0 && !p.X2 && !p.rowbias &&
+    const bool on = dz_option(DZ_OPT_F32_GEMM) != 0;      // (read per launch: the tests switch it in-process)
+    // 16-byte vector loads / stores: every base the kernel touches, and the per-batch strides, must keep that alignment
+    const auto al16 = [](const void* q) { return ((uintptr_t)q & 15) == 0; };
+    const bool aligned = al16(p.X) && al16(p.W) && al16(p.Y) && al16(p.bias) && al16(p.e0) && al16(p.e1) &&
+                         p.xbs % 4 == 0 && p.ybs % 4 == 0;
+    // the buffer descriptor of a batch spans Tin * ldx floats (rows may not overlap: ldx >= Cin), and the
+    // out-of-range sentinel offset 0x7f000000 must lie beyond both operands
+    const long long xbytes = (long long)p.Tin * p.ldx * 4, wbytes = (long long)p.Npad * p.Kpad * 4;
+    return on && aligned && p.X && p.W && p.Y && !p.Ysplit && !p.norm_on_load && p.pad == 0 && !p.X2 && !p.rowbias &&
            p.ksplit <= 1 && !p.partials && p.Npad % BN == 0 && p.K == p.Kpad && p.Cin % KT == 0 && p.Kpad >= KT && p.K == p.taps * p.Cin &&
-           p.ldx % 4 == 0 && p.ldy % 4 == 0 && p.Tout > 0 && p.Tout == p.Tin - (p.taps - 1) * p.dil &&
-           p.epi != DZ_EPI_POOL3 && (long long)p.Tin * p.ldx * 4 < (1ll << 31) && (long long)p.Npad * p.Kpad * 4 < (1ll << 31);
+           p.ldx >= p.Cin && p.ldx % 4 == 0 && p.ldy % 4 == 0 && p.Tout > 0 && p.Tout == p.Tin - (p.taps - 1) * p.dil &&
+           p.epi != DZ_EPI_POOL3 && xbytes < 0x7f000000ll && wbytes < 0x7f000000ll;
 }
 
 int dz_launch_gemm_f32(const DzConvGemm& p, hipStream_t st) {

@@ -521,6 +521,9 @@ __device__ __forceinline__ void gemm_pre_tile(const DzConvGemm& p, const int t0,
 template <int EPI, bool ILV>
 __global__ __launch_bounds__(256, 2) void gemm_pre_kernel(DzConvGemm p, int mbig, int msmall, int flags) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+#ifndef DZ_EXPERIMENTS
+    flags = 0;                   // the timing-only variants (wrong results) exist in the experiments build only
+#endif
     const int gy = p.Npad / BN, L = blockIdx.x;
     if (L < mbig * gy) {
         int bx, by, bz;
@@ -564,7 +567,7 @@ __global__ __launch_bounds__(64 * 2 * MW_BIG) void gemm_pre_big_kernel(DzConvGem
 // DZ_GEMM_BIG=1: 384 x 128 tiles for every launch with at least 8 such row tiles
 int big_tiles_mode() {
     static const int mode = [] {
-        const char* e = getenv("DZ_GEMM_BIG");
+        const char* e = dz_exp_env("DZ_GEMM_BIG");
         return e ? atoi(e) : 0;
     }();
     return mode;
@@ -574,7 +577,7 @@ int big_tiles_mode() {
 // interleaved one
 bool interleaved_loop() {
     static const bool on = [] {
-        const char* e = getenv("DZ_GP_LOOP");
+        const char* e = dz_exp_env("DZ_GP_LOOP");
         return !(e && e[0] == '0');
     }();
     return on;
@@ -582,7 +585,7 @@ bool interleaved_loop() {
 
 int dbg_flags() {      // DZ_GP_DBG: timing experiments of the interleaved loop (results are wrong)
     static const int f = [] {
-        const char* e = getenv("DZ_GP_DBG");
+        const char* e = dz_exp_env("DZ_GP_DBG");
         return e ? atoi(e) : 0;
     }();
     return f;
@@ -591,7 +594,7 @@ int dbg_flags() {      // DZ_GP_DBG: timing experiments of the interleaved loop 
 // DZ_GEMM_TAIL=1: 64 x 64 tiles for the rows of a mostly empty last round as well (see the header)
 bool tail_tiles_enabled() {
     static const bool on = [] {
-        const char* e = getenv("DZ_GEMM_TAIL");
+        const char* e = dz_exp_env("DZ_GEMM_TAIL");
         return e && e[0] == '1';
     }();
     return on;
@@ -607,10 +610,12 @@ int wg_slots() {   // resident workgroups of this kernel on the chip: 2 per CU (
 
 template <int EPI>
 int launch(const DzConvGemm& p, hipStream_t st) {
-    static DzAttrOnce attr_once, attr_ilv, attr_big;
-    DZ_HIP(attr_once.raise((const void*)gemm_pre_kernel<EPI, false>, (int)lds_bytes(2)));
+    static DzAttrOnce attr_ilv;
     DZ_HIP(attr_ilv.raise((const void*)gemm_pre_kernel<EPI, true>, (int)lds_bytes(2)));
     const int gx = (p.Tout + BM - 1) / BM, gy = p.Npad / BN, slots = wg_slots();
+#ifdef DZ_EXPERIMENTS
+    static DzAttrOnce attr_once, attr_big;
+    DZ_HIP(attr_once.raise((const void*)gemm_pre_kernel<EPI, false>, (int)lds_bytes(2)));
     {
         const int gxb = (p.Tout + 64 * MW_BIG - 1) / (64 * MW_BIG);
         const int mode = big_tiles_mode();
@@ -621,6 +626,7 @@ int launch(const DzConvGemm& p, hipStream_t st) {
             return 0;
         }
     }
+#endif
     int mbig = gx;
     const int tiles = gx * gy, rem = tiles % slots;
     if (4 * tiles < slots)
@@ -630,10 +636,12 @@ int launch(const DzConvGemm& p, hipStream_t st) {
     const int rows_left = p.Tout - mbig * BM;
     const int msmall = rows_left > 0 ? (rows_left + 63) / 64 : 0;
     const int nwg = mbig * gy + ((msmall + 7) / 8) * 8 * (2 * gy);
-    if (interleaved_loop())
-        DZ_LAUNCH((gemm_pre_kernel<EPI, true>), dim3(nwg), dim3(256), lds_bytes(2), st, p, mbig, msmall, dbg_flags());
-    else
+#ifdef DZ_EXPERIMENTS
+    if (!interleaved_loop())
         DZ_LAUNCH((gemm_pre_kernel<EPI, false>), dim3(nwg), dim3(256), lds_bytes(2), st, p, mbig, msmall, 0);
+    else
+#endif
+        DZ_LAUNCH((gemm_pre_kernel<EPI, true>), dim3(nwg), dim3(256), lds_bytes(2), st, p, mbig, msmall, dbg_flags());
     DZ_HIP(hipGetLastError());
     return 0;
 }
@@ -643,7 +651,7 @@ int launch(const DzConvGemm& p, hipStream_t st) {
 // DZ_GEMM_GEN: 1 = k_gemm_pre.hip's loop, 2 = k_gemm_g2.hip, 3 = k_gemm_g3.hip (persistent, Stream-K)
 int dz_gemm_gen() {
     static const int gen = [] {
-        const char* e = getenv("DZ_GEMM_GEN");
+        const char* e = dz_exp_env("DZ_GEMM_GEN");
         const int v = e ? atoi(e) : 1;
         return v == 2 || v == 3 ? v : 1;
     }();
@@ -674,7 +682,7 @@ int dz_launch_gemm_pre_pool(const DzConvGemm& p_in, const DzPoolFuse& q, hipStre
     // per launch: 157 MB with groups of 4, 145 with 2, 135 with 1; the weights — 3 MB — stay resident
     // either way).  DZ_POOL_AG overrides.
     static const int pool_ag = [] {
-        const char* e = getenv("DZ_POOL_AG");
+        const char* e = dz_exp_env("DZ_POOL_AG");
         return e && atoi(e) > 0 ? atoi(e) : 1;
     }();
     if (!p.agroup) p.agroup = pool_ag;
@@ -708,12 +716,13 @@ int dz_launch_gemm_pre(const DzConvGemm& p_in, hipStream_t st) {
                "gemm_pre: kb-major output planes need ldy %% 32 == 0, yplane = rows * ldy with rows >= Tout, Npad <= ldy");
     DZ_REQUIRE(p.Y == nullptr || (p.ldy % 4 == 0 && ((uintptr_t)p.Y & 15) == 0),
                "gemm_pre: f32 output needs ldy a multiple of 4 and a 16-byte aligned base");
+#ifdef DZ_EXPERIMENTS
     // generation 2 (k_gemm_g2.hip) for every launch outside the latency regime (there: 64 x 64 tiles below)
     if (dz_gemm_gen() >= 2 && 4 * ((p.Tout + BM - 1) / BM) * (p.Npad / BN) >= wg_slots()) {
         // generation 3 pays a hand-over of the accumulators per workgroup: only worth it for long k-loops
         // (DZ_G3_MINK, default 1024: tdnn2 / tdnn3 of the x-vector network; the others stay on generation 1)
         static const int g3_min_k = [] {
-            const char* e = getenv("DZ_G3_MINK");
+            const char* e = dz_exp_env("DZ_G3_MINK");
             return e ? atoi(e) : 1024;
         }();
         if (dz_gemm_gen() == 3) {
@@ -722,6 +731,7 @@ int dz_launch_gemm_pre(const DzConvGemm& p_in, hipStream_t st) {
             return dz_launch_gemm_g2(p, 0, st);
         }
     }
+#endif
     switch (p.epi) {
         case DZ_EPI_BIAS: return launch<DZ_EPI_BIAS>(p, st);
         case DZ_EPI_BIAS_LEAKY: return launch<DZ_EPI_BIAS_LEAKY>(p, st);

@@ -355,7 +355,7 @@ int dz_launch_gemm_split(const DzConvGemm& p_in, hipStream_t st) {
     // 46 -> 53 us), the step time does not change beyond noise (4 same-visit pairs: 2 wins, 2 losses),
     // so the 128 x 128 / 8-wave tiles stay the default.
     static const bool small_wg = [] {
-        const char* e = getenv("DZ_SPLIT_WM");
+        const char* e = dz_exp_env("DZ_SPLIT_WM");
         return e && e[0] == '2';
     }();
     switch (p.epi) {

@@ -250,28 +250,34 @@ int dz_launch_lstm(const float* gx, const float* whh, float* hout, void* hsplit,
     // CU-time, 1.61x the latency), and in the 64-stream pipeline 1.265 / 1.279 ms per step against 1.239 /
     // 1.229 in the same visit: the longer dependent chain of a lane costs more than the freed CUs return
     // (at 196 registers the two-chunk workgroup also keeps every GEMM workgroup off its CU).  Default: 1.
-    const char* e_nc = getenv("DZ_LSTM_NC");            // (read per launch: the tests switch it in-process)
-    const int nc = e_nc && e_nc[0] == '2' ? 2 : 1;
-    if (nc == 2) {
+#ifdef DZ_EXPERIMENTS
+    const char* e_nc = dz_exp_env("DZ_LSTM_NC");        // (read per launch: the tests switch it in-process)
+    // DZ_LSTM_PK=0: plain v_fma_f32 in the contraction (see the PK template parameter)
+    const char* e_pk = dz_exp_env("DZ_LSTM_PK");
+    if (e_nc && e_nc[0] == '2') {
         dim3 grid((B + 1) / 2, 2);
         if (unit_major)
             DZ_LAUNCH((lstm_rec_kernel<true, 2>), grid, dim3(512), 0, st, gx, whh, hout, hsp, hplane, B, T);
         else
             DZ_LAUNCH((lstm_rec_kernel<false, 2>), grid, dim3(512), 0, st, gx, whh, hout, hsp, hplane, B, T);
-    } else {
+        DZ_HIP(hipGetLastError());
+        return 0;
+    }
+    if (e_pk && e_pk[0] == '0') {
         dim3 grid(B, 2);
-        // DZ_LSTM_PK=0: plain v_fma_f32 in the contraction (see the PK template parameter)
-        const char* e_pk = getenv("DZ_LSTM_PK");
-        const bool pk = !(e_pk && e_pk[0] == '0');
-        if (unit_major && pk)
-            DZ_LAUNCH((lstm_rec_kernel<true, 1>), grid, dim3(512), 0, st, gx, whh, hout, hsp, hplane, B, T);
-        else if (unit_major)
+        if (unit_major)
             DZ_LAUNCH((lstm_rec_kernel<true, 1, false>), grid, dim3(512), 0, st, gx, whh, hout, hsp, hplane, B, T);
-        else if (pk)
-            DZ_LAUNCH((lstm_rec_kernel<false, 1>), grid, dim3(512), 0, st, gx, whh, hout, hsp, hplane, B, T);
         else
             DZ_LAUNCH((lstm_rec_kernel<false, 1, false>), grid, dim3(512), 0, st, gx, whh, hout, hsp, hplane, B, T);
+        DZ_HIP(hipGetLastError());
+        return 0;
     }
+#endif
+    dim3 grid(B, 2);
+    if (unit_major)
+        DZ_LAUNCH((lstm_rec_kernel<true, 1>), grid, dim3(512), 0, st, gx, whh, hout, hsp, hplane, B, T);
+    else
+        DZ_LAUNCH((lstm_rec_kernel<false, 1>), grid, dim3(512), 0, st, gx, whh, hout, hsp, hplane, B, T);
     DZ_HIP(hipGetLastError());
     return 0;
 }

@@ -166,6 +166,7 @@ __global__ __launch_bounds__(512) void lstm_mfma_kernel(const float* __restrict_
 }
 
 
+#ifdef DZ_EXPERIMENTS   // variants 1 / 2: measured, parity-tested, never the default
 // ---------------------------------------------------------------------------------------------
 // Variant with ONE accumulator per tile and the activation scales folded into the weights:
 //   W' = W_hh * s_row * 2^SH,  s_row = -log2(e) (i, f, o rows) or -2 log2(e) (g rows), split as
@@ -291,6 +292,8 @@ __global__ __launch_bounds__(512) void lstm_mfma1_kernel(const float* __restrict
     }
     if (s < T) step(s, g0);
 }
+
+#endif  // DZ_EXPERIMENTS
 
 }  // namespace
 
@@ -449,8 +452,12 @@ int dz_launch_lstm_mfma(const float* gx, const void* whh_split, float* hout, voi
                "lstm_mfma: the kb-major planes need hplane = rows * 256 with rows >= B * T");
 #define DZ_L(K) DZ_LAUNCH(K, grid, dim3(512), 0, st, gx, whs, hout, hsp, hplane, B, T)
     if (variant == 0) { if (unit_major) DZ_L(lstm_mfma_kernel<true>); else DZ_L(lstm_mfma_kernel<false>); }
+#ifdef DZ_EXPERIMENTS
     if (variant == 1) { if (unit_major) DZ_L((lstm_mfma1_kernel<true, 0>)); else DZ_L((lstm_mfma1_kernel<false, 0>)); }
     if (variant == 2) { if (unit_major) DZ_L((lstm_mfma1_kernel<true, 8>)); else DZ_L((lstm_mfma1_kernel<false, 8>)); }
+#else
+    DZ_REQUIRE(variant == 0 || variant == 3, "lstm_mfma: variants 1 / 2 exist in the experiments build only (variant %d)", variant);
+#endif
     if (variant == 3) DZ_L(lstm_mfma_dma_kernel);
 #undef DZ_L
     DZ_HIP(hipGetLastError());

@@ -84,7 +84,7 @@ class AudioRing:
         # there it can queue behind the D2H copy of a step whose results are not ready yet, and
         # the next step's forward passes then wait for the previous step's (measured: -17 %).
         # mode 2 = pinned host memory read IN PLACE by the scatter kernel (if the runtime can map it)
-        mode = 1 if block.is_cuda else (2 if block.is_pinned() and os.environ.get("DZ_RING_ZERO_COPY", "1") != "0" else 0)
+        mode = 1 if block.is_cuda else (2 if block.is_pinned() and _lib.exp_env("DZ_RING_ZERO_COPY", "1") != "0" else 0)
         _lib.check(self._lib.dz_ring_push(self._h, block.data_ptr(), block.stride(0), mode,
                                           cur.cuda_stream), "dz_ring_push")
         self._keep = (self._keep + [block])[-4:]
@@ -109,7 +109,7 @@ class AudioRing:
         place by the GPU and must stay untouched until that stream has passed this point."""
         k = len(rows)
         assert block.dtype == torch.float32 and tuple(block.shape) == (k, self.hop) and block.stride(1) == 1
-        mode = 1 if block.is_cuda else (2 if block.is_pinned() and os.environ.get("DZ_RING_ZERO_COPY", "1") != "0" else 0)
+        mode = 1 if block.is_cuda else (2 if block.is_pinned() and _lib.exp_env("DZ_RING_ZERO_COPY", "1") != "0" else 0)
         arr = (C.c_int * k)(*[int(r) for r in rows])
         _lib.check(self._lib.dz_ring_push_rows(self._h, block.data_ptr(), block.stride(0), mode, arr, k,
                                                torch.cuda.current_stream(self.device).cuda_stream), "dz_ring_push_rows")
@@ -180,14 +180,14 @@ class StreamBatch:
         self._steps = np.zeros(num_streams, dtype=np.int64)   # windows seen by each stream slot
         # sub-batches per network, each on its own HIP stream with its own scratch arena: the
         # x-projection GEMM of one sub-batch runs under the latency-bound recurrence of another
-        self.seg_split = max(1, min(int(os.environ.get("DZ_SEG_SPLIT", "1") if seg_split is None else seg_split), num_streams))
-        self.emb_split = max(1, min(int(os.environ.get("DZ_EMB_SPLIT", "1") if emb_split is None else emb_split), num_streams))
+        self.seg_split = max(1, min(int(_lib.exp_env("DZ_SEG_SPLIT", "1") if seg_split is None else seg_split), num_streams))
+        self.emb_split = max(1, min(int(_lib.exp_env("DZ_EMB_SPLIT", "1") if emb_split is None else emb_split), num_streams))
         # HIP stream priorities (0 normal, -1 high).  The segmentation chain is the long dependent one
         # (4 recurrences + their projections: ~2.2 ms in the pipeline, two lanes): its streams get the
         # high priority — round 3, two same-visit pairs: 1.215 vs 1.233 and 1.159 vs 1.180 ms per step
         # (gpurun_out/visit_r3l.log; in round 2, with longer small kernels in that chain, the effect was
         # inside the noise).  The embedding chain waits for the segmentation anyway and stays normal.
-        pa, pb = int(os.environ.get("DZ_PRIO_A", "-1")), int(os.environ.get("DZ_PRIO_B", "0"))
+        pa, pb = int(_lib.exp_env("DZ_PRIO_A", "-1")), int(_lib.exp_env("DZ_PRIO_B", "0"))
         # `depth` lanes, each with its own HIP streams and scratch arenas: step t runs on lane
         # t % depth, so a caller that keeps `depth` tickets between launch() and finish() has that
         # many steps on the GPU at once (the latency-bound recurrence of one step under the GEMMs
@@ -209,7 +209,7 @@ class StreamBatch:
         # 22.8 k xRT), so the default is one embedding stream per lane.
         # DZ_ABLATE=noemb | noseg: TIMING EXPERIMENT (results are wrong): one of the two networks is not launched,
         # to see what the step costs when the other one has the chip to itself
-        self._ablate = os.environ.get("DZ_ABLATE", "")
+        self._ablate = _lib.exp_env("DZ_ABLATE", "")
         # How the host waits.  With cores to spare the launching thread spins on the step's `done` event (lowest
         # latency) and the pool's workers poll 40 us for the next job; a rank that has ~2 cores for itself (8 ranks
         # on a node's 16 usable cores) cannot afford either: the event is then a blocking one (the thread sleeps in
@@ -223,17 +223,17 @@ class StreamBatch:
         mode = os.environ.get("DZ_WAIT", "auto")
         self.blocking_wait = mode == "block" or (mode == "auto" and self.cores_per_rank < 4)
         if self.cores_per_rank < 4:
-            os.environ.setdefault("DZ_POOL_SPIN_US", "0")          # read once by hostpool.cpp, at its first job
-        self.shared_stats = os.environ.get("DZ_SHARED_STATS", "1") != "0"
-        self.shared_emb = os.environ.get("DZ_SHARED_EMB", "0") != "0"
+            _lib.load().dz_host_pool_set_spin(0)                   # idle pool workers sleep at once
+        self.shared_stats = _lib.exp_env("DZ_SHARED_STATS", "1") != "0"
+        self.shared_emb = _lib.exp_env("DZ_SHARED_EMB", "0") != "0"
         self.lag = self.depth - 1 if self.shared_emb else 0
         # DZ_SEG_FRONT=1: the stateless front half of the segmentation network (SincNet + the first
         # x-projection, dz_seg_front) gets a stream of its own per lane.  launch(t + depth) is called
         # before finish(t), so on one stream the front half of step t + depth queues BEHIND the
         # recurrences of step t; on its own stream it runs under them and the lane's dependent chain is
         # the back half only (dz_seg_back: 4 recurrences, 3 projections, the MLP head).
-        self.seg_front = os.environ.get("DZ_SEG_FRONT", "0") != "0"
-        pf = int(os.environ.get("DZ_PRIO_F", "0"))
+        self.seg_front = _lib.exp_env("DZ_SEG_FRONT", "0") != "0"
+        pf = int(_lib.exp_env("DZ_PRIO_F", "0"))
         mk = lambda prio, k: [torch.cuda.Stream(self.device, priority=prio) for _ in range(k)]
         shared_b = mk(pb, self.emb_split) if self.shared_emb else None
         self.lanes = [dict(a=mk(pa, self.seg_split), b=shared_b or mk(pb, self.emb_split),
@@ -899,6 +899,12 @@ class FileBatch:
                     self.engine._wait(ticket)
                 finally:
                     ticket["busy"], ticket["keep"] = False, None
+            # the open files' pinned buffers may still be the source of a non_blocking upload: only a finished
+            # copy makes them safe to hand to the next run's loader thread
+            try:
+                torch.cuda.synchronize(self.engine.device)
+            except Exception:      # noqa: BLE001 — the original exception is the one to report
+                pass
             for f in open_files:
                 if f is not None:
                     self._pool.release(f["host"])

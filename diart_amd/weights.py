@@ -169,10 +169,14 @@ def lstm_whh_planes(whh: torch.Tensor, variant: int) -> torch.Tensor:
 
 def default_lstm_variant() -> int:
     """``DZ_LSTM``: ``valu`` (-1: one chain per CU on the f32 vector units even in the f16x3
-    precision) or the matrix-core variant 0 / 1 / 2 (``lstm_whh_planes``)."""
+    precision) or the matrix-core variant 0 / 3 (1 / 2: experiments build; ``lstm_whh_planes``)."""
     import os
     v = os.environ.get("DZ_LSTM", "valu")
-    return -1 if v == "valu" else int(v)
+    v = -1 if v == "valu" else int(v)
+    if v in (1, 2) and not _lib.EXPERIMENTS:
+        raise ValueError(f"DZ_LSTM={v}: matrix-core recurrence variants 1 / 2 exist in the experiments build only "
+                         "(DZ_EXPERIMENTS=1); the shipped library has valu, 0 and 3")
+    return v
 
 
 def _pad2(w: torch.Tensor, rows: int, cols: int) -> torch.Tensor:
@@ -211,7 +215,9 @@ class _Packed:
         """The matrix as two f16 planes (hi, lo * 2^11) for the split-f16 GEMM path; ``kb``: in the kb-major
         order of the layers that run on ``k_gemm_pre.hip`` / ``k_mlp_head.hip`` (``kb_major``)."""
         d = split_f16(t, name)
-        if kb and t.numel() and float(t.detach().abs().max()) >= KB_WEIGHT_LIMIT:
+        # (only the experiments build's generation 2 / 3 GEMM has this limit: the shipped k_gemm_pre.hip keeps
+        # two accumulators and takes any weight split_f16 accepts)
+        if kb and _lib.exp_env("DZ_GEMM_GEN", "1") in ("2", "3") and t.numel() and float(t.detach().abs().max()) >= KB_WEIGHT_LIMIT:
             # k_gemm_g2.hip multiplies the hi plane of a weight fragment by 2^11 in f16 (one accumulator per
             # fragment): exact while |w| < 32, infinite beyond
             raise ValueError(f"{name or 'matrix'}: |weight| up to {float(t.detach().abs().max()):g} >= {KB_WEIGHT_LIMIT:g} "
@@ -236,7 +242,7 @@ def _pack_sincnet(sd: Dict[str, torch.Tensor], pk: _Packed, prefix: str = "sincn
     w.wav_beta = float(g("wav_norm1d.bias").reshape(-1)[0])
     w.filt = pk.put(fold_sinc_filters(filt))
     import os
-    if split and os.environ.get("DZ_CONV0_SPLIT", "1") != "0":
+    if split and _lib.exp_env("DZ_CONV0_SPLIT", "1") != "0":
         # the unfolded bank, zero padded to [96][256], as f16 planes for the matrix-core kernel
         w.filt_split = pk.put_split(_pad2(filt, 96, 256), prefix + "sinc filter bank")
     w.in0_g, w.in0_b = pk.put(g("norm1d.0.weight")), pk.put(g("norm1d.0.bias"))

@@ -31,6 +31,18 @@ typedef struct dz_clu dz_clu;
 
 const char* dz_last_error(void);
 int dz_version(void);
+/* Run-time options of the library, by name; both return 2 (+ dz_last_error) for an unknown name.
+ *   "f32_gemm"  (default 1): the wide exact-f32 layers on k_gemm_f32.hip; 0 = on k_convgemm.hip
+ *   "pool_fuse" (default 1): statistics pooling inside the last x-vector layer's epilogue; 0 = two launches
+ * Process-wide, read at every launch: set them while no forward pass is being enqueued.               */
+int dz_set_option(const char* name, int value);
+int dz_get_option(const char* name, int* value);
+/* 1 when the library was compiled with -DDZ_EXPERIMENTS (diart_amd_experiments.h; the never-default kernels
+ * and the timing-only modes whose results are wrong exist in that build only), else 0.                */
+int dz_has_experiments(void);
+/* Host worker pool (clustering / output tail of the N streams of a step): how long an idle worker polls for
+ * the next job before it sleeps, in microseconds (default 40; 0 = sleep at once, for ranks with < 4 cores). */
+int dz_host_pool_set_spin(int microseconds);
 
 /* one context per (process, GPU) */
 int dz_ctx_create(int hip_device, dz_ctx** out);
@@ -296,7 +308,7 @@ typedef struct {
 int dz_k_convgemm(dz_ctx* ctx, const dz_convgemm_desc* desc, void* stream);
 /* the exact-f32 kernel of the wide layers alone (k_gemm_f32.hip; dz_k_convgemm routes to it by itself when the
  * layer is in its domain: f32 operands, no prologue / padding / split-K, Npad % 128 == 0, K = taps * Cin unpadded
- * with Cin % 32 == 0; DZ_F32_GEMM=0 keeps every layer on the round-1 kernel).  Same arithmetic per product (one
+ * with Cin % 32 == 0; dz_set_option("f32_gemm", 0) keeps every layer on the round-1 kernel).  Same arithmetic per product (one
  * exact f32 FMA), another order of the k sum.  Error if the layer is outside the domain.               */
 int dz_k_gemm_f32(dz_ctx* ctx, const dz_convgemm_desc* desc, void* stream);
 /* the same layer on the split-f16 matrix-core path (desc->Wsplit must be set)       */
@@ -304,15 +316,6 @@ int dz_k_gemm_split(dz_ctx* ctx, const dz_convgemm_desc* desc, void* stream);
 /* ... with the activations pre-split as well (desc->Wsplit and desc->Xsplit set; B = 1, K = taps*Cin
  * unpadded, Cin % 32 == 0): operand tiles go global -> LDS by LDS-DMA                            */
 int dz_k_gemm_pre(dz_ctx* ctx, const dz_convgemm_desc* desc, void* stream);
-/* generation 2 of the same layer (k_gemm_g2.hip: one accumulator per fragment, three LDS stages, counted
- * vmcnt); row_fragments = 2, 3, 4 -> 128 / 192 / 256 x 128 tiles, 0 = default.  dz_k_gemm_pre dispatches to it
- * with DZ_GEMM_GEN=2 outside the single-chunk latency regime.                                        */
-int dz_k_gemm_g2(dz_ctx* ctx, const dz_convgemm_desc* desc, int row_fragments, void* stream);
-/* generation 3 (k_gemm_g3.hip): the same loop as a persistent kernel, one workgroup per CU, every workgroup the
- * same number of k-tile iterations (a tile shared by two workgroups is finished by the one that holds its end);
- * row_fragments as above, 0 = default (4).  DZ_GEMM_GEN=3.  A timed-out hand-over is reported by dz_range_check
- * (error 7).                                                                                          */
-int dz_k_gemm_g3(dz_ctx* ctx, const dz_convgemm_desc* desc, int row_fragments, void* stream);
 /* SincNet stages 1 / 2 (DZ_EPI_POOL3, k = 5, 64 output columns, Cin 80 or 64, norm-on-load, dense
  * rows) on the dedicated kernel: input tile resident in LDS, weights in registers; same
  * descriptor, outputs and partials as the POOL3 call of dz_k_gemm_split                       */
@@ -329,9 +332,6 @@ int dz_k_seg_head(dz_ctx* ctx, const float* m1, const float* cw, const float* cb
                   int normalize, float* d_weights, void* stream);
 int dz_k_conv_pool(dz_ctx* ctx, const dz_convgemm_desc* desc, void* stream);
 int dz_k_convgemm_ntile(int t_out);
-/* measurement hook (tools/kbench.py): while d_stamps != NULL, dz_k_conv_pool launches record shader-clock
- * stamps of their phases, 2 x 64 per workgroup                                                      */
-int dz_k_conv_pool_debug(long long* d_stamps);
 /* d_stats (B, 2) = (mean, 1/sqrt(biased var + 1e-5)) of each window: InstanceNorm1d(1).  Inside
  * the forward passes the 8 slice moments stay separate and the consumer merges them; this entry
  * point runs the slice kernel plus the merge and synchronises the stream.                     */

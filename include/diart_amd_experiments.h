@@ -1,0 +1,28 @@
+/* Entry points that exist only in the EXPERIMENTS build of libdiart_amd (hipcc -DDZ_EXPERIMENTS;
+ * `python -m diart_amd.build --experiments` -> diart_amd/libdiart_amd_exp.so, loaded when DZ_EXPERIMENTS=1).
+ * Not part of the drop-in boundary: these are the never-default kernel generations kept for measurements
+ * (tools/g2bench.py, tools/g2ablate.py, tools/rec_contention.py; DESIGN.md "What was measured and left out").
+ * In that build DZ_* environment variables select alternative kernels, some of them timing-only
+ * instantiations whose RESULTS ARE WRONG (DZ_GP_DBG, DZ_CONV0_DBG, row_fragments >= 16 below).          */
+#ifndef DIART_AMD_EXPERIMENTS_H
+#define DIART_AMD_EXPERIMENTS_H
+#include "diart_amd.h"
+#ifdef __cplusplus
+extern "C" {
+#endif
+/* generation 2 of the same layer (k_gemm_g2.hip: one accumulator per fragment, three LDS stages, counted
+ * vmcnt); row_fragments = 2, 3, 4 -> 128 / 192 / 256 x 128 tiles, 0 = default.  dz_k_gemm_pre dispatches to it
+ * with DZ_GEMM_GEN=2 outside the single-chunk latency regime.                                        */
+int dz_k_gemm_g2(dz_ctx* ctx, const dz_convgemm_desc* desc, int row_fragments, void* stream);
+/* generation 3 (k_gemm_g3.hip): the same loop as a persistent kernel, one workgroup per CU, every workgroup the
+ * same number of k-tile iterations (a tile shared by two workgroups is finished by the one that holds its end);
+ * row_fragments as above, 0 = default (4).  DZ_GEMM_GEN=3.  A timed-out hand-over is reported by dz_range_check
+ * (error 7).                                                                                          */
+int dz_k_gemm_g3(dz_ctx* ctx, const dz_convgemm_desc* desc, int row_fragments, void* stream);
+/* measurement hook (tools/kbench.py): while d_stamps != NULL, dz_k_conv_pool launches record shader-clock
+ * stamps of their phases, 2 x 64 per workgroup                                                      */
+int dz_k_conv_pool_debug(long long* d_stamps);
+#ifdef __cplusplus
+}
+#endif
+#endif

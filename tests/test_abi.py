@@ -120,9 +120,12 @@ def test_every_device_kernel_bench_names_is_in_the_library(monkeypatch):
     bench = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(bench)
     syms = subprocess.run(["nm", "-C", str(_lib.lib_path())], capture_output=True, text=True, check=True).stdout
-    variants = [{}, {"DZ_LSTM_NC": "2"}, {"DZ_LSTM_PK": "0"}, {"DZ_LSTM": "0"}, {"DZ_LSTM": "1"}, {"DZ_LSTM": "2"},
-                {"DZ_LSTM": "3"}, {"DZ_GEMM_GEN": "2"}, {"DZ_GEMM_GEN": "3"}, {"DZ_POOL_FUSE": "0"}, {"DZ_SPLIT_WM": "2"}, {"DZ_CONV_POOL": "0"},
-                {"DZ_MLP_HEAD": "0"}, {"DZ_CONV0_SPLIT": "0"}, {"DZ_GP_LOOP": "0"}, {"DZ_F32_GEMM": "0"}]
+    variants = [{}, {"DZ_LSTM": "0"}, {"DZ_LSTM": "3"}, {"DZ_POOL_FUSE": "0"}, {"DZ_F32_GEMM": "0"}]
+    if _lib.experiments():           # DZ_EXPERIMENTS=1: the never-default kernels are in the library too
+        monkeypatch.setattr(bench, "EXPERIMENTS", True)
+        variants += [{"DZ_LSTM_NC": "2"}, {"DZ_LSTM_PK": "0"}, {"DZ_LSTM": "1"}, {"DZ_LSTM": "2"}, {"DZ_GEMM_GEN": "2"},
+                     {"DZ_GEMM_GEN": "3"}, {"DZ_SPLIT_WM": "2"}, {"DZ_CONV_POOL": "0"}, {"DZ_MLP_HEAD": "0"},
+                     {"DZ_CONV0_SPLIT": "0"}, {"DZ_GP_LOOP": "0"}]
     missing = []
     for env in variants:
         for k in ("DZ_LSTM_NC", "DZ_LSTM_PK", "DZ_LSTM", "DZ_GEMM_GEN", "DZ_POOL_FUSE", "DZ_SPLIT_WM", "DZ_CONV_POOL",
@@ -136,3 +139,54 @@ def test_every_device_kernel_bench_names_is_in_the_library(monkeypatch):
                 if sym + "(" not in syms and sym + "<" not in syms:       # (a template whose arguments bench leaves out)
                     missing.append((env, precision, tag, sym))
     assert not missing, missing
+
+
+def test_shipped_library_has_no_experiment_surface():
+    """The shipped libdiart_amd.so has one configuration per layer: no timing-only / debug entry points, no
+    never-default kernel generations, and it reads no DZ_* kernel-selection variable (they exist in the
+    experiments build, `python -m diart_amd.build --experiments`, loaded with DZ_EXPERIMENTS=1)."""
+    import shutil
+    import subprocess
+    from diart_amd import _lib
+    if _lib.experiments():
+        pytest.skip("the experiments build is loaded")
+    if shutil.which("nm") is None or shutil.which("strings") is None:
+        pytest.skip("binutils not available")
+    lib = _lib.lib_path()
+    exported = subprocess.run(["nm", "-D", "--defined-only", str(lib)], capture_output=True, text=True, check=True).stdout
+    names = [ln.split()[-1] for ln in exported.splitlines() if ln.strip()]
+    bad = [n for n in names if re.search(r"debug|dbg|gemm_g2|gemm_g3", n)]
+    assert not bad, bad
+    kernels = subprocess.run(["nm", "-C", str(lib)], capture_output=True, text=True, check=True).stdout
+    for never_default in ("gemm_g2_kernel", "gemm_g3_kernel", "lstm_mfma1_kernel", "gemm_pre_big_kernel",
+                          "lstm_rec_kernel<true, 2", "sinc_conv0_h_kernel<1>"):
+        assert never_default not in kernels, never_default
+    env_names = sorted(set(re.findall(r"^DZ_[A-Z0-9_]+$", subprocess.run(["strings", str(lib)], capture_output=True,
+                                                                      text=True, check=True).stdout, flags=re.M)))
+    assert env_names == ["DZ_PROF_TIMELINE"], env_names
+
+
+def test_product_reads_few_environment_switches():
+    """At most 15 DZ_* variables are read by the package (each documented in README.md); everything else goes
+    through `_lib.exp_env`, which answers with the shipped default unless DZ_EXPERIMENTS=1."""
+    read = set()
+    for f in (ROOT / "diart_amd").rglob("*.py"):
+        text = f.read_text()
+        read |= set(re.findall(r"os\.environ(?:\.get\(|\[|\.setdefault\()\s*\"(DZ_[A-Z0-9_]+)\"", text))
+        read |= set(re.findall(r"\"(DZ_[A-Z0-9_]+)\" (?:not )?in os\.environ", text))
+    read.add("DZ_PROF_TIMELINE")                     # the one variable the C side reads (csrc/api.hip)
+    assert len(read) <= 15, sorted(read)
+    readme = (ROOT / "README.md").read_text()
+    assert all(n in readme for n in read), sorted(n for n in read if n not in readme)
+
+
+def test_options_api():
+    from diart_amd import _lib
+    lib = _lib.load()
+    assert _lib.get_option("f32_gemm") == 1 and _lib.get_option("pool_fuse") == 1
+    _lib.set_option("pool_fuse", 0)
+    assert _lib.get_option("pool_fuse") == 0
+    _lib.set_option("pool_fuse", 1)
+    with pytest.raises(_lib.DiartAmdError):
+        _lib.set_option("gemm_gen", 2)               # not an option of the library
+    assert lib.dz_host_pool_set_spin(40) == 0

@@ -134,3 +134,28 @@ def test_errors_are_told(tmp_path):
     torch.save([1, 2, 3], f)
     with pytest.raises(ValueError, match="state dict"):
         checkpoint.read_state(f)
+
+
+def test_model_prefix_is_stripped_per_key_and_unknown_storages_are_named(tmp_path):
+    """one extra top-level entry beside `model.*` must not keep the prefix on every key; a tensor on a
+    storage class the reader does not know is an error that names the entry, not a silent drop."""
+    state = synth_segmentation_state(seed=6)
+    sd = {"model." + k: v for k, v in state.items()}
+    sd["loss_weight"] = torch.tensor([0.5])
+    f = tmp_path / "extra.ckpt"
+    torch.save({"state_dict": sd}, f)
+    got = _read_state(f)
+    assert set(got) == set(state) | {"loss_weight"} and torch.equal(got["sincnet.conv1d.1.weight"], state["sincnet.conv1d.1.weight"])
+    # a collision (both `x` and `model.x`) keeps the names as they are
+    g = tmp_path / "collide.ckpt"
+    torch.save({"state_dict": {"model.w": torch.ones(2), "w": torch.zeros(2)}}, g)
+    assert set(_read_state(g)) == {"model.w", "w"}
+    assert isinstance(checkpoint._rebuild_tensor(object(), 0, (2,), (1,)), checkpoint.UnknownStorage)
+    # what an unknown storage class unpickles to reaches read_state as a marker, and is named
+    orig = checkpoint.load_object
+    try:
+        checkpoint.load_object = lambda p: ({"state_dict": {"q.weight": checkpoint.UnknownStorage(), "w": torch.ones(1)}}, set())
+        with pytest.raises(ValueError, match="q.weight"):
+            checkpoint.read_state(f)
+    finally:
+        checkpoint.load_object = orig

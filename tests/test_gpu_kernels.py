@@ -297,7 +297,7 @@ def test_convgemm_pool3(gpu, Cin, Tin, split):
     (1, 130, 96, 5, 1, 128, 128, "relu_bn_tanh")])
 def test_gemm_f32_wide_layers(gpu, monkeypatch, B, Tin, Cin, taps, dil, N, Nstore, epi):
     """k_gemm_f32.hip (LDS-DMA operands, 128 x 128 tiles, v_mfma_f32_32x32x2_f32) against the f64 contraction and
-    against the round-1 kernel it replaces for these layers (k_convgemm.hip, DZ_F32_GEMM=0): the same products, one
+    against the round-1 kernel it replaces for these layers (k_convgemm.hip, option f32_gemm = 0): the same products, one
     exact f32 FMA each, in another order."""
     lib = _lib.load()
     g = torch.Generator().manual_seed(Tin + Cin + N)
@@ -328,9 +328,11 @@ def test_gemm_f32_wide_layers(gpu, monkeypatch, B, Tin, Cin, taps, dil, N, Nstor
         if which == "new":
             _lib.check(lib.dz_k_gemm_f32(_ctx(gpu), C.byref(d), None), "dz_k_gemm_f32")
         else:
-            monkeypatch.setenv("DZ_F32_GEMM", "0")
-            _lib.check(lib.dz_k_convgemm(_ctx(gpu), C.byref(d), None), "dz_k_convgemm")
-            monkeypatch.delenv("DZ_F32_GEMM")
+            _lib.set_option("f32_gemm", 0)
+            try:
+                _lib.check(lib.dz_k_convgemm(_ctx(gpu), C.byref(d), None), "dz_k_convgemm")
+            finally:
+                _lib.set_option("f32_gemm", 1)
         _sync()
         outs[which] = Y[:, :, :Nstore].cpu()
         if d.ldy > Nstore:
@@ -542,6 +544,8 @@ def test_gemm_pre(gpu, M, Cin, taps, dil, N, Nstore, epi, outs, kern):
         d.Ysplit, d.yplane = Yp.data_ptr(), M * N
     d.B, d.Tin, d.Tout, d.Tstore, d.Cin, d.taps, d.dil = 1, M, Tout, Tout, Cin, taps, dil
     d.K, d.Kpad, d.Npad, d.Nstore, d.ldx, d.ldy, d.epi = K, K, N, Nstore, Cin, N, code
+    if kern != "pre" and not _lib.experiments():
+        pytest.skip("generations 2 / 3 exist in the experiments build only (DZ_EXPERIMENTS=1)")
     if kern == "pre":
         _lib.check(_lib.load().dz_k_gemm_pre(_ctx(gpu), C.byref(d), None), "dz_k_gemm_pre")
     elif kern.startswith("g2"):

@@ -9,6 +9,7 @@ import numpy as np
 import pytest
 import torch
 
+from diart_amd import _lib
 from diart_amd import models as M
 from diart_amd.synth import (sliding_chunks, synth_embedding_state, synth_segmentation_state,
                              synth_stream)
@@ -169,7 +170,7 @@ def test_precisions_agree_with_each_other(gpu, chunks):
 def test_pooling_fused_into_tdnn5_equals_the_two_launch_path(gpu, oracle_models, monkeypatch):
     """Round 3: tdnn5 keeps its 128 x 128 output tile in LDS and reduces it to weighted moments there
     (k_gemm_pre.hip pooled epilogue + pool_combine) instead of writing 110 MB of frame features for
-    stats_pool to read back.  Same embeddings as the two-launch path (DZ_POOL_FUSE=0) and as the
+    stats_pool to read back.  Same embeddings as the two-launch path (option pool_fuse = 0) and as the
     oracle, for the de-duplicated call (K = 3 speakers per chunk), the reference-shaped rows call
     (K = 1) and the unweighted call; 12 chunks so that the launch uses big tiles (the latency regime
     keeps the two-launch path)."""
@@ -182,12 +183,15 @@ def test_pooling_fused_into_tdnn5_equals_the_two_launch_path(gpu, oracle_models,
     w[2, :, 100:] = 1e-8                                            # weight only in the first pieces
     outs = {}
     for fuse in ("1", "0"):
-        monkeypatch.setenv("DZ_POOL_FUSE", fuse)
-        emb = M.EmbeddingModel.from_state(synth_embedding_state(), max_batch=3 * B)
-        emb.to(gpu)
-        multi = emb.model.forward_multi(x.to(gpu), w.to(gpu)).cpu()
-        rows = emb(x.repeat(1, 3, 1).reshape(3 * B, 1, -1).to(gpu), w.reshape(3 * B, 293).to(gpu)).cpu().view(B, 3, 512)
-        plain = emb(x.to(gpu)).cpu()
+        _lib.set_option("pool_fuse", int(fuse))
+        try:
+            emb = M.EmbeddingModel.from_state(synth_embedding_state(), max_batch=3 * B)
+            emb.to(gpu)
+            multi = emb.model.forward_multi(x.to(gpu), w.to(gpu)).cpu()
+            rows = emb(x.repeat(1, 3, 1).reshape(3 * B, 1, -1).to(gpu), w.reshape(3 * B, 293).to(gpu)).cpu().view(B, 3, 512)
+            plain = emb(x.to(gpu)).cpu()
+        finally:
+            _lib.set_option("pool_fuse", 1)
         outs[fuse] = (multi, rows, plain)
     with torch.no_grad():
         ref = oracle_models[1].forward_multi(x, w.permute(0, 2, 1))

@@ -10,6 +10,7 @@ import numpy as np
 import pytest
 import torch
 
+from diart_amd import _lib
 from diart_amd import models as M
 from diart_amd.blocks import (OnlineSpeakerClustering, OverlapAwareSpeakerEmbedding,
                               SpeakerSegmentation)
@@ -137,19 +138,19 @@ def test_full_size_properties_64_streams(gpu):
     # (as for the segmentation above); the statistics pooling fused into tdnn5's epilogue (round 3)
     # merges per-TILE moments, and which 128-row tiles a chunk's frames fall into depends on the
     # chunk's position in the flattened batch: the same embedding to a few f32 ulps (deterministic for a
-    # given batch), bit-identical again on the two-launch path (DZ_POOL_FUSE=0)
+    # given batch), bit-identical again on the two-launch path (option pool_fuse = 0)
     for i in range(0, n, 16):
         part = emb.forward_multi(view[i:i + 16, None, :], w[i:i + 16], normalize=True)
         assert (e_all[i:i + 16] - part).abs().max().item() < 5e-7
     assert torch.equal(e_all, emb.forward_multi(view[:, None, :], w, normalize=True))     # run-to-run determinism
-    os.environ["DZ_POOL_FUSE"] = "0"
+    _lib.set_option("pool_fuse", 0)
     try:
         e_two = emb.forward_multi(view[:, None, :], w, normalize=True)
         for i in range(0, n, 16):
             assert torch.equal(e_two[i:i + 16], emb.forward_multi(view[i:i + 16, None, :], w[i:i + 16], normalize=True))
         assert (e_two - e_all).abs().max().item() < 5e-7
     finally:
-        del os.environ["DZ_POOL_FUSE"]
+        _lib.set_option("pool_fuse", 1)
     # different streams give different embeddings (the batch is not aliased)
     assert (e_all[0] - e_all[1]).abs().max().item() > 1e-3
 
@@ -358,6 +359,8 @@ def test_front_half_on_its_own_stream_is_the_same_arithmetic(gpu, monkeypatch):
     recurrences of step t (dz_seg_front / dz_seg_back).  Same kernels, same operands: bit-identical
     outputs, with depth + 1 steps in flight (the front half of a lane's next step overlaps its current
     back half; the handle's event guards the one buffer they share)."""
+    if not _lib.experiments():
+        pytest.skip("DZ_SEG_FRONT is honoured by the experiments build only")
     n, W, hop, steps = 8, 80000, 8000, 9
     audio = torch.from_numpy(synth_streams(n, (W + hop * steps) / 16000.0, seed0=910)).to(gpu)
     seg_sd, emb_sd = synth_segmentation_state(), synth_embedding_state()

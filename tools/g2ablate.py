@@ -9,6 +9,8 @@ import json
 import sys
 from pathlib import Path
 
+import os
+os.environ.setdefault("DZ_EXPERIMENTS", "1")     # needs libdiart_amd_exp.so (python -m diart_amd.build --experiments)
 import torch
 
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))

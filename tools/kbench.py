@@ -80,9 +80,9 @@ def convgemm(name, Bn, Tin, Cin, N, taps, dil, epi, Npad=None, pro=False, pool=F
     d.ksplit, d.ysplit = ksplit, Bn * Tstore * Npad
     d.agroup = args.agroup
     flop = 2.0 * Bn * Tout * K * N
-    os.environ["DZ_F32_GEMM"] = "0"                       # the round-1 exact-f32 kernel (k_convgemm.hip)
+    _lib.set_option("f32_gemm", 0)                        # the round-1 exact-f32 kernel (k_convgemm.hip)
     timeit(name, lambda: _lib.check(lib.dz_k_convgemm(ctx, C.byref(d), st), name), flop=flop)
-    del os.environ["DZ_F32_GEMM"]
+    _lib.set_option("f32_gemm", 1)
     if not pro and not pool and not ksplit and Npad % 128 == 0 and Cin % 32 == 0 and (not only or name in only or name + "_f32g2" in only):
         # k_gemm_f32.hip: what dz_k_convgemm routes these layers to by default
         y_old = Y.clone()
