@@ -212,10 +212,11 @@ def parse():
                     help="N = 1: measure HBM traffic / matrix-core busy per kernel LIVE with rocprofv3 --pmc child "
                          "passes of this command (on: headline precision, ~2 min; all: also the exact-f32 pass; "
                          "off: use the committed passes under profiles/)")
-    ap.add_argument("--config", type=int, default=2, choices=[2, 3],
+    ap.add_argument("--config", type=int, default=2, choices=[1, 2, 3, 5],
                     help="BASELINE.json configs index + 1: 2 = 64 streams, pyannote/segmentation + pyannote/embedding "
                          "(the metric's config, default); 3 = segmentation-3.0 (powerset) + ECAPA-TDNN through the "
-                         "blocks pipeline, batches of 32 consecutive windows")
+                         "blocks pipeline, batches of 32 consecutive windows; 5 = VoiceActivityDetection, 250 ms step, batch 1: "
+                         "p50 / p95 per-chunk latency; 1 = Benchmark on one 30 s WAV")
     ap.add_argument("--details", type=str, default=os.environ.get("DZ_BENCH_DETAILS", "gpurun_out/bench_details.json"),
                     help="side file for the full record (per-kernel tables, exact-f32 tables, rehearsal, notes); "
                          "stdout carries ONE compact JSON line (diart_amd/benchline.py)")
@@ -419,7 +420,7 @@ def pmc_live(precision):
     work = Path(tempfile.mkdtemp(prefix="dz_pmc_"))
     cmd = [sys.executable, str(ROOT / "bench.py"), "--steps", "3", "--warmup", "1", "--no-cpu-baseline",
            "--no-exact-f32", "--no-host-pass", "--pmc", "off", "--no-rehearsal", "--precision", precision]
-    env = dict(os.environ, PYTHONDONTWRITEBYTECODE="1", TMPDIR="/tmp")
+    env = dict(os.environ, PYTHONDONTWRITEBYTECODE="1", TMPDIR="/tmp", DZ_SETTLE_STEPS="0")
     passes = {"FETCH_SIZE": ["FETCH_SIZE"], "WRITE_SIZE": ["WRITE_SIZE"],
               "MFMA": ["SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CYCLES", "GRBM_GUI_ACTIVE"]}
     for tag, counters in passes.items():
@@ -617,6 +618,25 @@ def config3(args):
     elapsed = time.perf_counter() - t0
     cps = B * args.steps / elapsed
     gflop_chunk = 2.0 * (656_230_928 + 3 * ECAPA_MAC_PER_ROW) / 1e9
+    # ---- where a step's wall time goes (a few extra untimed steps; every phase of the synchronous blocks API ends
+    # in a `.cpu()`, so host clocks around the three calls of SpeakerDiarization.__call__ are honest) -------------
+    phases = {"stack": 0.0, "segmentation": 0.0, "embedding": 0.0, "finalise": 0.0}
+    nph = min(4, args.steps)
+    for i in range(nph):
+        w = chunks[(args.warmup + i) * B:(args.warmup + i + 1) * B]
+        t0 = time.perf_counter()
+        batch = torch.stack([torch.from_numpy(c.data) for c in w])
+        t1 = time.perf_counter()
+        seg_ = pipe.segmentation(batch)
+        t2 = time.perf_counter()
+        emb_ = pipe.embedding(batch, seg_)
+        t3 = time.perf_counter()
+        pipe.finalise(w, seg_, emb_)
+        t4 = time.perf_counter()
+        for k, v in zip(phases, (t1 - t0, t2 - t1, t3 - t2, t4 - t3)):
+            phases[k] += 1e3 * v / nph
+    phases = {k: round(v, 3) for k, v in phases.items()}
+    log(f"config 3 phases, ms per step: {phases}")
     # ---- per-kernel brackets (the dispatches' own timestamps), on a few extra steps after the timed region ------
     nprof = min(4, args.steps)
     lib.dz_prof_enable(1)
@@ -664,7 +684,7 @@ def config3(args):
         "config": {"workload": "configs[2]: single MI355X, pyannote/segmentation-3.0 (powerset) + speechbrain ECAPA-TDNN "
                                "architectures (random-init weights), 5 s window / 500 ms step, one synthetic stream through "
                                "the blocks pipeline in batches of 32 consecutive windows (96 embedding rows per step)",
-                   "chunks_per_step": B, "speech_turns_emitted": turns},
+                   "chunks_per_step": B, "speech_turns_emitted": turns, "host_phases_ms": phases},
         "roofline": dict(dom, traffic=None, whole_path_tflops=round(cps * gflop_chunk / 1e3, 2),
                          alg_gflop_per_chunk=round(gflop_chunk, 2), kernel_time_ms_per_step=round(tot, 3),
                          peak_note="f16 matrix peak / 3 for the layers on the split-f16 kernels (three MFMAs per "
@@ -676,12 +696,143 @@ def config3(args):
     emit(out, args.details)
 
 
+def config5(args):
+    """`bench.py --config 5`: BASELINE.json configs[4] — the VoiceActivityDetection pipeline (segmentation-only path,
+    /root/reference/src/diart/blocks/vad.py:127-191), 250 ms step, ONE stream, batch 1: per-chunk latency of
+    `pipeline([chunk])` clocked like the reference's Chronometer (utils.py:13-43: a host clock around the call, the
+    chunk handed over as host memory, H2D and D2H inside).  --steps = timed chunks (at least 200), --warmup = untimed
+    ones.  `value` = p50 in ms (lower is better); reference points of the README (:169): 12 ms CPU, 8 ms RTX 4060."""
+    from diart_amd import models as M
+    from diart_amd.blocks import VoiceActivityDetection, VoiceActivityDetectionConfig
+    from diart_amd.features import SlidingWindow, SlidingWindowFeature
+    from diart_amd.hostinfo import limit_host_threads
+    from diart_amd.models import default_precision
+    from diart_amd.synth import synth_segmentation_state, synth_stream
+    limit_host_threads()
+    if args.gpus != 1:
+        raise SystemExit("bench.py --config 5 is a single-GPU, single-stream line")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X GPU (the HIP path has no CPU fallback)")
+    device = torch.device("cuda", 0)
+    precision = args.precision or default_precision()
+    n, warm, step = max(args.steps, 200), max(args.warmup, 5), 0.25
+    SR = 16000
+    S, H = 5 * SR, int(round(step * SR))
+    stream = synth_stream(5, 5.0 + step * (n + warm + 2))
+    seg = M.SegmentationModel.from_state(synth_segmentation_state(), max_batch=1, precision=precision)
+    pipe = VoiceActivityDetection(VoiceActivityDetectionConfig(segmentation=seg, step=step, device=device))
+    times, turns = [], 0
+    import gc
+    for i in range(n + warm):
+        c = SlidingWindowFeature(stream[i * H:i * H + S, None], SlidingWindow(start=i * step, duration=1 / SR, step=1 / SR))
+        if i == warm:
+            gc.collect()
+            gc.freeze()
+            torch.cuda.synchronize()
+            t_all = time.perf_counter()
+        t0 = time.monotonic()
+        out = pipe([c])
+        times.append(1e3 * (time.monotonic() - t0))
+        turns += len(out[0][0])
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t_all
+    t = np.array(times[warm:])
+    lat = {"p50": round(float(np.percentile(t, 50)), 3), "p95": round(float(np.percentile(t, 95)), 3),
+           "mean": round(float(t.mean()), 3), "max": round(float(t.max()), 3)}
+    gflop = 1.312                                    # segmentation only (SURVEY.md 8d)
+    out = {
+        "metric": "per-chunk latency of VoiceActivityDetection([chunk]), p50", "value": lat["p50"], "unit": "ms",
+        "n_gpus": 1, "steps": n, "warmup": warm, "ms_per_step": round(1e3 * elapsed / n, 3), "higher_is_better": False,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32" if precision == "f32" else "f16x3", "data": "synthetic",
+        "config": {"workload": "configs[4]: VoiceActivityDetection pipeline (pyannote/segmentation architecture, random-init "
+                               "weights), 5 s window / 250 ms step, one synthetic 16 kHz stream, batch 1, chunk handed over "
+                               "as host memory (H2D + D2H inside the clocked call)",
+                   "chunks_per_step": 1, "speech_turns_emitted": turns,
+                   "reference_points_ms": {"cpu": 12, "rtx4060": 8, "source": "reference README.md:169"}},
+        "latency_ms": lat, "chunk_ms": 1e3 * step,
+        "roofline": {"kernel": "whole segmentation network at batch 1", "bound": "latency",
+                     "achieved": round(gflop / lat["p50"], 3), "peak": PEAK_F32_VECTOR_TFLOPS, "unit": "TFLOP/s",
+                     "frac": round(gflop / lat["p50"] / PEAK_F32_VECTOR_TFLOPS, 5), "traffic": None,
+                     "alg_gflop_per_launch": gflop,
+                     "note": "one chunk = 4 x 293 dependent recurrence steps on 2 of 256 CUs; latency-bound by construction"},
+        "cpu_baseline": None,
+    }
+    emit(out, args.details)
+
+
+def config1(args):
+    """`bench.py --config 1`: BASELINE.json configs[0] — `diart.benchmark` (the reference's Benchmark class,
+    /root/reference/src/diart/inference.py:392-432) on ONE 30 s 16 kHz WAV with SpeakerDiarization,
+    pyannote/segmentation + pyannote/embedding architectures, batch_size 32: 51 chunks (inference.py:81-83).  A step =
+    one complete run over the file (read WAV -> chunks -> pipeline -> RTTM written); `value` = chunks/s / 2."""
+    import tempfile
+    from diart_amd import models as M
+    from diart_amd.blocks import SpeakerDiarization, SpeakerDiarizationConfig
+    from diart_amd.hostinfo import limit_host_threads
+    from diart_amd.inference import Benchmark, write_wav
+    from diart_amd.models import default_precision
+    from diart_amd.synth import synth_embedding_state, synth_segmentation_state, synth_stream
+    limit_host_threads()
+    if args.gpus != 1:
+        raise SystemExit("bench.py --config 1 is a single-GPU line (one file); tools/benchmark_files.py --gpus N shards files")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X GPU (the HIP path has no CPU fallback)")
+    device = torch.device("cuda", 0)
+    precision = args.precision or default_precision()
+    seconds, B = 30.0, 32
+    work = Path(tempfile.mkdtemp(prefix="dz_config1_"))
+    (work / "wav").mkdir()
+    write_wav(work / "wav" / "synthetic_00.wav", synth_stream(1000, seconds), 16000)
+    cfg = SpeakerDiarizationConfig(
+        segmentation=M.SegmentationModel.from_state(synth_segmentation_state(), max_batch=B, precision=precision),
+        embedding=M.EmbeddingModel.from_state(synth_embedding_state(), max_batch=B, precision=precision),
+        latency=0.5, device=device)
+    bench = Benchmark(work / "wav", None, work / "rttm", show_report=False, batch_size=B)
+    chunks = int(np.ceil((seconds - 5.0 + 0.5) / 0.5))
+    for _ in range(max(1, args.warmup)):
+        bench(SpeakerDiarization, cfg)
+    torch.cuda.synchronize()
+    walls = []
+    t_all = time.perf_counter()
+    for _ in range(args.steps):
+        t0 = time.perf_counter()
+        bench(SpeakerDiarization, cfg)
+        walls.append(time.perf_counter() - t0)
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t_all
+    rttm = (work / "rttm" / "synthetic_00.rttm").read_text().splitlines()
+    import shutil
+    shutil.rmtree(work, ignore_errors=True)
+    cps = chunks * args.steps / elapsed
+    out = {
+        "metric": "real-time-factor xRT streams/GPU @500ms step", "value": round(cps / 2, 2),
+        "unit": "xRT 16 kHz streams (chunks/s / 2)", "n_gpus": 1, "steps": args.steps, "warmup": max(1, args.warmup),
+        "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32" if precision == "f32" else "f16x3", "data": "synthetic",
+        "config": {"workload": "configs[0]: Benchmark(SpeakerDiarization) on one 30 s 16 kHz WAV, pyannote/segmentation + "
+                               "pyannote/embedding architectures (random-init weights), batch_size 32, latency = step = 0.5 s; "
+                               "a step = the whole file (WAV read, 51 chunks, RTTM written)",
+                   "chunks_per_step": chunks, "path": bench.last_path, "rttm_lines": len(rttm)},
+        "file_seconds": seconds, "wall_s": {"p50": round(float(np.median(walls)), 4), "max": round(float(max(walls)), 4)},
+        "roofline": {"kernel": "whole file", "bound": "latency", "achieved": round(cps * ALG_GFLOP_PER_CHUNK / 1e3, 2),
+                     "peak": PEAK_F16_MATRIX_TFLOPS / SPLIT_PRODUCTS, "unit": "TFLOP/s",
+                     "frac": round(cps * ALG_GFLOP_PER_CHUNK / 1e3 / (PEAK_F16_MATRIX_TFLOPS / SPLIT_PRODUCTS), 5),
+                     "traffic": None, "note": "51 chunks in two batches (32 + 19): launch- and host-bound, not a kernel roofline"},
+        "cpu_baseline": None,
+    }
+    emit(out, args.details)
+
+
 def main():
     args = parse()
     if args.cpu_worker:
         return cpu_baseline_worker(args.cpu_chunks, args.cpu_threads, 20.0)
     if args.config == 3:
         return config3(args)
+    if args.config == 5:
+        return config5(args)
+    if args.config == 1:
+        return config1(args)
     from diart_amd import distributed as D
     # `python bench.py --gpus N` as ONE process: start the N ranks ourselves (torch.distributed.run,
     # one rank per GPU, RCCL); under the driver's own torchrun WORLD_SIZE is set and this is a no-op

@@ -406,3 +406,58 @@ def test_timeline_tool_splits_a_drain_into_steps(tmp_path):
     summary = json.loads(out.read_text())
     assert abs(summary["mean_period_us"] - 1000.0) < 1e-6
     assert abs(summary["steps"][0]["seg_span_us"] - 790.0) < 1e-6 and abs(summary["steps"][0]["seg_busy_us"] - 720.0) < 1e-6
+
+
+EIGHT_RANK_SCRIPT = r'''
+import json, os, sys, time, torch
+sys.path.insert(0, sys.argv[1])
+from diart_amd import benchline, distributed as D
+from diart_amd.hostinfo import bind_rank
+n = int(sys.argv[2])
+os.environ["DZ_FORCE_DEVICE"] = "0"          # CPU container: no GPU to count (rehearsal switch)
+rc = D.self_launch(n, os.path.abspath(__file__), sys.argv[1:])
+if rc is not None:
+    raise SystemExit(rc)
+rank, world, local = D.init_from_env("gloo")
+aff = bind_rank(local, int(os.environ.get("LOCAL_WORLD_SIZE", world)), 0)
+from diart_amd.synth import segmentation_spec, synth_segmentation_state
+cpu = torch.device("cpu")
+seg = D.broadcast_state(synth_segmentation_state() if rank == 0 else None, segmentation_spec(), cpu)
+wsum = float(sum(v.double().abs().sum().item() for v in seg.values()))
+wsums = [w[0] for w in D.gather_counts([wsum], cpu)]
+steps, units = 4, 64
+el = D.timed_max_over_ranks(lambda: time.sleep(0.01 * (1 + rank % 3)), None)
+if rank == 0:
+    full = json.loads(open(sys.argv[3]).read())           # a complete single-GPU record; the multi-rank fields live
+    full.update(n_gpus=world, value=round(D.whole_job_rate(units, steps, el, world) / 2, 2), steps=steps)
+    full["config"].update(weights_abs_sum_per_rank=wsums, dist_backend=torch.distributed.get_backend(),
+                          rccl_ranks=0, cpu_affinity=aff, parallelism=f"streams x{world}", chunks_per_step=world * units)
+    full["cpu_baseline"] = None
+    sys.stdout.write(benchline.line(full, None) + "\n")
+    sys.stdout.flush()
+torch.distributed.barrier()
+torch.distributed.destroy_process_group()
+'''
+
+
+def test_eight_ranks_from_one_command_print_one_compact_line(tmp_path):
+    """VERDICT r4 next #2: `bench.py --gpus 8` as ONE process — the real launcher (self_launch -> torch.distributed.run,
+    8 gloo ranks here), per-rank CPU placement, the flat weight broadcast, the max-over-ranks bracket, and rank 0's
+    line assembly: exactly one JSON object on stdout, < 4 KB, weights identical on all 8 ranks."""
+    import json
+    script = tmp_path / "eight.py"
+    script.write_text(EIGHT_RANK_SCRIPT)
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["PYTHONDONTWRITEBYTECODE"] = "1"
+    r = subprocess.run([sys.executable, str(script), str(ROOT), "8", str(ROOT / "profiles" / "r04_g_bench_driver_form.json")],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    assert len(lines[0]) < 4096
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and d["config"]["dist_backend"] == "gloo" and d["config"]["rccl_ranks"] == 0
+    w = d["config"]["weights_abs_sum_per_rank"]
+    assert w["min"] == w["max"] and w["min"] > 0
+    assert d["config"]["chunks_per_step"] == 512 and d["value"] > 0 and d["cpu_baseline"] is None
+    assert "bound" in d["config"]["cpu_affinity"]
