@@ -21,7 +21,7 @@ from .aggregation import BatchedOutputTail, DelayedAggregation
 from .clustering import OnlineSpeakerClustering
 from .embedding import OverlapAwareSpeakerEmbedding
 from .segmentation import SpeakerSegmentation
-from .utils import Binarize
+from .utils import Binarize, windows_batch
 
 
 def _latency(latency, step, duration):
@@ -124,9 +124,12 @@ class SpeakerDiarization(base.Pipeline):
     def __call__(self, waveforms: Sequence[SlidingWindowFeature]) -> Sequence[Tuple[Annotation, SlidingWindowFeature]]:
         batch_size = len(waveforms)
         assert batch_size >= 1, "Pipeline expected at least 1 input"
-        batch = torch.stack([torch.from_numpy(w.data) for w in waveforms])   # (batch, samples, channels)
         expected = int(np.rint(self.config.duration * self.config.sample_rate))
-        assert batch.shape[1] == expected, f"Expected {expected} samples per chunk, but got {batch.shape[1]}"
+        got = waveforms[0].data.shape[0]
+        assert all(w.data.shape[0] == got for w in waveforms), "chunks of different lengths in one batch"
+        assert got == expected, f"Expected {expected} samples per chunk, but got {got}"
+        # (batch, samples, channels) on the device, uploaded once for both blocks (blocks/utils.py)
+        batch = windows_batch(waveforms, self.config.device)
 
         segmentations = self.segmentation(batch)                 # (batch, frames, speakers), host
         embeddings = self.embedding(batch, segmentations)        # (batch, speakers, emb_dim), host

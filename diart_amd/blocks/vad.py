@@ -14,7 +14,7 @@ from . import base
 from .aggregation import DelayedAggregation
 from .diarization import _latency
 from .segmentation import SpeakerSegmentation
-from .utils import Binarize
+from .utils import Binarize, windows_batch
 
 
 def _repeat_label(label):
@@ -88,9 +88,11 @@ class VoiceActivityDetection(base.Pipeline):
 
     def __call__(self, waveforms: Sequence[SlidingWindowFeature]) -> Sequence[Tuple[Annotation, SlidingWindowFeature]]:
         assert len(waveforms) >= 1, "Pipeline expected at least 1 input"
-        batch = torch.stack([torch.from_numpy(w.data) for w in waveforms])
         expected = int(np.rint(self.config.duration * self.config.sample_rate))
-        assert batch.shape[1] == expected, f"Expected {expected} samples per chunk, but got {batch.shape[1]}"
+        got = waveforms[0].data.shape[0]
+        assert all(w.data.shape[0] == got for w in waveforms), "chunks of different lengths in one batch"
+        assert got == expected, f"Expected {expected} samples per chunk, but got {got}"
+        batch = windows_batch(waveforms, self.config.device)
         return self.finalise(waveforms, self.segmentation(batch))
 
     def finalise(self, waveforms: Sequence[SlidingWindowFeature], segmentations: torch.Tensor):

@@ -43,8 +43,9 @@ def test_bench_started_as_one_process_runs_two_ranks():
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["config"]["chunks_per_step"] == 128
     assert out["config"]["dist_backend"] == ("nccl" if two_gpus else "gloo")
-    ws = out["config"]["weights_abs_sum_per_rank"]
-    assert len(ws) == 2 and ws[0] == ws[1] > 0                        # identical weights on both ranks
+    ws = out["config"]["weights_abs_sum_per_rank"]                    # compact line: {min, max} over the ranks
+    assert ws["min"] == ws["max"] > 0                                 # identical weights on both ranks
+    assert out["config"]["rccl_ranks"] == (2 if two_gpus else 0) and len(lines[0]) < 4096
     assert "process group up" in r.stderr and out["value"] > 0
 
 

@@ -461,3 +461,31 @@ def test_eight_ranks_from_one_command_print_one_compact_line(tmp_path):
     assert w["min"] == w["max"] and w["min"] > 0
     assert d["config"]["chunks_per_step"] == 512 and d["value"] > 0 and d["cpu_baseline"] is None
     assert "bound" in d["config"]["cpu_affinity"]
+
+
+def test_windows_batch_span_detection_matches_torch_stack():
+    """blocks/utils.py: overlapping views of one buffer at a constant hop are recognised (one upload of the span,
+    a strided batch on the device); anything else falls back to torch.stack — identical values either way."""
+    import numpy as np
+    from diart_amd.blocks.utils import _common_span, windows_batch
+    from diart_amd.features import SlidingWindow, SlidingWindowFeature
+    rng = np.random.default_rng(0)
+    stream = rng.standard_normal(5000).astype(np.float32)
+    S, H = 800, 80
+    sw = lambda i: SlidingWindow(start=i * 0.5, duration=1 / 16000, step=1 / 16000)
+    views = [SlidingWindowFeature(stream[i * H:i * H + S, None], sw(i)) for i in range(12)]
+    span = _common_span([v.data for v in views])
+    assert span is not None
+    flat, hop, n = span
+    assert hop == H and n == S and flat.shape == (11 * H + S,) and np.array_equal(flat, stream[:11 * H + S])
+    want = torch.stack([torch.from_numpy(v.data) for v in views])
+    strided = torch.from_numpy(flat).as_strided((12, S, 1), (hop, 1, 1))
+    assert torch.equal(strided, want) and torch.equal(windows_batch(views), want)
+    # not views of one buffer / irregular hop / unaligned hop / copies: fall back
+    assert _common_span([v.data.copy() for v in views]) is None
+    assert _common_span([views[0].data, views[2].data, views[3].data]) is None
+    odd = [SlidingWindowFeature(stream[i * 81:i * 81 + S, None], sw(i)) for i in range(4)]
+    assert _common_span([v.data for v in odd]) is None and torch.equal(windows_batch(odd), torch.stack([torch.from_numpy(v.data) for v in odd]))
+    stereo = [SlidingWindowFeature(np.stack([stream[i * H:i * H + S]] * 2, 1), sw(i)) for i in range(3)]
+    assert _common_span([v.data for v in stereo]) is None
+    assert _common_span([views[0].data]) is None
