@@ -50,6 +50,8 @@ KERNELS = {
     # tile partials -> InstanceNorm scale / shift (exact-f32 path and DZ_FUSED_NORM=0 only: launch-bound)
     "finalize_norm": dict(mac=0, io=(10 * 64 * 2 + 2 * 64) * 4, w=0, bound="hbm"),
     "sinc_conv0": dict(mac=160_138_000, io=320_000 + 2658 * 80 * 4, w=128 * 96 * 4, bound="mfma_f32"),
+    # the first stage of BOTH networks in one launch (default precision; k_front.hip sinc_conv0_pair_kernel)
+    "sinc_conv0_pair": dict(mac=2 * 160_138_000, io=320_000 + 2 * 2658 * 80 * 4, w=2 * 192 * 256 * 2, bound="gemm"),
     "conv1_pool": dict(mac=63_696_000, io=(2658 * 80 + 884 * 64) * 4, w=64 * 416 * 4, bound="gemm"),
     "conv2_pool": dict(mac=15_840_000, io=(884 * 64 + 293 * 64) * 4, w=64 * 320 * 4, bound="gemm"),
     "lstm_proj0": dict(mac=F_SEG * 60 * 1024, io=F_SEG * (64 + 1024) * 4, w=1024 * 64 * 4, bound="gemm"),
@@ -87,7 +89,7 @@ def kernels_for(precision):
 
 
 # sinc_conv0 folds the (anti)symmetric FIR bank: 42 tiles x 192 frames x 96 columns x 128 taps
-EXECUTED_MAC = {"sinc_conv0": 42 * 192 * 96 * 128}
+EXECUTED_MAC = {"sinc_conv0": 42 * 192 * 96 * 128, "sinc_conv0_pair": 84 * 96 * 192 * 256}
 ALG_GFLOP_PER_CHUNK = 3.352   # 1.312 seg + 2.039 emb de-duplicated
 # Peaks from /opt/skills/guides/MI355X_MICROARCH.md (chip level, 256 CUs @ 2.4 GHz):
 PEAK_F16_MATRIX_TFLOPS = 2500.0  # v_mfma_f32_32x32x16_f16 / 16x16x32_f16, dense
@@ -139,6 +141,8 @@ def device_kernel(tag, precision):
             return sym, "mfma", PEAK_F16_MATRIX_TFLOPS / SPLIT_PRODUCTS, "TFLOP/s"
         pk = "false" if xenv("DZ_LSTM_PK", "1") == "0" else "true"      # packed-FMA template argument
         return f"lstm_rec_kernel<true, {lstm_chains_per_wg()}, {pk}>", "valu", PEAK_F32_VECTOR_TFLOPS, "TFLOP/s"
+    if tag == "sinc_conv0_pair":
+        return "sinc_conv0_pair_kernel", "mfma", PEAK_F16_MATRIX_TFLOPS / SPLIT_PRODUCTS, "TFLOP/s"
     if tag == "sinc_conv0" and split and xenv("DZ_CONV0_SPLIT", "1") != "0":
         return "sinc_conv0_h_kernel", "mfma", PEAK_F16_MATRIX_TFLOPS / SPLIT_PRODUCTS, "TFLOP/s"
     if k["bound"] == "mfma_f32" or not split:

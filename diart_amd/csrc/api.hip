@@ -106,9 +106,9 @@ static const char* kProfNames[PROF_TAGS] = {
     "stats_pool", "emb_linear", "l2norm", "osp", "powerset", "cdist", "lstm_proj0",
     // config 3 (ecapa_api.hip; DZ_T_ECAPA_* in dz_common.h)
     "ecapa_fbank", "ecapa_block0", "ecapa_wide1x1", "ecapa_res2net", "ecapa_se", "ecapa_asp", "ecapa_fc",
-    "", "", "", ""};
+    "sinc_conv0_pair", "", "", ""};
 enum { T_WAVE = 0, T_CONV0, T_FIN, T_CONV1, T_CONV2, T_PROJ, T_REC, T_MLP, T_CLS, T_TDNN1, T_TDNN2,
-       T_TDNN3, T_TDNN4, T_TDNN5, T_POOL, T_EMBLIN, T_L2, T_OSP, T_PSET, T_CDIST, T_PROJ0 };
+       T_TDNN3, T_TDNN4, T_TDNN5, T_POOL, T_EMBLIN, T_L2, T_OSP, T_PSET, T_CDIST, T_PROJ0, T_CONV0_PAIR = 28 };
 thread_local DzLaunchProf* dz_launch_prof = nullptr;
 thread_local int* dz_cur_oflag = nullptr;
 struct Prof {
@@ -328,11 +328,14 @@ static void sinc_out_norm(DzConvGemm& p, const dz_sincnet_weights& w, const Sinc
 // do not depend on the network) — NULL: compute them here.
 static int run_sincnet(const dz_sincnet_weights& w, const SincGeom& g, const SincScratch& s,
                        const float* wave, long long stride, int B, hipStream_t st,
-                       const float* ext_stats = nullptr) {
+                       const float* ext_stats = nullptr, bool ext_conv0 = false) {
     int rc;
     const float* stats = ext_stats ? ext_stats : s.stats;
-    if (!ext_stats)
+    // ext_conv0: y0 / part0 of these B windows are already (being) written on this stream's dependencies by
+    // dz_sinc_conv0_pair — the first stage of both networks in one launch
+    if (!ext_stats && !ext_conv0)
     { ProfScope ps(T_WAVE, B); if ((rc = dz_launch_wave_stats(wave, stride, B, g.S, s.stats, st))) return rc; }
+    if (!ext_conv0)
     { ProfScope ps(T_CONV0, B);
     rc = w.filt_split
              ? dz_launch_sinc_conv0_split(wave, stride, B, g.S, stats, 1, w.wav_gamma, w.wav_beta,
@@ -396,6 +399,7 @@ struct dz_seg {
     int Bm;
     bool pre;    // wide layers on k_gemm_pre.hip (activations travel as f16 hi/lo planes)
     const float* ext_stats;   // dz_seg_use_wave_stats: consumed (and cleared) by the next forward
+    int ext_conv0_B;          // dz_sinc_conv0_pair wrote y0 / part0 of this many chunks: consumed by the next forward
     char* arena;
     SincScratch ss;
     float *gx, *gx0, *h0, *h1, *m0, *m1, *logit;
@@ -437,6 +441,7 @@ extern "C" int dz_seg_create(dz_ctx* ctx, const dz_seg_weights* w, int max_batch
     dz_seg* s = new (std::nothrow) dz_seg;
     DZ_REQUIRE(s != nullptr, "dz_seg_create: out of memory");
     s->ctx = ctx; s->w = *w; s->g = g; s->Bm = max_batch; s->arena = nullptr; s->ext_stats = nullptr;
+    s->ext_conv0_B = 0;
     s->front_B = 0; s->ev_gx0_free = nullptr;
     DZ_HIP(hipEventCreateWithFlags(&s->ev_gx0_free, hipEventDisableTiming));
     s->pre = w->wih_split[1] && w->wih_split[2] && w->wih_split[3] &&
@@ -516,7 +521,11 @@ static int seg_forward(dz_seg* s, const float* d_wave, long long wave_stride, in
         if (phase == 1) DZ_HIP(hipStreamWaitEvent(st, s->ev_gx0_free, 0));   // (never recorded yet: no-op)
         const float* ext = s->ext_stats;
         s->ext_stats = nullptr;
-        if ((rc = run_sincnet(s->w.sinc, s->g, s->ss, d_wave, wave_stride, B, st, ext))) return rc;
+        const int pair_B = s->ext_conv0_B;
+        s->ext_conv0_B = 0;
+        DZ_REQUIRE(pair_B == 0 || pair_B == B, "dz_seg_forward: dz_sinc_conv0_pair ran for %d chunks, this call has %d",
+                   pair_B, B);
+        if ((rc = run_sincnet(s->w.sinc, s->g, s->ss, d_wave, wave_stride, B, st, ext, pair_B > 0))) return rc;
     }
 
     // 4 x { x-projection of both directions as one GEMM (N = 1024); persistent recurrence }.
@@ -623,6 +632,7 @@ struct dz_emb {
     int Bm, T[5];
     bool pre;    // tdnn2..5 on k_gemm_pre.hip (tdnn1 writes f16 hi/lo planes)
     const float* ext_stats;   // dz_emb_use_wave_stats: consumed (and cleared) by the next forward
+    int ext_conv0_B;          // dz_sinc_conv0_pair: see dz_seg
     char* arena;
     SincScratch ss;
     float *a, *b, *x5, *pooled, *parts, *ppart, *ps0;
@@ -666,6 +676,7 @@ extern "C" int dz_emb_create(dz_ctx* ctx, const dz_emb_weights* w, int max_batch
     dz_emb* e = new (std::nothrow) dz_emb;
     DZ_REQUIRE(e != nullptr, "dz_emb_create: out of memory");
     e->ctx = ctx; e->w = *w; e->g = g; e->Bm = max_batch; e->arena = nullptr; e->ext_stats = nullptr;
+    e->ext_conv0_B = 0;
     e->pending_B = 0; e->pending_in = nullptr;
     e->pre = w->tw_split[0] && w->tw_split[1] && w->tw_split[2] &&
              w->tw_split[3] && w->tw_split[4];
@@ -703,7 +714,10 @@ static int emb_frames(dz_emb* e, const float* d_wave, long long stride, int B, h
     int rc;
     const float* ext = e->ext_stats;
     e->ext_stats = nullptr;
-    if ((rc = run_sincnet(e->w.sinc, e->g, e->ss, d_wave, stride, B, st, ext))) return rc;
+    const int pair_B = e->ext_conv0_B;
+    e->ext_conv0_B = 0;
+    DZ_REQUIRE(pair_B == 0 || pair_B == B, "dz_emb_frames: dz_sinc_conv0_pair ran for %d chunks, this call has %d", pair_B, B);
+    if ((rc = run_sincnet(e->w.sinc, e->g, e->ss, d_wave, stride, B, st, ext, pair_B > 0))) return rc;
     const int cin[5] = {64, 512, 512, 512, 512};
     const int npad[5] = {512, 512, 512, 512, 1536};
     // Row pitch P = P2 for every activation.  tdnn1 normalises on load with per-chunk statistics, so
@@ -885,6 +899,33 @@ extern "C" int dz_wave_stats(dz_ctx* ctx, const float* d_wave, long long wave_st
     ProfScope ps(T_WAVE, batch);
     return dz_launch_wave_stats(d_wave, wave_stride, batch, num_samples, d_moments, (hipStream_t)stream);
 }
+// The first SincNet stage of BOTH networks in one launch (k_front.hip sinc_conv0_pair_kernel): writes y0 / part0
+// of the two handles; the next dz_seg_forward* / dz_emb_frames of each handle (same B, enqueued behind this launch:
+// the same stream, or one that waits for an event recorded after it) then starts at conv1.
+extern "C" int dz_sinc_conv0_pair(dz_seg* seg, dz_emb* emb, const float* d_wave, long long wave_stride, int batch,
+                                  const float* d_moments, const void* d_pair_planes, const float* d_pair_bsum,
+                                  void* stream) {
+    DZ_REQUIRE(seg && emb && d_moments && d_pair_planes && d_pair_bsum, "dz_sinc_conv0_pair: NULL argument");
+    DZ_REQUIRE(seg->ctx == emb->ctx, "dz_sinc_conv0_pair: the two handles belong to different contexts");
+    DZ_REQUIRE(batch >= 1 && batch <= seg->Bm && batch <= emb->Bm, "dz_sinc_conv0_pair: batch %d outside [1, %d]", batch,
+               seg->Bm < emb->Bm ? seg->Bm : emb->Bm);
+    DZ_REQUIRE(seg->g.S == emb->g.S && seg->g.nt0 == emb->g.nt0 && seg->g.P0 == emb->g.P0,
+               "dz_sinc_conv0_pair: the handles were created for different window lengths");
+    DZ_REQUIRE(seg->w.sinc.filt_split && emb->w.sinc.filt_split,
+               "dz_sinc_conv0_pair: both networks must be in the split-f16 precision (the exact-f32 path keeps one "
+               "launch per network)");
+    int rc;
+    if ((rc = check_wave("dz_sinc_conv0_pair", d_wave, wave_stride, seg->g.S))) return rc;
+    DZ_HIP(hipSetDevice(seg->ctx->device));
+    DzRangeScope range_scope(seg->ctx->oflag_dev);
+    { ProfScope ps(T_CONV0_PAIR, batch);
+      if ((rc = dz_launch_sinc_conv0_pair(d_wave, wave_stride, batch, seg->g.S, d_moments, d_pair_planes, d_pair_bsum,
+                                          seg->w.sinc.wav_gamma, emb->w.sinc.wav_gamma, seg->ss.y0, emb->ss.y0, seg->g.P0,
+                                          seg->ss.part0, emb->ss.part0, seg->g.nt0, (hipStream_t)stream)))
+          return rc; }
+    seg->ext_conv0_B = emb->ext_conv0_B = batch;
+    return 0;
+}
 extern "C" int dz_seg_use_wave_stats(dz_seg* seg, const float* d_moments) {
     DZ_REQUIRE(seg != nullptr, "dz_seg_use_wave_stats: NULL handle");
     seg->ext_stats = d_moments;
@@ -1061,6 +1102,22 @@ extern "C" int dz_k_sinc_conv0_split(dz_ctx* ctx, const float* d_wave, long long
                                       d_filt_split, d_y0, g.P0, d_partials, g.nt0, (hipStream_t)stream);
 }
 extern "C" int dz_k_conv0_split_ntile(int samples) { return sinc_geom(samples, true).nt0; }
+extern "C" int dz_k_sinc_conv0_pair(dz_ctx* ctx, const float* d_wave, long long stride, int batch, int samples,
+                                    const float* d_moments, const void* d_pair_planes, const float* d_pair_bsum,
+                                    float gamma_seg, float gamma_emb, float* d_y0_seg, float* d_y0_emb,
+                                    float* d_part_seg, float* d_part_emb, void* stream) {
+    DZ_REQUIRE(ctx && d_moments && d_pair_planes && d_pair_bsum && d_y0_seg && d_y0_emb && d_part_seg && d_part_emb,
+               "dz_k_sinc_conv0_pair: NULL argument");
+    const SincGeom g = sinc_geom(samples, true);
+    DZ_REQUIRE(batch >= 1 && g.F0 >= 3, "dz_k_sinc_conv0_pair: empty input");
+    int rc;
+    if ((rc = check_wave("dz_k_sinc_conv0_pair", d_wave, stride, samples))) return rc;
+    DZ_HIP(hipSetDevice(ctx->device));
+    DzRangeScope range_scope(ctx->oflag_dev);
+    return dz_launch_sinc_conv0_pair(d_wave, stride, batch, samples, d_moments, d_pair_planes, d_pair_bsum, gamma_seg,
+                                     gamma_emb, d_y0_seg, d_y0_emb, g.P0, d_part_seg, d_part_emb, g.nt0,
+                                     (hipStream_t)stream);
+}
 extern "C" int dz_k_finalize_norm(dz_ctx* ctx, const float* d_partials, int batch, int ntile,
                                   int channels, int frames, const float* d_gamma,
                                   const float* d_beta, float* d_scale, float* d_shift,

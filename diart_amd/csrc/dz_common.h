@@ -273,6 +273,11 @@ int dz_launch_sinc_conv0_split(const float* wave, long long stride, int B, int S
                                int stats_are_moments, float gamma, float beta, const void* filt_split,
                                float* y0, int P0, float* partials, int ntile, hipStream_t st);
 int dz_conv0_split_ntile(int F0);
+// the same stage of BOTH networks in one launch (160 filters, one split of the normalised samples; k_front.hip)
+int dz_launch_sinc_conv0_pair(const float* wave, long long stride, int B, int S, const float* moments,
+                              const void* pair_planes, const float* pair_bsum, float gamma_seg, float gamma_emb,
+                              float* y0_seg, float* y0_emb, int P0, float* part_seg, float* part_emb, int ntile,
+                              hipStream_t st);
 // partial (sum,sumsq) -> per (b,c) scale/shift of InstanceNorm1d(C, affine)
 int dz_launch_finalize_norm(const float* partials, int B, int ntile, int C, int T,
                             const float* gamma, const float* beta, float* scale, float* shift,

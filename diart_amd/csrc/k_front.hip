@@ -523,6 +523,236 @@ int dz_launch_sinc_conv0_split(const float* wave, long long stride, int B, int S
 }
 
 // ---------------------------------------------------------------------------
+// sinc_conv0_pair: the first SincNet stage of BOTH networks in one launch (round 5).
+//
+// The segmentation and the embedding network read the same window, and InstanceNorm1d(1) differs
+// between them only by its affine pair: with xh = (x - mean) * rstd,
+//     conv(gamma xh + beta)[c] = gamma * conv(xh)[c] + beta * sum_k filt[c][k]
+// so ONE split of xh serves both banks and (gamma, beta * sum) become an epilogue in front of the
+// |.|.  160 filters = 4 waves x 40: a wave owns three 16-filter blocks of v_mfma_f32_16x16x32_f16
+// (the third half empty: 48 slots, 83 % of the matrix work useful — the two separate launches padded
+// 80 to 96 as well, but ran three waves per workgroup, i.e. 2, 2, 1, 1 waves on the four SIMDs).
+// One workgroup of four waves per CU, ONE WAVE PER SIMD, up to 512 registers each: the bank
+// (48 slots x 256 taps x 2 planes) is 192 registers per lane, 18 independent accumulator chains
+// (3 frame blocks x 3 filter blocks x (main, cross)) keep a single wave's matrix pipe full.
+// Samples: the tile's four shifted f16 copies as in sinc_conv0_h (parked once for BOTH networks).
+// MFMA row r of a 16-row block carries pooled row pi(r) = 4 (r & 3) + (r >> 2), block bk = frames
+// 3 m + bk: MaxPool1d(3) is a maximum over the same register of three accumulators; copies start
+// 16 * (0, 0, 1, 2) bytes into their slots (at most 2-way conflicts in every ds_read_b128 lane group,
+// brute-forced against the group lists of MI355X_MICROARCH.md).
+// Outputs: y0 / partials of each network, in the layout sinc_conv0_h writes (conv_pool_h consumes).
+// ---------------------------------------------------------------------------
+typedef float cp_f32x4 __attribute__((ext_vector_type(4)));
+#define CP_SLOTS 192
+__device__ __forceinline__ int cp_copy_base(int c) { return c * CH_CP + 16 * ((0x2100 >> (4 * c)) & 15); }
+
+__global__ __launch_bounds__(256, 1) void sinc_conv0_pair_kernel(
+    const float* __restrict__ wave, long long stride, int S, const float* __restrict__ stats,
+    const unsigned short* __restrict__ fsp, const float* __restrict__ bsum, float gamma_seg, float gamma_emb,
+    float* __restrict__ y0_seg, float* __restrict__ y0_emb, int P0, float* __restrict__ part_seg,
+    float* __restrict__ part_emb, int ntile, int total, int* __restrict__ oflag) {
+    __shared__ __attribute__((aligned(256))) char lds_all[2 * CH_LDS + 1536 * 4 + 16];
+    char (*xs2)[CH_LDS] = reinterpret_cast<char (*)[CH_LDS]>(lds_all);
+    float* raw = reinterpret_cast<float*>(lds_all + 2 * CH_LDS);
+    float (*stat_s)[2] = reinterpret_cast<float (*)[2]>(lds_all + 2 * CH_LDS + 1536 * 4);
+    const int tid = threadIdx.x;
+    const int w = tid >> 6, l = tid & 63, n = l & 15, q = l >> 4;
+    const int wg = dz_xcd_contiguous(blockIdx.x, gridDim.x);
+    const int t_begin = (int)((long long)wg * total / gridDim.x);
+    const int t_end = (int)((long long)(wg + 1) * total / gridDim.x);
+    if (t_begin >= t_end) return;
+    const int b_first = t_begin / ntile;
+    if (tid < 2) {
+        const int bb = b_first + tid;
+        float mean = 0.f, rstd = 1.f;
+        if (bb * ntile < t_end) dz_ws_combine(stats, bb, S, &mean, &rstd);
+        stat_s[tid][0] = mean;
+        stat_s[tid][1] = rstd;
+    }
+    // ---- B fragments: slot 48 w + 16 j + n, taps 32 ks + 8 q .. + 7, hi and lo planes -----------------
+    ch_f16x8 bh[3][8], bl[3][8];
+    float bs[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const int slot = 48 * w + 16 * j + n;
+        const unsigned short* row = fsp + (long long)slot * 256 + 8 * q;
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+            bh[j][ks] = *reinterpret_cast<const ch_f16x8*>(row + 32 * ks);
+            bl[j][ks] = *reinterpret_cast<const ch_f16x8*>(row + CP_SLOTS * 256 + 32 * ks);
+        }
+        bs[j] = bsum[slot];
+    }
+    const float gam = w < 2 ? gamma_seg : gamma_emb;
+    float* __restrict__ y0 = w < 2 ? y0_seg : y0_emb;
+    float* __restrict__ partials = w < 2 ? part_seg : part_emb;
+    const int chb = 40 * (w & 1);
+    __syncthreads();
+
+    // raw samples of the NEXT tile by LDS-DMA, one dword per lane: wave w owns floats [384 w, 384 w + 384)
+    // of the tile's 1536-float window and later parks exactly those (its own vmcnt, no barrier);
+    // samples past the end of the chunk read as zeros (buffer bounds check)
+    auto fetch = [&](int t) {
+        const int bb = t / ntile, tile = t - bb * ntile;
+        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)(wave + (long long)bb * stride), 0, (unsigned)S * 4u, 0x00020000);
+        const int voff = (tile * (CH_FR * 10) + 384 * w + l) * 4;
+#pragma unroll
+        for (int i = 0; i < 6; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(
+                rsrc, (__attribute__((address_space(3))) void*)(raw + 384 * w + 64 * i), 4, voff + 256 * i, 0, 0, 0);
+    };
+    float amax = 0.f;
+    auto park = [&](int t, char* xs) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's six pieces have landed
+        const int bb = t / ntile, tile = t - bb * ntile;
+        const float mean = stat_s[bb - b_first][0], rstd = stat_s[bb - b_first][1];
+        const int s0 = tile * (CH_FR * 10);
+#pragma unroll
+        for (int it = 0; it < 3; ++it) {
+            const int j = 384 * w + 2 * (l + 64 * it), sidx = s0 + j;
+            if (j < CH_NS + 6) {
+                const float2 pvq = *reinterpret_cast<const float2*>(raw + j);
+                f32x2 x = {sidx < S ? (pvq.x - mean) * rstd : 0.f, sidx + 1 < S ? (pvq.y - mean) * rstd : 0.f};
+                amax = fmaxf(amax, fmaxf(fabsf(x[0]), fabsf(x[1])));
+                x[0] = __builtin_amdgcn_fmed3f(x[0], -65504.f, 65504.f);
+                x[1] = __builtin_amdgcn_fmed3f(x[1], -65504.f, 65504.f);
+                const ch_f16x2 hi = __builtin_convertvector(x, ch_f16x2);
+                const ch_f16x2 lo =
+                    __builtin_convertvector((x - __builtin_convertvector(hi, f32x2)) * 2048.f, ch_f16x2);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const int idx = j - 2 * c;            // copy_c[idx] = x[idx + 2c]
+                    if (idx >= 0 && idx < CH_NS) {
+                        char* d = xs + cp_copy_base(c) + 2 * idx;
+                        *reinterpret_cast<ch_f16x2*>(d) = hi;
+                        *reinterpret_cast<ch_f16x2*>(d + CH_PL) = lo;
+                    }
+                }
+            }
+        }
+    };
+
+    // A rows: lane (n, q) supplies frame 3 (16 gm + pi(n)) + bk, taps 8 q .. + 7 of every k-step
+    int aoff[3];
+#pragma unroll
+    for (int bk = 0; bk < 3; ++bk) {
+        const int f = 3 * (((n & 3) << 2) | (n >> 2)) + bk, c = f & 3;
+        aoff[bk] = cp_copy_base(c) + 2 * (10 * f - 2 * c + 8 * q);
+    }
+
+    fetch(t_begin);
+    park(t_begin, xs2[0]);
+    __syncthreads();
+    for (int t = t_begin; t < t_end; ++t) {
+        const char* xs = xs2[(t - t_begin) & 1];
+        if (t + 1 < t_end) fetch(t + 1);
+        const int bb = t / ntile, tile = t - bb * ntile;
+        float sum[3] = {0.f, 0.f, 0.f}, ssq[3] = {0.f, 0.f, 0.f};
+#pragma unroll 1
+        for (int gm = 0; gm < 2; ++gm) {
+            cp_f32x4 pm[3];
+            // the three frame blocks of a pooled-row group one after the other: six accumulator chains (3 filter
+            // blocks x (main, cross)) are live at a time, the maximum over bk accumulates in pm (more live
+            // accumulators made the allocator shuffle results through AGPRs behind s_nop stalls).  The A
+            // fragments of step it + 1 are requested before the nine MFMAs of step it (one wave per SIMD: nobody
+            // else hides the LDS latency).
+            const char* const ag = xs + 960 * gm;
+            ch_f16x8 ah = *reinterpret_cast<const ch_f16x8*>(ag + aoff[0]);
+            ch_f16x8 al = *reinterpret_cast<const ch_f16x8*>(ag + aoff[0] + CH_PL);
+            cp_f32x4 accm[3], accx[3];
+#pragma unroll
+            for (int it = 0; it < 24; ++it) {
+                const int bk = it >> 3, ks = it & 7;
+                if (ks == 0) {
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) accm[j] = accx[j] = cp_f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+                ch_f16x8 nh = ah, nl = al;
+                if (it + 1 < 24) {
+                    const char* np = ag + aoff[(it + 1) >> 3] + 64 * ((it + 1) & 7);
+                    nh = *reinterpret_cast<const ch_f16x8*>(np);
+                    nl = *reinterpret_cast<const ch_f16x8*>(np + CH_PL);
+                }
+#pragma unroll
+                for (int j = 0; j < 3; ++j) accx[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh[j][ks], accx[j], 0, 0, 0);
+#pragma unroll
+                for (int j = 0; j < 3; ++j) accm[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh[j][ks], accm[j], 0, 0, 0);
+#pragma unroll
+                for (int j = 0; j < 3; ++j) accx[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl[j][ks], accx[j], 0, 0, 0);
+                ah = nh;
+                al = nl;
+                if (ks == 7) {       // |gamma conv + beta sum|, MaxPool1d(3) over bk
+#pragma unroll
+                    for (int j = 0; j < 3; ++j)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const float v = fabsf(gam * (accm[j][i] + accx[j][i] * (1.f / 2048.f)) + bs[j]);
+                            pm[j][i] = bk == 0 ? v : fmaxf(pm[j][i], v);
+                        }
+                }
+            }
+            // The next tile's samples (this wave's share of them) BEFORE the last result stores: parking waits for
+            // the wave's LDS-DMA with vmcnt(0), which must not also wait for stores that were just issued (one wave
+            // per SIMD: nobody hides it).  Here the only stores in flight are those of gm = 0, a block of MFMAs old.
+            if (gm == 1 && t + 1 < t_end) park(t + 1, xs2[(t + 1 - t_begin) & 1]);
+            // pooled rows 16 gm + 4 i + q, channel chb + 16 j + n
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const int chl = 16 * j + n;
+                if (chl < 40) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int p = tile * 32 + 16 * gm + 4 * i + q;
+                        if (p < P0) {
+                            y0[((long long)bb * P0 + p) * 80 + chb + chl] = pm[j][i];
+                            sum[j] += pm[j][i];
+                            ssq[j] += pm[j][i] * pm[j][i];
+                        }
+                    }
+                }
+            }
+        }
+        // InstanceNorm partials of (chunk, tile, channel): the four lane groups q hold 8 pooled rows each
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            float s1 = sum[j], s2 = ssq[j];
+            s1 += __shfl_xor(s1, 16, 64);
+            s2 += __shfl_xor(s2, 16, 64);
+            s1 += __shfl_xor(s1, 32, 64);
+            s2 += __shfl_xor(s2, 32, 64);
+            const int chl = 16 * j + n;
+            if (q == 0 && chl < 40) {
+                float* pp = partials + (((long long)bb * ntile + tile) * 80 + chb + chl) * 2;
+                pp[0] = s1;
+                pp[1] = s2;
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    }
+    dz_flag_range(oflag, amax);
+}
+
+// fsp: f16 planes [2][192][256] of the PAIR bank (slot 48 w + i = filter 40 w + i of seg | emb, i < 40; the other
+// slots zero; weights.py pack_conv0_pair); bsum[192] = beta_net * sum_k filt[slot][k]; ntile = dz_conv0_split_ntile(F0)
+int dz_launch_sinc_conv0_pair(const float* wave, long long stride, int B, int S, const float* moments,
+                              const void* fsp, const float* bsum, float gamma_seg, float gamma_emb, float* y0_seg,
+                              float* y0_emb, int P0, float* part_seg, float* part_emb, int ntile, hipStream_t st) {
+    const int total = ntile * B;
+    static const int cus = [] {
+        int dev = 0, n = 256;
+        if (hipGetDevice(&dev) == hipSuccess) hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+        return n > 0 ? n : 256;
+    }();
+    const int grid = total < cus ? total : cus;        // one workgroup (one wave per SIMD) per CU
+    DZ_LAUNCH(sinc_conv0_pair_kernel, dim3(grid), dim3(256), 0, st, wave, stride, S, moments,
+              reinterpret_cast<const unsigned short*>(fsp), bsum, gamma_seg, gamma_emb, y0_seg, y0_emb, P0, part_seg,
+              part_emb, ntile, total, dz_cur_oflag);
+    DZ_HIP(hipGetLastError());
+    return 0;
+}
+
+// ---------------------------------------------------------------------------
 // finalize_norm: fixed-order (deterministic) reduction of the tile partials in fp64.
 // scale = gamma * rstd, shift = beta - mean * scale  (InstanceNorm1d, eps 1e-5, biased var)
 // ---------------------------------------------------------------------------

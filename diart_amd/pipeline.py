@@ -242,6 +242,14 @@ class StreamBatch:
         self.streams_a, self.streams_b = self.lanes[0]["a"], self.lanes[0]["b"]
         self.stream_a, self.stream_b = self.streams_a[0], self.streams_b[0]
         self.num_hip_streams = self.depth * self.seg_split + self.emb_split * (1 if self.shared_emb else self.depth)
+        # The first SincNet stage of BOTH networks in one launch (dz_sinc_conv0_pair, default precision: one split
+        # of the normalised window, 160 filters, one parking of the samples): on the lane's first segmentation
+        # stream, the embedding stream waits for it.  Not with sub-batches / the front-half stream (experiments).
+        self.conv0_pair = (_lib.exp_env("DZ_CONV0_PAIR", "1") != "0" and self.shared_stats
+                           and getattr(self.seg, "precision", "") == "f16x3" and getattr(self.emb, "precision", "") == "f16x3"
+                           and self.seg_split == 1 and self.emb_split == 1 and not self.seg_front and not self._ablate
+                           and hasattr(self.emb, "_state") and type(self.emb).__name__ == "HipEmbedding")
+        self._pair = None                                  # PackedConv0Pair, built at the first launch
         self._pending: List[dict] = []                     # launched, pooling not enqueued yet
         # where finish() spends its time: waiting for the GPU vs clustering + output tail on the host
         self.host_seconds = {"wait": 0.0, "work": 0.0}
@@ -291,7 +299,8 @@ class StreamBatch:
                  ev_front=[torch.cuda.Event() for _ in range(self.seg_split)],
                  ev_emb=[torch.cuda.Event() for _ in range(self.emb_split - 1)],
                  ev_frames=[torch.cuda.Event() for _ in range(self.emb_split)],
-                 ev_in=torch.cuda.Event(), done=torch.cuda.Event(blocking=self.blocking_wait))
+                 ev_in=torch.cuda.Event(), ev_conv0=torch.cuda.Event(),
+                 done=torch.cuda.Event(blocking=self.blocking_wait))
         self._slots.append(s)
         return s
 
@@ -407,6 +416,16 @@ class StreamBatch:
             _lib.check(lib.dz_wave_stats(self._ctx, base, stride, N, S, stats.data_ptr(), a0.cuda_stream),
                        "dz_wave_stats")
             slot["ev_in"].record(a0)
+        pair = self.conv0_pair and stats is not None
+        if pair:
+            if self._pair is None:
+                from .weights import PackedConv0Pair
+                self._pair = PackedConv0Pair(self.seg._state, self.emb._state, self.device)
+            a0 = lane["a"][0]
+            _lib.check(lib.dz_sinc_conv0_pair(hsegs[0], hembs[0], base, stride, N, stats.data_ptr(),
+                                              self._pair.planes.data_ptr(), self._pair.bsum.data_ptr(), a0.cuda_stream),
+                       "dz_sinc_conv0_pair")
+            slot["ev_conv0"].record(a0)
         for j, ((i0, i1), h, a, ev) in enumerate(zip(sa, hsegs, lane["a"], slot["ev_seg"])):
             a.wait_event(slot["ev_in"])
             if i1 == i0:                                 # fewer rows than sub-batches
@@ -436,7 +455,7 @@ class StreamBatch:
                        "dz_seg_forward_osp")
             ev.record(a)
         for (i0, i1), h, b, ev in zip(sb, hembs, lane["b"], slot["ev_frames"]):
-            b.wait_event(slot["ev_in"])
+            b.wait_event(slot["ev_conv0"] if pair else slot["ev_in"])
             if i1 > i0 and self._ablate != "noemb":
                 if stats is not None:
                     _lib.check(lib.dz_emb_use_wave_stats(h, stats[i0:].data_ptr()), "dz_emb_use_wave_stats")

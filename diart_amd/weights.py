@@ -258,6 +258,33 @@ def _pack_sincnet(sd: Dict[str, torch.Tensor], pk: _Packed, prefix: str = "sincn
     return w
 
 
+class PackedConv0Pair:
+    """Operands of ``dz_sinc_conv0_pair`` (csrc/k_front.hip): the sinc banks of the segmentation and the embedding
+    network as ONE f16x3 bank of 4 x 48 slots — wave ``w`` of the kernel owns slots ``48 w .. 48 w + 47``, of which
+    the first 40 hold filters ``40 w .. 40 w + 39`` of (seg 0..79 | emb 0..79) and the rest are zero — plus, per
+    slot, ``beta_net * sum_k filt[k]``: with xh the un-affine InstanceNorm1d(1) of the window,
+    ``conv(gamma xh + beta) = gamma conv(xh) + beta sum(filt)``, so one split of ``xh`` serves both networks."""
+
+    def __init__(self, seg_sd: Dict[str, torch.Tensor], emb_sd: Dict[str, torch.Tensor], device: torch.device,
+                 seg_prefix: str = "sincnet.", emb_prefix: str = "sincnet."):
+        banks, betas = [], []
+        for sd, prefix in ((seg_sd, seg_prefix), (emb_sd, emb_prefix)):
+            g = lambda k: sd[prefix + k].detach().cpu()
+            filt = sinc_filters(g("conv1d.0.filterbank.low_hz_"), g("conv1d.0.filterbank.band_hz_"),
+                                g("conv1d.0.filterbank.window_"), g("conv1d.0.filterbank.n_"))
+            assert filt.shape == (80, 251)
+            banks.append(filt)
+            betas.append(float(g("wav_norm1d.bias").reshape(-1)[0]))
+        full = torch.cat(banks, 0)                                   # (160, 251): seg | emb
+        slots = torch.zeros(192, 256, dtype=torch.float32)
+        bsum = torch.zeros(192, dtype=torch.float64)
+        for w in range(4):
+            slots[48 * w: 48 * w + 40, :251] = full[40 * w: 40 * w + 40]
+            bsum[48 * w: 48 * w + 40] = betas[w // 2] * full[40 * w: 40 * w + 40].double().sum(1)
+        self.planes = split_f16(slots, "sinc filter bank (pair)").to(device)      # int16 [2? see split_f16][192][256]
+        self.bsum = bsum.float().to(device)
+
+
 class PackedSegmentation:
     """``dz_seg_weights`` + the tensors behind it."""
 

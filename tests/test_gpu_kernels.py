@@ -130,6 +130,66 @@ def test_sinc_conv0_split(gpu, S):
     assert torch.allclose(ps[..., 1], (ref.double() ** 2).sum(2), rtol=1e-5)
 
 
+@pytest.mark.parametrize("S", [80000, 40000, 2661])
+def test_sinc_conv0_pair(gpu, S):
+    """Round 5: the first SincNet stage of BOTH networks in one launch (k_front.hip sinc_conv0_pair_kernel: one
+    split of the un-affine normalised window, the affine pair folded into the epilogue, 4 waves x 40 filters on
+    v_mfma_f32_16x16x32_f16).  Each network's y0 / partials against the torch restatement at the tolerances of the
+    one-network kernel, and against that kernel itself."""
+    from diart_amd.synth import synth_embedding_state, synth_segmentation_state, synth_stream
+    from diart_amd.weights import PackedConv0Pair, _pad2, sinc_filters, split_f16
+    seg_sd, emb_sd = synth_segmentation_state(), synth_embedding_state()
+    seg_sd = dict(seg_sd); emb_sd = dict(emb_sd)
+    # affine pairs that differ between the networks and are far from (1, 0)
+    seg_sd["sincnet.wav_norm1d.weight"], seg_sd["sincnet.wav_norm1d.bias"] = torch.tensor([1.3]), torch.tensor([-0.05])
+    emb_sd["sincnet.wav_norm1d.weight"], emb_sd["sincnet.wav_norm1d.bias"] = torch.tensor([-0.7]), torch.tensor([0.4])
+    pair = PackedConv0Pair(seg_sd, emb_sd, gpu)
+    B = 3
+    wave = synth_stream(5, 8.0)
+    x = torch.stack([torch.from_numpy(wave[i * 8000: i * 8000 + S].copy()) for i in range(B)])
+    x[1] *= 25.0
+    lib = _lib.load()
+    pad = torch.zeros(B, (S + 3) // 4 * 4 + 64)
+    pad[:, :S] = x
+    d = pad.to(gpu)
+    mom = torch.empty(B, lib.dz_wave_stats_floats(), device=gpu)
+    _lib.check(lib.dz_wave_stats(_ctx(gpu), d.data_ptr(), d.stride(0), B, S, mom.data_ptr(), None), "dz_wave_stats")
+    st = torch.empty(B, 2, device=gpu)
+    _lib.check(lib.dz_k_wave_stats(_ctx(gpu), d.data_ptr(), d.stride(0), B, S, st.data_ptr(), None))
+    nt = lib.dz_k_conv0_split_ntile(S)
+    P0 = ((S - 251) // 10 + 1) // 3
+    y = [torch.full((B, P0, 80), float("nan"), device=gpu) for _ in range(2)]
+    part = [torch.full((B, nt, 80, 2), float("nan"), device=gpu) for _ in range(2)]
+    gam = [1.3, -0.7]
+    bet = [-0.05, 0.4]
+    _lib.check(lib.dz_k_sinc_conv0_pair(_ctx(gpu), d.data_ptr(), d.stride(0), B, S, mom.data_ptr(), pair.planes.data_ptr(),
+                                        pair.bsum.data_ptr(), gam[0], gam[1], y[0].data_ptr(), y[1].data_ptr(),
+                                        part[0].data_ptr(), part[1].data_ptr(), None), "dz_k_sinc_conv0_pair")
+    _sync()
+    _lib.range_check(gpu.index or 0)
+    for k, sd in enumerate((seg_sd, emb_sd)):
+        p = "sincnet.conv1d.0.filterbank."
+        filt = sinc_filters(sd[p + "low_hz_"], sd[p + "band_hz_"], sd[p + "window_"], sd[p + "n_"])
+        xn = F.instance_norm(x[:, None, :].double()) * gam[k] + bet[k]
+        ref = F.max_pool1d(F.conv1d(xn, filt.double()[:, None, :], stride=10).abs(), 3, 3)
+        assert ref.shape[2] == P0
+        got = y[k].cpu().permute(0, 2, 1)
+        assert not torch.isnan(got).any(), k
+        assert _rel(got, ref.float()) < 2e-5, (k, _rel(got, ref.float()))
+        ps = part[k].cpu().double().sum(1)
+        assert not torch.isnan(ps).any()
+        assert torch.allclose(ps[..., 0], ref.sum(2), rtol=1e-5)
+        assert torch.allclose(ps[..., 1], (ref ** 2).sum(2), rtol=1e-5)
+        # the one-network kernel on the same inputs (it splits gamma xh + beta instead of xh: last-bits differences)
+        fs = split_f16(_pad2(filt, 96, 256)).to(gpu)
+        y1 = torch.full((B, P0, 80), float("nan"), device=gpu)
+        p1 = torch.full((B, nt, 80, 2), float("nan"), device=gpu)
+        _lib.check(lib.dz_k_sinc_conv0_split(_ctx(gpu), d.data_ptr(), d.stride(0), B, S, st.data_ptr(), gam[k], bet[k],
+                                             fs.data_ptr(), y1.data_ptr(), p1.data_ptr(), None))
+        _sync()
+        assert _rel(y[k].cpu(), y1.cpu()) < 5e-6, (k, _rel(y[k].cpu(), y1.cpu()))
+
+
 # --------------------------------------------------------------------------- #
 def _run_convgemm(gpu, X, W, bias, *, taps, dil, epi, Npad, Nstore, Kpad, e0=None, e1=None,
                   nscale=None, nshift=None, Tstore=None, ldy=None, ksplit=0, split=False):
