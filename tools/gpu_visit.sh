@@ -70,6 +70,19 @@ kbench)
 files)       # config 4 shape on one GPU (16 files, AMI hyper-parameters), and the one-file-at-a-time loop for comparison
   timeout -s KILL 300 python tools/benchmark_files.py --files 16 --seconds 600 --ami-hparams --workdir $OUT/bf16 2>&1 | tail -1 | cut -c1-400 | tee $OUT/file_benchmark_config4.json
   rm -rf $OUT/bf16 ;;
+ktest)       # quick: the kernel tests of the files named in KTEST (default: conv0 tests), then the conv0 lines of kbench
+  timeout -s KILL 600 python -m pytest ${KTEST:-tests/test_gpu_kernels.py -k conv0} -q -m gpu -p no:cacheprovider -x 2>&1 | grep -v amdgpu.ids | tail -15
+  timeout -s KILL 300 python tools/kbench.py --only ${KONLY:-sinc_conv0_split,sinc_conv0_pair} 2>&1 | grep -v amdgpu.ids | grep " us " | cut -c1-100 ;;
+ab)          # same-visit A/B of bench.py (200 steps, headline pass only) over environment settings: AB_A / AB_B, e.g.
+             # AB_A="DZ_EXPERIMENTS=1 DZ_CONV0_PAIR=0" AB_B="DZ_EXPERIMENTS=1"; alternating, ${AB_N:-2} rounds
+  for i in $(seq 1 ${AB_N:-2}); do
+    for arm in A B; do
+      if [ $arm = A ]; then E="$AB_A"; else E="$AB_B"; fi
+      env $E timeout -s KILL 300 python bench.py --steps ${AB_STEPS:-200} --warmup 10 --pmc off --no-cpu-baseline --no-rehearsal --no-exact-f32 --no-host-pass \
+        --details $OUT/ab_${arm}_${i}_details.json > $OUT/ab_${arm}_$i.json 2> $OUT/ab_${arm}_$i.err
+      echo "$arm$i [$E] $(python -c "import json,sys; d=json.load(open('$OUT/ab_${arm}_$i.json')); print(d['value'], d['ms_per_step'])" 2>&1 | tail -1)"
+    done
+  done ;;
 collect)     # LOCAL: judged copies
   for f in bench_driver.json bench_driver_details.json bench_200.json kernels_events_bench_run.json kernel_stats_f16x3.md kernel_stats_f32.md \
            rocprofv3_kernel_stats_f16x3.csv rocprofv3_kernel_stats_f32.csv kernels_events_rocprof_run_f16x3.json kernels_events_rocprof_run_f32.json \
