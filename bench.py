@@ -81,6 +81,8 @@ def kernels_for(precision):
     tile in LDS and writes per-tile weighted moments (k_gemm_pre.hip pooled epilogue), and the `stats_pool`
     tag is the small kernel that merges them (pool_combine)."""
     k = {n: dict(v) for n, v in KERNELS.items()}
+    if not EXPERIMENTS:
+        k.pop("sinc_conv0_pair", None)               # (the pair launch exists in the experiments build only)
     if precision == "f16x3" and os.environ.get("DZ_POOL_FUSE", "1") != "0":
         moments = POOL_PIECES * 3 * 1536 * 2 * 4
         k["tdnn5"]["io"] = F_SEG * 512 * 4 + moments + 3 * F_SEG * 4

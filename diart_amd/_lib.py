@@ -86,7 +86,6 @@ SIGNATURES = {
     "dz_wave_stats": (C.c_int, [vp, vp, C.c_longlong, C.c_int, C.c_int, vp, vp]),
     "dz_seg_use_wave_stats": (C.c_int, [vp, vp]),
     "dz_emb_use_wave_stats": (C.c_int, [vp, vp]),
-    "dz_sinc_conv0_pair": (C.c_int, [vp, vp, vp, C.c_longlong, C.c_int, vp, vp, vp, vp]),
     "dz_emb_pool": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]),
     "dz_emb_destroy": (C.c_int, [vp]),
     "dz_ecapa_frames_for": (C.c_int, [C.c_int]),
@@ -151,8 +150,6 @@ SIGNATURES = {
     "dz_k_sinc_conv0_split": (C.c_int, [vp, vp, C.c_longlong, C.c_int, C.c_int, vp, C.c_float,
                                         C.c_float, vp, vp, vp, vp]),
     "dz_k_conv0_split_ntile": (C.c_int, [C.c_int]),
-    "dz_k_sinc_conv0_pair": (C.c_int, [vp, vp, C.c_longlong, C.c_int, C.c_int, vp, vp, vp, C.c_float, C.c_float, vp, vp,
-                                       vp, vp, vp]),
     "dz_k_finalize_norm": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp]),
     "dz_k_lstm": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, vp]),
     "dz_k_lstm_mfma": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
@@ -168,6 +165,9 @@ EXPERIMENT_SIGNATURES = {
     "dz_k_gemm_g2": (C.c_int, [vp, vp, C.c_int, vp]),
     "dz_k_gemm_g3": (C.c_int, [vp, vp, C.c_int, vp]),
     "dz_k_conv_pool_debug": (C.c_int, [vp]),
+    "dz_sinc_conv0_pair": (C.c_int, [vp, vp, vp, C.c_longlong, C.c_int, vp, vp, vp, vp]),
+    "dz_k_sinc_conv0_pair": (C.c_int, [vp, vp, C.c_longlong, C.c_int, C.c_int, vp, vp, vp, C.c_float, C.c_float, vp, vp,
+                                       vp, vp, vp]),
 }
 
 

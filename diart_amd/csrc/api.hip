@@ -899,6 +899,7 @@ extern "C" int dz_wave_stats(dz_ctx* ctx, const float* d_wave, long long wave_st
     ProfScope ps(T_WAVE, batch);
     return dz_launch_wave_stats(d_wave, wave_stride, batch, num_samples, d_moments, (hipStream_t)stream);
 }
+#ifdef DZ_EXPERIMENTS
 // The first SincNet stage of BOTH networks in one launch (k_front.hip sinc_conv0_pair_kernel): writes y0 / part0
 // of the two handles; the next dz_seg_forward* / dz_emb_frames of each handle (same B, enqueued behind this launch:
 // the same stream, or one that waits for an event recorded after it) then starts at conv1.
@@ -926,6 +927,7 @@ extern "C" int dz_sinc_conv0_pair(dz_seg* seg, dz_emb* emb, const float* d_wave,
     seg->ext_conv0_B = emb->ext_conv0_B = batch;
     return 0;
 }
+#endif  // DZ_EXPERIMENTS
 extern "C" int dz_seg_use_wave_stats(dz_seg* seg, const float* d_moments) {
     DZ_REQUIRE(seg != nullptr, "dz_seg_use_wave_stats: NULL handle");
     seg->ext_stats = d_moments;
@@ -1102,6 +1104,7 @@ extern "C" int dz_k_sinc_conv0_split(dz_ctx* ctx, const float* d_wave, long long
                                       d_filt_split, d_y0, g.P0, d_partials, g.nt0, (hipStream_t)stream);
 }
 extern "C" int dz_k_conv0_split_ntile(int samples) { return sinc_geom(samples, true).nt0; }
+#ifdef DZ_EXPERIMENTS
 extern "C" int dz_k_sinc_conv0_pair(dz_ctx* ctx, const float* d_wave, long long stride, int batch, int samples,
                                     const float* d_moments, const void* d_pair_planes, const float* d_pair_bsum,
                                     float gamma_seg, float gamma_emb, float* d_y0_seg, float* d_y0_emb,
@@ -1118,6 +1121,7 @@ extern "C" int dz_k_sinc_conv0_pair(dz_ctx* ctx, const float* d_wave, long long 
                                      gamma_emb, d_y0_seg, d_y0_emb, g.P0, d_part_seg, d_part_emb, g.nt0,
                                      (hipStream_t)stream);
 }
+#endif  // DZ_EXPERIMENTS
 extern "C" int dz_k_finalize_norm(dz_ctx* ctx, const float* d_partials, int batch, int ntile,
                                   int channels, int frames, const float* d_gamma,
                                   const float* d_beta, float* d_scale, float* d_shift,

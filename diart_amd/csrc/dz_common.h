@@ -273,7 +273,8 @@ int dz_launch_sinc_conv0_split(const float* wave, long long stride, int B, int S
                                int stats_are_moments, float gamma, float beta, const void* filt_split,
                                float* y0, int P0, float* partials, int ntile, hipStream_t st);
 int dz_conv0_split_ntile(int F0);
-// the same stage of BOTH networks in one launch (160 filters, one split of the normalised samples; k_front.hip)
+// the same stage of BOTH networks in one launch (160 filters, one split of the normalised samples; k_front.hip;
+// experiments build only)
 int dz_launch_sinc_conv0_pair(const float* wave, long long stride, int B, int S, const float* moments,
                               const void* pair_planes, const float* pair_bsum, float gamma_seg, float gamma_emb,
                               float* y0_seg, float* y0_emb, int P0, float* part_seg, float* part_emb, int ntile,

@@ -522,6 +522,7 @@ int dz_launch_sinc_conv0_split(const float* wave, long long stride, int B, int S
     return 0;
 }
 
+#ifdef DZ_EXPERIMENTS
 // ---------------------------------------------------------------------------
 // sinc_conv0_pair: the first SincNet stage of BOTH networks in one launch (round 5).
 //
@@ -541,6 +542,14 @@ int dz_launch_sinc_conv0_split(const float* wave, long long stride, int B, int S
 // 16 * (0, 0, 1, 2) bytes into their slots (at most 2-way conflicts in every ds_read_b128 lane group,
 // brute-forced against the group lists of MI355X_MICROARCH.md).
 // Outputs: y0 / partials of each network, in the layout sinc_conv0_h writes (conv_pool_h consumes).
+//
+// EXPERIMENTS BUILD ONLY (DZ_CONV0_PAIR=1).  Measured on MI355X, 64 chunks (profiles/r05c_*): results equal to the
+// two one-network launches (tests/test_gpu_kernels.py::test_sinc_conv0_pair), but 200.9 us alone against 2 x 101.4 us,
+// and in the 64-stream pipeline 1.227 - 1.235 ms per step against 1.150 (same-visit A/B, 200 steps, twice): a
+// 420-register wave per SIMD shares its CU with nothing, so the launch serialises with every other stream, and
+// hipcc's schedule for ONE wave per SIMD leaves the matrix pipe idle behind accumulator read-backs, LDS waits and
+// the per-block epilogue.  DESIGN.md "measured and left out" has the arithmetic of why 160 filters do not balance
+// on four SIMDs at two waves each.
 // ---------------------------------------------------------------------------
 typedef float cp_f32x4 __attribute__((ext_vector_type(4)));
 #define CP_SLOTS 192
@@ -751,6 +760,8 @@ int dz_launch_sinc_conv0_pair(const float* wave, long long stride, int B, int S,
     DZ_HIP(hipGetLastError());
     return 0;
 }
+
+#endif  // DZ_EXPERIMENTS
 
 // ---------------------------------------------------------------------------
 // finalize_norm: fixed-order (deterministic) reduction of the tile partials in fp64.

@@ -242,10 +242,11 @@ class StreamBatch:
         self.streams_a, self.streams_b = self.lanes[0]["a"], self.lanes[0]["b"]
         self.stream_a, self.stream_b = self.streams_a[0], self.streams_b[0]
         self.num_hip_streams = self.depth * self.seg_split + self.emb_split * (1 if self.shared_emb else self.depth)
-        # The first SincNet stage of BOTH networks in one launch (dz_sinc_conv0_pair, default precision: one split
-        # of the normalised window, 160 filters, one parking of the samples): on the lane's first segmentation
-        # stream, the embedding stream waits for it.  Not with sub-batches / the front-half stream (experiments).
-        self.conv0_pair = (_lib.exp_env("DZ_CONV0_PAIR", "1") != "0" and self.shared_stats
+        # DZ_CONV0_PAIR=1 (experiments build): the first SincNet stage of BOTH networks in one launch
+        # (dz_sinc_conv0_pair: one split of the normalised window, 160 filters, one parking of the samples) on the
+        # lane's first segmentation stream, the embedding stream waits for it.  Correct, and slower: 1.23 vs 1.15 ms
+        # per step (csrc/k_front.hip has the numbers).
+        self.conv0_pair = (_lib.exp_env("DZ_CONV0_PAIR", "0") == "1" and self.shared_stats
                            and getattr(self.seg, "precision", "") == "f16x3" and getattr(self.emb, "precision", "") == "f16x3"
                            and self.seg_split == 1 and self.emb_split == 1 and not self.seg_front and not self._ablate
                            and hasattr(self.emb, "_state") and type(self.emb).__name__ == "HipEmbedding")

@@ -174,14 +174,6 @@ int dz_wave_stats(dz_ctx* ctx, const float* d_wave, long long wave_stride, int b
                   float* d_moments, void* stream);
 int dz_seg_use_wave_stats(dz_seg* seg, const float* d_moments);
 int dz_emb_use_wave_stats(dz_emb* emb, const float* d_moments);
-/* The first SincNet stage (InstanceNorm -> 80 sinc filters, stride 10 -> |.| -> MaxPool(3)) of BOTH networks in one
- * launch, default precision only: the two models read the same window (the reference runs SincNet once per model,
- * /root/reference/src/diart/models.py:133,262) and their InstanceNorm1d(1) differ by the affine pair only, which
- * moves into the epilogue.  d_pair_planes: f16 planes [2][192][256] of the pair bank, d_pair_bsum[192] =
- * beta_net * sum of the slot's taps (diart_amd/weights.py pack_conv0_pair); d_moments from dz_wave_stats.  The next
- * dz_seg_forward* / dz_emb_frames of each handle (same batch, ordered behind this launch) starts at conv1.     */
-int dz_sinc_conv0_pair(dz_seg* seg, dz_emb* emb, const float* d_wave, long long wave_stride, int batch,
-                       const float* d_moments, const void* d_pair_planes, const float* d_pair_bsum, void* stream);
 
 /* The two halves of dz_emb_forward_multi.  dz_emb_frames (SincNet + TDNN stack, 99.5 % of the
  * embedding FLOPs) does not depend on the segmentation, so it can run on a second stream while
@@ -356,11 +348,6 @@ int dz_k_sinc_conv0_split(dz_ctx* ctx, const float* d_wave, long long stride, in
                           const float* d_stats, float gamma, float beta, const void* d_filt_split,
                           float* d_y0, float* d_partials, void* stream);
 int dz_k_conv0_split_ntile(int samples);
-/* sinc_conv0 of both networks in one launch (kernel level; outputs as two dz_k_sinc_conv0_split calls)  */
-int dz_k_sinc_conv0_pair(dz_ctx* ctx, const float* d_wave, long long stride, int batch, int samples,
-                         const float* d_moments, const void* d_pair_planes, const float* d_pair_bsum, float gamma_seg,
-                         float gamma_emb, float* d_y0_seg, float* d_y0_emb, float* d_part_seg, float* d_part_emb,
-                         void* stream);
 int dz_k_finalize_norm(dz_ctx* ctx, const float* d_partials, int batch, int ntile, int channels,
                        int frames, const float* d_gamma, const float* d_beta, float* d_scale,
                        float* d_shift, void* stream);

@@ -22,6 +22,19 @@ int dz_k_gemm_g3(dz_ctx* ctx, const dz_convgemm_desc* desc, int row_fragments, v
 /* measurement hook (tools/kbench.py): while d_stamps != NULL, dz_k_conv_pool launches record shader-clock
  * stamps of their phases, 2 x 64 per workgroup                                                      */
 int dz_k_conv_pool_debug(long long* d_stamps);
+/* The first SincNet stage (InstanceNorm -> 80 sinc filters, stride 10 -> |.| -> MaxPool(3)) of BOTH networks in one
+ * launch, default precision only: the two models read the same window (the reference runs SincNet once per model,
+ * /root/reference/src/diart/models.py:133,262) and their InstanceNorm1d(1) differ by the affine pair only, which
+ * moves into the epilogue.  d_pair_planes: f16 planes [2][192][256] of the pair bank, d_pair_bsum[192] =
+ * beta_net * sum of the slot's taps (diart_amd/weights.py pack_conv0_pair); d_moments from dz_wave_stats.  The next
+ * dz_seg_forward* / dz_emb_frames of each handle (same batch, ordered behind this launch) starts at conv1.     */
+int dz_sinc_conv0_pair(dz_seg* seg, dz_emb* emb, const float* d_wave, long long wave_stride, int batch,
+                       const float* d_moments, const void* d_pair_planes, const float* d_pair_bsum, void* stream);
+/* sinc_conv0 of both networks in one launch (kernel level; outputs as two dz_k_sinc_conv0_split calls)  */
+int dz_k_sinc_conv0_pair(dz_ctx* ctx, const float* d_wave, long long stride, int batch, int samples,
+                         const float* d_moments, const void* d_pair_planes, const float* d_pair_bsum, float gamma_seg,
+                         float gamma_emb, float* d_y0_seg, float* d_y0_emb, float* d_part_seg, float* d_part_emb,
+                         void* stream);
 #ifdef __cplusplus
 }
 #endif

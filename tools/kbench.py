@@ -189,17 +189,18 @@ y0s = torch.empty(B, 2658, 80, device=dev)
 timeit("sinc_conv0_split", lambda: _lib.check(lib.dz_k_sinc_conv0_split(ctx, wave.data_ptr(), 80000, B, 80000, stats.data_ptr(), 1.0, 0.0,
                                                                        fsplit.data_ptr(), y0s.data_ptr(), part0s.data_ptr(), st)),
        flop=2.0 * B * 7975 * 251 * 80)
-# both networks' first stage in one launch (round 5)
-pair_planes = _sp16(torch.randn(192, 256) * 0.05).to(dev)
-pair_bsum = torch.zeros(192, device=dev)
-mom = torch.empty(B, lib.dz_wave_stats_floats(), device=dev)
-_lib.check(lib.dz_wave_stats(ctx, wave.data_ptr(), 80000, B, 80000, mom.data_ptr(), st))
-y0e, part0e = torch.empty(B, 2658, 80, device=dev), torch.empty(B, nt_s, 80, 2, device=dev)
-timeit("sinc_conv0_pair", lambda: _lib.check(lib.dz_k_sinc_conv0_pair(ctx, wave.data_ptr(), 80000, B, 80000, mom.data_ptr(),
-                                                                     pair_planes.data_ptr(), pair_bsum.data_ptr(), 1.0, 1.0,
-                                                                     y0s.data_ptr(), y0e.data_ptr(), part0s.data_ptr(),
-                                                                     part0e.data_ptr(), st)),
-       flop=2.0 * B * 7975 * 251 * 160)
+# both networks' first stage in one launch (round 5; experiments build: DZ_EXPERIMENTS=1)
+if _lib.experiments():
+    pair_planes = _sp16(torch.randn(192, 256) * 0.05).to(dev)
+    pair_bsum = torch.zeros(192, device=dev)
+    mom = torch.empty(B, lib.dz_wave_stats_floats(), device=dev)
+    _lib.check(lib.dz_wave_stats(ctx, wave.data_ptr(), 80000, B, 80000, mom.data_ptr(), st))
+    y0e, part0e = torch.empty(B, 2658, 80, device=dev), torch.empty(B, nt_s, 80, 2, device=dev)
+    timeit("sinc_conv0_pair", lambda: _lib.check(lib.dz_k_sinc_conv0_pair(ctx, wave.data_ptr(), 80000, B, 80000, mom.data_ptr(),
+                                                                         pair_planes.data_ptr(), pair_bsum.data_ptr(), 1.0, 1.0,
+                                                                         y0s.data_ptr(), y0e.data_ptr(), part0s.data_ptr(),
+                                                                         part0e.data_ptr(), st)),
+           flop=2.0 * B * 7975 * 251 * 160)
 # ---- implicit-GEMM layers ------------------------------------------------------------------
 convgemm("conv1_pool", B, 2658, 80, 60, 5, 1, _lib.EPI_POOL3, Npad=64, pro=True, pool=True)
 convgemm("conv2_pool", B, 884, 64, 60, 5, 1, _lib.EPI_POOL3, Npad=64, pro=True, pool=True)
