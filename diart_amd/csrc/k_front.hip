@@ -311,6 +311,16 @@ __device__ __forceinline__ int ch_copy_base(int c) {
 }
 __device__ __forceinline__ int ch_pi(int i) { return ((i & 3) << 2) | ((i >> 2) & 3) | (i & 16); }
 
+// Round 5 re-measured where this kernel stands (profiles/r05e_pmc_conv0.json, isolated, 64 chunks): the matrix pipes
+// are busy 28 % of the launch (74.3 M SQ_VALU_MFMA_BUSY_CYCLES = 2.32 M MFMAs x 32 over 1024 SIMDs x 260 k cycles), the
+// LDS 18 % (a third of that bank conflicts), and the waves sit in s_waitcnt / the tile barrier 59 % of their cycles.
+// Two rebuilds that attack the 2, 2, 1, 1 wave placement and the 80 -> 96 padding were measured and dropped: four
+// waves per workgroup as 2 x 32 filters on 32x32x16 + 2 x (16 filters, half the tile) on 16x16x32 (17 % fewer MFMA
+// cycles, one heavy + one light wave per SIMD): 100 - 105 us against 99.6 us, whatever the role rotation; and one
+// launch for both networks (sinc_conv0_pair below, experiments build).  The vendor's own f16 GEMM stops at ~1.0 of
+// 2.5 PFLOP/s on random operands on this chip (profiles/r05b_gemm_yardstick.json): against THAT ceiling the kernel's
+// 0.28 is ~0.65, and what is left is latency inside a wave (LDS round trip -> three dependent-issue MFMAs, two waves
+// per SIMD at most because the bank lives in registers), not SIMD balance.
 // Persistent: the grid is at most two workgroups per CU, each walks a contiguous range of (chunk,
 // tile) pairs with its B fragments resident; the samples of tile t+1 are fetched into registers
 // before the MFMA loop of tile t and parked in the other LDS buffer after it (one barrier per tile).

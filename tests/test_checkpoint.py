@@ -159,3 +159,27 @@ def test_model_prefix_is_stripped_per_key_and_unknown_storages_are_named(tmp_pat
             checkpoint.read_state(f)
     finally:
         checkpoint.load_object = orig
+
+
+def test_verify_real_tool_checks_checkpoints_without_a_gpu(tmp_path):
+    """tools/verify_real.py, step 1 (the part that runs anywhere): Lightning-style checkpoints of the two
+    architectures are found, read as tensors and matched against the architectures' key / shape lists; a
+    checkpoint with a missing layer is refused by name."""
+    import json
+    import subprocess
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    seg, emb = synth_segmentation_state(seed=8), synth_embedding_state(seed=9)
+    torch.save({"state_dict": {"model." + k: v for k, v in seg.items()}, "epoch": 3}, tmp_path / "segmentation.ckpt")
+    torch.save({k: v for k, v in emb.items()}, tmp_path / "embedding.bin")
+    r = subprocess.run([sys.executable, str(root / "tools" / "verify_real.py"), "--ckpt", str(tmp_path), "--skip-gates"],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    rep = json.loads(r.stdout[r.stdout.index("{"):])
+    assert rep["segmentation_keys"]["missing"] == [] and rep["embedding_keys"]["wrong_shape"] == []
+    bad = dict(emb)
+    del bad["embedding.weight"]
+    torch.save(bad, tmp_path / "embedding.bin")
+    r = subprocess.run([sys.executable, str(root / "tools" / "verify_real.py"), "--ckpt", str(tmp_path), "--skip-gates"],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "embedding.weight" in r.stderr

@@ -1,0 +1,189 @@
+#!/usr/bin/env python
+"""One command for the first box that HAS the gated weights and the AMI audio.
+
+    python tools/verify_real.py --ckpt DIR --ami DIR [--gpus 8] [--expected FILE.rttm] [--latency 0.5]
+
+turns SURVEY.md rows a4 / a8 (network graphs pinned on real checkpoints) and g2 (BASELINE.json configs[3]: AMI DER
+against the reference's published online output) from "cannot run here" into numbers:
+
+ 1. checkpoints  — `--ckpt` holds `segmentation.{bin,ckpt,safetensors}` / `embedding.*` (the `pytorch_model.bin` of
+    pyannote/segmentation and pyannote/embedding; /root/reference/README.md:101-109 says how to obtain them).  They
+    are read as tensors only (diart_amd/checkpoint.py: no pyannote import, no pickle code execution) and checked
+    against the architecture's key / shape list.
+ 2. tensor gates — `tests/test_gpu_parity_r2.py::test_real_checkpoints_load_and_match_the_oracle` with
+    `DZ_CKPT_DIR=--ckpt`, both arithmetic modes: the HIP forward against the CPU oracle LOADED WITH THE SAME
+    CHECKPOINT (strict state-dict load = the restated graph has the checkpoint's parameterisation), segmentation
+    max |d| < 1e-4, embeddings relative L2 < 1e-4.  (The oracle stays test infrastructure: this tool runs pytest,
+    it does not import it.)
+ 3. config 4     — `--ami` holds `<uri>.wav` (16 kHz mono; AMI test set, SDM or headset mix) and, for scoring,
+    `<uri>.rttm` ground truth next to them or under `--ami/rttm/`.  `Benchmark(SpeakerDiarization)` with the paper's
+    AMI hyper-parameters tau / rho / delta = 0.507 / 0.006 / 1.057 (/root/reference/README.md:386-400), latency
+    `--latency`, files sharded over `--gpus` ranks by longest-processing-time (one process per GPU, weights broadcast
+    over RCCL); RTTMs are written to `--out`.  Reports DER vs ground truth and the DER of our hypothesis AGAINST the
+    reference's own published hypothesis `expected_outputs/online/<latency>s/AMI.rttm`
+    (`--expected`, default /root/reference/expected_outputs/online/0.5s/AMI.rttm when that path exists) — the
+    north-star's "DER within 0.5 pt of reference on AMI-SDM".
+
+It cannot run in the build container (no weights, no audio): every step fails loudly with what is missing.
+"""
+import argparse
+import json
+import os
+import subprocess
+import sys
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+
+
+def find_ckpt(d: Path, stem: str):
+    for ext in (".safetensors", ".bin", ".ckpt", ""):
+        for cand in (d / f"{stem}{ext}", d / stem / "pytorch_model.bin", d / stem / "model.safetensors"):
+            if cand.is_file():
+                return cand
+    return None
+
+
+def main():
+    ap = argparse.ArgumentParser(description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
+    ap.add_argument("--ckpt", required=True, help="directory with segmentation.* and embedding.* checkpoints")
+    ap.add_argument("--ami", default="", help="directory with <uri>.wav (+ <uri>.rttm ground truth); empty = steps 1-2 only")
+    ap.add_argument("--gpus", type=int, default=0, help="start this many ranks (one per GPU) for step 3")
+    ap.add_argument("--latency", type=float, default=0.5)
+    ap.add_argument("--batch-size", type=int, default=32)
+    ap.add_argument("--expected", default="", help="the reference's published hypothesis (one RTTM with every file)")
+    ap.add_argument("--out", default="gpurun_out/verify_real")
+    ap.add_argument("--skip-gates", action="store_true", help="skip step 2 (pytest tensor gates)")
+    ap.add_argument("--worker", action="store_true", help=argparse.SUPPRESS)
+    args = ap.parse_args()
+
+    import torch
+    from diart_amd import distributed as D
+    if args.ami and args.gpus > 1 and not args.worker:
+        # steps 1-2 once, in this process; step 3 as N ranks of this same script
+        pass
+    ckpt = Path(args.ckpt)
+    if not ckpt.is_dir():
+        raise SystemExit(f"verify_real: --ckpt {ckpt} is not a directory")
+    seg_f, emb_f = find_ckpt(ckpt, "segmentation"), find_ckpt(ckpt, "embedding")
+    if not seg_f or not emb_f:
+        raise SystemExit(f"verify_real: need segmentation.* and embedding.* under {ckpt} (found {seg_f}, {emb_f}); "
+                         "they are the pytorch_model.bin files of pyannote/segmentation and pyannote/embedding")
+    report = {"checkpoints": {"segmentation": str(seg_f), "embedding": str(emb_f)}}
+
+    from diart_amd.models import _read_state
+    from diart_amd.synth import embedding_spec, segmentation_spec
+    seg_sd, emb_sd = _read_state(seg_f), _read_state(emb_f)
+    if not args.worker:
+        # ---- 1. key / shape coverage ------------------------------------------------------------------
+        k_spk = int(seg_sd["classifier.weight"].shape[0])
+        for name, sd, spec in (("segmentation", seg_sd, segmentation_spec(num_speakers=k_spk)), ("embedding", emb_sd, embedding_spec())):
+            want = {k: tuple(s) for k, s, _ in spec}
+            missing = [k for k in want if k not in sd]
+            wrong = [(k, tuple(sd[k].shape), want[k]) for k in want if k in sd and tuple(sd[k].shape) != want[k]]
+            extra = sorted(k for k in sd if k not in want)
+            report[name + "_keys"] = {"needed": len(want), "missing": missing, "wrong_shape": wrong, "unused": extra[:20]}
+            if missing or wrong:
+                raise SystemExit(f"verify_real: {name} checkpoint does not have the architecture's parameters: "
+                                 f"missing {missing[:5]}, wrong shapes {wrong[:5]}")
+        print("[verify_real] 1. checkpoints carry every parameter of both architectures "
+              f"(segmentation: {k_spk} output classes)", flush=True)
+        # ---- 2. tensor gates on real weights, both arithmetic modes ------------------------------------
+        if not args.skip_gates:
+            gates = {}
+            for precision in ("f16x3", "f32"):
+                env = dict(os.environ, DZ_CKPT_DIR=str(ckpt), DZ_PRECISION=precision)
+                r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-m", "gpu", "-p", "no:cacheprovider",
+                                    str(ROOT / "tests" / "test_gpu_parity_r2.py"), "-k", "real_checkpoints"],
+                                   env=env, capture_output=True, text=True, cwd=str(ROOT))
+                gates[precision] = {"rc": r.returncode, "tail": r.stdout.strip().splitlines()[-1:] if r.stdout else []}
+                print(f"[verify_real] 2. HIP vs oracle on the real checkpoints, precision {precision}: "
+                      f"{'PASS' if r.returncode == 0 else 'FAIL'} {gates[precision]['tail']}", flush=True)
+                if r.returncode != 0:
+                    print(r.stdout[-3000:], r.stderr[-2000:], file=sys.stderr)
+            report["tensor_gates"] = gates
+        if not args.ami:
+            print(json.dumps(report, indent=1))
+            return
+        # ---- 3. as N ranks -----------------------------------------------------------------------------
+        if args.gpus > 1:
+            rc = D.self_launch(args.gpus, str(Path(__file__).resolve()), [a for a in sys.argv[1:]] + ["--worker"])
+            raise SystemExit(rc)
+
+    # ---- 3. config 4 (this process is the only rank, or one of --gpus ranks) ------------------------------
+    from diart_amd import models as M
+    from diart_amd.blocks import SpeakerDiarization, SpeakerDiarizationConfig
+    from diart_amd.features import Annotation, load_rttm
+    from diart_amd.hostinfo import bind_rank, limit_host_threads
+    from diart_amd.inference import Benchmark, DistributedBenchmark, wav_duration
+    from diart_amd.metrics import DiarizationErrorRate
+    limit_host_threads()
+    rank, world, local = D.init_from_env()
+    device = torch.device("cuda", int(os.environ.get("DZ_FORCE_DEVICE", local)))
+    torch.cuda.set_device(device)
+    bind_rank(local, int(os.environ.get("LOCAL_WORLD_SIZE", world)))
+    ami = Path(args.ami)
+    wavs = sorted(p for p in ami.iterdir() if p.suffix.lower() == ".wav")
+    if not wavs:
+        raise SystemExit(f"verify_real: no .wav files under {ami}")
+    ref_dir = ami if (ami / f"{wavs[0].stem}.rttm").is_file() else (ami / "rttm" if (ami / "rttm").is_dir() else None)
+    out = Path(args.out) / f"rttm_latency{args.latency:g}s"
+    if world > 1:      # only rank 0 read the files' values; the others receive them (one flat RCCL broadcast each)
+        seg_sd = D.broadcast_state(seg_sd if rank == 0 else None, D.state_spec(seg_sd), device)
+        emb_sd = D.broadcast_state(emb_sd if rank == 0 else None, D.state_spec(emb_sd), device)
+    k_spk = int(seg_sd["classifier.weight"].shape[0])
+    seg_keys = {k for k, _, _ in segmentation_spec(num_speakers=k_spk)}
+    emb_keys = {k for k, _, _ in embedding_spec()}
+    cfg = SpeakerDiarizationConfig(
+        segmentation=M.SegmentationModel.from_state({k: v for k, v in seg_sd.items() if k in seg_keys}, max_batch=args.batch_size),
+        embedding=M.EmbeddingModel.from_state({k: v for k, v in emb_sd.items() if k in emb_keys}, max_batch=args.batch_size),
+        latency=args.latency, tau_active=0.507, rho_update=0.006, delta_new=1.057, device=device)
+    bench = DistributedBenchmark(Benchmark(ami, ref_dir, out, show_report=False, batch_size=args.batch_size))
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    t0 = time.perf_counter()
+    metric = bench(SpeakerDiarization, cfg)
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    wall = time.perf_counter() - t0
+    if rank == 0:
+        audio_s = sum(wav_duration(p) for p in wavs)
+        report["config4"] = {"files": len(wavs), "audio_hours": round(audio_s / 3600, 3), "n_gpus": world, "wall_s": round(wall, 2),
+                             "x_real_time": round(audio_s / wall, 1), "latency_s": args.latency, "rttm_dir": str(out),
+                             "hyper_parameters": {"tau_active": 0.507, "rho_update": 0.006, "delta_new": 1.057}}
+        if ref_dir is not None:
+            report["config4"]["der_vs_ground_truth_percent"] = round(100 * abs(metric), 3)
+            report["config4"]["per_file"] = metric.report()
+        else:
+            report["config4"]["der_vs_ground_truth_percent"] = None
+            report["config4"]["note"] = "no <uri>.rttm ground truth next to the audio: hypotheses written, not scored"
+        expected = Path(args.expected) if args.expected else Path(f"/root/reference/expected_outputs/online/{args.latency:g}s/AMI.rttm")
+        if expected.is_file():
+            theirs = load_rttm(expected)                       # {uri: Annotation}: the reference's own online output
+            m2 = DiarizationErrorRate(collar=0.0, skip_overlap=False)
+            scored = 0
+            for p in wavs:
+                hyp_f = out / f"{p.stem}.rttm"
+                if p.stem in theirs and hyp_f.is_file():
+                    mine = load_rttm(hyp_f).get(p.stem, Annotation(uri=p.stem))
+                    m2(theirs[p.stem], mine)                    # their hypothesis as the "reference" of the comparison
+                    scored += 1
+            report["config4"]["der_vs_reference_hypothesis_percent"] = round(100 * abs(m2), 3) if scored else None
+            report["config4"]["files_compared_with_reference_hypothesis"] = scored
+            report["config4"]["expected_rttm"] = str(expected)
+        else:
+            report["config4"]["der_vs_reference_hypothesis_percent"] = None
+            report["config4"]["expected_rttm"] = f"{expected} not found (pass --expected)"
+        print(json.dumps(report, indent=1), flush=True)
+        Path(args.out).mkdir(parents=True, exist_ok=True)
+        (Path(args.out) / "verify_real.json").write_text(json.dumps(report, indent=1))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
