@@ -320,7 +320,10 @@ __device__ __forceinline__ int ch_pi(int i) { return ((i & 3) << 2) | ((i >> 2) 
 // launch for both networks (sinc_conv0_pair below, experiments build).  The vendor's own f16 GEMM stops at ~1.0 of
 // 2.5 PFLOP/s on random operands on this chip (profiles/r05b_gemm_yardstick.json): against THAT ceiling the kernel's
 // 0.28 is ~0.65, and what is left is latency inside a wave (LDS round trip -> three dependent-issue MFMAs, two waves
-// per SIMD at most because the bank lives in registers), not SIMD balance.
+// per SIMD at most because the bank lives in registers), not SIMD balance.  A third rebuild — this kernel with its
+// fragment reads issued one step ahead through inline-asm ds_read_b128 + counted lgkmcnt waits (hipcc funnels them
+// through one register quad: read, wait, MFMA, read ...) — measured 99.4 us against 99.4 us and 1.152 / 1.171 vs
+// 1.154 / 1.225 ms per step (r05f): the LDS round trip is not what the waves wait for either.  Kept as it was.
 // Persistent: the grid is at most two workgroups per CU, each walks a contiguous range of (chunk,
 // tile) pairs with its B fragments resident; the samples of tile t+1 are fetched into registers
 // before the MFMA loop of tile t and parked in the other LDS buffer after it (one barrier per tile).
