@@ -455,6 +455,12 @@ def pmc_live(precision):
                 log(f"pmc: {script} failed: " + r.stderr[-300:])
                 return None
             out[key] = json.loads(Path(argv[-1]).read_text())
+        keep = os.environ.get("DZ_PMC_KEEP")          # keep the two per-kernel tables (the committed fall-back of --pmc off)
+        if keep:
+            Path(keep).mkdir(parents=True, exist_ok=True)
+            suffix = "_f32" if precision == "f32" else ""
+            (Path(keep) / f"traffic{suffix}.json").write_text(json.dumps(out["traffic"], indent=1))
+            (Path(keep) / f"mfma_util{suffix}.json").write_text(json.dumps(out["mfma"], indent=1))
     finally:
         shutil.rmtree(work, ignore_errors=True)
     out["source"] = (f"live: rocprofv3 --pmc passes (FETCH_SIZE / WRITE_SIZE / SQ_VALU_MFMA_BUSY_CYCLES, separate runs, "

@@ -22,7 +22,7 @@ exp_tests)   # the experiments build: the never-default kernels against the same
 smoke)
   timeout -s KILL 200 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1 ;;
 driver)      # exactly what the driver runs
-  timeout -s KILL 900 python3 bench.py --gpus 1 --steps 20 --warmup 5 --details $OUT/bench_driver_details.json > $OUT/bench_driver.json 2> $OUT/bench_driver.err
+  DZ_PMC_KEEP=$OUT/pmc_tables timeout -s KILL 900 python3 bench.py --gpus 1 --steps 20 --warmup 5 --pmc all --details $OUT/bench_driver_details.json > $OUT/bench_driver.json 2> $OUT/bench_driver.err
   echo "exit $? chars $(wc -c < $OUT/bench_driver.json)"; cut -c1-260 $OUT/bench_driver.json ;;
 driver2)     # twice more, short form (no PMC children, no CPU leg): run-to-run spread of the 20-step region
   for i in 1 2; do
@@ -83,14 +83,22 @@ ab)          # same-visit A/B of bench.py (200 steps, headline pass only) over e
       echo "$arm$i [$E] $(python -c "import json,sys; d=json.load(open('$OUT/ab_${arm}_$i.json')); print(d['value'], d['ms_per_step'])" 2>&1 | tail -1)"
     done
   done ;;
+verify_dry)  # tools/verify_real.py end to end on a stand-in corpus (synthetic checkpoints + WAVs): twice, the second run
+             # scored against the first one's RTTMs as "the reference's hypothesis" (must be 0 %)
+  python tools/make_dry_corpus.py $OUT/dry 4 120 > /dev/null
+  timeout -s KILL 600 python tools/verify_real.py --ckpt $OUT/dry/ckpt --ami $OUT/dry/ami --out $OUT/dry/run1 2>&1 | grep -v amdgpu.ids | grep "verify_real\|x_real_time\|der_vs" | cut -c1-200
+  cat $OUT/dry/run1/rttm_latency0.5s/*.rttm > $OUT/dry/expected.rttm
+  timeout -s KILL 600 python tools/verify_real.py --ckpt $OUT/dry/ckpt --ami $OUT/dry/ami --out $OUT/dry/run2 --skip-gates --expected $OUT/dry/expected.rttm 2>&1 | grep "der_vs_reference_hypothesis\|files_compared" | cut -c1-200
+  cp $OUT/dry/run2/verify_real.json $OUT/verify_real_dry_run.json; rm -rf $OUT/dry ;;
 collect)     # LOCAL: judged copies
   for f in bench_driver.json bench_driver_details.json bench_200.json kernels_events_bench_run.json kernel_stats_f16x3.md kernel_stats_f32.md \
            rocprofv3_kernel_stats_f16x3.csv rocprofv3_kernel_stats_f32.csv kernels_events_rocprof_run_f16x3.json kernels_events_rocprof_run_f32.json \
            bench_config3.json bench_config5.json bench_config1.json bench_8_ranks.json bench_2_ranks.json gemm_yardstick.json kbench_isolated.json \
-           long_horizon.txt file_benchmark_config4.json pytest_gpu_experiments.txt bench_driver_short_1.json bench_driver_short_2.json; do
+           long_horizon.txt file_benchmark_config4.json pytest_gpu_experiments.txt bench_driver_short_1.json bench_driver_short_2.json verify_real_dry_run.json; do
     [ -f $OUT/$f ] && cp $OUT/$f profiles/${TAG}_$f
   done
   [ -f $OUT/pytest_gpu.txt ] && tail -3 $OUT/pytest_gpu.txt > profiles/${TAG}_pytest_gpu_tail.txt
+  for f in traffic.json traffic_f32.json mfma_util.json mfma_util_f32.json; do [ -f $OUT/pmc_tables/$f ] && cp $OUT/pmc_tables/$f profiles/$f; done
   ls profiles | grep "^${TAG}_" ;;
 *) echo "unknown section $SEC" ;;
 esac
