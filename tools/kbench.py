@@ -158,7 +158,7 @@ timeit("lstm", lambda: _lib.check(lib.dz_k_lstm(ctx, gx.data_ptr(), whh.data_ptr
        flop=2.0 * B * F * 2 * 512 * 128)
 from diart_amd.weights import lstm_whh_planes  # noqa: E402
 hout2 = torch.empty(B, F, 256, device=dev)
-for variant in (0, 1, 2, 3):
+for variant in ((0, 1, 2, 3) if _lib.experiments() else (0, 3)):      # 1 / 2: experiments build only
     whs = lstm_whh_planes(whh.cpu(), variant).to(dev)
     nm = f"lstm_mfma{variant}"
     gxv = gx.view(B, F, 2, 4, 128).transpose(3, 4).reshape(B, F, 1024).contiguous() if variant == 3 else gx
