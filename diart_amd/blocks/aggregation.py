@@ -26,6 +26,16 @@ def _rows(buffer: SlidingWindowFeature, focus: Segment, mode: str) -> np.ndarray
     return np.clip(np.arange(first, last), 0, buffer.data.shape[0] - 1)
 
 
+def _crop(data: np.ndarray, buffer: SlidingWindowFeature, focus: Segment, mode: str) -> np.ndarray:
+    """``data[_rows(buffer, focus, mode)]`` (a fresh array, like ``crop``): a contiguous range that lies inside the
+    buffer — every call but the first / last of a stream — is one memcpy instead of an 8000-element gather (the
+    audio passthrough of a 500 ms region was 50 us of a pipeline call's ~75 us host time per chunk)."""
+    first, last = buffer.sliding_window.crop_range(focus, mode, fixed=focus.duration)
+    if 0 <= first <= last <= data.shape[0]:
+        return data[first:last].copy()
+    return data[np.clip(np.arange(first, last), 0, data.shape[0] - 1)]
+
+
 class AggregationStrategy:
     """hamming | mean | first over the frames of ``focus`` shared by the buffers."""
 
@@ -44,15 +54,15 @@ class AggregationStrategy:
 
     def aggregate(self, buffers: List[SlidingWindowFeature], focus: Segment) -> np.ndarray:
         if self.name == "first":
-            return buffers[0].data[_rows(buffers[0], focus, self.cropping_mode)]
-        crops = [b.data[_rows(b, focus, self.cropping_mode)] for b in buffers]
+            return _crop(buffers[0].data, buffers[0], focus, self.cropping_mode)
+        crops = [_crop(b.data, b, focus, self.cropping_mode) for b in buffers]
         if self.name == "mean":
             return np.mean(np.stack(crops), axis=0)
         num_frames = buffers[0].data.shape[0]
         h = self._hamming.get(num_frames)
         if h is None:
             h = self._hamming[num_frames] = np.expand_dims(np.hamming(num_frames), axis=-1)
-        hamming = np.stack([h[_rows(b, focus, self.cropping_mode)] for b in buffers])
+        hamming = np.stack([_crop(h, b, focus, self.cropping_mode) for b in buffers])
         return np.sum(hamming * np.stack(crops), axis=0) / np.sum(hamming, axis=0)
 
     def __call__(self, buffers: List[SlidingWindowFeature], focus: Segment) -> SlidingWindowFeature:

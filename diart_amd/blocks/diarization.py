@@ -131,8 +131,15 @@ class SpeakerDiarization(base.Pipeline):
         # (batch, samples, channels) on the device, uploaded once for both blocks (blocks/utils.py)
         batch = windows_batch(waveforms, self.config.device)
 
-        segmentations = self.segmentation(batch)                 # (batch, frames, speakers), host
-        embeddings = self.embedding(batch, segmentations)        # (batch, speakers, emb_dim), host
+        if batch.is_cuda:
+            # the segmentation stays on the device for the embedding block (OSP weights / masks are computed there
+            # anyway); one synchronising copy per result instead of host round trips between the two blocks
+            seg_dev = self.segmentation.forward_device(batch)
+            embeddings = self.embedding(batch, seg_dev)          # (batch, speakers, emb_dim), host
+            segmentations = seg_dev.cpu()                        # (batch, frames, speakers), host
+        else:
+            segmentations = self.segmentation(batch)
+            embeddings = self.embedding(batch, segmentations)
         return self.finalise(waveforms, segmentations, embeddings)
 
     def finalise(self, waveforms: Sequence[SlidingWindowFeature], segmentations: torch.Tensor,

@@ -34,6 +34,15 @@ class SpeakerSegmentation:
     def from_pretrained(model, use_hf_token=True, device: Optional[torch.device] = None):
         return SpeakerSegmentation(SegmentationModel.from_pretrained(model, use_hf_token), device)
 
+    def forward_device(self, waveform: TemporalFeatures) -> torch.Tensor:
+        """``__call__`` without the trip to the host: (batch, frames, speakers) on the model's device, nothing
+        synchronised — for a pipeline that feeds the embedding block from it and copies both results once."""
+        wave = self.formatter.cast(waveform)
+        if wave.shape[2] != 1:
+            raise ValueError(f"expected mono audio, got {wave.shape[2]} channels")
+        with torch.no_grad():
+            return self.model(wave.transpose(1, 2).to(self.device))
+
     def __call__(self, waveform: TemporalFeatures) -> TemporalFeatures:
         wave = self.formatter.cast(waveform)            # (batch, samples, channels) float32
         if wave.shape[2] != 1:
