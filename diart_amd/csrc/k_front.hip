@@ -334,7 +334,19 @@ __global__ __launch_bounds__(192, 2) void sinc_conv0_h_kernel(
     const float* __restrict__ wave, long long stride, int S, const float* __restrict__ stats,
     int stats_are_moments, float gamma, float beta, const unsigned short* __restrict__ fsp,
     float* __restrict__ y0, int P0, float* __restrict__ partials, int ntile, int total,
-    int* __restrict__ oflag) {
+    int* __restrict__ oflag, long long* __restrict__ dbg) {
+    // dbg (experiments build, tools/conv0_phases.py): per wave 5 shader-clock stamps per tile + HW_ID in slot 63
+    long long* dq = nullptr;
+    int dn = 0;
+#ifdef DZ_EXPERIMENTS
+    if (dbg && (threadIdx.x & 63) == 0) {
+        dq = dbg + ((long long)blockIdx.x * 3 + (threadIdx.x >> 6)) * 64;
+        dq[63] = (long long)__builtin_amdgcn_s_getreg((31 << 11) | 4);      // HW_REG_HW_ID: wave / SIMD / CU / SE ids
+    }
+#define C0_STAMP() do { if (dq && dn < 60) dq[dn++] = __builtin_readcyclecounter(); } while (0)
+#else
+#define C0_STAMP() do { } while (0)
+#endif
     // one LDS object (a second one makes hipcc drain vmcnt before every ds_read while an LDS-DMA is
     // in flight): [2][CH_LDS] sample copies | raw[1536] f32 landing zone | (mean, rstd) of 2 chunks
     __shared__ __attribute__((aligned(256))) char lds_all[2 * CH_LDS + 1536 * 4 + 16];
@@ -437,6 +449,7 @@ __global__ __launch_bounds__(192, 2) void sinc_conv0_h_kernel(
     __syncthreads();
     for (int t = t_begin; t < t_end; ++t) {
         const char* xs = xs2[(t - t_begin) & 1];
+        C0_STAMP();
         if (t + 1 < t_end) fetch(t + 1);
         ch_f32x16 pmax;
 #pragma unroll
@@ -466,10 +479,12 @@ __global__ __launch_bounds__(192, 2) void sinc_conv0_h_kernel(
                 pmax[r] = bk == 0 ? v : fmaxf(pmax[r], v);
             }
         }
+        C0_STAMP();
         // the next tile's samples first: parking waits for this wave's LDS-DMA (vmcnt), which must
         // not also wait for the result stores below
         if (t + 1 < t_end && !(DBG & 1)) park(t + 1, xs2[(t + 1 - t_begin) & 1]);
         if (DBG & 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        C0_STAMP();
         // pooled rows + InstanceNorm partials: C/D column = lane & 31 = filter, row rho <-> m = pi(rho)
         const int bb = t / ntile, tile = t - bb * ntile;
         float sum = 0.f, ssq = 0.f;
@@ -495,8 +510,320 @@ __global__ __launch_bounds__(192, 2) void sinc_conv0_h_kernel(
             pp[0] = sum;
             pp[1] = ssq;
         }
+        C0_STAMP();
         // LDS-only barrier (the parked copies become visible; the stores above drain on their own)
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        C0_STAMP();
+    }
+#undef C0_STAMP
+    dz_flag_range(oflag, amax);
+}
+
+// ---------------------------------------------------------------------------
+// sinc_conv0_v2 (round 5): the same stage, rebuilt from a per-wave phase profile of sinc_conv0_h
+// (tools/conv0_phases.py: of a tile's 17.2 k cycles a wave spends 10.0 k in the MFMA phase — 144 MFMAs = 4.6 k busy
+// cycles — 3.4 k parking the next tile's samples, 3.1 k ISSUING 16 dword stores, 0.7 k at the barrier).
+//   * FOUR waves, roles by the SIMD a wave landed on (HW_ID): two HEAVY waves own a 32-filter block each
+//     (v_mfma_f32_32x32x16_f16, bank in 128 registers, exactly sinc_conv0_h's arithmetic), two LIGHT waves own the
+//     last 16 filters on v_mfma_f32_16x16x32_f16 for one pooled-row half of the tile each (a quarter of a heavy
+//     wave's matrix time, no zero filter columns) AND do all the fetching and parking of the next tile's samples.
+//     The second workgroup of a CU takes the complementary SIMDs for its heavy waves: every SIMD carries one heavy
+//     and one light wave, matrix work and VALU / LDS-write work side by side.
+//   * fragment reads one step ahead through inline-asm ds_read_b128 with counted lgkmcnt waits (hipcc funnels
+//     them through one register quad: read, wait, MFMA, read ...);
+//   * results staged through a per-wave LDS tile and stored as dwordx4 rows (4 store instructions per wave and
+//     tile instead of 16: the store phase is issue-bound).
+// Same LDS sample copies, outputs and partials as sinc_conv0_h (the light waves' channels 64..79 accumulate in
+// another order: last-bit differences there).
+// ---------------------------------------------------------------------------
+typedef float cq_f32x4 __attribute__((ext_vector_type(4)));
+#define CQ_STAGE 4608                      /* bytes of result staging per wave: 32 rows x 36 floats            */
+#define CQ_LDS (2 * CH_LDS + 1536 * 4 + 16 + 2 * 2 * 16 * 2 * 4 + 4 * CQ_STAGE + 16)
+__device__ __forceinline__ char* stage_all_end(char* lds) { return lds + CQ_LDS - 16; }
+__global__ __launch_bounds__(256, 2) void sinc_conv0_v2_kernel(
+    const float* __restrict__ wave, long long stride, int S, const float* __restrict__ stats,
+    int stats_are_moments, float gamma, float beta, const unsigned short* __restrict__ fsp,
+    float* __restrict__ y0, int P0, float* __restrict__ partials, int ntile, int total,
+    int* __restrict__ oflag, int rot_period, int rot_mode) {
+    // [2][CH_LDS] sample copies | raw[1536] landing zone | (mean, rstd) of 2 chunks | light sums [2][2][16][2] | staging
+    __shared__ __attribute__((aligned(256))) char lds_all[CQ_LDS];
+    char (*xs2)[CH_LDS] = reinterpret_cast<char (*)[CH_LDS]>(lds_all);
+    float* raw = reinterpret_cast<float*>(lds_all + 2 * CH_LDS);
+    float (*stat_s)[2] = reinterpret_cast<float (*)[2]>(lds_all + 2 * CH_LDS + 1536 * 4);
+    float* lsum = reinterpret_cast<float*>(lds_all + 2 * CH_LDS + 1536 * 4 + 16);     // [t & 1][half][16][2]
+    const int tid = threadIdx.x;
+    const int w = tid >> 6, l = tid & 63;
+    float* stage = reinterpret_cast<float*>(lds_all + 2 * CH_LDS + 1536 * 4 + 16 + 512 + w * CQ_STAGE);
+    const int wg = dz_xcd_contiguous(blockIdx.x, gridDim.x);
+    const int t_begin = (int)((long long)wg * total / gridDim.x);
+    const int t_end = (int)((long long)(wg + 1) * total / gridDim.x);
+    if (t_begin >= t_end) return;
+    const int b_first = t_begin / ntile;
+    // a workgroup's four waves sit on the four SIMDs of its CU (cyclic placement from a varying start): the role
+    // follows the SIMD.  First workgroup of a CU: heavy on SIMDs 0 / 1, light on 2 / 3; second: the other way round.
+    // (Correctness never depends on that placement: the waves publish their SIMD ids, and unless the four are
+    // distinct the roles fall back to the wave index.)
+    const int simd = (__builtin_amdgcn_s_getreg((31 << 11) | 4) >> 4) & 3;
+    int* simd_of = reinterpret_cast<int*>(stage_all_end(lds_all));
+    if (l == 0) simd_of[w] = simd;
+    __syncthreads();
+    const bool by_simd = ((1 << simd_of[0]) | (1 << simd_of[1]) | (1 << simd_of[2]) | (1 << simd_of[3])) == 15;
+    const int rot = rot_mode == 1 ? 0 : (((int)blockIdx.x / rot_period) & 1) ^ (rot_mode == 2);
+    const int slot = by_simd ? simd : w;
+    const bool heavy = ((slot >> 1) & 1) == rot;
+    const int half = slot & 1;             // heavy: filter block 0 / 1; light: pooled-row half 0 / 1 of the tile
+
+    if (tid < 2) {
+        const int bb = b_first + tid;
+        float mean = 0.f, rstd = 1.f;
+        if (bb * ntile < t_end) {
+            if (stats_are_moments)
+                dz_ws_combine(stats, bb, S, &mean, &rstd);
+            else
+                mean = stats[2 * bb], rstd = stats[2 * bb + 1];
+        }
+        stat_s[tid][0] = mean;
+        stat_s[tid][1] = rstd;
+    }
+    __syncthreads();
+    float amax = 0.f;
+
+    if (heavy) {
+        // ================= a 32-filter block: sinc_conv0_h's arithmetic, no parking =================
+        const int li = l & 31, g = l >> 5;
+        ch_f16x8 bh[16], bl[16];
+        {
+            const unsigned short* row = fsp + (long long)(32 * half + li) * 256 + 8 * g;
+#pragma unroll
+            for (int ks = 0; ks < 16; ++ks) {
+                bh[ks] = *reinterpret_cast<const ch_f16x8*>(row + 16 * ks);
+                bl[ks] = *reinterpret_cast<const ch_f16x8*>(row + 96 * 256 + 16 * ks);
+            }
+        }
+        const int m_a = ch_pi(li);
+        int aoff[3];
+#pragma unroll
+        for (int bk = 0; bk < 3; ++bk) {
+            const int f = 3 * m_a + bk, c = f & 3;
+            aoff[bk] = ch_copy_base(c) + 2 * (10 * f - 2 * c + 8 * g);
+        }
+        const int ch = 32 * half + li;
+        __syncthreads();                   // (the light waves park the first tile before this barrier)
+        for (int t = t_begin; t < t_end; ++t) {
+            const char* xs = xs2[(t - t_begin) & 1];
+            unsigned abase[3];
+#pragma unroll
+            for (int bk = 0; bk < 3; ++bk)
+                abase[bk] = (unsigned)(unsigned long long)(__attribute__((address_space(3))) const char*)(xs + aoff[bk]);
+#define CQ_LD(it, H, L)                                                                                        \
+    do {                                                                                                       \
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(H) : "v"(abase[(it) >> 4]), "n"(32 * ((it) & 15)));          \
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(L) : "v"(abase[(it) >> 4]), "n"(32 * ((it) & 15) + CH_PL)); \
+    } while (0)
+            ch_f32x16 pmax, accm, accx;
+            ch_f16x8 fh[2], fl[2];
+            CQ_LD(0, fh[0], fl[0]);
+#define CQ_STEP(it)                                                                                        \
+    {                                                                                                      \
+        constexpr int bk_ = (it) >> 4, ks_ = (it) & 15, cur_ = (it) & 1;                                   \
+        if (ks_ == 0) {                                                                                    \
+            _Pragma("unroll") for (int r = 0; r < 16; ++r) accm[r] = accx[r] = 0.f;                        \
+        }                                                                                                  \
+        if ((it) + 1 < 48) {                                                                               \
+            CQ_LD(((it) + 1 < 48 ? (it) + 1 : 47), fh[((it) + 1) & 1], fl[((it) + 1) & 1]);                \
+            asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(fh[cur_]), "+v"(fl[cur_]));                         \
+        } else {                                                                                           \
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fh[cur_]), "+v"(fl[cur_]));                         \
+        }                                                                                                  \
+        accx = __builtin_amdgcn_mfma_f32_32x32x16_f16(fl[cur_], bh[ks_], accx, 0, 0, 0);                   \
+        accm = __builtin_amdgcn_mfma_f32_32x32x16_f16(fh[cur_], bh[ks_], accm, 0, 0, 0);                   \
+        accx = __builtin_amdgcn_mfma_f32_32x32x16_f16(fh[cur_], bl[ks_], accx, 0, 0, 0);                   \
+        if (ks_ == 15) {                                                                                   \
+            _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                               \
+                const float v = fabsf(accm[r] + accx[r] * (1.f / 2048.f));                                 \
+                pmax[r] = bk_ == 0 ? v : fmaxf(pmax[r], v);                                                \
+            }                                                                                              \
+        }                                                                                                  \
+    }
+#define CQ_STEP4(b) CQ_STEP((b)) CQ_STEP((b) + 1) CQ_STEP((b) + 2) CQ_STEP((b) + 3)
+#define CQ_STEP16(b) CQ_STEP4((b)) CQ_STEP4((b) + 4) CQ_STEP4((b) + 8) CQ_STEP4((b) + 12)
+            CQ_STEP16(0) CQ_STEP16(16) CQ_STEP16(32)
+#undef CQ_STEP16
+#undef CQ_STEP4
+#undef CQ_STEP
+#undef CQ_LD
+            // results: stage the 32 x 32 tile (row = pooled row, pitch 36 floats), store rows as dwordx4
+            const int bb = t / ntile, tile = t - bb * ntile;
+            float sum = 0.f, ssq = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = ch_pi((r & 3) + 8 * (r >> 2) + 4 * g);
+                stage[m * 36 + li] = pmax[r];
+                if (tile * 32 + m < P0) {
+                    sum += pmax[r];
+                    ssq += pmax[r] * pmax[r];
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // this wave's own writes (LDS ops of a wave retire in order)
+#pragma unroll
+            for (int pass = 0; pass < 4; ++pass) {
+                const int m = 8 * pass + (l >> 3), quad = l & 7, p = tile * 32 + m;
+                const f32x4 v = *reinterpret_cast<const f32x4*>(stage + m * 36 + 4 * quad);
+                if (p < P0) *reinterpret_cast<f32x4*>(y0 + ((long long)bb * P0 + p) * 80 + 32 * half + 4 * quad) = v;
+            }
+            sum += __shfl_xor(sum, 32, 64);
+            ssq += __shfl_xor(ssq, 32, 64);
+            if (g == 0) {
+                float* pp = partials + (((long long)bb * ntile + tile) * 80 + ch) * 2;
+                pp[0] = sum;
+                pp[1] = ssq;
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        }
+    } else {
+        // ====== the last 16 filters for one pooled-row half of the tile + ALL fetching / parking of samples ======
+        const int n = l & 15, q = l >> 4;
+        ch_f16x8 bh[8], bl[8];
+        {
+            const unsigned short* row = fsp + (long long)(64 + n) * 256 + 8 * q;
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) {
+                bh[ks] = *reinterpret_cast<const ch_f16x8*>(row + 32 * ks);
+                bl[ks] = *reinterpret_cast<const ch_f16x8*>(row + 96 * 256 + 32 * ks);
+            }
+        }
+        // raw samples of the NEXT tile by LDS-DMA, one dword per lane: light wave `half` owns floats
+        // [640 half, 640 half + 640) of the tile's window and later parks exactly those (its own vmcnt)
+        auto fetch = [&](int t) {
+            const int bb = t / ntile, tile = t - bb * ntile;
+            const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+                (void*)(wave + (long long)bb * stride), 0, (unsigned)S * 4u, 0x00020000);
+            const int voff = (tile * (CH_FR * 10) + 640 * half + l) * 4;
+#pragma unroll
+            for (int i = 0; i < 10; ++i)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(
+                    rsrc, (__attribute__((address_space(3))) void*)(raw + 640 * half + 64 * i), 4, voff + 256 * i, 0, 0, 0);
+        };
+        auto park = [&](int t, char* xs) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const int bb = t / ntile, tile = t - bb * ntile;
+            const float mean = stat_s[bb - b_first][0], rstd = stat_s[bb - b_first][1];
+            const int s0 = tile * (CH_FR * 10);
+#pragma unroll
+            for (int it = 0; it < 5; ++it) {
+                const int j = 640 * half + 2 * (l + 64 * it), sidx = s0 + j;
+                if (j < CH_NS + 6) {
+                    const float2 pvq = *reinterpret_cast<const float2*>(raw + j);
+                    f32x2 x = {sidx < S ? ((pvq.x - mean) * rstd) * gamma + beta : 0.f,
+                               sidx + 1 < S ? ((pvq.y - mean) * rstd) * gamma + beta : 0.f};
+                    amax = fmaxf(amax, fmaxf(fabsf(x[0]), fabsf(x[1])));
+                    x[0] = __builtin_amdgcn_fmed3f(x[0], -65504.f, 65504.f);
+                    x[1] = __builtin_amdgcn_fmed3f(x[1], -65504.f, 65504.f);
+                    const ch_f16x2 hi = __builtin_convertvector(x, ch_f16x2);
+                    const ch_f16x2 lo =
+                        __builtin_convertvector((x - __builtin_convertvector(hi, f32x2)) * 2048.f, ch_f16x2);
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const int idx = j - 2 * c;
+                        if (idx >= 0 && idx < CH_NS) {
+                            char* d = xs + ch_copy_base(c) + 2 * idx;
+                            *reinterpret_cast<ch_f16x2*>(d) = hi;
+                            *reinterpret_cast<ch_f16x2*>(d + CH_PL) = lo;
+                        }
+                    }
+                }
+            }
+        };
+        // the partial of channels 64..79 of a tile = the two light waves' halves, added in a fixed order by the
+        // half-0 wave one barrier after both wrote them
+        auto light_partial = [&](int t) {
+            if (half == 0 && l < 32) {
+                const int bb = t / ntile, tile = t - bb * ntile;
+                const float* ls = lsum + ((t - t_begin) & 1) * 64;
+                partials[(((long long)bb * ntile + tile) * 80 + 64) * 2 + l] = ls[l] + ls[32 + l];
+            }
+        };
+        int aoff[3];
+#pragma unroll
+        for (int bk = 0; bk < 3; ++bk) {
+            const int f = 3 * (16 * half + (((n & 3) << 2) | (n >> 2))) + bk, c = f & 3;
+            aoff[bk] = ch_copy_base(c) + 2 * (10 * f - 2 * c + 8 * q);
+        }
+        const int ch = 64 + n;
+        fetch(t_begin);
+        park(t_begin, xs2[0]);
+        __syncthreads();
+        for (int t = t_begin; t < t_end; ++t) {
+            const char* xs = xs2[(t - t_begin) & 1];
+            if (t + 1 < t_end) fetch(t + 1);
+            if (t > t_begin) light_partial(t - 1);           // both halves of tile t - 1 are in LDS since the barrier
+            unsigned abase[3];
+#pragma unroll
+            for (int bk = 0; bk < 3; ++bk)
+                abase[bk] = (unsigned)(unsigned long long)(__attribute__((address_space(3))) const char*)(xs + aoff[bk]);
+#define CQ_LD(it, H, L)                                                                                        \
+    do {                                                                                                       \
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(H) : "v"(abase[(it) >> 3]), "n"(64 * ((it) & 7)));          \
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(L) : "v"(abase[(it) >> 3]), "n"(64 * ((it) & 7) + CH_PL)); \
+    } while (0)
+            cq_f32x4 pm, accm, accx;
+            ch_f16x8 fh[2], fl[2];
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // (the compiler's own LDS traffic above is not counted below)
+            CQ_LD(0, fh[0], fl[0]);
+#define CQ_STEP(it)                                                                                        \
+    {                                                                                                      \
+        constexpr int bk_ = (it) >> 3, ks_ = (it) & 7, cur_ = (it) & 1;                                    \
+        if (ks_ == 0) accm = accx = cq_f32x4{0.f, 0.f, 0.f, 0.f};                                          \
+        if ((it) + 1 < 24) {                                                                               \
+            CQ_LD(((it) + 1 < 24 ? (it) + 1 : 23), fh[((it) + 1) & 1], fl[((it) + 1) & 1]);                \
+            asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(fh[cur_]), "+v"(fl[cur_]));                         \
+        } else {                                                                                           \
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fh[cur_]), "+v"(fl[cur_]));                         \
+        }                                                                                                  \
+        accx = __builtin_amdgcn_mfma_f32_16x16x32_f16(fl[cur_], bh[ks_], accx, 0, 0, 0);                   \
+        accm = __builtin_amdgcn_mfma_f32_16x16x32_f16(fh[cur_], bh[ks_], accm, 0, 0, 0);                   \
+        accx = __builtin_amdgcn_mfma_f32_16x16x32_f16(fh[cur_], bl[ks_], accx, 0, 0, 0);                   \
+        if (ks_ == 7) {                                                                                    \
+            _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                \
+                const float v = fabsf(accm[i] + accx[i] * (1.f / 2048.f));                                 \
+                pm[i] = bk_ == 0 ? v : fmaxf(pm[i], v);                                                    \
+            }                                                                                              \
+        }                                                                                                  \
+    }
+#define CQ_STEP8(b) CQ_STEP((b)) CQ_STEP((b) + 1) CQ_STEP((b) + 2) CQ_STEP((b) + 3) CQ_STEP((b) + 4) CQ_STEP((b) + 5) CQ_STEP((b) + 6) CQ_STEP((b) + 7)
+            CQ_STEP8(0) CQ_STEP8(8) CQ_STEP8(16)
+#undef CQ_STEP8
+#undef CQ_STEP
+#undef CQ_LD
+            if (t + 1 < t_end) park(t + 1, xs2[(t + 1 - t_begin) & 1]);
+            const int bb = t / ntile, tile = t - bb * ntile;
+            float sum = 0.f, ssq = 0.f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {                         // D row 4 q + i <-> pooled row pi16 = 4 i + q of this half
+                stage[(4 * i + q) * 20 + n] = pm[i];
+                if (tile * 32 + 16 * half + 4 * i + q < P0) {
+                    sum += pm[i];
+                    ssq += pm[i] * pm[i];
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            {
+                const int m = l >> 2, quad = l & 3, p = tile * 32 + 16 * half + m;
+                const f32x4 v = *reinterpret_cast<const f32x4*>(stage + m * 20 + 4 * quad);
+                if (p < P0) *reinterpret_cast<f32x4*>(y0 + ((long long)bb * P0 + p) * 80 + 64 + 4 * quad) = v;
+            }
+            sum += __shfl_xor(sum, 16, 64);
+            ssq += __shfl_xor(ssq, 16, 64);
+            sum += __shfl_xor(sum, 32, 64);
+            ssq += __shfl_xor(ssq, 32, 64);
+            if (q == 0) {
+                float* ls = lsum + ((t - t_begin) & 1) * 64 + half * 32 + 2 * n;
+                ls[0] = sum;
+                ls[1] = ssq;
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        }
+        light_partial(t_end - 1);
     }
     dz_flag_range(oflag, amax);
 }
@@ -510,10 +837,32 @@ int dz_launch_sinc_conv0_split(const float* wave, long long stride, int B, int S
                                float* y0, int P0, float* partials, int ntile, hipStream_t st) {
     const int total = ntile * B;
     const int grid = total < 512 ? total : 512;    // two resident workgroups per CU
+#ifdef DZ_EXPERIMENTS
+    long long* const dbg_ptr = dz_conv_pool_dbg;   // the stamp buffer of dz_k_conv_pool_debug (tools/conv0_phases.py)
+#else
+    long long* const dbg_ptr = nullptr;
+#endif
+    {
+        static const int cus = [] {
+            int dev = 0, n = 256;
+            if (hipGetDevice(&dev) == hipSuccess) hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+            return n > 0 ? n : 256;
+        }();
+        // DZ_CONV0_V2 (experiments build): 0 = sinc_conv0_h below; DZ_CONV0_ROT: 1 = no complementary roles, 2 = inverted
+        const char* e_v2 = dz_exp_env("DZ_CONV0_V2");
+        const char* e_rot = dz_exp_env("DZ_CONV0_ROT");
+        if (!(e_v2 && e_v2[0] == '0')) {
+            DZ_LAUNCH(sinc_conv0_v2_kernel, dim3(grid), dim3(256), 0, st, wave, stride, S, stats, stats_are_moments, gamma,
+                      beta, reinterpret_cast<const unsigned short*>(fsp), y0, P0, partials, ntile, total, dz_cur_oflag,
+                      cus, e_rot ? atoi(e_rot) : 0);
+            DZ_HIP(hipGetLastError());
+            return 0;
+        }
+    }
 #define DZ_C0(D)                                                                                          \
     DZ_LAUNCH(sinc_conv0_h_kernel<D>, dim3(grid), dim3(192), 0, st, wave, stride, S, stats,                \
               stats_are_moments, gamma, beta, reinterpret_cast<const unsigned short*>(fsp), y0, P0,        \
-              partials, ntile, total, dz_cur_oflag)
+              partials, ntile, total, dz_cur_oflag, dbg_ptr)
 #ifdef DZ_EXPERIMENTS
     const char* e_dbg = dz_exp_env("DZ_CONV0_DBG");     // timing-only instantiations: results are wrong
     switch (e_dbg ? atoi(e_dbg) : 0) {
