@@ -537,6 +537,7 @@ __global__ __launch_bounds__(192, 2) void sinc_conv0_h_kernel(
 // another order: last-bit differences there).
 // ---------------------------------------------------------------------------
 typedef float cq_f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned cq_u32x4 __attribute__((ext_vector_type(4)));
 #define CQ_STAGE 4608                      /* bytes of result staging per wave: 32 rows x 36 floats            */
 #define CQ_LDS (2 * CH_LDS + 1536 * 4 + 16 + 2 * 2 * 16 * 2 * 4 + 4 * CQ_STAGE + 16)
 __device__ __forceinline__ char* stage_all_end(char* lds) { return lds + CQ_LDS - 16; }
@@ -544,7 +545,16 @@ __global__ __launch_bounds__(256, 2) void sinc_conv0_v2_kernel(
     const float* __restrict__ wave, long long stride, int S, const float* __restrict__ stats,
     int stats_are_moments, float gamma, float beta, const unsigned short* __restrict__ fsp,
     float* __restrict__ y0, int P0, float* __restrict__ partials, int ntile, int total,
-    int* __restrict__ oflag, int rot_period, int rot_mode) {
+    int* __restrict__ oflag, int rot_period, int rot_mode, long long* __restrict__ dbg) {
+    // dbg (experiments build, tools/conv0_phases.py): per wave shader-clock stamps per tile + (HW_ID | role << 32) in slot 63
+    long long* dq = nullptr;
+    int dn = 0;
+#ifdef DZ_EXPERIMENTS
+    if (dbg && (threadIdx.x & 63) == 0) dq = dbg + ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * 64;
+#define CQ_STAMP() do { if (dq && dn < 60) dq[dn++] = __builtin_readcyclecounter(); } while (0)
+#else
+#define CQ_STAMP() do { } while (0)
+#endif
     // [2][CH_LDS] sample copies | raw[1536] landing zone | (mean, rstd) of 2 chunks | light sums [2][2][16][2] | staging
     __shared__ __attribute__((aligned(256))) char lds_all[CQ_LDS];
     char (*xs2)[CH_LDS] = reinterpret_cast<char (*)[CH_LDS]>(lds_all);
@@ -572,6 +582,9 @@ __global__ __launch_bounds__(256, 2) void sinc_conv0_v2_kernel(
     const int slot = by_simd ? simd : w;
     const bool heavy = ((slot >> 1) & 1) == rot;
     const int half = slot & 1;             // heavy: filter block 0 / 1; light: pooled-row half 0 / 1 of the tile
+#ifdef DZ_EXPERIMENTS
+    if (dq) dq[63] = (long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) | ((long long)(heavy ? 1 : 0) << 32) | ((long long)half << 33);
+#endif
 
     if (tid < 2) {
         const int bb = b_first + tid;
@@ -611,6 +624,7 @@ __global__ __launch_bounds__(256, 2) void sinc_conv0_v2_kernel(
         __syncthreads();                   // (the light waves park the first tile before this barrier)
         for (int t = t_begin; t < t_end; ++t) {
             const char* xs = xs2[(t - t_begin) & 1];
+            CQ_STAMP();
             unsigned abase[3];
 #pragma unroll
             for (int bk = 0; bk < 3; ++bk)
@@ -652,6 +666,8 @@ __global__ __launch_bounds__(256, 2) void sinc_conv0_v2_kernel(
 #undef CQ_STEP4
 #undef CQ_STEP
 #undef CQ_LD
+            CQ_STAMP();
+            CQ_STAMP();          // (no parking on a heavy wave: the phase is empty, the slot keeps the five-stamp layout)
             // results: stage the 32 x 32 tile (row = pooled row, pitch 36 floats), store rows as dwordx4
             const int bb = t / ntile, tile = t - bb * ntile;
             float sum = 0.f, ssq = 0.f;
@@ -665,11 +681,21 @@ __global__ __launch_bounds__(256, 2) void sinc_conv0_v2_kernel(
                 }
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // this wave's own writes (LDS ops of a wave retire in order)
+            {
+                // the chunk's y0 as a buffer of P0 rows: a row >= P0 of the ragged last tile lands beyond num_records
+                // and is dropped by the hardware — no per-row branch, 32-bit offsets
+                const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc(
+                    (void*)(y0 + (long long)bb * P0 * 80), 0, (unsigned)P0 * 320u, 0x00020000);
+                f32x4 v[4];
 #pragma unroll
-            for (int pass = 0; pass < 4; ++pass) {
-                const int m = 8 * pass + (l >> 3), quad = l & 7, p = tile * 32 + m;
-                const f32x4 v = *reinterpret_cast<const f32x4*>(stage + m * 36 + 4 * quad);
-                if (p < P0) *reinterpret_cast<f32x4*>(y0 + ((long long)bb * P0 + p) * 80 + 32 * half + 4 * quad) = v;
+                for (int pass = 0; pass < 4; ++pass)
+                    v[pass] = *reinterpret_cast<const f32x4*>(stage + (8 * pass + (l >> 3)) * 36 + 4 * (l & 7));
+#pragma unroll
+                for (int pass = 0; pass < 4; ++pass) {
+                    const int p = tile * 32 + 8 * pass + (l >> 3);
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(cq_u32x4, v[pass]), yr,
+                                                           (p * 80 + 32 * half + 4 * (l & 7)) * 4, 0, 0);
+                }
             }
             sum += __shfl_xor(sum, 32, 64);
             ssq += __shfl_xor(ssq, 32, 64);
@@ -678,7 +704,9 @@ __global__ __launch_bounds__(256, 2) void sinc_conv0_v2_kernel(
                 pp[0] = sum;
                 pp[1] = ssq;
             }
+            CQ_STAMP();
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            CQ_STAMP();
         }
     } else {
         // ====== the last 16 filters for one pooled-row half of the tile + ALL fetching / parking of samples ======
@@ -704,31 +732,42 @@ __global__ __launch_bounds__(256, 2) void sinc_conv0_v2_kernel(
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(
                     rsrc, (__attribute__((address_space(3))) void*)(raw + 640 * half + 64 * i), 4, voff + 256 * i, 0, 0, 0);
         };
+        // normalise (InstanceNorm1d(1)), split, write the four shifted copies: 4 samples per lane and pass, 8-byte
+        // writes, no per-copy bounds checks — copy c takes x[j] at index j - 2 c, and the few indices that fall
+        // outside [0, CH_NS) (j < 6 at the head, j >= CH_NS at the tail) land in the padding between the planes /
+        // copy slots (CH_PL - 2 CH_NS = 128 bytes behind every plane, >= 192 bytes in front of copies 1 - 3; copy 0
+        // never goes negative), where nobody reads
         auto park = [&](int t, char* xs) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             const int bb = t / ntile, tile = t - bb * ntile;
             const float mean = stat_s[bb - b_first][0], rstd = stat_s[bb - b_first][1];
             const int s0 = tile * (CH_FR * 10);
+            typedef _Float16 cq_f16x4 __attribute__((ext_vector_type(4)));
 #pragma unroll
-            for (int it = 0; it < 5; ++it) {
-                const int j = 640 * half + 2 * (l + 64 * it), sidx = s0 + j;
-                if (j < CH_NS + 6) {
-                    const float2 pvq = *reinterpret_cast<const float2*>(raw + j);
-                    f32x2 x = {sidx < S ? ((pvq.x - mean) * rstd) * gamma + beta : 0.f,
-                               sidx + 1 < S ? ((pvq.y - mean) * rstd) * gamma + beta : 0.f};
-                    amax = fmaxf(amax, fmaxf(fabsf(x[0]), fabsf(x[1])));
-                    x[0] = __builtin_amdgcn_fmed3f(x[0], -65504.f, 65504.f);
-                    x[1] = __builtin_amdgcn_fmed3f(x[1], -65504.f, 65504.f);
-                    const ch_f16x2 hi = __builtin_convertvector(x, ch_f16x2);
-                    const ch_f16x2 lo =
-                        __builtin_convertvector((x - __builtin_convertvector(hi, f32x2)) * 2048.f, ch_f16x2);
+            for (int it = 0; it < 3; ++it) {
+                const int j = 640 * half + 4 * (l + 64 * it), sidx = s0 + j;        // 3 x 256 samples cover the wave's 640
+                if (j < 640 * half + 640 && j < CH_NS + 8) {
+                    const f32x4 pv = *reinterpret_cast<const f32x4*>(raw + j);
+                    f32x4 x;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        x[e] = sidx + e < S ? ((pv[e] - mean) * rstd) * gamma + beta : 0.f;
+                        amax = fmaxf(amax, fabsf(x[e]));
+                        x[e] = __builtin_amdgcn_fmed3f(x[e], -65504.f, 65504.f);
+                    }
+                    const cq_f16x4 hi = __builtin_convertvector(x, cq_f16x4);
+                    const cq_f16x4 lo = __builtin_convertvector((x - __builtin_convertvector(hi, f32x4)) * 2048.f, cq_f16x4);
 #pragma unroll
                     for (int c = 0; c < 4; ++c) {
-                        const int idx = j - 2 * c;
-                        if (idx >= 0 && idx < CH_NS) {
-                            char* d = xs + ch_copy_base(c) + 2 * idx;
-                            *reinterpret_cast<ch_f16x2*>(d) = hi;
-                            *reinterpret_cast<ch_f16x2*>(d + CH_PL) = lo;
+                        char* d = xs + ch_copy_base(c) + 2 * (j - 2 * c);               // 4-byte aligned (j % 4 == 0)
+                        if (c & 1) {                                                      // j - 2 c = 2 mod 4: two 4-byte halves
+                            *reinterpret_cast<ch_f16x2*>(d) = ch_f16x2{hi[0], hi[1]};
+                            *reinterpret_cast<ch_f16x2*>(d + 4) = ch_f16x2{hi[2], hi[3]};
+                            *reinterpret_cast<ch_f16x2*>(d + CH_PL) = ch_f16x2{lo[0], lo[1]};
+                            *reinterpret_cast<ch_f16x2*>(d + CH_PL + 4) = ch_f16x2{lo[2], lo[3]};
+                        } else {
+                            *reinterpret_cast<cq_f16x4*>(d) = hi;
+                            *reinterpret_cast<cq_f16x4*>(d + CH_PL) = lo;
                         }
                     }
                 }
@@ -755,6 +794,7 @@ __global__ __launch_bounds__(256, 2) void sinc_conv0_v2_kernel(
         __syncthreads();
         for (int t = t_begin; t < t_end; ++t) {
             const char* xs = xs2[(t - t_begin) & 1];
+            CQ_STAMP();
             if (t + 1 < t_end) fetch(t + 1);
             if (t > t_begin) light_partial(t - 1);           // both halves of tile t - 1 are in LDS since the barrier
             unsigned abase[3];
@@ -795,7 +835,9 @@ __global__ __launch_bounds__(256, 2) void sinc_conv0_v2_kernel(
 #undef CQ_STEP8
 #undef CQ_STEP
 #undef CQ_LD
+            CQ_STAMP();
             if (t + 1 < t_end) park(t + 1, xs2[(t + 1 - t_begin) & 1]);
+            CQ_STAMP();
             const int bb = t / ntile, tile = t - bb * ntile;
             float sum = 0.f, ssq = 0.f;
 #pragma unroll
@@ -808,9 +850,11 @@ __global__ __launch_bounds__(256, 2) void sinc_conv0_v2_kernel(
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             {
+                const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc(
+                    (void*)(y0 + (long long)bb * P0 * 80), 0, (unsigned)P0 * 320u, 0x00020000);
                 const int m = l >> 2, quad = l & 3, p = tile * 32 + 16 * half + m;
                 const f32x4 v = *reinterpret_cast<const f32x4*>(stage + m * 20 + 4 * quad);
-                if (p < P0) *reinterpret_cast<f32x4*>(y0 + ((long long)bb * P0 + p) * 80 + 64 + 4 * quad) = v;
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(cq_u32x4, v), yr, (p * 80 + 64 + 4 * quad) * 4, 0, 0);
             }
             sum += __shfl_xor(sum, 16, 64);
             ssq += __shfl_xor(ssq, 16, 64);
@@ -821,10 +865,13 @@ __global__ __launch_bounds__(256, 2) void sinc_conv0_v2_kernel(
                 ls[0] = sum;
                 ls[1] = ssq;
             }
+            CQ_STAMP();
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            CQ_STAMP();
         }
         light_partial(t_end - 1);
     }
+#undef CQ_STAMP
     dz_flag_range(oflag, amax);
 }
 
@@ -854,7 +901,7 @@ int dz_launch_sinc_conv0_split(const float* wave, long long stride, int B, int S
         if (!(e_v2 && e_v2[0] == '0')) {
             DZ_LAUNCH(sinc_conv0_v2_kernel, dim3(grid), dim3(256), 0, st, wave, stride, S, stats, stats_are_moments, gamma,
                       beta, reinterpret_cast<const unsigned short*>(fsp), y0, P0, partials, ntile, total, dz_cur_oflag,
-                      cus, e_rot ? atoi(e_rot) : 0);
+                      cus, e_rot ? atoi(e_rot) : 0, dbg_ptr);
             DZ_HIP(hipGetLastError());
             return 0;
         }

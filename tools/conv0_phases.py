@@ -31,38 +31,40 @@ run = lambda: _lib.check(lib.dz_k_sinc_conv0_split(ctx, wave.data_ptr(), S, B, S
                                                    y0.data_ptr(), part.data_ptr(), st))
 for _ in range(3):
     run()
-stamps = torch.zeros(512 * 3 * 64, dtype=torch.int64, device=dev)
+NW = 3 if os.environ.get("DZ_CONV0_V2") == "0" else 4          # waves per workgroup: sinc_conv0_h / sinc_conv0_v2
+stamps = torch.zeros(512 * NW * 64, dtype=torch.int64, device=dev)
 lib.dz_k_conv_pool_debug(stamps.data_ptr())
 run()
 torch.cuda.synchronize()
 lib.dz_k_conv_pool_debug(None)
-s = stamps.cpu().numpy().reshape(512, 3, 64)
+s = stamps.cpu().numpy().reshape(512, NW, 64)
 NAMES = ["fetch issue + MFMA phase (3 blocks x 16 k-steps)", "park next tile", "stores + partials", "wait at the tile barrier"]
 hw = s[:, :, 63]
 simd, cu, se, sh, xcc = (hw >> 4) & 3, (hw >> 8) & 15, (hw >> 13) & 7, (hw >> 12) & 1, 0
 # waves per (physical CU, SIMD): key CU by (se, sh, cu) — per XCD the ids repeat, so count the distribution of SIMD loads
 per_cu = collections.defaultdict(lambda: [0, 0, 0, 0])
 for wg in range(512):
-    for w in range(3):
+    for w in range(NW):
         per_cu[(int(se[wg, w]), int(sh[wg, w]), int(cu[wg, w]))][int(simd[wg, w])] += 1
 loads = collections.Counter(tuple(sorted(v, reverse=True)) for v in per_cu.values())
 print("waves per SIMD, per (se, sh, cu) id (ids repeat across the 8 XCDs: divide by 8):", dict(loads))
 # the SIMDs of the three waves of one workgroup
 wg_pat = collections.Counter(tuple(int(x) for x in simd[wg]) for wg in range(512))
-print("SIMD of (wave 0, wave 1, wave 2) of a workgroup:", dict(wg_pat.most_common(8)))
-rows = {0: [], 1: [], 2: []}
+print("SIMD of the waves of a workgroup:", dict(wg_pat.most_common(8)))
+role = (hw >> 32) & 1                      # v2: 1 = heavy wave
+rows = {0: [], 1: [], 2: [], 3: []}
 for wg in range(512):
-    for w in range(3):
+    for w in range(NW):
         v = s[wg, w, :60]
         n = int((v != 0).sum()) // 5
         for t in range(1, n):            # skip the first tile (prologue effects)
             seg = v[5 * t:5 * t + 5].astype(np.float64)
             nxt = v[5 * (t + 1)] if t + 1 < n else None
-            rows[w].append(np.diff(seg))
+            rows[w if NW == 3 else int(role[wg, w])].append(np.diff(seg))
 out = {}
-for w in range(3):
+for w in (range(3) if NW == 3 else range(2)):
     r = np.array(rows[w])
-    print(f"wave {w}: {len(r)} tiles, mean cycles per tile {r.sum(1).mean():.0f}")
+    print(f"{('wave %d' % w) if NW == 3 else ('light waves', 'heavy waves')[w]}: {len(r)} tiles, mean cycles per tile {r.sum(1).mean():.0f}")
     for nm, m, p10, p90 in zip(NAMES, r.mean(0), np.percentile(r, 10, axis=0), np.percentile(r, 90, axis=0)):
         print(f"    {nm:52s} {m:8.0f}   (p10 {p10:.0f}, p90 {p90:.0f})")
     out[f"wave{w}"] = dict(zip(NAMES, [round(float(x)) for x in r.mean(0)]))
