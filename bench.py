@@ -146,7 +146,8 @@ def device_kernel(tag, precision):
     if tag == "sinc_conv0_pair":
         return "sinc_conv0_pair_kernel", "mfma", PEAK_F16_MATRIX_TFLOPS / SPLIT_PRODUCTS, "TFLOP/s"
     if tag == "sinc_conv0" and split and xenv("DZ_CONV0_SPLIT", "1") != "0":
-        return "sinc_conv0_h_kernel", "mfma", PEAK_F16_MATRIX_TFLOPS / SPLIT_PRODUCTS, "TFLOP/s"
+        sym = "sinc_conv0_h_kernel<0>" if xenv("DZ_CONV0_V2", "1") == "0" else "sinc_conv0_v2_kernel"
+        return sym, "mfma", PEAK_F16_MATRIX_TFLOPS / SPLIT_PRODUCTS, "TFLOP/s"
     if k["bound"] == "mfma_f32" or not split:
         sym = {"sinc_conv0": "sinc_conv0_kernel", "conv1_pool": "convgemm_kernel<64, true, 4>",
                "conv2_pool": "convgemm_kernel<64, true, 4>", "lstm_proj": "convgemm_kernel<128, false, 0>",

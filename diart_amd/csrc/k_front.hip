@@ -311,24 +311,21 @@ __device__ __forceinline__ int ch_copy_base(int c) {
 }
 __device__ __forceinline__ int ch_pi(int i) { return ((i & 3) << 2) | ((i >> 2) & 3) | (i & 16); }
 
-// Round 5 re-measured where this kernel stands (profiles/r05e_pmc_conv0.json, isolated, 64 chunks): the matrix pipes
-// are busy 28 % of the launch (74.3 M SQ_VALU_MFMA_BUSY_CYCLES = 2.32 M MFMAs x 32 over 1024 SIMDs x 260 k cycles), the
-// LDS 18 % (a third of that bank conflicts), and the waves sit in s_waitcnt / the tile barrier 59 % of their cycles.
-// Two rebuilds that attack the 2, 2, 1, 1 wave placement and the 80 -> 96 padding were measured and dropped: four
-// waves per workgroup as 2 x 32 filters on 32x32x16 + 2 x (16 filters, half the tile) on 16x16x32 (17 % fewer MFMA
-// cycles, one heavy + one light wave per SIMD): 100 - 105 us against 99.6 us, whatever the role rotation; and one
-// launch for both networks (sinc_conv0_pair below, experiments build).  The vendor's own f16 GEMM stops at ~1.0 of
-// 2.5 PFLOP/s on random operands on this chip (profiles/r05b_gemm_yardstick.json): against THAT ceiling the kernel's
-// 0.28 is ~0.65, and what is left is latency inside a wave (LDS round trip -> three dependent-issue MFMAs, two waves
-// per SIMD at most because the bank lives in registers), not SIMD balance.  A third rebuild — this kernel with its
-// fragment reads issued one step ahead through inline-asm ds_read_b128 + counted lgkmcnt waits (hipcc funnels them
-// through one register quad: read, wait, MFMA, read ...) — measured 99.4 us against 99.4 us and 1.152 / 1.171 vs
-// 1.154 / 1.225 ms per step (r05f): the LDS round trip is not what the waves wait for either.  Kept as it was.
+// sinc_conv0_h: the three-wave kernel of rounds 2 - 4, since round 5 built into the EXPERIMENTS library only
+// (DZ_CONV0_V2=0 selects it there: the A/B arm of profiles/r05j_conv0_v2_ab.json and the subject of the phase profile
+// that led to sinc_conv0_v2 below).  What round 5 measured on it (profiles/r05e_pmc_conv0.json, isolated, 64
+// chunks): matrix pipes busy 28 % of the launch, LDS 18 % (a third of that bank conflicts), waves in s_waitcnt / the
+// tile barrier 59 % of their cycles.  Three single-cause rebuilds each measured no gain — four waves in two roles
+// without read pipelining (100 - 105 us against 99.6), one launch for both networks (sinc_conv0_pair below), and
+// this kernel with its fragment reads issued one step ahead (99.4 against 99.4 us) — because the tile's time has
+// three comparable parts (profiles/r05j_conv0_phases_old_kernel.json) and each rebuild removed one while the tile
+// barrier kept the others; sinc_conv0_v2 removes them together.
 // Persistent: the grid is at most two workgroups per CU, each walks a contiguous range of (chunk,
 // tile) pairs with its B fragments resident; the samples of tile t+1 are fetched into registers
 // before the MFMA loop of tile t and parked in the other LDS buffer after it (one barrier per tile).
 // DBG (timing experiments, DZ_CONV0_DBG; results are wrong): 1 = no parking of the next tile's samples, 2 = no
 // MFMAs, 4 = no fragment reads inside the tile loop, 8 = no result stores / partials
+#ifdef DZ_EXPERIMENTS
 template <int DBG = 0>
 __global__ __launch_bounds__(192, 2) void sinc_conv0_h_kernel(
     const float* __restrict__ wave, long long stride, int S, const float* __restrict__ stats,
@@ -518,6 +515,7 @@ __global__ __launch_bounds__(192, 2) void sinc_conv0_h_kernel(
 #undef C0_STAMP
     dz_flag_range(oflag, amax);
 }
+#endif  // DZ_EXPERIMENTS (sinc_conv0_h)
 
 // ---------------------------------------------------------------------------
 // sinc_conv0_v2 (round 5): the same stage, rebuilt from a per-wave phase profile of sinc_conv0_h
@@ -884,49 +882,44 @@ int dz_launch_sinc_conv0_split(const float* wave, long long stride, int B, int S
                                float* y0, int P0, float* partials, int ntile, hipStream_t st) {
     const int total = ntile * B;
     const int grid = total < 512 ? total : 512;    // two resident workgroups per CU
+    static const int cus = [] {
+        int dev = 0, n = 256;
+        if (hipGetDevice(&dev) == hipSuccess) hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+        return n > 0 ? n : 256;
+    }();
+    int rot_mode = 0;
+    long long* dbg_ptr = nullptr;
 #ifdef DZ_EXPERIMENTS
-    long long* const dbg_ptr = dz_conv_pool_dbg;   // the stamp buffer of dz_k_conv_pool_debug (tools/conv0_phases.py)
-#else
-    long long* const dbg_ptr = nullptr;
-#endif
-    {
-        static const int cus = [] {
-            int dev = 0, n = 256;
-            if (hipGetDevice(&dev) == hipSuccess) hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
-            return n > 0 ? n : 256;
-        }();
-        // DZ_CONV0_V2 (experiments build): 0 = sinc_conv0_h below; DZ_CONV0_ROT: 1 = no complementary roles, 2 = inverted
-        const char* e_v2 = dz_exp_env("DZ_CONV0_V2");
-        const char* e_rot = dz_exp_env("DZ_CONV0_ROT");
-        if (!(e_v2 && e_v2[0] == '0')) {
-            DZ_LAUNCH(sinc_conv0_v2_kernel, dim3(grid), dim3(256), 0, st, wave, stride, S, stats, stats_are_moments, gamma,
-                      beta, reinterpret_cast<const unsigned short*>(fsp), y0, P0, partials, ntile, total, dz_cur_oflag,
-                      cus, e_rot ? atoi(e_rot) : 0, dbg_ptr);
-            DZ_HIP(hipGetLastError());
-            return 0;
-        }
-    }
+    dbg_ptr = dz_conv_pool_dbg;                    // the stamp buffer of dz_k_conv_pool_debug (tools/conv0_phases.py)
+    // DZ_CONV0_ROT: 1 = no complementary roles, 2 = inverted; DZ_CONV0_V2=0: the three-wave kernel of rounds 2 - 4
+    const char* e_rot = dz_exp_env("DZ_CONV0_ROT");
+    if (e_rot) rot_mode = atoi(e_rot);
+    const char* e_v2 = dz_exp_env("DZ_CONV0_V2");
+    if (e_v2 && e_v2[0] == '0') {
 #define DZ_C0(D)                                                                                          \
     DZ_LAUNCH(sinc_conv0_h_kernel<D>, dim3(grid), dim3(192), 0, st, wave, stride, S, stats,                \
               stats_are_moments, gamma, beta, reinterpret_cast<const unsigned short*>(fsp), y0, P0,        \
               partials, ntile, total, dz_cur_oflag, dbg_ptr)
-#ifdef DZ_EXPERIMENTS
-    const char* e_dbg = dz_exp_env("DZ_CONV0_DBG");     // timing-only instantiations: results are wrong
-    switch (e_dbg ? atoi(e_dbg) : 0) {
-        case 1: DZ_C0(1); break;
-        case 2: DZ_C0(2); break;
-        case 4: DZ_C0(4); break;
-        case 8: DZ_C0(8); break;
-        case 9: DZ_C0(9); break;
-        case 13: DZ_C0(13); break;
-        case 15: DZ_C0(15); break;
-        case 6: DZ_C0(6); break;
-        default: DZ_C0(0); break;
-    }
-#else
-    DZ_C0(0);
-#endif
+        const char* e_dbg = dz_exp_env("DZ_CONV0_DBG");     // timing-only instantiations: results are wrong
+        switch (e_dbg ? atoi(e_dbg) : 0) {
+            case 1: DZ_C0(1); break;
+            case 2: DZ_C0(2); break;
+            case 4: DZ_C0(4); break;
+            case 8: DZ_C0(8); break;
+            case 9: DZ_C0(9); break;
+            case 13: DZ_C0(13); break;
+            case 15: DZ_C0(15); break;
+            case 6: DZ_C0(6); break;
+            default: DZ_C0(0); break;
+        }
 #undef DZ_C0
+        DZ_HIP(hipGetLastError());
+        return 0;
+    }
+#endif
+    DZ_LAUNCH(sinc_conv0_v2_kernel, dim3(grid), dim3(256), 0, st, wave, stride, S, stats, stats_are_moments, gamma, beta,
+              reinterpret_cast<const unsigned short*>(fsp), y0, P0, partials, ntile, total, dz_cur_oflag, cus, rot_mode,
+              dbg_ptr);
     DZ_HIP(hipGetLastError());
     return 0;
 }
