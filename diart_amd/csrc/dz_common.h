@@ -451,6 +451,8 @@ int dz_launch_se_mean(const float* x, int T, int C, int ldx, int rows, const int
                       hipStream_t st);
 int dz_launch_se_apply(const float* x, int ldx, const float* gate, const float* resid, int ldr,
                        float* out, int ldo, int rows, int T, int C, hipStream_t st);
+int dz_launch_se_apply_planes(const float* x, int ldx, const float* gate, const float* resid, int ldr, float* out,
+                              int ldo, void* planes, long long plane, int rows, int T, int C, hipStream_t st);
 int dz_launch_asp_gstats(const float* x, int T, int C, int rows, const int* nmask, float* g,
                          hipStream_t st);
 int dz_launch_asp_pool(const float* x, const float* logit, int T, int C, int rows, const int* nmask,

@@ -8,7 +8,8 @@
 
 namespace {
 
-enum { MIN_NUM_SAMPLES = 640, HOP = 160, NFFT = 400, C1 = 1024, C3 = 3072, EMB = 192, FC_SPLIT = 16, SE_SPLIT = 8 };
+enum { MIN_NUM_SAMPLES = 640, HOP = 160, NFFT = 400, C1 = 1024, C3 = 3072, EMB = 192, FC_SPLIT = 16, SE_SPLIT = 8,
+       PLANE_SLACK = 16384 };
 
 struct Carve {
     char* base = nullptr;
@@ -34,6 +35,8 @@ struct dz_ecapa {
     // device buffers
     float *sig, *spec, *pw, *melp, *feats, *b0, *t1, *res, *t2, *cat, *mfa, *a1;
     float *smean, *sfc1, *gate, *gstat, *rb, *pooled, *parts;
+    // split-f16 precision: the inputs of the wide 1 x 1 layers as kb-major f16 planes (k_gemm_pre.hip), [2][C / 32][N T][32]
+    unsigned short *b0s, *ress, *cats;
     int *lens, *nvalid, *nmask, *tooshort;
     int lastN, lastT;
 };
@@ -59,6 +62,16 @@ static void ecapa_carve(dz_ecapa* e, Carve& a) {
     e->rb = a.take<float>(N * 128);
     e->pooled = a.take<float>(N * 2 * C3);
     e->parts = a.take<float>((size_t)FC_SPLIT * N * EMB);
+    e->b0s = e->ress = e->cats = nullptr;
+    if (e->w.mfa.wsplit) {
+        // (+ PLANE_SLACK: a 128-row tile that starts inside the last rows of a plane's last k-block reads up to 127
+        // rows x 64 bytes past it — zeros through the buffer bounds check when the resource ends there, but a
+        // consumer that reads a COLUMN SLICE of a plane (tdnn1 of blocks 1 and 2: k-blocks [32 (i - 1), 32 i) of
+        // the concatenation) has a resource that ends further on, so the bytes must exist)
+        e->b0s = a.take<unsigned short>(2 * NT * C1 + PLANE_SLACK);
+        e->ress = a.take<unsigned short>(2 * NT * C1 + PLANE_SLACK);
+        e->cats = a.take<unsigned short>(2 * NT * C3 + PLANE_SLACK);
+    }
     e->lens = a.take<int>(N);
     e->nvalid = a.take<int>(N);
     e->nmask = a.take<int>(N);
@@ -114,7 +127,8 @@ extern "C" int dz_ecapa_destroy(dz_ecapa* e) {
 static int gemm(int tag, int rows_n, hipStream_t st, const float* X, int ldx, long long xbs, int B, int T, int Cin, int taps,
                 int dil, int pad, const dz_layer& L, const float* bias, int Kpad, int Npad, int Nstore,
                 float* Y, int ldy, long long ybs, int epi, const float* X2 = nullptr,
-                const float* rowbias = nullptr, int ksplit = 0, long long ysplit = 0) {
+                const float* rowbias = nullptr, int ksplit = 0, long long ysplit = 0, void* Yplanes = nullptr,
+                long long yplane = 0) {
     DzConvGemm p;
     memset(&p, 0, sizeof(p));
     p.X = X; p.W = L.w; p.bias = bias ? bias : L.b; p.e0 = L.s; p.e1 = L.h; p.Y = Y;
@@ -128,11 +142,27 @@ static int gemm(int tag, int rows_n, hipStream_t st, const float* X, int ldx, lo
     if (L.wsplit && (epi == DZ_EPI_RELU_BN || epi == DZ_EPI_BIAS) && !rowbias && ksplit <= 1 && Cin % 8 == 0) {
         p.Wsplit = L.wsplit;
         p.Npad = (Npad + 127) / 128 * 128;       // (the DFT's planes are packed with 512 rows)
+        p.Ysplit = Yplanes;                      // the next wide layer's input, written by this epilogue
+        p.yplane = yplane;
         DzProfScope ps(tag, rows_n);
         return dz_launch_gemm_split(p, st);
     }
+    DZ_REQUIRE(Yplanes == nullptr, "ecapa: plane output asked of a layer that is not on the split-f16 path");
     DzProfScope ps(tag, rows_n);
     return dz_launch_convgemm(p, st);
+}
+
+// a wide 1 x 1 layer with BOTH operands pre-split (k_gemm_pre.hip): rows x Cin -> rows x Npad, ReLU -> BN, f32 out.
+// Xplanes = the k-block of the layer's first input column inside planes of `pcols` columns (hi | lo, xplane apart)
+static int gemm_pre(int tag, int rows_n, hipStream_t st, const void* Xplanes, long long xplane, int pcols, long long rows,
+                    int Cin, const dz_layer& L, int Npad, float* Y) {
+    DzConvGemm p;
+    memset(&p, 0, sizeof(p));
+    p.Xsplit = Xplanes; p.xplane = xplane; p.ldx = pcols; p.Wsplit = L.wsplit; p.bias = L.b; p.e0 = L.s; p.e1 = L.h;
+    p.Y = Y; p.B = 1; p.Tin = p.Tout = p.Tstore = (int)rows; p.Cin = Cin; p.taps = 1; p.dil = 1; p.K = p.Kpad = Cin;
+    p.Npad = p.Nstore = Npad; p.ldy = Npad; p.epi = DZ_EPI_RELU_BN;
+    DzProfScope ps(tag, rows_n);
+    return dz_launch_gemm_pre(p, st);
 }
 
 extern "C" int dz_ecapa_forward(dz_ecapa* e, const float* d_wave, long long wave_stride,
@@ -201,33 +231,53 @@ extern "C" int dz_ecapa_forward(dz_ecapa* e, const float* d_wave, long long wave
     { DzProfScope ps(DZ_T_ECAPA_FBANK, N); if ((rc = dz_launch_fbank_post(e->melp, T, N, e->nvalid, e->feats, st))) return rc; }
 
     // ---- 3. ECAPA-TDNN -------------------------------------------------------------------------
+    // Split-f16 precision: the seven wide 1 x 1 layers (tdnn1 / tdnn2 of the three blocks, the MFA convolution: 84 % of
+    // the network's MACs) run on k_gemm_pre.hip — both operands as ready f16 planes moved by LDS-DMA — so whatever
+    // produces their input (block 0, the Res2Net convolutions, the squeeze-excitation's gate + residual pass) also
+    // writes it as kb-major planes of N T rows; the f32 copies stay for the consumers that are not GEMMs.
+    const bool pre = e->b0s != nullptr;
+    const long long p1 = NT * C1, p3 = NT * C3;          // elements between the hi and lo planes
     // block 0: Conv1d(80 -> 1024, k5) -> ReLU -> BN
     if ((rc = gemm(DZ_T_ECAPA_BLOCK0, N, st, e->feats, 80, (long long)T * 80, N, T, 80, 5, 1, 2, w.block0, nullptr, 416, C1, C1,
-                   e->b0, C1, (long long)T * C1, DZ_EPI_RELU_BN)))
+                   e->b0, C1, (long long)T * C1, DZ_EPI_RELU_BN, nullptr, nullptr, 0, 0, pre ? e->b0s : nullptr, p1)))
         return rc;
     const int dil[3] = {2, 3, 4};
     for (int i = 0; i < 3; ++i) {
         const dz_seres2net& b = w.ser[i];
         const float* xin = i == 0 ? e->b0 : e->cat + (size_t)(i - 1) * C1;
         const int ldin = i == 0 ? C1 : C3;
-        // tdnn1 (1x1)
-        if ((rc = gemm(DZ_T_ECAPA_WIDE, N, st, xin, ldin, 0, 1, (int)NT, C1, 1, 1, 0, b.tdnn1, nullptr, C1, C1, C1, e->t1, C1, 0,
-                       DZ_EPI_RELU_BN)))
-            return rc;
+        // tdnn1 (1x1): block 0 reads block0's planes, blocks 1 / 2 columns [1024 (i - 1), 1024 i) of the concatenation's
+        if (pre)
+            rc = i == 0 ? gemm_pre(DZ_T_ECAPA_WIDE, N, st, e->b0s, p1, C1, NT, C1, b.tdnn1, C1, e->t1)
+                        : gemm_pre(DZ_T_ECAPA_WIDE, N, st, e->cats + (size_t)(i - 1) * (C1 / 32) * NT * 32, p3, C3, NT, C1, b.tdnn1,
+                                   C1, e->t1);
+        else
+            rc = gemm(DZ_T_ECAPA_WIDE, N, st, xin, ldin, 0, 1, (int)NT, C1, 1, 1, 0, b.tdnn1, nullptr, C1, C1, C1, e->t1, C1, 0,
+                      DZ_EPI_RELU_BN);
+        if (rc) return rc;
         // Res2Net: y0 = x0; y1 = f1(x1); yi = fi(xi + y(i-1))
-        DZ_HIP(hipMemcpy2DAsync(e->res, sizeof(float) * C1, e->t1, sizeof(float) * C1, sizeof(float) * 128,
-                                (size_t)NT, hipMemcpyDeviceToDevice, st));
+        if (pre) {      // (y0 is only read by tdnn2: planes alone)
+            DzProfScope ps(DZ_T_ECAPA_RES2, N);
+            if ((rc = dz_launch_se_apply_planes(e->t1, C1, nullptr, nullptr, 0, nullptr, 0, e->ress, p1, N, T, 128, st))) return rc;
+        } else {
+            DZ_HIP(hipMemcpy2DAsync(e->res, sizeof(float) * C1, e->t1, sizeof(float) * C1, sizeof(float) * 128,
+                                    (size_t)NT, hipMemcpyDeviceToDevice, st));
+        }
         for (int j = 1; j < 8; ++j) {
             const float* x2 = j >= 2 ? e->res + (j - 1) * 128 : nullptr;
+            // (y7 has no f32 reader when tdnn2 takes the planes)
             if ((rc = gemm(DZ_T_ECAPA_RES2, N, st, e->t1 + j * 128, C1, (long long)T * C1, N, T, 128, 3, dil[i], dil[i], b.res[j - 1],
-                           nullptr, 384, 128, 128, e->res + j * 128, C1, (long long)T * C1, DZ_EPI_RELU_BN,
-                           x2)))
+                           nullptr, 384, 128, 128, pre && j == 7 ? nullptr : e->res + j * 128, C1, (long long)T * C1, DZ_EPI_RELU_BN,
+                           x2, nullptr, 0, 0, pre ? e->ress + (size_t)j * 4 * NT * 32 : nullptr, p1)))
                 return rc;
         }
         // tdnn2 (1x1)
-        if ((rc = gemm(DZ_T_ECAPA_WIDE, N, st, e->res, C1, 0, 1, (int)NT, C1, 1, 1, 0, b.tdnn2, nullptr, C1, C1, C1, e->t2, C1, 0,
-                       DZ_EPI_RELU_BN)))
-            return rc;
+        if (pre)
+            rc = gemm_pre(DZ_T_ECAPA_WIDE, N, st, e->ress, p1, C1, NT, C1, b.tdnn2, C1, e->t2);
+        else
+            rc = gemm(DZ_T_ECAPA_WIDE, N, st, e->res, C1, 0, 1, (int)NT, C1, 1, 1, 0, b.tdnn2, nullptr, C1, C1, C1, e->t2, C1, 0,
+                      DZ_EPI_RELU_BN);
+        if (rc) return rc;
         // squeeze-excitation + residual, written straight into its slice of the concatenation
         { DzProfScope ps(DZ_T_ECAPA_SE, N); if ((rc = dz_launch_se_mean(e->t2, T, C1, C1, N, e->nmask, e->smean, st))) return rc; }
         // squeeze (N rows x 1024 -> 128): one output tile, so the K loop is split 8 ways (a lone workgroup
@@ -240,13 +290,20 @@ extern "C" int dz_ecapa_forward(dz_ecapa* e, const float* d_wave, long long wave
                        DZ_EPI_BIAS_SIGMOID)))
             return rc;
         { DzProfScope ps(DZ_T_ECAPA_SE, N);
-          if ((rc = dz_launch_se_apply(e->t2, C1, e->gate, xin, ldin, e->cat + (size_t)i * C1, C3, N, T, C1, st)))
-              return rc; }
+          if (pre)      // f32 for the next block's residual, planes for its tdnn1 and the MFA convolution
+              rc = dz_launch_se_apply_planes(e->t2, C1, e->gate, xin, ldin, e->cat + (size_t)i * C1, C3,
+                                             e->cats + (size_t)i * (C1 / 32) * NT * 32, p3, N, T, C1, st);
+          else
+              rc = dz_launch_se_apply(e->t2, C1, e->gate, xin, ldin, e->cat + (size_t)i * C1, C3, N, T, C1, st);
+          if (rc) return rc; }
     }
     // multi-layer feature aggregation
-    if ((rc = gemm(DZ_T_ECAPA_WIDE, N, st, e->cat, C3, 0, 1, (int)NT, C3, 1, 1, 0, w.mfa, nullptr, C3, C3, C3, e->mfa, C3, 0,
-                   DZ_EPI_RELU_BN)))
-        return rc;
+    if (pre)
+        rc = gemm_pre(DZ_T_ECAPA_WIDE, N, st, e->cats, p3, C3, NT, C3, w.mfa, C3, e->mfa);
+    else
+        rc = gemm(DZ_T_ECAPA_WIDE, N, st, e->cat, C3, 0, 1, (int)NT, C3, 1, 1, 0, w.mfa, nullptr, C3, C3, C3, e->mfa, C3, 0,
+                  DZ_EPI_RELU_BN);
+    if (rc) return rc;
     // attentive statistics pooling with global context: W [x; mean; std] = Wx x + Wms [mean; std]
     { DzProfScope ps(DZ_T_ECAPA_ASP, N); if ((rc = dz_launch_asp_gstats(e->mfa, T, C3, N, e->nmask, e->gstat, st))) return rc; }
     dz_layer wms = {w.asp_wms, w.zeros, nullptr, nullptr};

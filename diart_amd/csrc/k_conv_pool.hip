@@ -55,11 +55,11 @@ __global__ __launch_bounds__(256, 2) void conv_pool_h_kernel(
     int total, int* __restrict__ oflag, long long* __restrict__ dbg) {
     using G = Geo<CIN>;
     // dbg (kbench only): shader-clock stamps of the phases of every tile, wave 0 / wave 3 lane 0 of each workgroup
+#ifdef DZ_EXPERIMENTS       // phase stamps for tools/conv_pool_phases.py: experiments build only
     long long* dq = nullptr;
     if (dbg && (threadIdx.x & 63) == 0 && ((threadIdx.x >> 6) == 0 || (threadIdx.x >> 6) == 3))
         dq = dbg + ((long long)blockIdx.x * 2 + (threadIdx.x >> 7)) * 64;
     int dn = 0;
-#ifdef DZ_EXPERIMENTS       // phase stamps for tools/conv_pool_phases.py: experiments build only
 #define DZ_STAMP() do { if (dq && dn < 64) dq[dn++] = __builtin_readcyclecounter(); } while (0)
 #else
 #define DZ_STAMP() do { } while (0)

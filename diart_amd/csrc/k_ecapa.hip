@@ -161,6 +161,45 @@ __global__ void se_apply_kernel(const float* __restrict__ x, int ldx, const floa
     *reinterpret_cast<f32x4*>(out + rt * ldo + c) = o;
 }
 
+// The same element-wise pass (GATE) or a plain copy (!GATE) of a 128-column-aligned block of columns that ALSO
+// writes the result as the two f16 planes a k_gemm_pre.hip consumer reads (kb-major, dz_kb in dz_common.h: a
+// plane of R rows is [C / 32][R][32]).  A wave owns 8 rows x 32 columns (lane = 8 * row + column quad): its f32
+// accesses are eight full 128-byte lines and its plane writes 512 contiguous bytes per plane (eight 64-byte
+// rows of one k-block) — the row-major lane order of se_apply_kernel would scatter 8-byte pieces over eight
+// k-blocks.  `out` may be NULL (planes only).
+typedef _Float16 se_f16x4 __attribute__((ext_vector_type(4)));
+template <bool GATE>
+__global__ __launch_bounds__(256) void se_apply_planes_kernel(
+    const float* __restrict__ x, int ldx, const float* __restrict__ gate, const float* __restrict__ resid, int ldr,
+    float* __restrict__ out, int ldo, unsigned short* __restrict__ planes, long long plane, long long R, int T, int C,
+    int* __restrict__ oflag) {
+    const int tid = threadIdx.x;
+    const int c = blockIdx.x * 128 + (tid >> 6) * 32 + (tid & 7) * 4;
+    const long long rt = (long long)blockIdx.y * 8 + ((tid >> 3) & 7);
+    if (rt >= R || c >= C) return;
+    f32x4 o = *reinterpret_cast<const f32x4*>(x + rt * ldx + c);
+    if (GATE) {
+        const f32x4 g = *reinterpret_cast<const f32x4*>(gate + (rt / T) * C + c);
+        const f32x4 r = *reinterpret_cast<const f32x4*>(resid + rt * ldr + c);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = g[e] * o[e] + r[e];     // (the arithmetic of se_apply_kernel)
+    }
+    if (out) *reinterpret_cast<f32x4*>(out + rt * ldo + c) = o;
+    float amax = 0.f;
+    f32x4 v;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        amax = fmaxf(amax, fabsf(o[e]));
+        v[e] = __builtin_amdgcn_fmed3f(o[e], -65504.f, 65504.f);
+    }
+    const se_f16x4 hi = __builtin_convertvector(v, se_f16x4);
+    const se_f16x4 lo = __builtin_convertvector((v - __builtin_convertvector(hi, f32x4)) * 2048.f, se_f16x4);
+    const long long idx = dz_kb(rt, c, R);
+    *reinterpret_cast<se_f16x4*>(planes + idx) = hi;
+    *reinterpret_cast<se_f16x4*>(planes + plane + idx) = lo;
+    dz_flag_range(oflag, amax);
+}
+
 // global-context statistics: g[row][c] = mean, g[row][C + c] = sqrt(max(var, 1e-12)) over the
 // nmask[row] valid frames with weights 1 / nmask
 __global__ __launch_bounds__(256) void asp_gstats_kernel(const float* __restrict__ x, int T, int C,
@@ -313,6 +352,25 @@ int dz_launch_se_apply(const float* x, int ldx, const float* gate, const float* 
     const long long total4 = (long long)rows * T * (C / 4);
     DZ_LAUNCH(se_apply_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, st, x,
                        ldx, gate, resid, ldr, out, ldo, T, C, total4);
+    DZ_HIP(hipGetLastError());
+    return 0;
+}
+// gate == NULL: planes (and out, if given) = x.  x / out / resid point at the block's first column; `planes` at the
+// k-block of that column (plane base + (column / 32) * R * 32), `plane` = elements between the hi and lo planes,
+// R = rows * T = rows of a plane.
+int dz_launch_se_apply_planes(const float* x, int ldx, const float* gate, const float* resid, int ldr, float* out,
+                              int ldo, void* planes, long long plane, int rows, int T, int C, hipStream_t st) {
+    DZ_REQUIRE(x && planes && C % 32 == 0 && ldx % 4 == 0 && (out == nullptr || ldo % 4 == 0) && plane % 4 == 0,
+               "se_apply_planes: bad operands");
+    DZ_REQUIRE(gate == nullptr || (resid != nullptr && ldr % 4 == 0), "se_apply_planes: gate without residual");
+    const long long R = (long long)rows * T;
+    const dim3 grid((C + 127) / 128, (unsigned)((R + 7) / 8));
+    if (gate)
+        DZ_LAUNCH(se_apply_planes_kernel<true>, grid, dim3(256), 0, st, x, ldx, gate, resid, ldr, out, ldo,
+                  reinterpret_cast<unsigned short*>(planes), plane, R, T, C, dz_cur_oflag);
+    else
+        DZ_LAUNCH(se_apply_planes_kernel<false>, grid, dim3(256), 0, st, x, ldx, gate, resid, ldr, out, ldo,
+                  reinterpret_cast<unsigned short*>(planes), plane, R, T, C, dz_cur_oflag);
     DZ_HIP(hipGetLastError());
     return 0;
 }

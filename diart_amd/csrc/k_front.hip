@@ -545,9 +545,9 @@ __global__ __launch_bounds__(256, 2) void sinc_conv0_v2_kernel(
     float* __restrict__ y0, int P0, float* __restrict__ partials, int ntile, int total,
     int* __restrict__ oflag, int rot_period, int rot_mode, long long* __restrict__ dbg) {
     // dbg (experiments build, tools/conv0_phases.py): per wave shader-clock stamps per tile + (HW_ID | role << 32) in slot 63
+#ifdef DZ_EXPERIMENTS
     long long* dq = nullptr;
     int dn = 0;
-#ifdef DZ_EXPERIMENTS
     if (dbg && (threadIdx.x & 63) == 0) dq = dbg + ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * 64;
 #define CQ_STAMP() do { if (dq && dn < 60) dq[dn++] = __builtin_readcyclecounter(); } while (0)
 #else
@@ -786,7 +786,6 @@ __global__ __launch_bounds__(256, 2) void sinc_conv0_v2_kernel(
             const int f = 3 * (16 * half + (((n & 3) << 2) | (n >> 2))) + bk, c = f & 3;
             aoff[bk] = ch_copy_base(c) + 2 * (10 * f - 2 * c + 8 * q);
         }
-        const int ch = 64 + n;
         fetch(t_begin);
         park(t_begin, xs2[0]);
         __syncthreads();
@@ -884,7 +883,8 @@ int dz_launch_sinc_conv0_split(const float* wave, long long stride, int B, int S
     const int grid = total < 512 ? total : 512;    // two resident workgroups per CU
     static const int cus = [] {
         int dev = 0, n = 256;
-        if (hipGetDevice(&dev) == hipSuccess) hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
+            n = 256;
         return n > 0 ? n : 256;
     }();
     int rot_mode = 0;

@@ -393,11 +393,12 @@ class PackedEcapa:
             shift = g(prefix + ".norm.bias") - g(prefix + ".norm.running_mean") * scale
             return _pad1(scale, npad), _pad1(shift, npad)
 
-        def layer(dst, prefix, cin_pad, npad, kpad, norm=True, weight=None, wide=False):
+        def layer(dst, prefix, cin_pad, npad, kpad, norm=True, weight=None, wide=False, kb=False):
             cw = g(prefix + ".conv.weight") if weight is None else weight
             dst.w = pk.put(_conv_pack(cw, cin_pad, npad, kpad))
-            if wide and split:   # also as split-f16 planes: the layer runs on k_gemm_split.hip
-                dst.wsplit = pk.put_split(_conv_pack(cw, cin_pad, npad, kpad), prefix)
+            if wide and split:   # also as split-f16 planes: the layer runs on k_gemm_split.hip, or (kb: planes in
+                #                  kb-major order) with pre-split activations on k_gemm_pre.hip
+                dst.wsplit = pk.put_split(_conv_pack(cw, cin_pad, npad, kpad), prefix, kb=kb)
             dst.b = pk.put(_pad1(g(prefix + ".conv.bias"), npad))
             if norm:
                 sc, sh = bn(prefix.rsplit(".conv", 1)[0] + ".norm", npad)
@@ -412,13 +413,13 @@ class PackedEcapa:
         layer(w.block0, "blocks.0.conv", 80, 1024, 416, wide=True)
         for i in range(3):
             p, b = f"blocks.{i + 1}", w.ser[i]
-            layer(b.tdnn1, p + ".tdnn1.conv", 1024, 1024, 1024, wide=True)
+            layer(b.tdnn1, p + ".tdnn1.conv", 1024, 1024, 1024, wide=True, kb=True)
             for j in range(7):
                 layer(b.res[j], p + f".res2net_block.blocks.{j}.conv", 128, 128, 384, wide=True)
-            layer(b.tdnn2, p + ".tdnn2.conv", 1024, 1024, 1024, wide=True)
+            layer(b.tdnn2, p + ".tdnn2.conv", 1024, 1024, 1024, wide=True, kb=True)
             layer(b.se1, p + ".se_block.conv1", 1024, 128, 1024, norm=False)
             layer(b.se2, p + ".se_block.conv2", 128, 1024, 128, norm=False)
-        layer(w.mfa, "mfa.conv", 3072, 3072, 3072, wide=True)
+        layer(w.mfa, "mfa.conv", 3072, 3072, 3072, wide=True, kb=True)
         aw = g("asp.tdnn.conv.conv.weight")                           # (128, 9216, 1)
         layer(w.asp_tdnn, "asp.tdnn.conv", 3072, 128, 3072, weight=aw[:, :3072])
         w.asp_wms = pk.put(aw[:, 3072:, 0].contiguous())             # (128, 6144)
