@@ -159,7 +159,7 @@ def test_shipped_library_has_no_experiment_surface():
     assert not bad, bad
     kernels = subprocess.run(["nm", "-C", str(lib)], capture_output=True, text=True, check=True).stdout
     for never_default in ("gemm_g2_kernel", "gemm_g3_kernel", "lstm_mfma1_kernel", "gemm_pre_big_kernel",
-                          "lstm_rec_kernel<true, 2", "sinc_conv0_h_kernel", "sinc_conv0_pair_kernel"):
+                          "lstm_rec_kernel<true, 2", "sinc_conv0_h_kernel", "sinc_conv0_pair_kernel", "conv_pool_v2_kernel"):
         assert never_default not in kernels, never_default
     env_names = sorted(set(re.findall(r"^DZ_[A-Z0-9_]+$", subprocess.run(["strings", str(lib)], capture_output=True,
                                                                       text=True, check=True).stdout, flags=re.M)))

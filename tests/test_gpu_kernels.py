@@ -348,6 +348,53 @@ def test_convgemm_pool3(gpu, Cin, Tin, split):
     assert torch.allclose(ps[..., 1], (ref ** 2).sum(2), rtol=1e-5, atol=1e-4)
 
 
+@pytest.mark.parametrize("v2", [False, True], ids=["conv_pool_h", "conv_pool_v2"])
+@pytest.mark.parametrize("B,Cin,Tin", [(20, 80, 2658), (60, 60, 884), (300, 60, 101)])
+def test_conv_pool_many_tiles_per_workgroup(gpu, monkeypatch, B, Cin, Tin, v2):
+    """k_conv_pool.hip at batch sizes where a persistent workgroup walks SEVERAL tiles (560 - 600 tiles on 512 / 256
+    workgroups): chunk changes inside a workgroup's range, the ragged last tile of every chunk and — for
+    conv_pool_v2 (experiments build, DZ_CONV_POOL_V2=1) — the double-buffered input and the hand-over of finished
+    blocks to the service waves.  Against the f64 layer; conv_pool_v2 also against conv_pool_h (the same products,
+    added in another order)."""
+    if v2 and not _lib.experiments():
+        pytest.skip("conv_pool_v2 is only in the experiments build")
+    g = torch.Generator().manual_seed(B + Cin)
+    Cout, taps = 60, 5
+    cin_pad = 80 if Cin == 80 else 64
+    x = torch.randn(B, Cin, Tin, generator=g).abs()
+    w = torch.randn(Cout, Cin, taps, generator=g) / math.sqrt(Cin * taps)
+    bias = torch.randn(Cout, generator=g) * 0.1
+    kpad = (taps * cin_pad + 31) // 32 * 32
+    Wp = _pack(w, cin_pad, 64, kpad)
+    X = torch.zeros(B, Tin, cin_pad)
+    X[:, :, :Cin] = x.permute(0, 2, 1)
+    nscale, nshift = torch.zeros(B, cin_pad), torch.zeros(B, cin_pad)
+    nscale[:, :Cin] = torch.rand(B, Cin, generator=g) + 0.5
+    nshift[:, :Cin] = torch.randn(B, Cin, generator=g) * 0.2 - 0.3
+    xin = F.leaky_relu(x * nscale[:, :Cin, None] + nshift[:, :Cin, None], 0.01)
+    ref = F.max_pool1d(F.conv1d(xin.double(), w.double(), bias.double()), 3, 3)
+    Tp = ref.shape[2]
+    bp = torch.cat([bias, torch.zeros(4)])
+    run = lambda: _run_convgemm(gpu, X, Wp, bp, taps=taps, dil=1, epi=_lib.EPI_POOL3, Npad=64, Nstore=64, Kpad=kpad,
+                                nscale=nscale, nshift=nshift, Tstore=Tp, ldy=64, split="convpool")
+    if v2:
+        Y0, part0 = run()
+        monkeypatch.setenv("DZ_CONV_POOL_V2", "1")
+    Y, part = run()
+    got = Y[:, :, :Cout].permute(0, 2, 1).double()
+    assert not torch.isnan(Y).any() and not torch.isnan(part).any()
+    assert (Y[:, :, Cout:] == 0).all()
+    assert (got - ref).abs().max().item() < 3e-5 * max(1.0, ref.abs().max().item())
+    ps = part.double().sum(1)[:, :Cout]
+    assert torch.allclose(ps[..., 0], ref.sum(2), rtol=1e-5, atol=1e-4)
+    assert torch.allclose(ps[..., 1], (ref ** 2).sum(2), rtol=1e-5, atol=1e-4)
+    Y2, part2 = run()                                     # deterministic
+    assert torch.equal(Y, Y2) and torch.equal(part, part2)
+    if v2:
+        assert (Y - Y0).abs().max().item() < 2e-6 * max(1.0, Y0.abs().max().item())
+        assert torch.allclose(part, part0, rtol=1e-5, atol=1e-4)
+
+
 @pytest.mark.parametrize("B,Tin,Cin,taps,dil,N,Nstore,epi", [
     (1, 64 * 289, 512, 3, 2, 512, 512, "tdnn"),          # config-2 tdnn2, flattened
     (1, 1000, 512, 1, 1, 1536, 1500, "tdnn"),            # tdnn5: stored columns end inside a 4-column group

@@ -1,6 +1,7 @@
 #!/usr/bin/env python
 """Where a conv_pool_h tile spends its time: shader-clock stamps of the phases (dz_k_conv_pool_debug),
-config-2 shape (64 chunks), both layers.  usage: python tools/conv_pool_phases.py"""
+config-2 shape (64 chunks), both layers.  usage: python tools/conv_pool_phases.py
+DZ_CONV_POOL_V2=1: the same for conv_pool_v2 (matrix / service waves)."""
 import ctypes as C
 import sys
 from pathlib import Path
@@ -37,6 +38,45 @@ for name, B, Tin, Cin in (("conv1", 64, 2658, 80), ("conv2", 64, 884, 64)):
     d.xbs, d.ybs, d.epi = Tin * Cin, (Tout // 3) * 64, _lib.EPI_POOL3
     for _ in range(3):
         _lib.check(lib.dz_k_conv_pool(ctx, C.byref(d), st), name)
+    if os.environ.get("DZ_CONV_POOL_V2") == "1":      # conv_pool_v2: 8 waves per workgroup, 5 stamps per iteration
+        stamps = torch.zeros(256 * 8 * 64, dtype=torch.int64, device=dev)
+        lib.dz_k_conv_pool_debug(stamps.data_ptr())
+        _lib.check(lib.dz_k_conv_pool(ctx, C.byref(d), st), name)
+        torch.cuda.synchronize()
+        lib.dz_k_conv_pool_debug(None)
+        s = stamps.cpu().numpy().reshape(256, 8, 64)
+        place = {}
+        for role, label, names in ((1, "matrix waves", ["norm update", "MFMA phase + block hand-over", "-", "-", "tile barrier"]),
+                                   (0, "service waves", ["norm update", "exchange reads of tile t-1 + fetch issue of tile t+1",
+                                                         "finish tile t-1 (max, stores, sums) + partials of tile t-2",
+                                                         "park tile t+1 (wait loads, normalise, split, LDS writes)", "tile barrier"])):
+            rows = []
+            for wg in range(256):
+                sims = tuple(int((s[wg, w, 63] >> 4) & 3) for w in range(8) if s[wg, w, 63])
+                if role == 1 and sims:
+                    roles = tuple(int((s[wg, w, 63] >> 32) & 1) for w in range(8))
+                    place[(sims, roles)] = place.get((sims, roles), 0) + 1
+                for w in range(8):
+                    v = s[wg, w]
+                    if not v[63] or ((int(v[63]) >> 32) & 1) != role:
+                        continue
+                    n = int((v[:60] != 0).sum())
+                    its = n // 5
+                    for it in range(its):
+                        seg = v[5 * it:5 * it + 5]
+                        nxt = v[5 * it + 5] if 5 * it + 5 < n else None
+                        dd = list(np.diff(seg))
+                        # phase 0 of the NEXT iteration starts at this one's last stamp
+                        rows.append((it, its, dd))
+            # middle iterations only (steady state): skip the first two and the last two of every wave
+            mid = np.array([dd for it, its, dd in rows if 2 <= it < its - 2], dtype=np.float64)
+            if len(mid) == 0:
+                mid = np.array([dd for it, its, dd in rows], dtype=np.float64)
+            print(f"{name} {label}: {len(mid)} steady-state iterations, mean cycles {mid.sum(1).mean():.0f} (from the first stamp to after the barrier)")
+            for nm, m, p10, p90 in zip(names[1:] , mid.mean(0), np.percentile(mid, 10, 0), np.percentile(mid, 90, 0)):
+                print(f"    {m:8.0f} (p10 {p10:6.0f}, p90 {p90:6.0f})  {nm}")
+        print("   (SIMD of waves 0..7, roles) x workgroups:", sorted(place.items(), key=lambda kv: -kv[1])[:4])
+        continue
     stamps = torch.zeros(512 * 2 * 64, dtype=torch.int64, device=dev)
     lib.dz_k_conv_pool_debug(stamps.data_ptr())
     _lib.check(lib.dz_k_conv_pool(ctx, C.byref(d), st), name)
