@@ -21,6 +21,7 @@
 // Workgroup = 4 waves, two workgroups per CU; partials layout and tile size (96 conv frames) are
 // those of the POOL3 GEMM epilogue, so finalize_norm and every consumer are unchanged.
 #include "dz_common.h"
+#include <type_traits>
 
 #ifdef DZ_EXPERIMENTS
 extern long long* dz_conv_pool_dbg;      // set by dz_k_conv_pool_debug (phase stamps, tools/conv_pool_phases.py)
@@ -45,7 +46,7 @@ struct Geo {
     static constexpr int PLANE = ROWS * PITCH;
     static constexpr int XCH = 2 * 3 * 16 * 64 * 4;    // exchange: [nt][block][reg][lane] f32
     static constexpr int NORM = 2 * CIN * 4;           // scale | shift of the current chunk
-    static constexpr int LDS = 2 * PLANE + XCH + NORM;
+    static constexpr int LDS = 2 * PLANE + XCH + NORM + 2 * 64 * 2 * 4;   // + the k-halves' (sum, sumsq) of a tile
     static_assert(CIN % 16 == 0 && (PITCH / 16) % 2 == 1, "row pitch must be an odd multiple of 16 bytes");
 };
 
@@ -74,6 +75,8 @@ __global__ __launch_bounds__(256, 2) void conv_pool_h_kernel(
     char* xs = lds;                                                  // [2 planes][ROWS][PITCH]
     float* xch = reinterpret_cast<float*>(lds + 2 * G::PLANE);       // [2][3][16][64]
     float* nrm = reinterpret_cast<float*>(lds + 2 * G::PLANE + G::XCH);   // scale[CIN] | shift[CIN]
+    float* psum = reinterpret_cast<float*>(lds + 2 * G::PLANE + G::XCH + G::NORM);   // [k-half][64 ch][sum, sumsq] of a tile
+    long long ptile = -1;                                             // tile whose sums are in psum
     const int tid = threadIdx.x;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6), l = tid & 63, li = l & 31, g = l >> 5;
     const int nt = w & 1, kh = w >> 1;                                // channel block, k-half
@@ -107,21 +110,16 @@ __global__ __launch_bounds__(256, 2) void conv_pool_h_kernel(
     constexpr int C4 = CIN / 4;
     constexpr int NPK = (ROWS * C4 + 255) / 256;
     f32x4 pv[NPK];
+    // Buffer loads: rows are dense (ldx = CIN), so the tile is ONE span of memory and piece idx = tid + 256 i sits
+    // at byte 16 idx of it — no address arithmetic, no branches; what lies past the chunk's end reads as zeros
+    // through the bounds check (pieces past the tile's own rows are loaded and ignored).
     auto fetch = [&](int t) {
         const int b = t / ntile, t0 = (t - b * ntile) * FR;
-        const float* Xb = X + (long long)b * Tin * CIN;
-        // the (row, column) of every piece is loop invariant: left to itself the compiler hoists all
-        // 2 x NPK of them out of the tile loop and keeps them live through the MFMA phase (spills)
-        int tid_l = tid;
-        asm volatile("" : "+v"(tid_l));
+        const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)(X + ((long long)b * Tin + t0) * CIN), 0, (unsigned)(Tin - t0) * (CIN * 4u), 0x00020000);
 #pragma unroll
-        for (int i = 0; i < NPK; ++i) {
-            const int idx = tid_l + 256 * i;
-            const int r = idx / C4, c4 = idx - r * C4;
-            pv[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            if (idx < ROWS * C4 && t0 + r < Tin)
-                pv[i] = *reinterpret_cast<const f32x4*>(Xb + (long long)(t0 + r) * CIN + 4 * c4);
-        }
+        for (int i = 0; i < NPK; ++i)
+            pv[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xr, 16 * tid + 4096 * i, 0, 0));
     };
 
     for (int t = t_begin; t < t_end; ++t) {
@@ -144,6 +142,8 @@ __global__ __launch_bounds__(256, 2) void conv_pool_h_kernel(
             cur_b = b;
         }
         __syncthreads();                        // previous tile's fragment / exchange reads are done
+        // (and both k-halves' sums of the previous tile are in LDS: k-half 0's + k-half 1's, tid = 2 ch + {sum, sumsq})
+        if (ptile >= 0 && tid < 128) partials[ptile * 128 + tid] = psum[tid] + psum[128 + tid];
         DZ_STAMP();
         // ---- park the tile: normalise + LeakyReLU, split, two planes --------------------------
         int tid_p = tid;
@@ -153,18 +153,24 @@ __global__ __launch_bounds__(256, 2) void conv_pool_h_kernel(
             const int idx = tid_p + 256 * i;
             if (idx < ROWS * C4) {
                 const int r = idx / C4, c4 = idx - r * C4;
-                f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                if (t0 + r < Tin) {
-                    v = pv[i];
-                    const f32x4 sc = *reinterpret_cast<const f32x4*>(nrm + 4 * c4);
-                    const f32x4 sh = *reinterpret_cast<const f32x4*>(nrm + CIN + 4 * c4);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        v[e] = leaky(v[e] * sc[e] + sh[e]);
-                        amax = fmaxf(amax, fabsf(v[e]));
-                        v[e] = __builtin_amdgcn_fmed3f(v[e], -65504.f, 65504.f);
-                    }
-                }
+                // Packed f32 arithmetic where the ISA has it (v_pk_fma / v_pk_mul: two elements per instruction),
+                // LeakyReLU as max(x, slope x) (slope in (0, 1)), rows past the chunk's end zeroed by a packed
+                // multiply: ~33 vector instructions per 4 elements instead of ~45.  A SIMD does not overlap these
+                // with the MFMAs of the other resident workgroup's wave (conv_pool_v2 below: measured), so every
+                // vector instruction of the tile loop is tile time.
+                const f32x4 sc = *reinterpret_cast<const f32x4*>(nrm + 4 * c4);
+                const f32x4 sh = *reinterpret_cast<const f32x4*>(nrm + CIN + 4 * c4);
+                const f32x2 in01 = t0 + r < Tin ? (f32x2){1.f, 1.f} : (f32x2){0.f, 0.f};
+                f32x2 va = {pv[i][0], pv[i][1]}, vb = {pv[i][2], pv[i][3]};
+                va = __builtin_elementwise_fma(va, (f32x2){sc[0], sc[1]}, (f32x2){sh[0], sh[1]});
+                vb = __builtin_elementwise_fma(vb, (f32x2){sc[2], sc[3]}, (f32x2){sh[2], sh[3]});
+                const f32x2 sa = va * DZ_LEAKY_SLOPE, sb = vb * DZ_LEAKY_SLOPE;
+                f32x4 v = {fmaxf(va[0], sa[0]), fmaxf(va[1], sa[1]), fmaxf(vb[0], sb[0]), fmaxf(vb[1], sb[1])};
+                va = (f32x2){v[0], v[1]} * in01;
+                vb = (f32x2){v[2], v[3]} * in01;
+                amax = fmaxf(amax, fmaxf(fmaxf(fabsf(va[0]), fabsf(va[1])), fmaxf(fabsf(vb[0]), fabsf(vb[1]))));
+                v = (f32x4){__builtin_amdgcn_fmed3f(va[0], -65504.f, 65504.f), __builtin_amdgcn_fmed3f(va[1], -65504.f, 65504.f),
+                            __builtin_amdgcn_fmed3f(vb[0], -65504.f, 65504.f), __builtin_amdgcn_fmed3f(vb[1], -65504.f, 65504.f)};
                 const f16x4 hi = __builtin_convertvector(v, f16x4);
                 const f16x4 lo = __builtin_convertvector((v - __builtin_convertvector(hi, f32x4)) * 2048.f, f16x4);
                 char* d = xs + r * G::PITCH + 8 * c4;
@@ -199,47 +205,59 @@ __global__ __launch_bounds__(256, 2) void conv_pool_h_kernel(
             for (int r = 0; r < 16; ++r) part[bk][r] = accm[r] + accx[r] * (1.f / 2048.f);
         }
         DZ_STAMP();
-        // ---- the k-halves meet: half 1 hands its partial sums over ------------------------------
-        if (kh == 1) {
+        // ---- the k-halves meet.  Each half finishes EIGHT of the sixteen accumulator rows (k-half 0: registers 0..7,
+        // k-half 1: 8..15) and hands the other eight of its partial sums over: all four waves add, pool, store and
+        // sum (rounds 2 - 4: half 1 handed over everything and idled while half 0 finished the tile — 3.1 k of a
+        // tile's 16.6 k cycles) -----------------------------------------------------------------------------------
+        // (kh is wave-uniform: two straight-line instantiations, compile-time register indices)
+        auto hand_over = [&](auto KH) {
+            constexpr int give = decltype(KH)::value ? 0 : 8;      // first register of the rows the OTHER half finishes
 #pragma unroll
             for (int bk = 0; bk < 3; ++bk)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) xch[((nt * 3 + bk) * 16 + r) * 64 + l] = part[bk][r];
-        }
+                for (int q = 0; q < 8; ++q) xch[((nt * 3 + bk) * 16 + give + q) * 64 + l] = part[bk][give + q];
+        };
+        if (kh) hand_over(std::integral_constant<int, 1>{});
+        else hand_over(std::integral_constant<int, 0>{});
         __syncthreads();
         DZ_STAMP();
-        if (kh == 0) {
-            f32x16 pmax;
-#pragma unroll
-            for (int bk = 0; bk < 3; ++bk)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const float v = (part[bk][r] + xch[((nt * 3 + bk) * 16 + r) * 64 + l]) + bv;
-                    pmax[r] = bk == 0 ? v : fmaxf(pmax[r], v);
-                }
-            // pooled rows + partials: C/D column = lane & 31 = channel, row rho = pooled row
+        auto finish = [&](auto KH) {
+            constexpr int own = decltype(KH)::value ? 8 : 0;       // first register of the rows THIS half finishes
             const int ch = 32 * nt + li;
             float sum = 0.f, ssq = 0.f;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int pr = tile * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
+            for (int q = 0; q < 8; ++q) {
+                float pm = 0.f;
+#pragma unroll
+                for (int bk = 0; bk < 3; ++bk) {
+                    // (k-half 0's sum + k-half 1's sum) + bias, whichever wave adds them
+                    const float v = (part[bk][own + q] + xch[((nt * 3 + bk) * 16 + own + q) * 64 + l]) + bv;
+                    pm = bk == 0 ? v : fmaxf(pm, v);
+                }
+                // pooled rows + partials: C/D column = lane & 31 = channel, register rr -> pooled row (rr & 3) + 8 (rr >> 2) + 4 g
+                constexpr int rr0 = own;
+                const int pr = tile * 32 + ((rr0 + q) & 3) + 8 * ((rr0 + q) >> 2) + 4 * g;
                 if (pr < Tstore) {
-                    const float v = pmax[r];
-                    Y[((long long)b * Tstore + pr) * 64 + ch] = v;
-                    sum += v;
-                    ssq += v * v;
+                    Y[((long long)b * Tstore + pr) * 64 + ch] = pm;
+                    sum += pm;
+                    ssq += pm * pm;
                 }
             }
             sum += __shfl_xor(sum, 32, 64);
             ssq += __shfl_xor(ssq, 32, 64);
-            if (g == 0) {
-                float* pp = partials + (((long long)b * ntile + tile) * 64 + ch) * 2;
-                pp[0] = sum;
-                pp[1] = ssq;
+            if (g == 0) {                                  // this half's 16 rows of channel ch; the halves meet at the next barrier
+                psum[(decltype(KH)::value * 64 + ch) * 2] = sum;
+                psum[(decltype(KH)::value * 64 + ch) * 2 + 1] = ssq;
             }
-        }
+        };
+        if (kh) finish(std::integral_constant<int, 1>{});
+        else finish(std::integral_constant<int, 0>{});
+        ptile = (long long)b * ntile + tile;
         DZ_STAMP();
     }
+    // the last tile's partials
+    __syncthreads();
+    if (tid < 128) partials[ptile * 128 + tid] = psum[tid] + psum[128 + tid];
 #undef DZ_STAMP
     dz_flag_range(oflag, amax);
 }
