@@ -139,7 +139,7 @@ static int gemm(int tag, int rows_n, hipStream_t st, const float* X, int ldx, lo
     // every layer that comes with split-f16 planes (default precision: block 0, the wide 1x1 layers, the
     // Res2Net convolutions with their reflect padding and second input, the attention's output
     // convolution, the DFT) runs the same contraction on the f16 matrix cores (k_gemm_split.hip)
-    if (L.wsplit && (epi == DZ_EPI_RELU_BN || epi == DZ_EPI_BIAS) && !rowbias && ksplit <= 1 && Cin % 8 == 0) {
+    if (L.wsplit && (epi == DZ_EPI_RELU_BN || epi == DZ_EPI_BIAS || epi == DZ_EPI_RELU_BN_TANH) && ksplit <= 1 && Cin % 8 == 0) {
         p.Wsplit = L.wsplit;
         p.Npad = (Npad + 127) / 128 * 128;       // (the DFT's planes are packed with 512 rows)
         p.Ysplit = Yplanes;                      // the next wide layer's input, written by this epilogue

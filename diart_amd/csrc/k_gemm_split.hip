@@ -282,9 +282,10 @@ __global__ __launch_bounds__(128 * WM) void gemm_split_kernel(DzConvGemm p) {
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
         const int n = n0 + wn * 32 * NB + nb * 32 + li;
-        const float bv = p.bias[n];
+        float bv = p.bias[n];
+        if (p.rowbias) bv += p.rowbias[(long long)b * p.Npad + n];       // per-batch-item bias (ECAPA's attention TDNN)
         float e0 = 1.f, e1 = 0.f;
-        if (EPI == DZ_EPI_TDNN || EPI == DZ_EPI_RELU_BN) {
+        if (EPI == DZ_EPI_TDNN || EPI == DZ_EPI_RELU_BN || EPI == DZ_EPI_RELU_BN_TANH) {
             e0 = p.e0[n];
             e1 = p.e1[n];
         }
@@ -297,6 +298,7 @@ __global__ __launch_bounds__(128 * WM) void gemm_split_kernel(DzConvGemm p) {
             if (EPI == DZ_EPI_BIAS_LEAKY) v = leaky(v);
             if (EPI == DZ_EPI_TDNN) v = leaky(v) * e0 + e1;
             if (EPI == DZ_EPI_RELU_BN) v = fmaxf(v, 0.f) * e0 + e1;
+            if (EPI == DZ_EPI_RELU_BN_TANH) v = tanhf(fmaxf(v, 0.f) * e0 + e1);     // (k_convgemm.hip's expression)
             if (Yb && ok && nok) Yb[(long long)t * p.ldy + n] = v;
             if (Ypl) dz_store_split(Ypl, dz_kb(yrow0 + t, n, yrows), nok ? v : 0.f, ok, li & 1, amax);
         }
@@ -324,7 +326,9 @@ int dz_launch_gemm_split(const DzConvGemm& p_in, hipStream_t st) {
     DZ_REQUIRE(p.Kpad % KT == 0 && p.Cin % 8 == 0 && p.ldx % 4 == 0 && p.K % 8 == 0,
                "gemm_split: bad K/Cin/ldx (Cin and K must be multiples of 8)");
     DZ_REQUIRE(p.K <= p.Kpad && p.K == p.taps * p.Cin, "gemm_split: K mismatch");
-    DZ_REQUIRE(p.rowbias == nullptr && p.ksplit <= 1, "gemm_split: row bias / split-K are f32-path features");
+    DZ_REQUIRE(p.ksplit <= 1, "gemm_split: split-K is an f32-path feature");
+    DZ_REQUIRE(p.rowbias == nullptr || p.epi == DZ_EPI_RELU_BN_TANH || p.epi == DZ_EPI_RELU_BN || p.epi == DZ_EPI_BIAS,
+               "gemm_split: a row bias is built with the BIAS / RELU_BN / RELU_BN_TANH epilogues");
     DZ_REQUIRE((p.pad == 0 && p.X2 == nullptr) || !p.norm_on_load,
                "gemm_split: padding / a second input are not built together with norm-on-load");
     DZ_REQUIRE(p.pad >= 0 && p.Tout > 0 && p.Tout == (p.pad ? p.Tin : p.Tin - (p.taps - 1) * p.dil),
@@ -373,6 +377,9 @@ int dz_launch_gemm_split(const DzConvGemm& p_in, hipStream_t st) {
         case DZ_EPI_RELU_BN:   // ECAPA-TDNN's 1x1 layers: conv -> ReLU -> folded BatchNorm
             DZ_REQUIRE(!pro, "gemm_split: RELU_BN has no norm-on-load instance");
             DZ_SP(4, 2, false, DZ_EPI_RELU_BN);
+        case DZ_EPI_RELU_BN_TANH:   // ... and the attention TDNN of its pooling: -> tanh
+            DZ_REQUIRE(!pro, "gemm_split: RELU_BN_TANH has no norm-on-load instance");
+            DZ_SP(4, 2, false, DZ_EPI_RELU_BN_TANH);
     }
 #undef DZ_SP
     dz_set_error("gemm_split: epilogue %d is not built on the split-f16 path", p.epi);

@@ -421,7 +421,7 @@ class PackedEcapa:
             layer(b.se2, p + ".se_block.conv2", 128, 1024, 128, norm=False)
         layer(w.mfa, "mfa.conv", 3072, 3072, 3072, wide=True, kb=True)
         aw = g("asp.tdnn.conv.conv.weight")                           # (128, 9216, 1)
-        layer(w.asp_tdnn, "asp.tdnn.conv", 3072, 128, 3072, weight=aw[:, :3072])
+        layer(w.asp_tdnn, "asp.tdnn.conv", 3072, 128, 3072, weight=aw[:, :3072], wide=True)
         w.asp_wms = pk.put(aw[:, 3072:, 0].contiguous())             # (128, 6144)
         layer(w.asp_conv, "asp.conv", 128, 3072, 128, norm=False, wide=True)
         sc, sh = bn("asp_bn", 6144)

@@ -202,7 +202,7 @@ typedef struct {
     const float* s;   /* [Npad] folded BatchNorm scale (NULL if the layer has no norm)        */
     const float* h;   /* [Npad] folded BatchNorm shift                                        */
     const void* wsplit; /* optional split-f16 planes of w: the layer then runs on the f16 matrix cores.  Row-major
-                           [2][Npad][Kpad] for block0, the Res2Net convolutions and asp_conv (dz_k_gemm_split);
+                           [2][Npad][Kpad] for block0, the Res2Net convolutions, asp_tdnn and asp_conv (dz_k_gemm_split);
                            kb-major [2][Kpad / 32][Npad][32] for the wide 1 x 1 layers tdnn1, tdnn2 and mfa, which
                            read pre-split activations (dz_k_gemm_pre, see dz_convgemm_desc.Xsplit)       */
 } dz_layer;

@@ -194,7 +194,7 @@ def test_sinc_conv0_pair(gpu, S):
 
 # --------------------------------------------------------------------------- #
 def _run_convgemm(gpu, X, W, bias, *, taps, dil, epi, Npad, Nstore, Kpad, e0=None, e1=None,
-                  nscale=None, nshift=None, Tstore=None, ldy=None, ksplit=0, split=False):
+                  nscale=None, nshift=None, Tstore=None, ldy=None, ksplit=0, split=False, rowbias=None):
     """X (B,Tin,Cin) channels-last; W (Npad,Kpad) packed.  ``split``: run the split-f16 MFMA kernel
     (dz_k_gemm_split, weights as f16 hi/lo planes) instead of the exact-f32 one."""
     lib = _lib.load()
@@ -216,6 +216,10 @@ def _run_convgemm(gpu, X, W, bias, *, taps, dil, epi, Npad, Nstore, Kpad, e0=Non
         dsc, dsh = nscale.contiguous().to(gpu), nshift.contiguous().to(gpu)
         d.nscale, d.nshift, d.nld, d.norm_on_load = dsc.data_ptr(), dsh.data_ptr(), nscale.shape[1], 1
         keep += [dsc, dsh]
+    if rowbias is not None:
+        drb = rowbias.contiguous().to(gpu)
+        d.rowbias = drb.data_ptr()
+        keep.append(drb)
     ntile = lib.dz_k_convgemm_ntile(Tout)
     part = None
     if epi == _lib.EPI_POOL3:
@@ -346,6 +350,27 @@ def test_convgemm_pool3(gpu, Cin, Tin, split):
     ps = part.double().sum(1)[:, :Cout]
     assert torch.allclose(ps[..., 0], ref.sum(2), rtol=1e-5, atol=1e-4)
     assert torch.allclose(ps[..., 1], (ref ** 2).sum(2), rtol=1e-5, atol=1e-4)
+
+
+@pytest.mark.parametrize("split", [False, True], ids=["f32", "f16x3"])
+def test_convgemm_row_bias_relu_bn_tanh(gpu, split):
+    """ECAPA's attention TDNN (speechbrain AttentiveStatisticsPooling.tdnn + tanh): 1 x 1, 3072 -> 128, a per-batch-item
+    bias (the global-context columns folded into one vector per row), ReLU -> folded BatchNorm -> tanh; the exact-f32
+    kernel and, since round 5, the split-f16 one (it used to fall back to the f32 kernel for this layer)."""
+    g = torch.Generator().manual_seed(31)
+    B, T, Cin, N = 3, 157, 3072, 128
+    X = torch.randn(B, T, Cin, generator=g)
+    W = torch.randn(N, Cin, generator=g) / math.sqrt(Cin)
+    bias = torch.randn(N, generator=g) * 0.1
+    rb = torch.randn(B, N, generator=g) * 0.3
+    s0, s1 = torch.rand(N, generator=g) + 0.5, torch.randn(N, generator=g) * 0.1
+    Y, _ = _run_convgemm(gpu, X, W, bias, taps=1, dil=1, epi=_lib.EPI_RELU_BN_TANH, Npad=N, Nstore=N, Kpad=Cin, e0=s0, e1=s1,
+                         rowbias=rb, split=split)
+    ref = torch.tanh(torch.relu(X.double() @ W.double().t() + bias.double() + rb.double()[:, None, :]) * s0.double() + s1.double())
+    assert not torch.isnan(Y).any()
+    err = (Y.double() - ref).abs().max().item()
+    print(f"row bias + tanh, {'f16x3' if split else 'f32'}: max |d| {err:.2e}")
+    assert err < 1e-5            # K = 3072 products accumulated in f32; |y| <= 1
 
 
 @pytest.mark.parametrize("v2", [False, True], ids=["conv_pool_h", "conv_pool_v2"])
