@@ -575,7 +575,9 @@ __global__ __launch_bounds__(256, 2) void sinc_conv0_v2_kernel(
     int* simd_of = reinterpret_cast<int*>(stage_all_end(lds_all));
     if (l == 0) simd_of[w] = simd;
     __syncthreads();
-    const bool by_simd = ((1 << simd_of[0]) | (1 << simd_of[1]) | (1 << simd_of[2]) | (1 << simd_of[3])) == 15;
+    // (rot_mode, experiments build: 1 = no complementary roles, 2 = inverted, 3 = roles by wave index — the fall-back, so
+    // that a test can run it on hardware that always places the four waves on four SIMDs)
+    const bool by_simd = rot_mode != 3 && ((1 << simd_of[0]) | (1 << simd_of[1]) | (1 << simd_of[2]) | (1 << simd_of[3])) == 15;
     const int rot = rot_mode == 1 ? 0 : (((int)blockIdx.x / rot_period) & 1) ^ (rot_mode == 2);
     const int slot = by_simd ? simd : w;
     const bool heavy = ((slot >> 1) & 1) == rot;
@@ -891,7 +893,7 @@ int dz_launch_sinc_conv0_split(const float* wave, long long stride, int B, int S
     long long* dbg_ptr = nullptr;
 #ifdef DZ_EXPERIMENTS
     dbg_ptr = dz_conv_pool_dbg;                    // the stamp buffer of dz_k_conv_pool_debug (tools/conv0_phases.py)
-    // DZ_CONV0_ROT: 1 = no complementary roles, 2 = inverted; DZ_CONV0_V2=0: the three-wave kernel of rounds 2 - 4
+    // DZ_CONV0_ROT: 1 = no complementary roles, 2 = inverted, 3 = roles by wave index; DZ_CONV0_V2=0: the three-wave kernel of rounds 2 - 4
     const char* e_rot = dz_exp_env("DZ_CONV0_ROT");
     if (e_rot) rot_mode = atoi(e_rot);
     const char* e_v2 = dz_exp_env("DZ_CONV0_V2");

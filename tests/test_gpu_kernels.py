@@ -352,6 +352,64 @@ def test_convgemm_pool3(gpu, Cin, Tin, split):
     assert torch.allclose(ps[..., 1], (ref ** 2).sum(2), rtol=1e-5, atol=1e-4)
 
 
+@pytest.mark.parametrize("mode", [None, "DZ_CONV0_ROT=1", "DZ_CONV0_ROT=2", "DZ_CONV0_ROT=3", "DZ_CONV0_V2=0"],
+                         ids=["shipped", "no-complementary-roles", "inverted-roles", "roles-by-wave-index", "three-wave-kernel"])
+def test_sinc_conv0_split_many_tiles_per_workgroup(gpu, monkeypatch, mode):
+    """sinc_conv0_v2 at a batch where a persistent workgroup walks 6 - 7 tiles (40 chunks x 84 tiles on 512 workgroups):
+    the double-buffered sample copies, the light waves' deferred partials, chunk changes inside a workgroup's range and
+    two workgroups per CU with complementary roles.  Experiments build: the other role assignments — among them the
+    fall-back by wave index, which this hardware never takes by itself — and the three-wave kernel of rounds 2 - 4
+    must give the same rows (heavy-wave channels bit for bit)."""
+    if mode and not _lib.experiments():
+        pytest.skip("role / kernel switches exist in the experiments build only")
+    from diart_amd.synth import synth_segmentation_state, synth_stream
+    from diart_amd.weights import sinc_filters, split_f16, _pad2
+    sd = synth_segmentation_state()
+    p = "sincnet.conv1d.0.filterbank."
+    filt = sinc_filters(sd[p + "low_hz_"], sd[p + "band_hz_"], sd[p + "window_"], sd[p + "n_"])
+    B, S = 40, 80000
+    wave = synth_stream(7, 30.0)
+    x = torch.stack([torch.from_numpy(wave[i * 8000: i * 8000 + S].copy()) for i in range(B)])
+    x[3] *= 25.0
+    gamma, beta = 0.9, 0.02
+    xn = F.instance_norm(x[:, None, :]) * gamma + beta
+    ref = F.max_pool1d(F.conv1d(xn, filt[:, None, :], stride=10).abs(), 3, 3)
+    P0 = ref.shape[2]
+    lib = _lib.load()
+    d = torch.zeros(B, S + 64)
+    d[:, :S] = x
+    d = d.to(gpu)
+    st = torch.empty(B, 2, device=gpu)
+    _lib.check(lib.dz_k_wave_stats(_ctx(gpu), d.data_ptr(), d.stride(0), B, S, st.data_ptr(), None))
+    fs = split_f16(_pad2(filt, 96, 256)).to(gpu)
+    nt = lib.dz_k_conv0_split_ntile(S)
+
+    def run():
+        y0 = torch.full((B, P0, 80), float("nan"), device=gpu)
+        part = torch.full((B, nt, 80, 2), float("nan"), device=gpu)
+        _lib.check(lib.dz_k_sinc_conv0_split(_ctx(gpu), d.data_ptr(), d.stride(0), B, S, st.data_ptr(), gamma, beta,
+                                             fs.data_ptr(), y0.data_ptr(), part.data_ptr(), None))
+        _sync()
+        return y0.cpu(), part.cpu()
+
+    base_y, base_p = run()
+    if mode:
+        k, v = mode.split("=")
+        monkeypatch.setenv(k, v)
+    y0, part = run()
+    got = y0.permute(0, 2, 1)
+    assert not torch.isnan(got).any() and not torch.isnan(part).any()
+    assert _rel(got, ref) < 2e-5
+    ps = part.double().sum(1)
+    assert torch.allclose(ps[..., 0], ref.double().sum(2), rtol=1e-5)
+    assert torch.allclose(ps[..., 1], (ref.double() ** 2).sum(2), rtol=1e-5)
+    y1, part1 = run()
+    assert torch.equal(y0, y1) and torch.equal(part, part1)              # deterministic
+    assert torch.equal(y0[:, :, :64], base_y[:, :, :64])                   # 32x32x16 arithmetic: every variant
+    assert (y0 - base_y).abs().max().item() <= 2e-6 * base_y.abs().max().item()
+    assert torch.allclose(part, base_p, rtol=1e-5, atol=1e-5)
+
+
 @pytest.mark.parametrize("split", [False, True], ids=["f32", "f16x3"])
 def test_convgemm_row_bias_relu_bn_tanh(gpu, split):
     """ECAPA's attention TDNN (speechbrain AttentiveStatisticsPooling.tdnn + tanh): 1 x 1, 3072 -> 128, a per-batch-item
