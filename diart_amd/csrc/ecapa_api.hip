@@ -290,8 +290,8 @@ extern "C" int dz_ecapa_forward(dz_ecapa* e, const float* d_wave, long long wave
                        DZ_EPI_BIAS_SIGMOID)))
             return rc;
         { DzProfScope ps(DZ_T_ECAPA_SE, N);
-          if (pre)      // f32 for the next block's residual, planes for its tdnn1 and the MFA convolution
-              rc = dz_launch_se_apply_planes(e->t2, C1, e->gate, xin, ldin, e->cat + (size_t)i * C1, C3,
+          if (pre)      // f32 for the next block's residual (the last block has none), planes for its tdnn1 and the MFA convolution
+              rc = dz_launch_se_apply_planes(e->t2, C1, e->gate, xin, ldin, i < 2 ? e->cat + (size_t)i * C1 : nullptr, C3,
                                              e->cats + (size_t)i * (C1 / 32) * NT * 32, p3, N, T, C1, st);
           else
               rc = dz_launch_se_apply(e->t2, C1, e->gate, xin, ldin, e->cat + (size_t)i * C1, C3, N, T, C1, st);
