@@ -16,10 +16,14 @@
 //     wave (nt, kh) owns output channels 32 nt .. +31 and one half of the k-steps;
 //   * MaxPool1d(3) is an element-wise maximum: the 96 frames are computed as three 32-row MFMA
 //     blocks, block b = frames {3 m + b}, so pooled row m sits in the same lane and register of
-//     all three (the trick of sinc_conv0_h_kernel, k_front.hip);
-//   * the two k-halves meet once per tile through LDS (12 KiB per 32-channel block).
-// Workgroup = 4 waves, two workgroups per CU; partials layout and tile size (96 conv frames) are
-// those of the POOL3 GEMM epilogue, so finalize_norm and every consumer are unchanged.
+//     all three (the trick of the sinc_conv0 kernels, k_front.hip);
+//   * the two k-halves meet once per tile through LDS: each hands the other the half of its accumulator rows it
+//     does not finish, so all four waves add, pool, store and sum (round 5; before, half 1 handed over everything
+//     and idled through the finishing pass).
+// Workgroup = 4 waves, two workgroups per CU (the size that fits beside a recurrence workgroup); partials layout and
+// tile size (96 conv frames) are those of the POOL3 GEMM epilogue, so finalize_norm and every consumer are unchanged.
+// Round 5 also trimmed the vector work of the tile loop — buffer loads (no address arithmetic), packed-f32 parking —
+// after conv_pool_v2 (below, experiments build) showed that vector instructions are not hidden under MFMAs.
 #include "dz_common.h"
 #include <type_traits>
 
