@@ -60,6 +60,7 @@ extern "C" int dz_ctx_create(int hip_device, dz_ctx** out) {
     DZ_REQUIRE(c != nullptr, "dz_ctx_create: out of memory");
     c->device = hip_device;
     c->oflag_host = c->oflag_dev = nullptr;
+    c->conv0_frag = nullptr;
     DZ_HIP(hipSetDevice(hip_device));
     DZ_HIP(hipHostMalloc((void**)&c->oflag_host, sizeof(int), hipHostMallocMapped));
     *c->oflag_host = 0;
@@ -69,6 +70,7 @@ extern "C" int dz_ctx_create(int hip_device, dz_ctx** out) {
 }
 extern "C" int dz_ctx_destroy(dz_ctx* ctx) {
     if (ctx && ctx->oflag_host) (void)hipHostFree(ctx->oflag_host);
+    if (ctx && ctx->conv0_frag) (void)hipFree(ctx->conv0_frag);
     delete ctx;
     return 0;
 }
@@ -289,7 +291,9 @@ static int run_gemm(DzConvGemm& p, const void* split, hipStream_t st) {
 
 struct SincScratch {
     float *stats, *y0, *part0, *sc0, *sh0, *y1, *part1, *sc1, *sh1, *y2, *part2, *sc2, *sh2;
+    void* bank_frag;     // the sinc bank in sinc_conv0_v2's fragment order (filled once, at create)
     void carve(Arena& a, const SincGeom& g, int Bm) {
+        bank_frag = a.take((size_t)dz_sinc_bank_frag_bytes() / 4);
         stats = a.take((size_t)Bm * 2 * DZ_WS_G);   // slice moments of the waveform
         y0 = a.take((size_t)Bm * g.P0 * 80);
         part0 = a.take((size_t)Bm * g.nt0 * 80 * 2);
@@ -339,7 +343,7 @@ static int run_sincnet(const dz_sincnet_weights& w, const SincGeom& g, const Sin
     { ProfScope ps(T_CONV0, B);
     rc = w.filt_split
              ? dz_launch_sinc_conv0_split(wave, stride, B, g.S, stats, 1, w.wav_gamma, w.wav_beta,
-                                          w.filt_split, s.y0, g.P0, s.part0, g.nt0, st)
+                                          w.filt_split, s.y0, g.P0, s.part0, g.nt0, st, s.bank_frag)
              : dz_launch_sinc_conv0(wave, stride, B, g.S, stats, 1, w.wav_gamma, w.wav_beta, w.filt,
                                     s.y0, g.P0, s.part0, g.nt0, st);
     if (rc) return rc; }
@@ -458,6 +462,11 @@ extern "C" int dz_seg_create(dz_ctx* ctx, const dz_seg_weights* w, int max_batch
     Arena real;
     real.base = s->arena; real.size = measure.used;
     seg_carve(s, real);
+    if (w->sinc.filt_split) {      // (the weights are final when a handle is created: one repack per handle)
+        int rc = dz_launch_sinc_bank_frag(w->sinc.filt_split, s->ss.bank_frag, nullptr);
+        if (!rc && hipStreamSynchronize(nullptr) != hipSuccess) rc = 1;
+        if (rc) { (void)hipFree(s->arena); delete s; return rc; }
+    }
     *out = s;
     return 0;
 }
@@ -697,6 +706,11 @@ extern "C" int dz_emb_create(dz_ctx* ctx, const dz_emb_weights* w, int max_batch
     Arena real;
     real.base = e->arena; real.size = measure.used;
     emb_carve(e, real);
+    if (w->sinc.filt_split) {
+        int rc = dz_launch_sinc_bank_frag(w->sinc.filt_split, e->ss.bank_frag, nullptr);
+        if (!rc && hipStreamSynchronize(nullptr) != hipSuccess) rc = 1;
+        if (rc) { (void)hipFree(e->arena); delete e; return rc; }
+    }
     *out = e;
     return 0;
 }
@@ -1100,8 +1114,11 @@ extern "C" int dz_k_sinc_conv0_split(dz_ctx* ctx, const float* d_wave, long long
     DZ_REQUIRE(g.P0 > 0, "dz_k_sinc_conv0_split: %d samples is too short", samples);
     DZ_HIP(hipSetDevice(ctx->device));
     DzRangeScope range_scope(ctx->oflag_dev);
+    // kernel-level entry: the bank goes into fragment order on every call (the handles do it once, at create)
+    if (!ctx->conv0_frag) DZ_HIP(hipMalloc(&ctx->conv0_frag, (size_t)dz_sinc_bank_frag_bytes()));
+    if ((rc = dz_launch_sinc_bank_frag(d_filt_split, ctx->conv0_frag, (hipStream_t)stream))) return rc;
     return dz_launch_sinc_conv0_split(d_wave, stride, batch, samples, d_stats, 0, gamma, beta,
-                                      d_filt_split, d_y0, g.P0, d_partials, g.nt0, (hipStream_t)stream);
+                                      d_filt_split, d_y0, g.P0, d_partials, g.nt0, (hipStream_t)stream, ctx->conv0_frag);
 }
 extern "C" int dz_k_conv0_split_ntile(int samples) { return sinc_geom(samples, true).nt0; }
 #ifdef DZ_EXPERIMENTS

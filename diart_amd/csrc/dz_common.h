@@ -271,7 +271,10 @@ int dz_launch_sinc_conv0(const float* wave, long long stride, int B, int S, cons
 // unfolded bank; partials tiles are 96 frames: ntile = dz_conv0_split_ntile(F0)
 int dz_launch_sinc_conv0_split(const float* wave, long long stride, int B, int S, const float* stats,
                                int stats_are_moments, float gamma, float beta, const void* filt_split,
-                               float* y0, int P0, float* partials, int ntile, hipStream_t st);
+                               float* y0, int P0, float* partials, int ntile, hipStream_t st, const void* ffrag = nullptr);
+// the bank in sinc_conv0_v2's fragment order (dz_sinc_bank_frag_bytes() bytes): one tiny launch per weight set
+int dz_sinc_bank_frag_bytes();
+int dz_launch_sinc_bank_frag(const void* fsp, void* frag, hipStream_t st);
 int dz_conv0_split_ntile(int F0);
 // the same stage of BOTH networks in one launch (160 filters, one split of the normalised samples; k_front.hip;
 // experiments build only)
@@ -465,4 +468,5 @@ struct dz_ctx {
     // host memory (kernels store 1 into it; the host reads it without a copy: dz_range_check)
     int* oflag_host;
     int* oflag_dev;
+    void* conv0_frag;    // dz_k_sinc_conv0_split: scratch for the bank in fragment order (lazily allocated)
 };

@@ -536,6 +536,28 @@ __global__ __launch_bounds__(192, 2) void sinc_conv0_h_kernel(
 // ---------------------------------------------------------------------------
 typedef float cq_f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned cq_u32x4 __attribute__((ext_vector_type(4)));
+
+// The bank in the order sinc_conv0_v2's waves load it (16-byte vectors): heavy block h in {0, 1}:
+// [h][plane][k-step 16][lane 64] (lane = filter li + 32 g: taps 16 ks + 8 g .. + 7 of filter 32 h + li), then the
+// light waves' 16 filters: [plane][k-step 8][lane 64] (lane = n + 16 q: taps 32 ks + 8 q .. + 7 of filter 64 + n).
+// With the row-major planes every lane reads 16 bytes of its own 512-byte row: 32 cache lines per load instruction,
+// 1 024 line requests per heavy wave — 7 - 10 k cycles of a workgroup's prologue went into issuing them
+// (tools/conv0_phases.py, "own prologue loads issued").  Here an instruction reads 1 KiB of contiguous memory.
+#define DZ_BANK_FRAG_HEAVY (2 * 2 * 16 * 64)                    /* vectors of the two heavy blocks */
+#define DZ_BANK_FRAG_VECS (DZ_BANK_FRAG_HEAVY + 2 * 8 * 64)     /* 5 120 vectors = 80 KiB          */
+__global__ void sinc_bank_frag_kernel(const unsigned short* __restrict__ fsp, cq_u32x4* __restrict__ out) {
+    const int v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= DZ_BANK_FRAG_VECS) return;
+    int plane, row, tap;
+    if (v < DZ_BANK_FRAG_HEAVY) {
+        const int lane = v & 63, ks = (v >> 6) & 15, pl = (v >> 10) & 1, h = v >> 11;
+        plane = pl; row = 32 * h + (lane & 31); tap = 16 * ks + 8 * (lane >> 5);
+    } else {
+        const int u = v - DZ_BANK_FRAG_HEAVY, lane = u & 63, ks = (u >> 6) & 7, pl = u >> 9;
+        plane = pl; row = 64 + (lane & 15); tap = 32 * ks + 8 * (lane >> 4);
+    }
+    out[v] = *reinterpret_cast<const cq_u32x4*>(fsp + ((long long)plane * 96 + row) * 256 + tap);
+}
 #define CQ_STAGE 4608                      /* bytes of result staging per wave: 32 rows x 36 floats            */
 #define CQ_LDS (2 * CH_LDS + 1536 * 4 + 16 + 2 * 2 * 16 * 2 * 4 + 4 * CQ_STAGE + 16)
 __device__ __forceinline__ char* stage_all_end(char* lds) { return lds + CQ_LDS - 16; }
@@ -543,12 +565,15 @@ __global__ __launch_bounds__(256, 2) void sinc_conv0_v2_kernel(
     const float* __restrict__ wave, long long stride, int S, const float* __restrict__ stats,
     int stats_are_moments, float gamma, float beta, const unsigned short* __restrict__ fsp,
     float* __restrict__ y0, int P0, float* __restrict__ partials, int ntile, int total,
-    int* __restrict__ oflag, int rot_period, int rot_mode, long long* __restrict__ dbg) {
+    int* __restrict__ oflag, int rot_period, int rot_mode, long long* __restrict__ dbg,
+    const unsigned short* __restrict__ ffrag) {
+    // ffrag: the bank in FRAGMENT order (sinc_bank_frag_kernel below), or NULL: fsp's row-major planes.
     // dbg (experiments build, tools/conv0_phases.py): per wave shader-clock stamps per tile + (HW_ID | role << 32) in slot 63
 #ifdef DZ_EXPERIMENTS
     long long* dq = nullptr;
     int dn = 0;
     if (dbg && (threadIdx.x & 63) == 0) dq = dbg + ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * 64;
+    if (dq) dq[62] = __builtin_readcyclecounter();          // kernel entry (slot 61: exit)
 #define CQ_STAMP() do { if (dq && dn < 60) dq[dn++] = __builtin_readcyclecounter(); } while (0)
 #else
 #define CQ_STAMP() do { } while (0)
@@ -574,7 +599,10 @@ __global__ __launch_bounds__(256, 2) void sinc_conv0_v2_kernel(
     const int simd = (__builtin_amdgcn_s_getreg((31 << 11) | 4) >> 4) & 3;
     int* simd_of = reinterpret_cast<int*>(stage_all_end(lds_all));
     if (l == 0) simd_of[w] = simd;
-    __syncthreads();
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#ifdef DZ_EXPERIMENTS
+    if (dq) dq[60] = __builtin_readcyclecounter();          // roles known
+#endif
     // (rot_mode, experiments build: 1 = no complementary roles, 2 = inverted, 3 = roles by wave index — the fall-back, so
     // that a test can run it on hardware that always places the four waves on four SIMDs)
     const bool by_simd = rot_mode != 3 && ((1 << simd_of[0]) | (1 << simd_of[1]) | (1 << simd_of[2]) | (1 << simd_of[3])) == 15;
@@ -586,26 +614,40 @@ __global__ __launch_bounds__(256, 2) void sinc_conv0_v2_kernel(
     if (dq) dq[63] = (long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) | ((long long)(heavy ? 1 : 0) << 32) | ((long long)half << 33);
 #endif
 
-    if (tid < 2) {
-        const int bb = b_first + tid;
-        float mean = 0.f, rstd = 1.f;
-        if (bb * ntile < t_end) {
-            if (stats_are_moments)
-                dz_ws_combine(stats, bb, S, &mean, &rstd);
-            else
-                mean = stats[2 * bb], rstd = stats[2 * bb + 1];
+    // (mean, rstd) of the one or two chunks this workgroup touches.  Called by every wave AFTER it has issued its own
+    // prologue loads (filter bank to registers, first tile by LDS-DMA): the moments' round trip to L2 and the f64
+    // combine run under those instead of in front of them, and the barriers of the prologue wait on LDS only
+    // (__syncthreads() would drain vmcnt, i.e. serialise the bank loads with everything): prologue 18 k -> see
+    // tools/conv0_phases.py ("prologue").
+    auto chunk_stats = [&]() {
+        if (tid < 2) {
+            const int bb = b_first + tid;
+            float mean = 0.f, rstd = 1.f;
+            if (bb * ntile < t_end) {
+                if (stats_are_moments)
+                    dz_ws_combine(stats, bb, S, &mean, &rstd);
+                else
+                    mean = stats[2 * bb], rstd = stats[2 * bb + 1];
+            }
+            stat_s[tid][0] = mean;
+            stat_s[tid][1] = rstd;
         }
-        stat_s[tid][0] = mean;
-        stat_s[tid][1] = rstd;
-    }
-    __syncthreads();
+    };
+    auto lds_barrier = [&]() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
     float amax = 0.f;
 
     if (heavy) {
         // ================= a 32-filter block: sinc_conv0_h's arithmetic, no parking =================
         const int li = l & 31, g = l >> 5;
         ch_f16x8 bh[16], bl[16];
-        {
+        if (ffrag) {       // fragment order: every load instruction of the wave reads 1 KiB of contiguous memory
+            const ch_f16x8* fr = reinterpret_cast<const ch_f16x8*>(ffrag) + (half * 2) * 16 * 64 + l;
+#pragma unroll
+            for (int ks = 0; ks < 16; ++ks) {
+                bh[ks] = fr[ks * 64];
+                bl[ks] = fr[(16 + ks) * 64];
+            }
+        } else {           // row-major planes: lane (filter, k-half) reads 16 bytes of ITS row — 32 lines per instruction
             const unsigned short* row = fsp + (long long)(32 * half + li) * 256 + 8 * g;
 #pragma unroll
             for (int ks = 0; ks < 16; ++ks) {
@@ -621,7 +663,18 @@ __global__ __launch_bounds__(256, 2) void sinc_conv0_v2_kernel(
             aoff[bk] = ch_copy_base(c) + 2 * (10 * f - 2 * c + 8 * g);
         }
         const int ch = 32 * half + li;
-        __syncthreads();                   // (the light waves park the first tile before this barrier)
+#ifdef DZ_EXPERIMENTS
+        if (dq) dq[59] = __builtin_readcyclecounter();      // own loads issued
+#endif
+        chunk_stats();
+#ifdef DZ_EXPERIMENTS
+        if (dq) dq[58] = __builtin_readcyclecounter();      // statistics done (wave 0) / nothing
+#endif
+        lds_barrier();                     // the statistics are published
+#ifdef DZ_EXPERIMENTS
+        if (dq) dq[57] = __builtin_readcyclecounter();
+#endif
+        lds_barrier();                     // the light waves have parked the first tile
         for (int t = t_begin; t < t_end; ++t) {
             const char* xs = xs2[(t - t_begin) & 1];
             CQ_STAMP();
@@ -712,7 +765,14 @@ __global__ __launch_bounds__(256, 2) void sinc_conv0_v2_kernel(
         // ====== the last 16 filters for one pooled-row half of the tile + ALL fetching / parking of samples ======
         const int n = l & 15, q = l >> 4;
         ch_f16x8 bh[8], bl[8];
-        {
+        if (ffrag) {
+            const ch_f16x8* fr = reinterpret_cast<const ch_f16x8*>(ffrag) + DZ_BANK_FRAG_HEAVY + l;
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) {
+                bh[ks] = fr[ks * 64];
+                bl[ks] = fr[(8 + ks) * 64];
+            }
+        } else {
             const unsigned short* row = fsp + (long long)(64 + n) * 256 + 8 * q;
 #pragma unroll
             for (int ks = 0; ks < 8; ++ks) {
@@ -789,8 +849,19 @@ __global__ __launch_bounds__(256, 2) void sinc_conv0_v2_kernel(
             aoff[bk] = ch_copy_base(c) + 2 * (10 * f - 2 * c + 8 * q);
         }
         fetch(t_begin);
+#ifdef DZ_EXPERIMENTS
+        if (dq) dq[59] = __builtin_readcyclecounter();
+#endif
+        chunk_stats();
+#ifdef DZ_EXPERIMENTS
+        if (dq) dq[58] = __builtin_readcyclecounter();
+#endif
+        lds_barrier();
+#ifdef DZ_EXPERIMENTS
+        if (dq) dq[57] = __builtin_readcyclecounter();
+#endif
         park(t_begin, xs2[0]);
-        __syncthreads();
+        lds_barrier();
         for (int t = t_begin; t < t_end; ++t) {
             const char* xs = xs2[(t - t_begin) & 1];
             CQ_STAMP();
@@ -870,6 +941,9 @@ __global__ __launch_bounds__(256, 2) void sinc_conv0_v2_kernel(
         }
         light_partial(t_end - 1);
     }
+#ifdef DZ_EXPERIMENTS
+    if (dq) dq[61] = __builtin_readcyclecounter();
+#endif
 #undef CQ_STAMP
     dz_flag_range(oflag, amax);
 }
@@ -878,9 +952,17 @@ int dz_conv0_split_ntile(int F0) { return (F0 + CH_FR - 1) / CH_FR; }
 
 // fsp: the UNFOLDED bank as f16 planes [2][96][256] (weights.py split_f16 of the zero-padded
 // [96][256] filter matrix); partials [B][ntile][80][2] with ntile = dz_conv0_split_ntile(F0)
+int dz_sinc_bank_frag_bytes() { return DZ_BANK_FRAG_VECS * 16; }
+int dz_launch_sinc_bank_frag(const void* fsp, void* frag, hipStream_t st) {
+    DZ_LAUNCH(sinc_bank_frag_kernel, dim3((DZ_BANK_FRAG_VECS + 255) / 256), dim3(256), 0, st,
+              reinterpret_cast<const unsigned short*>(fsp), reinterpret_cast<cq_u32x4*>(frag));
+    DZ_HIP(hipGetLastError());
+    return 0;
+}
+
 int dz_launch_sinc_conv0_split(const float* wave, long long stride, int B, int S, const float* stats,
                                int stats_are_moments, float gamma, float beta, const void* fsp,
-                               float* y0, int P0, float* partials, int ntile, hipStream_t st) {
+                               float* y0, int P0, float* partials, int ntile, hipStream_t st, const void* ffrag) {
     const int total = ntile * B;
     const int grid = total < 512 ? total : 512;    // two resident workgroups per CU
     static const int cus = [] {
@@ -921,7 +1003,7 @@ int dz_launch_sinc_conv0_split(const float* wave, long long stride, int B, int S
 #endif
     DZ_LAUNCH(sinc_conv0_v2_kernel, dim3(grid), dim3(256), 0, st, wave, stride, S, stats, stats_are_moments, gamma, beta,
               reinterpret_cast<const unsigned short*>(fsp), y0, P0, partials, ntile, total, dz_cur_oflag, cus, rot_mode,
-              dbg_ptr);
+              dbg_ptr, reinterpret_cast<const unsigned short*>(ffrag));
     DZ_HIP(hipGetLastError());
     return 0;
 }

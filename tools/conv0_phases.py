@@ -68,6 +68,25 @@ for w in (range(3) if NW == 3 else range(2)):
     for nm, m, p10, p90 in zip(NAMES, r.mean(0), np.percentile(r, 10, axis=0), np.percentile(r, 90, axis=0)):
         print(f"    {nm:52s} {m:8.0f}   (p10 {p10:.0f}, p90 {p90:.0f})")
     out[f"wave{w}"] = dict(zip(NAMES, [round(float(x)) for x in r.mean(0)]))
+if NW == 4 and (s[:, :, 62] != 0).any():
+    # the launch as a whole: entry (slot 62) / exit (slot 61) stamps of every wave, first loop stamp in slot 0
+    ent, ext, first = s[:, :, 62].astype(np.float64), s[:, :, 61].astype(np.float64), s[:, :, 0].astype(np.float64)
+    ok = (ent > 0) & (ext > 0)
+    t0 = ent[ok].min()
+    ntiles = np.array([(int((s[wg, w, :60] != 0).sum()) // 5) for wg in range(512) for w in range(NW)]).reshape(512, NW)
+    print(f"launch, shader clock: first entry -> last exit {ext[ok].max() - t0:.0f} cycles; entry skew (p50 / p90 / max) "
+          f"{np.percentile(ent[ok] - t0, 50):.0f} / {np.percentile(ent[ok] - t0, 90):.0f} / {(ent[ok] - t0).max():.0f}; "
+          f"prologue = entry -> first tile (mean / p90) {(first[ok] - ent[ok]).mean():.0f} / {np.percentile(first[ok] - ent[ok], 90):.0f}; "
+          f"a wave's life entry -> exit (mean) {(ext[ok] - ent[ok]).mean():.0f}; tiles per workgroup {ntiles[:, 0].min()} - {ntiles[:, 0].max()}")
+    if (s[:, :, 60] != 0).any():
+        st = [s[:, :, k].astype(np.float64) for k in (62, 60, 59, 58, 57, 0)]
+        names = ["entry -> roles known (HW_ID publish + barrier)", "-> own prologue loads issued (bank to registers / first tile by LDS-DMA)",
+                 "-> chunk statistics (lanes 0 - 1 of wave 0)", "-> statistics barrier", "-> first tile parked + barrier (loop starts)"]
+        for r_, lab in ((1, "heavy"), (0, "light")):
+            m = ok & (role == r_)
+            print(f"  prologue of the {lab} waves, mean cycles: " + "; ".join(f"{n_} {(b_[m] - a_[m]).mean():.0f}" for n_, a_, b_ in zip(names, st, st[1:])))
+    out["launch"] = {"first_entry_to_last_exit": float(ext[ok].max() - t0), "entry_skew_p90": float(np.percentile(ent[ok] - t0, 90)),
+                     "prologue_mean": float((first[ok] - ent[ok]).mean()), "wave_life_mean": float((ext[ok] - ent[ok]).mean())}
 # MFMA phase by how many waves share the SIMD (from HW_ID): co-resident waves = waves with the same (se, sh, cu, simd) ... ids repeat
 Path("gpurun_out").mkdir(exist_ok=True)
 Path("gpurun_out/conv0_phases.json").write_text(json.dumps({"phases": out, "simd_loads": {str(k): v for k, v in loads.items()},
