@@ -60,7 +60,9 @@ extern "C" int dz_ctx_create(int hip_device, dz_ctx** out) {
     DZ_REQUIRE(c != nullptr, "dz_ctx_create: out of memory");
     c->device = hip_device;
     c->oflag_host = c->oflag_dev = nullptr;
-    c->conv0_frag = nullptr;
+    c->conv0_frag = c->convp_frag = nullptr;
+    c->conv0_src = c->convp_src = nullptr;
+    c->convp_cin = c->convp_kpad = 0;
     DZ_HIP(hipSetDevice(hip_device));
     DZ_HIP(hipHostMalloc((void**)&c->oflag_host, sizeof(int), hipHostMallocMapped));
     *c->oflag_host = 0;
@@ -71,6 +73,7 @@ extern "C" int dz_ctx_create(int hip_device, dz_ctx** out) {
 extern "C" int dz_ctx_destroy(dz_ctx* ctx) {
     if (ctx && ctx->oflag_host) (void)hipHostFree(ctx->oflag_host);
     if (ctx && ctx->conv0_frag) (void)hipFree(ctx->conv0_frag);
+    if (ctx && ctx->convp_frag) (void)hipFree(ctx->convp_frag);
     delete ctx;
     return 0;
 }
@@ -236,8 +239,8 @@ extern "C" int dz_emb_frames_for(int num_samples) {
 }
 
 // ---- run-time options (dz_common.h) ----------------------------------------------------------------
-static int g_options[DZ_OPT_COUNT] = {1, 1};
-static const char* const kOptionNames[DZ_OPT_COUNT] = {"f32_gemm", "pool_fuse"};
+static int g_options[DZ_OPT_COUNT] = {1, 1, 0};
+static const char* const kOptionNames[DZ_OPT_COUNT] = {"f32_gemm", "pool_fuse", "pack_cache"};
 int dz_option(int id) { return id >= 0 && id < DZ_OPT_COUNT ? __atomic_load_n(&g_options[id], __ATOMIC_RELAXED) : 0; }
 static int option_index(const char* name) {
     for (int i = 0; name && i < DZ_OPT_COUNT; ++i)
@@ -280,10 +283,10 @@ static bool conv_pool_enabled() {
 }
 
 // exact-f32 MFMA kernel, or the split-f16 kernel when the layer came with split planes
-static int run_gemm(DzConvGemm& p, const void* split, hipStream_t st) {
+static int run_gemm(DzConvGemm& p, const void* split, hipStream_t st, const void* wfrag = nullptr) {
     if (split) {
         p.Wsplit = split;
-        if (p.epi == DZ_EPI_POOL3 && conv_pool_enabled()) return dz_launch_conv_pool(p, st);
+        if (p.epi == DZ_EPI_POOL3 && conv_pool_enabled()) return dz_launch_conv_pool(p, st, wfrag);
         return dz_launch_gemm_split(p, st);
     }
     return dz_launch_convgemm(p, st);
@@ -291,9 +294,11 @@ static int run_gemm(DzConvGemm& p, const void* split, hipStream_t st) {
 
 struct SincScratch {
     float *stats, *y0, *part0, *sc0, *sh0, *y1, *part1, *sc1, *sh1, *y2, *part2, *sc2, *sh2;
-    void* bank_frag;     // the sinc bank in sinc_conv0_v2's fragment order (filled once, at create)
+    void *bank_frag, *w1_frag, *w2_frag;     // the sinc bank / conv1 / conv2 weights in their kernels' fragment order (filled once, at create)
     void carve(Arena& a, const SincGeom& g, int Bm) {
         bank_frag = a.take((size_t)dz_sinc_bank_frag_bytes() / 4);
+        w1_frag = a.take((size_t)dz_conv_pool_wfrag_bytes(80) / 4);
+        w2_frag = a.take((size_t)dz_conv_pool_wfrag_bytes(64) / 4);
         stats = a.take((size_t)Bm * 2 * DZ_WS_G);   // slice moments of the waveform
         y0 = a.take((size_t)Bm * g.P0 * 80);
         part0 = a.take((size_t)Bm * g.nt0 * 80 * 2);
@@ -309,6 +314,19 @@ struct SincScratch {
         sh2 = a.take((size_t)Bm * 64);
     }
 };
+
+// the register-resident operands of the SincNet kernels in fragment order: once per handle (the weights are final then)
+static int sinc_repack(const dz_sincnet_weights& w, const SincScratch& s) {
+    int rc = 0;
+    if (w.filt_split) rc = dz_launch_sinc_bank_frag(w.filt_split, s.bank_frag, nullptr);
+    if (!rc && w.w1_split) rc = dz_launch_conv_pool_wfrag(80, w.w1_split, 416, s.w1_frag, nullptr);
+    if (!rc && w.w2_split) rc = dz_launch_conv_pool_wfrag(64, w.w2_split, 320, s.w2_frag, nullptr);
+    if (!rc && hipStreamSynchronize(nullptr) != hipSuccess) {
+        dz_set_error("sinc_repack: hipStreamSynchronize failed");
+        rc = 1;
+    }
+    return rc;
+}
 
 static bool sinc_fused_norm(const dz_sincnet_weights& w) {
     return w.w1_split && w.w2_split && conv_pool_enabled() && fused_norm_enabled();
@@ -364,7 +382,7 @@ static int run_sincnet(const dz_sincnet_weights& w, const SincGeom& g, const Sin
     p.Kpad = 416; p.Npad = 64; p.Nstore = 64; p.ldx = 80; p.ldy = 64; p.Tstore = g.P1;
     p.xbs = (long long)g.P0 * 80; p.ybs = (long long)g.P1 * 64;
     p.norm_on_load = 1; p.epi = DZ_EPI_POOL3;
-    { ProfScope ps(T_CONV1, B); if ((rc = run_gemm(p, w.w1_split, st))) return rc; }
+    { ProfScope ps(T_CONV1, B); if ((rc = run_gemm(p, w.w1_split, st, s.w1_frag))) return rc; }
     if (!fused)
     { ProfScope ps(T_FIN, B);
     if ((rc = dz_launch_finalize_norm(s.part1, B, g.nt1, 64, g.P1, w.in1_g, w.in1_b, s.sc1, s.sh1,
@@ -377,7 +395,7 @@ static int run_sincnet(const dz_sincnet_weights& w, const SincGeom& g, const Sin
     p.Y = s.y2; p.partials = s.part2;
     p.Tin = g.P1; p.Tout = g.T2; p.Cin = 64; p.K = 320; p.Kpad = 320; p.ldx = 64;
     p.Tstore = g.P2; p.xbs = (long long)g.P1 * 64; p.ybs = (long long)g.P2 * 64;
-    { ProfScope ps(T_CONV2, B); if ((rc = run_gemm(p, w.w2_split, st))) return rc; }
+    { ProfScope ps(T_CONV2, B); if ((rc = run_gemm(p, w.w2_split, st, s.w2_frag))) return rc; }
     if (fused) return 0;
     ProfScope ps(T_FIN, B);
     return dz_launch_finalize_norm(s.part2, B, g.nt2, 64, g.P2, w.in2_g, w.in2_b, s.sc2, s.sh2, st);
@@ -462,11 +480,7 @@ extern "C" int dz_seg_create(dz_ctx* ctx, const dz_seg_weights* w, int max_batch
     Arena real;
     real.base = s->arena; real.size = measure.used;
     seg_carve(s, real);
-    if (w->sinc.filt_split) {      // (the weights are final when a handle is created: one repack per handle)
-        int rc = dz_launch_sinc_bank_frag(w->sinc.filt_split, s->ss.bank_frag, nullptr);
-        if (!rc && hipStreamSynchronize(nullptr) != hipSuccess) rc = 1;
-        if (rc) { (void)hipFree(s->arena); delete s; return rc; }
-    }
+    if (int rc = sinc_repack(w->sinc, s->ss)) { (void)hipFree(s->arena); delete s; return rc; }
     *out = s;
     return 0;
 }
@@ -706,11 +720,7 @@ extern "C" int dz_emb_create(dz_ctx* ctx, const dz_emb_weights* w, int max_batch
     Arena real;
     real.base = e->arena; real.size = measure.used;
     emb_carve(e, real);
-    if (w->sinc.filt_split) {
-        int rc = dz_launch_sinc_bank_frag(w->sinc.filt_split, e->ss.bank_frag, nullptr);
-        if (!rc && hipStreamSynchronize(nullptr) != hipSuccess) rc = 1;
-        if (rc) { (void)hipFree(e->arena); delete e; return rc; }
-    }
+    if (int rc = sinc_repack(w->sinc, e->ss)) { (void)hipFree(e->arena); delete e; return rc; }
     *out = e;
     return 0;
 }
@@ -1066,7 +1076,15 @@ extern "C" int dz_k_conv_pool(dz_ctx* ctx, const dz_convgemm_desc* d, void* stre
     DZ_REQUIRE(ctx && d, "dz_k_conv_pool: NULL argument");
     DZ_HIP(hipSetDevice(ctx->device));
     DzRangeScope range_scope(ctx->oflag_dev);
-    return dz_launch_conv_pool(*d, (hipStream_t)stream);
+    // kernel-level entry: the weights go into fragment order on every call (the handles do it once, at create)
+    DZ_REQUIRE(d->Wsplit && (d->Cin == 80 || d->Cin == 64), "dz_k_conv_pool: Wsplit is NULL or Cin is not 80 / 64");
+    if (!ctx->convp_frag) DZ_HIP(hipMalloc(&ctx->convp_frag, (size_t)dz_conv_pool_wfrag_bytes(80)));
+    int rc;
+    if (!(dz_option(DZ_OPT_PACK_CACHE) && ctx->convp_src == d->Wsplit && ctx->convp_cin == d->Cin && ctx->convp_kpad == d->Kpad)) {
+        if ((rc = dz_launch_conv_pool_wfrag(d->Cin, d->Wsplit, d->Kpad, ctx->convp_frag, (hipStream_t)stream))) return rc;
+        ctx->convp_src = d->Wsplit; ctx->convp_cin = d->Cin; ctx->convp_kpad = d->Kpad;
+    }
+    return dz_launch_conv_pool(*d, (hipStream_t)stream, ctx->convp_frag);
 }
 #ifdef DZ_EXPERIMENTS
 // phase time stamps of conv_pool_h (tools/kbench.py): 2 x 64 shader-clock stamps per workgroup
@@ -1115,8 +1133,13 @@ extern "C" int dz_k_sinc_conv0_split(dz_ctx* ctx, const float* d_wave, long long
     DZ_HIP(hipSetDevice(ctx->device));
     DzRangeScope range_scope(ctx->oflag_dev);
     // kernel-level entry: the bank goes into fragment order on every call (the handles do it once, at create)
+    // (option "pack_cache", off by default: skip the repack when the bank pointer is the one of the previous call —
+    // for the timing tools, whose weights do not change; a framework's allocator may hand the same address out again)
     if (!ctx->conv0_frag) DZ_HIP(hipMalloc(&ctx->conv0_frag, (size_t)dz_sinc_bank_frag_bytes()));
-    if ((rc = dz_launch_sinc_bank_frag(d_filt_split, ctx->conv0_frag, (hipStream_t)stream))) return rc;
+    if (!(dz_option(DZ_OPT_PACK_CACHE) && ctx->conv0_src == d_filt_split)) {
+        if ((rc = dz_launch_sinc_bank_frag(d_filt_split, ctx->conv0_frag, (hipStream_t)stream))) return rc;
+        ctx->conv0_src = d_filt_split;
+    }
     return dz_launch_sinc_conv0_split(d_wave, stride, batch, samples, d_stats, 0, gamma, beta,
                                       d_filt_split, d_y0, g.P0, d_partials, g.nt0, (hipStream_t)stream, ctx->conv0_frag);
 }

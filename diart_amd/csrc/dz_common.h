@@ -24,7 +24,7 @@ static inline const char* dz_exp_env(const char* name) { return getenv(name); }
 //   f32_gemm  (1): exact-f32 wide layers on k_gemm_f32.hip; 0 keeps them on k_convgemm.hip (the kernel the
 //                  prologue layers use anyway; tests compare the two)
 //   pool_fuse (1): statistics pooling inside tdnn5's epilogue; 0 = tdnn5 + stats_pool (the exact-f32 form)
-enum { DZ_OPT_F32_GEMM = 0, DZ_OPT_POOL_FUSE, DZ_OPT_COUNT };
+enum { DZ_OPT_F32_GEMM = 0, DZ_OPT_POOL_FUSE, DZ_OPT_PACK_CACHE, DZ_OPT_COUNT };
 int dz_option(int id);
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -298,7 +298,10 @@ int dz_launch_gemm_f32(const DzConvGemm& p, hipStream_t st);
 int dz_launch_gemm_split(const DzConvGemm& p, hipStream_t st);
 // k_conv_pool.hip: SincNet stages 1 / 2 (k = 5 conv + MaxPool1d(3) + partials) with the input tile
 // resident in LDS and the weights in registers; descriptor as the POOL3 call of dz_launch_gemm_split
-int dz_launch_conv_pool(const DzConvGemm& p, hipStream_t st);
+// wfrag: p.Wsplit in conv_pool_h's fragment order (dz_launch_conv_pool_wfrag, dz_conv_pool_wfrag_bytes(Cin) bytes), or NULL
+int dz_launch_conv_pool(const DzConvGemm& p, hipStream_t st, const void* wfrag = nullptr);
+int dz_conv_pool_wfrag_bytes(int Cin);
+int dz_launch_conv_pool_wfrag(int Cin, const void* wsplit, int Kpad, void* out, hipStream_t st);
 // k_gemm_pre.hip: both operands pre-split into f16 planes, tiles loaded by LDS-DMA
 int dz_launch_gemm_pre(const DzConvGemm& p, hipStream_t st);
 // k_gemm_g2.hip: generation 2 of the same layer (single accumulator, three LDS stages, counted vmcnt);
@@ -469,4 +472,8 @@ struct dz_ctx {
     int* oflag_host;
     int* oflag_dev;
     void* conv0_frag;    // dz_k_sinc_conv0_split: scratch for the bank in fragment order (lazily allocated)
+    void* convp_frag;    // dz_k_conv_pool: the same for its weights
+    const void* conv0_src;                 // option "pack_cache": what the two scratch buffers were packed from
+    const void* convp_src;
+    int convp_cin, convp_kpad;
 };

@@ -63,7 +63,7 @@ __global__ __launch_bounds__(256, 2) void conv_pool_h_kernel(
     const float* __restrict__ ngamma, const float* __restrict__ nbeta,
     const unsigned short* __restrict__ wsp, int Kpad,
     const float* __restrict__ bias, float* __restrict__ Y, float* __restrict__ partials, int ntile,
-    int total, int* __restrict__ oflag, long long* __restrict__ dbg) {
+    int total, int* __restrict__ oflag, long long* __restrict__ dbg, const unsigned short* __restrict__ wfrag) {
     using G = Geo<CIN>;
     // dbg (kbench only): shader-clock stamps of the phases of every tile, wave 0 / wave 3 lane 0 of each workgroup
 #ifdef DZ_EXPERIMENTS       // phase stamps for tools/conv_pool_phases.py: experiments build only
@@ -71,7 +71,8 @@ __global__ __launch_bounds__(256, 2) void conv_pool_h_kernel(
     if (dbg && (threadIdx.x & 63) == 0 && ((threadIdx.x >> 6) == 0 || (threadIdx.x >> 6) == 3))
         dq = dbg + ((long long)blockIdx.x * 2 + (threadIdx.x >> 7)) * 64;
     int dn = 0;
-#define DZ_STAMP() do { if (dq && dn < 64) dq[dn++] = __builtin_readcyclecounter(); } while (0)
+    if (dq) dq[62] = __builtin_readcyclecounter();            // kernel entry
+#define DZ_STAMP() do { if (dq && dn < 62) dq[dn++] = __builtin_readcyclecounter(); } while (0)
 #else
 #define DZ_STAMP() do { } while (0)
 #endif
@@ -92,7 +93,18 @@ __global__ __launch_bounds__(256, 2) void conv_pool_h_kernel(
 
     // ---- weight fragments of this wave: channels 32 nt + li, k = 16 ks + 8 g .. +7 -------------
     f16x8 bh[G::KS0], bl[G::KS0];
-    {
+    if (wfrag) {
+        // the weights in FRAGMENT order (conv_pool_wfrag_kernel below; repacked once per handle): every load
+        // instruction of the wave reads 1 KiB of contiguous memory.  With the row-major planes each lane reads 16
+        // bytes of its own row — 32 cache lines per instruction — and a workgroup that lives for 1 - 4 tiles spent
+        // 7 - 9 k cycles (16 - 28 % of its life, tools/conv_pool_phases.py) getting its weights.
+        const f16x8* fr = reinterpret_cast<const f16x8*>(wfrag) + (long long)((nt * 2 + kh) * 2) * G::KS0 * 64 + l;
+#pragma unroll
+        for (int i = 0; i < G::KS0; ++i) {
+            bh[i] = fr[i * 64];
+            bl[i] = fr[(G::KS0 + i) * 64];
+        }
+    } else {
         const unsigned short* row = wsp + (long long)(32 * nt + li) * Kpad + 8 * g;
 #pragma unroll
         for (int i = 0; i < G::KS0; ++i) {
@@ -266,6 +278,24 @@ __global__ __launch_bounds__(256, 2) void conv_pool_h_kernel(
     dz_flag_range(oflag, amax);
 }
 
+
+// [nt 2][k-half 2][plane 2][fragment i < KS0][lane 64] vectors of 8 f16: lane (li, g) of wave (nt, kh) holds the taps
+// 16 ks + 8 g .. + 7 of output channel 32 nt + li, ks = ks_lo(kh) + i (fragments past a half's last k-step repeat its
+// first one, like the loads they replace)
+template <int CIN>
+__global__ void conv_pool_wfrag_kernel(const unsigned short* __restrict__ wsp, int Kpad, f32x4* __restrict__ out) {
+    using G = Geo<CIN>;
+    const int v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= 2 * 2 * 2 * G::KS0 * 64) return;
+    const int lane = v & 63;
+    int rest = v >> 6;
+    const int i = rest % G::KS0;
+    rest /= G::KS0;
+    const int plane = rest & 1, kh = (rest >> 1) & 1, nt = rest >> 2;
+    const int ks_lo = kh ? G::KS0 : 0, ks_n = kh ? G::KS - G::KS0 : G::KS0;
+    const int ks = ks_lo + (i < ks_n ? i : 0);
+    out[v] = *reinterpret_cast<const f32x4*>(wsp + ((long long)plane * 64 + 32 * nt + (lane & 31)) * Kpad + 16 * ks + 8 * (lane >> 5));
+}
 
 #ifdef DZ_EXPERIMENTS
 // ---------------------------------------------------------------------------
@@ -715,7 +745,7 @@ int launch_v2(const DzConvGemm& p, hipStream_t st) {
 #endif
 
 template <int CIN>
-int launch(const DzConvGemm& p, hipStream_t st) {
+int launch(const DzConvGemm& p, hipStream_t st, const void* wfrag) {
     using G = Geo<CIN>;
     static DzAttrOnce attr_once;
     DZ_HIP(attr_once.raise((const void*)conv_pool_h_kernel<CIN>, (int)G::LDS));
@@ -725,16 +755,31 @@ int launch(const DzConvGemm& p, hipStream_t st) {
     DZ_LAUNCH((conv_pool_h_kernel<CIN>), dim3(grid), dim3(256), G::LDS, st, p.X, p.Tin, p.Tout, p.Tstore,
               p.nscale, p.nshift, p.npart, p.npart_tiles, p.npart_T, p.ngamma, p.nbeta,
               reinterpret_cast<const unsigned short*>(p.Wsplit), p.Kpad, p.bias, p.Y,
-              p.partials, ntile, total, p.oflag ? p.oflag : dz_cur_oflag, dz_conv_pool_dbg);
+              p.partials, ntile, total, p.oflag ? p.oflag : dz_cur_oflag, dz_conv_pool_dbg,
+              reinterpret_cast<const unsigned short*>(wfrag));
     DZ_HIP(hipGetLastError());
     return 0;
 }
 
 }  // namespace
 
+int dz_conv_pool_wfrag_bytes(int Cin) { return 2 * 2 * 2 * (Cin == 80 ? Geo<80>::KS0 : Geo<64>::KS0) * 64 * 16; }
+int dz_launch_conv_pool_wfrag(int Cin, const void* wsplit, int Kpad, void* out, hipStream_t st) {
+    DZ_REQUIRE((Cin == 80 || Cin == 64) && wsplit && out && Kpad >= 5 * Cin, "conv_pool_wfrag: bad operands");
+    const int n = dz_conv_pool_wfrag_bytes(Cin) / 16;
+    if (Cin == 80)
+        DZ_LAUNCH(conv_pool_wfrag_kernel<80>, dim3((n + 255) / 256), dim3(256), 0, st, reinterpret_cast<const unsigned short*>(wsplit),
+                  Kpad, reinterpret_cast<f32x4*>(out));
+    else
+        DZ_LAUNCH(conv_pool_wfrag_kernel<64>, dim3((n + 255) / 256), dim3(256), 0, st, reinterpret_cast<const unsigned short*>(wsplit),
+                  Kpad, reinterpret_cast<f32x4*>(out));
+    DZ_HIP(hipGetLastError());
+    return 0;
+}
+
 // same descriptor as the POOL3 call of dz_launch_gemm_split (k = 5, dil = 1, Npad = 64, norm-on-load,
 // X / Y dense: xbs = Tin * Cin, ybs = Tstore * 64, ldx = Cin, ldy = 64)
-int dz_launch_conv_pool(const DzConvGemm& p, hipStream_t st) {
+int dz_launch_conv_pool(const DzConvGemm& p, hipStream_t st, const void* wfrag) {
     DZ_REQUIRE(p.Wsplit && p.X && p.Y && p.partials && p.bias, "conv_pool: NULL operand");
     DZ_REQUIRE((p.nscale && p.nshift) || (p.npart && p.ngamma && p.nbeta && p.npart_tiles > 0 && p.npart_T > 0),
                "conv_pool: needs nscale / nshift or the producer's partials + affine");
@@ -752,5 +797,5 @@ int dz_launch_conv_pool(const DzConvGemm& p, hipStream_t st) {
     const char* e_v2 = dz_exp_env("DZ_CONV_POOL_V2");
     if (e_v2 && e_v2[0] == '1') return p.Cin == 80 ? launch_v2<80>(p, st) : launch_v2<64>(p, st);
 #endif
-    return p.Cin == 80 ? launch<80>(p, st) : launch<64>(p, st);
+    return p.Cin == 80 ? launch<80>(p, st, wfrag) : launch<64>(p, st, wfrag);
 }

@@ -34,6 +34,9 @@ int dz_version(void);
 /* Run-time options of the library, by name; both return 2 (+ dz_last_error) for an unknown name.
  *   "f32_gemm"  (default 1): the wide exact-f32 layers on k_gemm_f32.hip; 0 = on k_convgemm.hip
  *   "pool_fuse" (default 1): statistics pooling inside the last x-vector layer's epilogue; 0 = two launches
+ *   "pack_cache" (default 0): dz_k_sinc_conv0_split / dz_k_conv_pool re-order their register-resident operand into the
+ *               kernel's fragment order on every call (the handles do it once, at create); 1 = skip that when the operand
+ *               pointer is the previous call's (timing tools with fixed weights only)
  * Process-wide, read at every launch: set them while no forward pass is being enqueued.               */
 int dz_set_option(const char* name, int value);
 int dz_get_option(const char* name, int* value);

@@ -19,6 +19,7 @@ from diart_amd.weights import split_f16  # noqa: E402
 
 dev = torch.device("cuda", 0)
 lib, ctx = _lib.load(), _lib.context(0)
+_lib.set_option("pack_cache", 1)      # fixed weights: the kernel-level entries pack their operand once
 B, S = 64, 80000
 st = torch.cuda.current_stream(dev).cuda_stream
 nt = lib.dz_k_conv0_split_ntile(S)

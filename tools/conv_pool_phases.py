@@ -17,6 +17,7 @@ from diart_amd.weights import split_f16  # noqa: E402
 
 dev = torch.device("cuda", 0)
 lib, ctx = _lib.load(), _lib.context(0)
+_lib.set_option("pack_cache", 1)      # fixed weights: the kernel-level entries pack their operand once
 st = torch.cuda.current_stream(dev).cuda_stream
 NAMES = ["fetch issue -> barrier A (norm update, wait prev readers)", "park (wait loads, normalise, split, LDS writes)",
          "barrier B", "MFMA phase", "exchange write + barrier C", "epilogue (kh 0) / idle (kh 1)"]
@@ -83,6 +84,12 @@ for name, B, Tin, Cin in (("conv1", 64, 2658, 80), ("conv2", 64, 884, 64)):
     torch.cuda.synchronize()
     lib.dz_k_conv_pool_debug(None)
     s = stamps.cpu().numpy().reshape(512, 2, 64)
+    if (s[:, :, 62] != 0).any():
+        ok = (s[:, :, 62] != 0) & (s[:, :, 0] != 0)
+        pro = (s[:, :, 0] - s[:, :, 62])[ok].astype(np.float64)
+        ntl = np.array([int((s[wg, 0, :62] != 0).sum()) // 7 for wg in range(512)])
+        print(f"{name}: prologue (kernel entry -> first tile's first stamp) mean {pro.mean():.0f}, p90 {np.percentile(pro, 90):.0f} cycles; "
+              f"tiles per workgroup {ntl[ntl > 0].min()} - {ntl.max()}")
     for wv, label in ((0, "wave 0 (k-half 0: epilogue)"), (1, "wave 3 (k-half 1)")):
         rows = []
         for wg in range(512):
