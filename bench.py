@@ -112,6 +112,9 @@ def xenv(name, default=""):
 
 
 
+RECURRENCE = {}      # precision -> "valu" | "0" | "3", filled when the engines are built
+
+
 def lstm_chains_per_wg():
     """k_lstm.hip: one chain per workgroup unless DZ_LSTM_NC=2 (experiment)."""
     e = xenv("DZ_LSTM_NC", "")
@@ -129,7 +132,9 @@ def device_kernel(tag, precision):
     DEVICE kernel, so the layers that share one instantiation are one entry."""
     split = precision == "f16x3"
     pre = split                                                       # wide layers on k_gemm_pre.hip
-    lstm = os.environ.get("DZ_LSTM", "valu")                          # weights.default_lstm_variant
+    # the recurrence the ENGINE of this precision runs (StreamBatch.recurrence: the matrix-core form for >= 32 streams
+    # unless DZ_LSTM says otherwise), else weights.default_lstm_variant
+    lstm = RECURRENCE.get(precision) or os.environ.get("DZ_LSTM", "valu")
     k = KERNELS[tag]
     fused_pool = split and pre and os.environ.get("DZ_POOL_FUSE", "1") != "0"
     if k["bound"] == "hbm":
@@ -921,10 +926,13 @@ def main():
     usable = usable_cores()
     host_threads = max(1, min(8, usable))
     def make_pipe(prec):
-        return StreamBatch(HipSegmentation(seg_state, max_batch=n, precision=prec),
-                           HipEmbedding(emb_state, max_batch=n, precision=prec),
-                           n, device=device, cluster_threads=host_threads,
-                           tail=not args.no_tail)
+        p_ = StreamBatch(HipSegmentation(seg_state, max_batch=n, precision=prec),
+                         HipEmbedding(emb_state, max_batch=n, precision=prec),
+                         n, device=device, cluster_threads=host_threads,
+                         tail=not args.no_tail)
+        if p_.recurrence:
+            RECURRENCE[prec] = p_.recurrence
+        return p_
 
     pipe = make_pipe(precision)
 
@@ -1168,7 +1176,7 @@ def main():
                        "rccl_ranks": (torch.distributed.get_world_size() if world > 1 and torch.distributed.get_backend() == "nccl"
                                       else 0), "cpu_affinity": affinity,
                        "weights_abs_sum_per_rank": wsums, "host_threads_per_rank": host_threads,
-                       "steps_in_flight": pipe.max_inflight, "lanes": pipe.depth, "seg_sub_batches": pipe.seg_split,
+                       "steps_in_flight": pipe.max_inflight, "lanes": pipe.depth, "recurrence": pipe.recurrence or os.environ.get("DZ_LSTM", "valu"), "seg_sub_batches": pipe.seg_split,
                        "hip_streams": pipe.num_hip_streams,
                        "exact_f32_value": exact["value"] if exact else None,
                        "host_fed_value": host_fed["value"] if host_fed else None},

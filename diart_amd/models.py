@@ -159,12 +159,20 @@ class HipSegmentation(_HipModule):
         self.num_speakers = p.num_speakers
         return p
 
-    def _create(self, num_samples, cap):
+    def _create(self, num_samples, cap, throughput: bool = False):
+        """``throughput``: the handle of an engine that keeps several steps in flight (``StreamBatch``): the matrix-core
+        recurrence (``PackedSegmentation.struct_throughput``) instead of the low-latency one."""
         h = _lib.vp()
         lib = _lib.load()
-        _lib.check(lib.dz_seg_create(_lib.context(self.device.index), C.byref(self._packed.struct),
+        w = self._packed.struct_throughput if throughput else self._packed.struct
+        _lib.check(lib.dz_seg_create(_lib.context(self.device.index), C.byref(w),
                                      cap, num_samples, C.byref(h)), "dz_seg_create")
         return h
+
+    def throughput_recurrence(self) -> str:
+        """What a throughput handle of this model runs its recurrence on: "valu" | "0" | "3" (bench.py names the kernel)."""
+        p = self._packed
+        return str(int(p.struct_throughput.lstm_variant)) if p.struct_throughput.whh_split[0] else "valu"
 
     def _destroy(self, h):
         _lib.load().dz_seg_destroy(h)

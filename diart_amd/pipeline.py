@@ -192,7 +192,17 @@ class StreamBatch:
         # t % depth, so a caller that keeps `depth` tickets between launch() and finish() has that
         # many steps on the GPU at once (the latency-bound recurrence of one step under the GEMMs
         # of the others).  A lane is reused in stream order, which also orders its arenas.
-        self.depth = max(1, int(os.environ.get("DZ_DEPTH", "2") if depth is None else depth))
+        # Round 5: with >= 64 streams per step the recurrence runs on the matrix cores (16 chains per workgroup: a
+        # seventh of the CU-time, twice the latency of a layer) and SIX steps are in flight instead of two — the longer
+        # dependent chain of a lane hides under five other steps, and the 128 CUs the one-chain-per-CU recurrence held
+        # for most of a step go to the GEMM-shaped kernels: 30 300 -> 33 500 xRT in same-visit pairs
+        # (profiles/r05u_recurrence_lanes_grid.json; in round 4, with the slower front end, the same pair measured
+        # equal).  Fewer streams (FileBatch's 32 windows per step lost 11 % with it), the exact-f32 precision and an
+        # explicit DZ_LSTM keep what they had; the synchronous blocks API always runs the low-latency recurrence.
+        self.throughput = (num_streams >= 64 and "DZ_LSTM" not in os.environ
+                           and getattr(self.seg, "precision", "f32") == "f16x3")
+        self.recurrence = self.seg.throughput_recurrence() if self.throughput else None    # None: the model's default
+        self.depth = max(1, int(os.environ.get("DZ_DEPTH", "6" if self.throughput else "2") if depth is None else depth))
         # How many launched-but-unfinished steps a throughput caller (bench.py, FileBatch) keeps: `depth` lanes
         # run concurrently, the steps beyond that wait IN THE STREAMS of their lane, so that a lane's next
         # step starts the moment the previous one ends instead of after the host has come back from
@@ -315,7 +325,7 @@ class StreamBatch:
         got = self._sub.get((S, lane))
         if got is None:
             sa, sb = self._ranges(self.n, self.seg_split), self._ranges(self.n, self.emb_split)
-            hs = [self.seg._create(S, max(1, -(-self.n // self.seg_split))) for _ in sa]
+            hs = [self.seg._create(S, max(1, -(-self.n // self.seg_split)), throughput=self.throughput) for _ in sa]
             he = [self.emb._create(S, max(1, -(-self.n // self.emb_split))) for _ in sb]
             got = self._sub[(S, lane)] = (hs, he, sa, sb)
         return got

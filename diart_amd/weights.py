@@ -167,6 +167,9 @@ def lstm_whh_planes(whh: torch.Tensor, variant: int) -> torch.Tensor:
     return torch.stack([hi, lo], dim=1).view(torch.int16).contiguous()
 
 
+THROUGHPUT_LSTM_VARIANT = 3      # k_lstm_mfma.hip, the LDS-DMA form: what a throughput engine runs unless DZ_LSTM says otherwise
+
+
 def default_lstm_variant() -> int:
     """``DZ_LSTM``: ``valu`` (-1: one chain per CU on the f32 vector units even in the f16x3
     precision) or the matrix-core variant 0 / 3 (1 / 2: experiments build; ``lstm_whh_planes``)."""
@@ -297,6 +300,7 @@ class PackedSegmentation:
         w = _lib.SegWeights()
         w.sinc = _pack_sincnet(sd, pk, split=split)
         lstm_variant = default_lstm_variant()
+        whh_tp = []
         for layer in range(4):
             # rows of the stacked W_ih (and the bias) go unit-major, dir*512 + unit*4 + gate, so the
             # x-projection GEMM writes the four gates of a unit next to each other and the recurrence
@@ -319,6 +323,11 @@ class PackedSegmentation:
                 pk.tensors.append(d)
                 w.whh_split[layer] = d.data_ptr()
                 w.lstm_variant = lstm_variant
+            if split:                         # ... and always for the throughput engines (struct_throughput below)
+                tv = lstm_variant if lstm_variant >= 0 else THROUGHPUT_LSTM_VARIANT
+                d = lstm_whh_planes(whh, tv).to(pk.device)
+                pk.tensors.append(d)
+                whh_tp.append(d.data_ptr())
         w.lin0_w, w.lin0_b = pk.put(g("linear.0.weight")), pk.put(g("linear.0.bias"))
         w.lin1_w, w.lin1_b = pk.put(g("linear.1.weight")), pk.put(g("linear.1.bias"))
         if split:
@@ -337,6 +346,16 @@ class PackedSegmentation:
             w.num_speakers = ncls
         self.struct, self.pack = w, pk
         self.num_speakers = int(w.num_speakers)
+        # The same weights for a THROUGHPUT engine (StreamBatch with many streams per launch and several steps in
+        # flight): the recurrence on the matrix cores, 16 chains per workgroup — a seventh of the CU-time at twice the
+        # latency of the one-chain-per-CU kernel the synchronous blocks API keeps.
+        self.struct_throughput = w
+        if split and whh_tp and lstm_variant < 0:
+            tw = _lib.SegWeights.from_buffer_copy(w)
+            for layer in range(4):
+                tw.whh_split[layer] = whh_tp[layer]
+            tw.lstm_variant = THROUGHPUT_LSTM_VARIANT
+            self.struct_throughput = tw
 
 
 class PackedEmbedding:
