@@ -535,8 +535,15 @@ def build_roofline(table, precision, n_sampled, pmc):
         return e
 
     per_kernel = [entry(g, v) for g, v in sorted(groups.items(), key=lambda kv: -kv[1]["ms"])]
-    # the dominant kernel = the device kernel with the largest total time, whatever bounds it
-    roof = dict(per_kernel[0])
+    # The dominant kernel = the device kernel with the largest share of the chip's CU-TIME, whatever bounds it: its total
+    # time x the fraction of the 256 CUs its launches occupy (`cus_occupied`: the recurrence kernels hold 8 - 128 CUs for
+    # their whole duration; every other kernel is launched to fill the chip).  By plain time the matrix-core recurrence
+    # (four launches of ~0.5 ms on EIGHT CUs, under the other steps' kernels) would lead with 3 % of the machine.
+    cu_time = {e["kernel"]: groups[e["kernel"]]["ms"] * min(1.0, e.get("cus_occupied", 256.0) / 256.0) for e in per_kernel}
+    tot_cu = sum(cu_time.values()) or 1.0
+    for e in per_kernel:
+        e["share_of_cu_time"] = round(cu_time[e["kernel"]] / tot_cu, 4)
+    roof = dict(max(per_kernel, key=lambda e: cu_time[e["kernel"]]))
     roof["peak_note"] = {
         "mfma": ("f16 matrix peak 2500 TFLOP/s / 3: the split-f16 path spends three f16 MFMAs per algorithmic "
                  "product; `achieved` counts algorithmic FLOPs only" if roof["peak"] > 200 else "exact-f32 matrix peak"),

@@ -58,7 +58,8 @@ config1)
 ranks2|ranks8)   # the multi-rank path of bench.py as ONE command; on a one-GPU box every rank shares the GPU (gloo rehearsal)
   N=${SEC#ranks}
   NG=$(python -c "import torch;print(torch.cuda.device_count())")
-  if [ "$NG" -ge "$N" ]; then ENVX="X=1"; else ENVX="DZ_FORCE_DEVICE=0 DZ_DIST_BACKEND=gloo"; fi
+  # (rehearsal: N ranks on ONE GPU — each keeps the two-lane engine, N x 6 lanes of the 64-stream default would only queue)
+  if [ "$NG" -ge "$N" ]; then ENVX="X=1"; else ENVX="DZ_FORCE_DEVICE=0 DZ_DIST_BACKEND=gloo DZ_DEPTH=2 DZ_LSTM=valu"; fi
   env $ENVX timeout -s KILL 600 python bench.py --gpus $N --steps 20 --warmup 5 --no-cpu-baseline --no-exact-f32 --no-host-pass --no-rehearsal --pmc off --details $OUT/bench_${N}_ranks_details.json > $OUT/bench_${N}_ranks.json 2> $OUT/bench_${N}_ranks.err
   echo "exit $? lines $(grep -c '^{' $OUT/bench_${N}_ranks.json) chars $(wc -c < $OUT/bench_${N}_ranks.json)"; cut -c1-700 $OUT/bench_${N}_ranks.json
   grep -E "process group up|cpu affinity" $OUT/bench_${N}_ranks.err | cut -c1-200 | head -16 ;;
