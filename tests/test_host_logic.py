@@ -489,3 +489,25 @@ def test_windows_batch_span_detection_matches_torch_stack():
     stereo = [SlidingWindowFeature(np.stack([stream[i * H:i * H + S]] * 2, 1), sw(i)) for i in range(3)]
     assert _common_span([v.data for v in stereo]) is None
     assert _common_span([views[0].data]) is None
+
+
+def test_throughput_weights_carry_the_matrix_core_recurrence(monkeypatch):
+    """Round 5: a packed segmentation model holds TWO weight structs — `struct` (what the synchronous blocks API runs:
+    the one-chain-per-CU recurrence unless DZ_LSTM says otherwise) and `struct_throughput` (what a StreamBatch of >= 64
+    streams creates its handles from: the same pointers plus W_hh as f16 planes for the matrix-core recurrence, variant
+    3).  Exact f32 has no such form; an explicit DZ_LSTM applies to both."""
+    from diart_amd.synth import synth_segmentation_state
+    from diart_amd.weights import PackedSegmentation, THROUGHPUT_LSTM_VARIANT
+    monkeypatch.delenv("DZ_LSTM", raising=False)
+    sd = synth_segmentation_state()
+    p = PackedSegmentation(sd, torch.device("cpu"), precision="f16x3")
+    assert not p.struct.whh_split[0] and all(p.struct_throughput.whh_split[i] for i in range(4))
+    assert p.struct_throughput.lstm_variant == THROUGHPUT_LSTM_VARIANT == 3
+    for name in ("whh", "wih", "wih_split", "bih"):                     # everything else is shared, not copied
+        assert list(getattr(p.struct, name)) == list(getattr(p.struct_throughput, name)), name
+    assert p.struct.lin0_split == p.struct_throughput.lin0_split and p.struct.sinc.filt_split == p.struct_throughput.sinc.filt_split
+    p32 = PackedSegmentation(sd, torch.device("cpu"), precision="f32")
+    assert p32.struct_throughput is p32.struct and not p32.struct.whh_split[0]
+    monkeypatch.setenv("DZ_LSTM", "0")
+    p0 = PackedSegmentation(sd, torch.device("cpu"), precision="f16x3")
+    assert p0.struct_throughput is p0.struct and p0.struct.whh_split[0] and p0.struct.lstm_variant == 0
