@@ -19,8 +19,10 @@ int dz_k_gemm_g2(dz_ctx* ctx, const dz_convgemm_desc* desc, int row_fragments, v
  * row_fragments as above, 0 = default (4).  DZ_GEMM_GEN=3.  A timed-out hand-over is reported by dz_range_check
  * (error 7).                                                                                          */
 int dz_k_gemm_g3(dz_ctx* ctx, const dz_convgemm_desc* desc, int row_fragments, void* stream);
-/* measurement hook (tools/kbench.py): while d_stamps != NULL, dz_k_conv_pool launches record shader-clock
- * stamps of their phases, 2 x 64 per workgroup                                                      */
+/* measurement hook (tools/conv_pool_phases.py, tools/conv0_phases.py): while d_stamps != NULL, the dz_k_conv_pool and
+ * dz_k_sinc_conv0_split launches record per-wave shader-clock stamps of a tile's phases (+ kernel entry / exit and the
+ * wave's HW_ID) there: 64 x 8 bytes per stamped wave — conv_pool_h 512 x 2 waves, conv_pool_v2 256 x 8, sinc_conv0_v2
+ * 512 x 4, the three-wave conv0 kernel 512 x 3                                                                        */
 int dz_k_conv_pool_debug(long long* d_stamps);
 /* The first SincNet stage (InstanceNorm -> 80 sinc filters, stride 10 -> |.| -> MaxPool(3)) of BOTH networks in one
  * launch, default precision only: the two models read the same window (the reference runs SincNet once per model,
