@@ -335,6 +335,9 @@ int dz_k_mlp_head(dz_ctx* ctx, const void* xsplit, long long xplane, const void*
 int dz_k_seg_head(dz_ctx* ctx, const float* m1, const float* cw, const float* cb, int batch, int frames,
                   int classes, int speakers, int powerset, float* d_seg, float gamma, float beta,
                   int normalize, float* d_weights, void* stream);
+/* (dz_k_conv_pool and dz_k_sinc_conv0_split first re-order their register-resident operand — desc->Wsplit / d_filt_split —
+ * into the kernel's fragment order, in a scratch buffer of the CONTEXT: calls that share a context must be stream-ordered.
+ * The network handles keep their own re-ordered copies, made once in dz_seg_create / dz_emb_create.)               */
 int dz_k_conv_pool(dz_ctx* ctx, const dz_convgemm_desc* desc, void* stream);
 int dz_k_convgemm_ntile(int t_out);
 /* d_stats (B, 2) = (mean, 1/sqrt(biased var + 1e-5)) of each window: InstanceNorm1d(1).  Inside
