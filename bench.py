@@ -143,7 +143,7 @@ def device_kernel(tag, precision):
                 "seg_classifier": "seg_head_kernel"}[tag], "hbm", PEAK_HBM_GBPS, "GB/s"
     if k["bound"] == "rec":
         if split and lstm != "valu":
-            sym = {"0": "lstm_mfma_kernel<true>", "3": "lstm_mfma_dma_kernel"}.get(
+            sym = {"0": "lstm_mfma_kernel<true>", "3": "lstm_mfma_dma_kernel", "4": "lstm_mfma_pipe_kernel"}.get(
                 lstm, "lstm_mfma1_kernel<true, %d>" % (0 if lstm == "1" else 8))
             return sym, "mfma", PEAK_F16_MATRIX_TFLOPS / SPLIT_PRODUCTS, "TFLOP/s"
         pk = "false" if xenv("DZ_LSTM_PK", "1") == "0" else "true"      # packed-FMA template argument

@@ -1186,8 +1186,8 @@ extern "C" int dz_k_lstm_planes(dz_ctx* ctx, const float* d_gx, const float* d_w
     DZ_REQUIRE(batch >= 1 && frames >= 1, "dz_k_lstm_planes: empty input");
     DZ_HIP(hipSetDevice(ctx->device));
     if (d_whh_split)
-        return dz_launch_lstm_mfma(d_gx, d_whh_split, nullptr, d_hsplit, hplane, batch, frames, 0,
-                                   variant, (hipStream_t)stream);
+        return dz_launch_lstm_mfma(d_gx, d_whh_split, nullptr, d_hsplit, hplane, batch, frames, variant >= 3 ? 1 : 0,
+                                   variant, (hipStream_t)stream);     // (variants 3 / 4 exist for unit-major gx only)
     return dz_launch_lstm(d_gx, d_whh, nullptr, d_hsplit, hplane, batch, frames, 0, (hipStream_t)stream);
 }
 extern "C" int dz_k_lstm_mfma(dz_ctx* ctx, const float* d_gx, const void* d_whh_split, float* d_hout,

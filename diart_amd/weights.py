@@ -157,6 +157,14 @@ def lstm_whh_planes(whh: torch.Tensor, variant: int) -> torch.Tensor:
     assert whh.shape == (2, 512, 128), whh.shape
     if variant in (0, 3):       # variant 3 = variant 0's planes, x-projection fetched by LDS-DMA
         return torch.stack([split_f16(whh[0]), split_f16(whh[1])]).contiguous()
+    if variant == 4:
+        # the software-pipelined kernel: every gate row carries its activation scale (LSTM_GATE_SCALE: an accumulator
+        # is then the exp2 argument), and the contraction index is re-ordered so that each half of K holds two of a
+        # lane's four cells: column k' = 64 a + 2 p + e  <-  hidden unit u = 4 p + 2 a + e
+        scale = torch.tensor(LSTM_GATE_SCALE, dtype=torch.float64).view(1, 4, 1, 1)
+        w = (whh.double().view(2, 4, 128, 128) * scale).float().view(2, 512, 128)
+        w = w[:, :, lstm_k_order()].contiguous()
+        return torch.stack([split_f16(w[0], "lstm.weight_hh (scaled)"), split_f16(w[1], "lstm.weight_hh (scaled)")]).contiguous()
     sh = {1: 0, 2: 8}[variant]
     log2e = 1.44269504088896341
     scale = torch.full((4, 1, 1), -log2e, dtype=torch.float64)
@@ -167,18 +175,39 @@ def lstm_whh_planes(whh: torch.Tensor, variant: int) -> torch.Tensor:
     return torch.stack([hi, lo], dim=1).view(torch.int16).contiguous()
 
 
-THROUGHPUT_LSTM_VARIANT = 3      # k_lstm_mfma.hip, the LDS-DMA form: what a throughput engine runs unless DZ_LSTM says otherwise
+# variant 4: exp(-x) = exp2(LSTM_GATE_SCALE x) for the gates i, f, o (sigmoid) and exp(-2x) for g (tanh), PyTorch's gate
+# order i, f, g, o; folded into W_ih, the biases and W_hh of a variant-4 engine
+LSTM_GATE_SCALE = (-1.44269504088896341, -1.44269504088896341, -2.88539008177792681, -1.44269504088896341)
+
+
+def lstm_k_order() -> torch.Tensor:
+    """hidden unit held by column k' of a variant-4 ``W_hh`` plane (and of ``h_t`` in the kernel's LDS)."""
+    k = torch.arange(128)
+    return 4 * ((k & 63) >> 1) + 2 * (k >> 6) + (k & 1)
+
+
+def lstm_scale_gx(t: torch.Tensor, unit_major: bool = True) -> torch.Tensor:
+    """rows of a stacked ``[1024][...]`` x-projection operand (weights or bias; row = dir*512 + unit*4 + gate when
+    ``unit_major``, else dir*512 + gate*128 + unit) times the activation scale of their gate (variant 4)."""
+    sc = torch.tensor(LSTM_GATE_SCALE, dtype=torch.float64)
+    rows = torch.arange(t.shape[0])
+    g = (rows & 3) if unit_major else ((rows % 512) // 128)
+    shape = (-1,) + (1,) * (t.dim() - 1)
+    return (t.double() * sc[g].view(shape)).float()
+
+
+THROUGHPUT_LSTM_VARIANT = 4      # k_lstm_mfma.hip, the software-pipelined form: what a throughput engine runs unless DZ_LSTM says otherwise
 
 
 def default_lstm_variant() -> int:
     """``DZ_LSTM``: ``valu`` (-1: one chain per CU on the f32 vector units even in the f16x3
-    precision) or the matrix-core variant 0 / 3 (1 / 2: experiments build; ``lstm_whh_planes``)."""
+    precision) or the matrix-core variant 0 / 3 / 4 (1 / 2: experiments build; ``lstm_whh_planes``)."""
     import os
     v = os.environ.get("DZ_LSTM", "valu")
     v = -1 if v == "valu" else int(v)
     if v in (1, 2) and not _lib.EXPERIMENTS:
         raise ValueError(f"DZ_LSTM={v}: matrix-core recurrence variants 1 / 2 exist in the experiments build only "
-                         "(DZ_EXPERIMENTS=1); the shipped library has valu, 0 and 3")
+                         "(DZ_EXPERIMENTS=1); the shipped library has valu, 0, 3 and 4")
     return v
 
 
@@ -300,7 +329,7 @@ class PackedSegmentation:
         w = _lib.SegWeights()
         w.sinc = _pack_sincnet(sd, pk, split=split)
         lstm_variant = default_lstm_variant()
-        whh_tp = []
+        whh_tp, proj_tp = [], []
         for layer in range(4):
             # rows of the stacked W_ih (and the bias) go unit-major, dir*512 + unit*4 + gate, so the
             # x-projection GEMM writes the four gates of a unit next to each other and the recurrence
@@ -308,13 +337,22 @@ class PackedSegmentation:
             um = lambda t: t.reshape(2, 4, 128, *t.shape[1:]).transpose(1, 2).reshape(t.shape).contiguous()
             wih = um(torch.cat([g(f"lstm.weight_ih_l{layer}"), g(f"lstm.weight_ih_l{layer}_reverse")], 0))
             kpad = 64 if layer == 0 else 256
-            w.wih[layer] = pk.put(_pad2(wih, 1024, kpad))
-            if split:
+            bias = um(torch.cat([g(f"lstm.bias_ih_l{layer}") + g(f"lstm.bias_hh_l{layer}"),
+                                 g(f"lstm.bias_ih_l{layer}_reverse") + g(f"lstm.bias_hh_l{layer}_reverse")], 0))
+
+            def put_proj(wm, bv, tag):
+                """-> (f32 W_ih, its split planes or None, bias) on the device"""
                 # layer 0 runs on k_gemm_split.hip (row-major planes), layers 1..3 on k_gemm_pre.hip (kb-major)
-                w.wih_split[layer] = pk.put_split(_pad2(wih, 1024, kpad), f"lstm.weight_ih_l{layer}", kb=layer > 0)
-            bias = torch.cat([g(f"lstm.bias_ih_l{layer}") + g(f"lstm.bias_hh_l{layer}"),
-                              g(f"lstm.bias_ih_l{layer}_reverse") + g(f"lstm.bias_hh_l{layer}_reverse")], 0)
-            w.bih[layer] = pk.put(um(bias))
+                sp = pk.put_split(_pad2(wm, 1024, kpad), f"lstm.weight_ih_l{layer}{tag}", kb=layer > 0) if split else None
+                return pk.put(_pad2(wm, 1024, kpad)), sp, pk.put(bv)
+
+            w.wih[layer], sp, w.bih[layer] = put_proj(wih, bias, "")
+            if split:
+                w.wih_split[layer] = sp
+            if split and lstm_variant == 4:     # the engine's own recurrence is variant 4: its x-projection carries the gate scales
+                w.wih[layer], w.wih_split[layer], w.bih[layer] = put_proj(lstm_scale_gx(wih), lstm_scale_gx(bias), " (scaled)")
+            elif split and lstm_variant < 0 and THROUGHPUT_LSTM_VARIANT == 4:
+                proj_tp.append(put_proj(lstm_scale_gx(wih), lstm_scale_gx(bias), " (scaled)"))
             whh = torch.stack([g(f"lstm.weight_hh_l{layer}"), g(f"lstm.weight_hh_l{layer}_reverse")], 0)
             assert whh.shape == (2, 512, 128)
             w.whh[layer] = pk.put(whh)
@@ -354,6 +392,8 @@ class PackedSegmentation:
             tw = _lib.SegWeights.from_buffer_copy(w)
             for layer in range(4):
                 tw.whh_split[layer] = whh_tp[layer]
+                if proj_tp:
+                    tw.wih[layer], tw.wih_split[layer], tw.bih[layer] = proj_tp[layer]
             tw.lstm_variant = THROUGHPUT_LSTM_VARIANT
             self.struct_throughput = tw
 

@@ -110,8 +110,11 @@ typedef struct {
      * runs 16 chains per workgroup on the matrix cores (k_lstm_mfma.hip); NULL = one chain per CU on
      * the f32 vector units (k_lstm.hip, exact f32)                                               */
     const void* whh_split[4];
-    int lstm_variant;            /* how whh_split was prepared (weights.py lstm_whh_planes): 0 = split_f16 of
-                                    W_hh; 1 / 2 = activation scales folded in, H scaled by 2^0 / 2^8 */
+    int lstm_variant;            /* how whh_split was prepared (weights.py lstm_whh_planes): 0 / 3 = split_f16 of
+                                    W_hh (3: gx by LDS-DMA); 1 / 2 (experiments build) = activation scales folded
+                                    in, H scaled by 2^0 / 2^8; 4 = the software-pipelined kernel: gate rows times
+                                    -log2(e) (i, f, o) / -2 log2(e) (g), columns in the kernel's k' order, AND
+                                    wih / wih_split / bih carry the same row scales (gx arrives pre-scaled)      */
 } dz_seg_weights;
 
 typedef struct {
@@ -364,13 +367,14 @@ int dz_k_finalize_norm(dz_ctx* ctx, const float* d_partials, int batch, int ntil
 int dz_k_lstm(dz_ctx* ctx, const float* d_gx, const float* d_whh, float* d_hout, int batch,
               int frames, void* stream);
 /* the same recurrence on the f16 matrix cores, 16 chains per workgroup; d_whh_split / variant as
- * dz_seg_weights.whh_split / lstm_variant; unit_major != 0: gx columns are dir*512 + unit*4 + gate */
+ * dz_seg_weights.whh_split / lstm_variant; unit_major != 0: gx columns are dir*512 + unit*4 + gate
+ * (variants 3 / 4: unit-major only; variant 4: gx already times the gates' activation scales)      */
 int dz_k_lstm_mfma(dz_ctx* ctx, const float* d_gx, const void* d_whh_split, float* d_hout,
                    int batch, int frames, int unit_major, int variant, void* stream);
 /* either recurrence kernel (d_whh_split NULL: the f32 vector kernel on d_whh) writing h as the two
  * f16 planes of hplane / 256 >= B*T rows x 256 columns a dz_k_gemm_pre consumer reads, in kb-major order
  * (see dz_convgemm_desc.Xsplit): hi = f16(h) at d_hsplit, lo = f16((h - hi) * 2^11) hplane elements
- * further; gx in PyTorch column order                                                            */
+ * further; gx in PyTorch column order (variants 3 / 4: unit-major, as dz_k_lstm_mfma)             */
 int dz_k_lstm_planes(dz_ctx* ctx, const float* d_gx, const float* d_whh, const void* d_whh_split,
                      int variant, void* d_hsplit, long long hplane, int batch, int frames, void* stream);
 int dz_k_stats_pool(dz_ctx* ctx, const float* d_x, int frames, int channels, int ldx,

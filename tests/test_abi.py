@@ -120,7 +120,7 @@ def test_every_device_kernel_bench_names_is_in_the_library(monkeypatch):
     bench = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(bench)
     syms = subprocess.run(["nm", "-C", str(_lib.lib_path())], capture_output=True, text=True, check=True).stdout
-    variants = [{}, {"DZ_LSTM": "0"}, {"DZ_LSTM": "3"}, {"DZ_POOL_FUSE": "0"}, {"DZ_F32_GEMM": "0"}]
+    variants = [{}, {"DZ_LSTM": "0"}, {"DZ_LSTM": "3"}, {"DZ_LSTM": "4"}, {"DZ_POOL_FUSE": "0"}, {"DZ_F32_GEMM": "0"}]
     if _lib.experiments():           # DZ_EXPERIMENTS=1: the never-default kernels are in the library too
         monkeypatch.setattr(bench, "EXPERIMENTS", True)
         variants += [{"DZ_LSTM_NC": "2"}, {"DZ_LSTM_PK": "0"}, {"DZ_LSTM": "1"}, {"DZ_LSTM": "2"}, {"DZ_GEMM_GEN": "2"},

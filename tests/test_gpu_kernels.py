@@ -546,8 +546,8 @@ def test_gemm_f32_wide_layers(gpu, monkeypatch, B, Tin, Cin, taps, dil, N, Nstor
 
 
 # --------------------------------------------------------------------------- #
-@pytest.mark.parametrize("kernel", ["valu", "mfma0", "mfma0_um", "mfma1", "mfma1_um", "mfma2", "mfma2_um", "mfma3_um"])
-@pytest.mark.parametrize("B,T", [(1, 293), (3, 40), (17, 64), (32, 293)])
+@pytest.mark.parametrize("kernel", ["valu", "mfma0", "mfma0_um", "mfma1", "mfma1_um", "mfma2", "mfma2_um", "mfma3_um", "mfma4_um"])
+@pytest.mark.parametrize("B,T", [(1, 293), (3, 40), (17, 64), (32, 293), (5, 1), (2, 2), (64, 293)])
 def test_lstm_recurrence(gpu, B, T, kernel):
     """k_lstm.hip (one chain per CU, exact f32) and k_lstm_mfma.hip (16 chains per workgroup on the
     f16 matrix cores, split operands; both gx column orders) against torch.nn.LSTM on the CPU —
@@ -577,6 +577,9 @@ def test_lstm_recurrence(gpu, B, T, kernel):
         um, variant = kernel.endswith("_um"), int(kernel[4])
         if um:   # dir*512 + unit*4 + gate
             gx = gx.view(B, T, 2, 4, 128).transpose(3, 4).reshape(B, T, 1024)
+        if variant == 4:   # the software-pipelined kernel takes the x-projection times the gates' activation scales
+            from diart_amd.weights import LSTM_GATE_SCALE
+            gx = (gx.double().view(B, T, 256, 4) * torch.tensor(LSTM_GATE_SCALE, dtype=torch.float64)).float().view(B, T, 1024)
         dgx = gx.contiguous().to(gpu)
         dw = lstm_whh_planes(whh, variant).to(gpu)
         _lib.check(lib.dz_k_lstm_mfma(_ctx(gpu), dgx.data_ptr(), dw.data_ptr(), hout.data_ptr(), B, T,
@@ -866,7 +869,7 @@ def test_gemm_split_plane_output(gpu):
     assert (got - want).abs().max().item() < 2.0 ** -21 * want.abs().max().item()
 
 
-@pytest.mark.parametrize("kernel", ["valu", "mfma0", "mfma1"])
+@pytest.mark.parametrize("kernel", ["valu", "mfma0", "mfma1", "mfma4"])
 def test_lstm_plane_output(gpu, kernel):
     """Both recurrence kernels writing h as f16 (hi, lo) planes == their f32 output split."""
     from diart_amd.weights import lstm_whh_planes
@@ -887,7 +890,10 @@ def test_lstm_plane_output(gpu, kernel):
     else:
         v = int(kernel[4])
         dw = lstm_whh_planes(whh, v).to(gpu)
-        _lib.check(lib.dz_k_lstm_mfma(_ctx(gpu), gx.data_ptr(), dw.data_ptr(), hf.data_ptr(), B, T, 0, v, None))
+        if v == 4:      # unit-major columns by definition (kernel and dz_k_lstm_planes alike)
+            _lib.check(lib.dz_k_lstm_mfma(_ctx(gpu), gx.data_ptr(), dw.data_ptr(), hf.data_ptr(), B, T, 1, v, None))
+        else:
+            _lib.check(lib.dz_k_lstm_mfma(_ctx(gpu), gx.data_ptr(), dw.data_ptr(), hf.data_ptr(), B, T, 0, v, None))
         _lib.check(lib.dz_k_lstm_planes(_ctx(gpu), gx.data_ptr(), None, dw.data_ptr(), v, hp.data_ptr(),
                                         B * T * 256, B, T, None))
     _sync()

@@ -502,9 +502,11 @@ def test_throughput_weights_carry_the_matrix_core_recurrence(monkeypatch):
     sd = synth_segmentation_state()
     p = PackedSegmentation(sd, torch.device("cpu"), precision="f16x3")
     assert not p.struct.whh_split[0] and all(p.struct_throughput.whh_split[i] for i in range(4))
-    assert p.struct_throughput.lstm_variant == THROUGHPUT_LSTM_VARIANT == 3
-    for name in ("whh", "wih", "wih_split", "bih"):                     # everything else is shared, not copied
-        assert list(getattr(p.struct, name)) == list(getattr(p.struct_throughput, name)), name
+    assert p.struct_throughput.lstm_variant == THROUGHPUT_LSTM_VARIANT == 4
+    assert list(p.struct.whh) == list(p.struct_throughput.whh)          # everything else is shared, not copied ...
+    for name in ("wih", "wih_split", "bih"):     # ... but the x-projection of a variant-4 engine carries the gates' activation scales
+        a, b = list(getattr(p.struct, name)), list(getattr(p.struct_throughput, name))
+        assert all(a) and all(b) and not set(a) & set(b), name
     assert p.struct.lin0_split == p.struct_throughput.lin0_split and p.struct.sinc.filt_split == p.struct_throughput.sinc.filt_split
     p32 = PackedSegmentation(sd, torch.device("cpu"), precision="f32")
     assert p32.struct_throughput is p32.struct and not p32.struct.whh_split[0]

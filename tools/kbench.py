@@ -159,11 +159,14 @@ timeit("lstm", lambda: _lib.check(lib.dz_k_lstm(ctx, gx.data_ptr(), whh.data_ptr
        flop=2.0 * B * F * 2 * 512 * 128)
 from diart_amd.weights import lstm_whh_planes  # noqa: E402
 hout2 = torch.empty(B, F, 256, device=dev)
-for variant in ((0, 1, 2, 3) if _lib.experiments() else (0, 3)):      # 1 / 2: experiments build only
+for variant in ((0, 1, 2, 3, 4) if _lib.experiments() else (0, 3, 4)):      # 1 / 2: experiments build only
     whs = lstm_whh_planes(whh.cpu(), variant).to(dev)
     nm = f"lstm_mfma{variant}"
-    gxv = gx.view(B, F, 2, 4, 128).transpose(3, 4).reshape(B, F, 1024).contiguous() if variant == 3 else gx
-    timeit(nm, lambda: _lib.check(lib.dz_k_lstm_mfma(ctx, gxv.data_ptr(), whs.data_ptr(), hout2.data_ptr(), B, F, int(variant == 3), variant, st)),
+    gxv = gx.view(B, F, 2, 4, 128).transpose(3, 4).reshape(B, F, 1024).contiguous() if variant >= 3 else gx
+    if variant == 4:      # (its x-projection carries the gates' activation scales)
+        from diart_amd.weights import LSTM_GATE_SCALE
+        gxv = (gxv.view(B, F, 256, 4) * torch.tensor(LSTM_GATE_SCALE, device=dev)).view(B, F, 1024).contiguous()
+    timeit(nm, lambda: _lib.check(lib.dz_k_lstm_mfma(ctx, gxv.data_ptr(), whs.data_ptr(), hout2.data_ptr(), B, F, int(variant >= 3), variant, st)),
            flop=2.0 * B * F * 2 * 512 * 128)
     if "lstm" in results and nm in results:
         torch.cuda.synchronize()
