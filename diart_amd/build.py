@@ -22,6 +22,9 @@ SOURCES = ["api.hip", "ecapa_api.hip", "k_front.hip", "k_convgemm.hip", "k_gemm_
 # -DDZ_EXPERIMENTS only (csrc/dz_common.h "build flavours"): the never-default GEMM generations
 EXPERIMENT_SOURCES = ["experiments/k_gemm_g2.hip", "experiments/k_gemm_g3.hip"]
 ARCH = "gfx950"
+# per-source flags.  k_lstm_mfma.hip: the cell update beside the recurrence's MFMAs stays plain f32 instructions (hipcc's
+# SLP vectoriser would pack adjacent adds / multiplies into v_pk_*_f32, which cost more beside MFMAs than the two they replace)
+EXTRA_FLAGS = {"k_lstm_mfma.hip": ["-fno-slp-vectorize"]}
 
 
 def _hipcc() -> str:
@@ -56,7 +59,7 @@ def build(force: bool = False, verbose: bool = False, experiments: bool = False)
         s = CSRC / src
         o = objdir / (s.stem + ".o")
         if force or _stale(o, [s, *headers]):
-            cmd = [hipcc, *flags, "-x", "hip", "-c", str(s), "-o", str(o)]
+            cmd = [hipcc, *flags, *EXTRA_FLAGS.get(src, []), "-x", "hip", "-c", str(s), "-o", str(o)]
             r = subprocess.run(cmd, capture_output=True, text=True)
             if r.returncode != 0:
                 raise RuntimeError(f"hipcc failed on {src}:\n{r.stderr}")

@@ -437,11 +437,12 @@ __global__ __launch_bounds__(512) void lstm_mfma_dma_kernel(const float* __restr
 }
 
 // ---------------------------------------------------------------------------------------------
-// Variant 4 = the software-pipelined form (round 6).  Variant 3 spends 1 536 of a step's ~3 280 cycles in the
-// matrix pipe: hipcc leaves the cell update of the last tile(s) (~75 vector instructions, 22 transcendental)
-// behind the last MFMA, then comes the LDS round trip of h and the barrier — per step everything waits for
-// everything.  Here the step is cut in two along K so that half of its MFMAs never depend on the cells that
-// are still being computed:
+// Variant 4 = the software-pipelined form (round 6).  What a step of variant 3 costs was taken apart with
+// timing-only builds (tools/rec_modes.py, profiles/r06a_rec_modes_*.json): 96 MFMAs per SIMD are ~1 990 cycles
+// (v_mfma_f32_16x16x32_f16 issues every ~20 cycles, not 16), and every other part of the step ran AFTER them:
+// the cell update of the last tiles (~75 vector instructions, 22 transcendental) behind the last MFMA, then
+// the LDS round trip of h and the barrier.  Here the step is cut in two along K so that half of its MFMAs
+// never depend on the cells that are still being computed:
 //
 //   * k-permutation.  Lane (wave w, q, n) owns the cells of units 16w + 4q + j, j = 0..3 (tile j).  The
 //     contraction index is re-ordered so that k' = 64 (j >> 1) + 2 (4w + q) + (j & 1): k-half 0 is exactly the
@@ -449,62 +450,64 @@ __global__ __launch_bounds__(512) void lstm_mfma_dma_kernel(const float* __restr
 //     match; h_t in LDS lives in k' order, a lane's pair of cells is one 4-byte store per plane).
 //   * schedule of step s, M(j, kh) = the 6 MFMAs of tile j over k-half kh:
 //       barrier P_s   (h_{s-1} half 0 visible; x-projection of step s landed)
-//         M(3,1) of step s-1 | M(0,0) || cell 2 of s-1 | M(1,0) || cell 3 of s-1 -> h_{s-1} half 1 -> LDS | M(2,0)
+//         M(3,1) of step s-1 || exps of cell 2' | M(0,0) || exps of cell 3' | M(1,0) || pair (2,3)' -> h_{s-1} half 1 -> LDS
 //       barrier Q_s   (h_{s-1} half 1 visible)
-//         M(3,0) | M(0,1) | M(1,1) || cell 0 | M(2,1) || cell 1 -> h_s half 0 -> LDS
+//         M(2,0) | M(0,1) | M(1,1) || exps of cell 0 | M(3,0) || exps of cell 1 | M(2,1) || pair (0,1) -> h_s half 0 -> LDS
 //     Every cell update runs under MFMAs that do not need it, and the LDS read after each barrier is covered by
-//     six MFMAs whose operands were fetched before it.  One buffer of h suffices (a half is rewritten only
-//     after the barrier behind its last read).
+//     six MFMAs whose operands were fetched before it.
 //   * fewer vector instructions per cell (a SIMD issues MFMAs and vector instructions through one port,
 //     DESIGN.md 5.4): the x-projection is the C operand of the first MFMA of a tile (no add, no zero fill); the
 //     activation scales are folded into the weights (gx and W_hh rows carry -log2 e, the g rows -2 log2 e:
 //     weights.py, `lstm_variant` 4), so an accumulator IS the exp2 argument; and with E_x = exp(-x)
 //         c' = c / (1 + E_f) + (1 - E_g) / ((1 + E_i)(1 + E_g)),   h = (1 - E_c) / ((1 + E_o)(1 + E_c))
 //     needs 5 exp2 + 3 rcp per cell instead of 5 + 5 (E_g, E_c clamped at 2^64: the quotients are then exact
-//     limits, never inf * 0).  h_t goes to HBM through buffer descriptors whose scalar offset carries the
-//     step: no address arithmetic in the loop, stores of absent outputs / chains fall off the descriptor.
-// gx: unit-major AND pre-scaled; whh_split: lstm_whh_planes(whh, 4).
+//     limits, never inf * 0).  Plain f32 instructions only: packed-f32 ones beside MFMAs cost more than the
+//     two they replace (MI355X_MICROARCH.md price list; this file is compiled with -fno-slp-vectorize).
+//   * h_t -> HBM through LDS.  A vector-memory instruction costs its wave 40 - 60 issue cycles whatever it
+//     moves (six 4- / 8-byte stores per wave and step: +1 900 cycles per step): the planes of h_{s-1} are
+//     complete in LDS behind Q_s, each wave reads 16 bytes per lane of them (one plane, four chains, 8 units per
+//     lane: two ds_read_b64, k' -> unit order is a dword shuffle) and writes them with ONE 16-byte store —
+//     64 contiguous bytes per (chain, k-block), the kb-major layout of the consumer.  h is double buffered in
+//     LDS for that.  The four LDS-DMA pieces of the x-projection are spread over the step for the same reason.
+// gx: unit-major AND pre-scaled; whh_split: lstm_whh_planes(whh, 4).  F32OUT (kernel-level entry only): h also as
+// f32 rows (8-byte stores per pair of cells, one barrier late).  MODE (experiments build, timing only, WRONG
+// results): 4 = no stores of h, 16 = no cell arithmetic, 32 = no LDS-DMA, 128 = no barriers.
 // ---------------------------------------------------------------------------------------------
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
-
-// Cell update of variant 4 in two stages.  Stage A (one cell): the exp2 arguments of its four gates -> E = exp(-x)
-// (i, f, o; exp(-2x) for g, clamped at 2^64).  Stage B (a PAIR of cells, every operation a packed-f32 one): with
-// cs = -2 log2(e) c the running cell state,
-//     cs' = cs / (1 + E_f) + K2 (1 - E_g) / ((1 + E_i)(1 + E_g)),  E_c = exp2(min(cs', 64)),
-//     h   = (1 - E_c) / ((1 + E_o)(1 + E_c))
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 constexpr float K2 = -2.88539008177792681f;
+
+// stage A (one cell): the exp2 arguments of its four gates (main + cross * 2^-11) -> E = exp(-x) (i, f, o), exp(-2x) (g)
 __device__ __forceinline__ f32x4 cell_exps(const f32x4& am, const f32x4& ax) {
-    const f32x2 lo2 = {LO_UNSCALE, LO_UNSCALE};
-    const f32x2 p01 = __builtin_elementwise_fma((f32x2){ax[0], ax[1]}, lo2, (f32x2){am[0], am[1]});
-    const f32x2 p23 = __builtin_elementwise_fma((f32x2){ax[2], ax[3]}, lo2, (f32x2){am[2], am[3]});
-    return (f32x4){__builtin_amdgcn_exp2f(p01[0]), __builtin_amdgcn_exp2f(p01[1]),
-                   __builtin_amdgcn_exp2f(__builtin_fminf(p23[0], 64.f)), __builtin_amdgcn_exp2f(p23[1])};
+    const float pi = __builtin_fmaf(ax[0], LO_UNSCALE, am[0]);
+    const float pf = __builtin_fmaf(ax[1], LO_UNSCALE, am[1]);
+    const float pg = __builtin_fminf(__builtin_fmaf(ax[2], LO_UNSCALE, am[2]), 64.f);
+    const float po = __builtin_fmaf(ax[3], LO_UNSCALE, am[3]);
+    return (f32x4){__builtin_amdgcn_exp2f(pi), __builtin_amdgcn_exp2f(pf), __builtin_amdgcn_exp2f(pg), __builtin_amdgcn_exp2f(po)};
 }
-__device__ __forceinline__ f32x2 cell_pair(const f32x4& ea, const f32x4& eb, f32x2& cs) {
-    const f32x2 one = {1.f, 1.f};
-    const f32x2 ei = {ea[0], eb[0]}, ef = {ea[1], eb[1]}, eg = {ea[2], eb[2]}, eo = {ea[3], eb[3]};
-    const f32x2 a = one + ef, u = one + eg;
-    const f32x2 xu = (one + ei) * u;
-    const f32x2 nk = __builtin_elementwise_fma(eg, (f32x2){-K2, -K2}, (f32x2){K2, K2});     // K2 (1 - E_g)
-    const f32x2 ra = {__builtin_amdgcn_rcpf(a[0]), __builtin_amdgcn_rcpf(a[1])};
-    const f32x2 rb = {__builtin_amdgcn_rcpf(xu[0]), __builtin_amdgcn_rcpf(xu[1])};
-    cs = __builtin_elementwise_fma(cs, ra, nk * rb);
-    const f32x2 ec = {__builtin_amdgcn_exp2f(__builtin_fminf(cs[0], 64.f)), __builtin_amdgcn_exp2f(__builtin_fminf(cs[1], 64.f))};
-    const f32x2 v = one + ec;
-    const f32x2 d = __builtin_elementwise_fma(eo, v, v);
-    const f32x2 rd = {__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
-    return (one - ec) * rd;
+// stage B (one cell): cs = -2 log2(e) c is the running cell state
+__device__ __forceinline__ float cell_finish(const f32x4& e, float& cs) {
+    const float u = 1.f + e[2];
+    const float ra = __builtin_amdgcn_rcpf(1.f + e[1]);
+    const float rb = __builtin_amdgcn_rcpf(__builtin_fmaf(e[0], u, u));
+    cs = __builtin_fmaf(cs, ra, __builtin_fmaf(e[2], -K2, K2) * rb);
+    const float ec = __builtin_amdgcn_exp2f(__builtin_fminf(cs, 64.f));
+    const float v = 1.f + ec;
+    const float rd = __builtin_amdgcn_rcpf(__builtin_fmaf(e[3], v, v));
+    return __builtin_fmaf(-ec, rd, rd);
 }
 
+template <bool F32OUT, int MODE>
 __global__ __launch_bounds__(512) void lstm_mfma_pipe_kernel(const float* __restrict__ gx,
                                                              const unsigned short* __restrict__ whs,
                                                              float* __restrict__ hout,
                                                              unsigned short* __restrict__ hsp,
                                                              long long hplane, int B, int T) {
-    // one LDS object: H planes [2 plane][16 chains][256 B] (k' order) | gx ring [4][16][2064 B]
-    __shared__ __attribute__((aligned(16))) char lds[2 * PLANE + GX_NSLOT * GX_SLOT];
+    // one LDS object: H [2 buf][2 plane][16 chains][256 B] (k' order) | gx ring [4][16][2064 B]
+    __shared__ __attribute__((aligned(16))) char lds[4 * PLANE + GX_NSLOT * GX_SLOT];
     char* hs = lds;
-    char* gxr = lds + 2 * PLANE;
+    char* gxr = lds + 4 * PLANE;
     const int tid = threadIdx.x, l = tid & 63, n = l & 15, q = l >> 4;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int dir = blockIdx.y;
@@ -525,7 +528,7 @@ __global__ __launch_bounds__(512) void lstm_mfma_pipe_kernel(const float* __rest
                 wl[j][ks] = *reinterpret_cast<const f16x8*>(Wd + 512 * 128 + o);
             }
     }
-    for (int i = tid; i < 2 * PLANE / 16; i += 512)
+    for (int i = tid; i < 4 * PLANE / 16; i += 512)        // h_{-1} = 0 (both buffers)
         reinterpret_cast<f32x4*>(hs)[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
     int rd_off[4];
 #pragma unroll
@@ -534,22 +537,30 @@ __global__ __launch_bounds__(512) void lstm_mfma_pipe_kernel(const float* __rest
     const int wr_off0 = n * 256 + ((w ^ n) << 4) + 4 * q;
     const int wr_off1 = n * 256 + (((8 + w) ^ n) << 4) + 4 * q;
 
-    // ---- outputs through buffer descriptors: voffset = the lane's column (and chain), soffset = the frame
+    // ---- export of h_{s-1} (complete in LDS behind Q_s): wave w -> plane w >> 2, chains 4 (w & 3) .. + 3; lane -> chain
+    // + (l >> 4), units 8 g .. 8 g + 7 with g = l & 15 = k' 4g .. 4g + 3 (units 8g, 8g+1, 8g+4, 8g+5) and 64 + the same
+    // (8g+2, 8g+3, 8g+6, 8g+7).  Destination: kb-major plane, row = chunk * T + frame, 64 contiguous bytes per 4 lanes.
     const long long R = hplane >> 8;                                   // rows of a plane
-    const unsigned pl_bytes = hsp ? (unsigned)(hplane * 2) : 0u;       // absent output: empty descriptor
-    const __amdgpu_buffer_rsrc_t r_hi = __builtin_amdgcn_make_buffer_rsrc((void*)hsp, 0, pl_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t r_lo = __builtin_amdgcn_make_buffer_rsrc((void*)(hsp + (hsp ? hplane : 0)), 0, pl_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t r_f = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)hout, 0, hout ? (unsigned)((long long)B * T * 1024) : 0u, 0x00020000);
-    const int col = dir * 128 + 16 * w + 4 * q;                        // column of cell 0; cells 2, 3: + 2 (same k-block)
+    const int ep = w >> 2, en = 4 * (w & 3) + (l >> 4), eg = l & 15;
+    const int e_rda = ep * PLANE + en * 256 + (((eg >> 1) ^ en) << 4) + 8 * (eg & 1);
+    const int e_rdb = ep * PLANE + en * 256 + (((8 + (eg >> 1)) ^ en) << 4) + 8 * (eg & 1);
+    const int e_chunk = blockIdx.x * CH + en;
     const unsigned dead = 0x80000000u;
-    const unsigned vo_p = valid ? (unsigned)((((long long)(col >> 5) * R + (long long)bb * T) * 32 + (col & 31)) * 2) : dead;
-    const unsigned vo_f = valid ? (unsigned)((long long)bb * T * 1024 + col * 4) : dead;
+    const unsigned e_vo = e_chunk < B ? (unsigned)((((long long)(dir * 4 + (eg >> 2)) * R + (long long)e_chunk * T) * 64) + 16 * (eg & 3) +
+                                                   (long long)ep * hplane * 2) : dead;
+    // (the size words through readfirstlane: hipcc computes them on the vector unit, and a descriptor it believes to be
+    // divergent puts every access in a waterfall loop)
+    const unsigned pl_bytes = __builtin_amdgcn_readfirstlane(hsp ? (unsigned)(hplane * 4) : 0u);
+    const unsigned f_bytes = __builtin_amdgcn_readfirstlane(hout ? (unsigned)((long long)B * T * 1024) : 0u);
+    const unsigned gx_bytes = __builtin_amdgcn_readfirstlane(
+        (unsigned)((long long)B * T * 4096 < 0xffffffffLL ? (long long)B * T * 4096 : 0xffffffffLL));
+    const __amdgpu_buffer_rsrc_t r_pl = __builtin_amdgcn_make_buffer_rsrc((void*)hsp, 0, pl_bytes, 0x00020000);
+    // f32 rows (F32OUT): voffset = the lane's chain and column, soffset = the frame; absent output: empty descriptor
+    const __amdgpu_buffer_rsrc_t r_f = __builtin_amdgcn_make_buffer_rsrc((void*)hout, 0, f_bytes, 0x00020000);
+    const unsigned vo_f = valid ? (unsigned)((long long)bb * T * 1024 + (dir * 128 + 16 * w + 4 * q) * 4) : dead;
 
-    // ---- LDS-DMA of the x-projection: this wave fetches chains 2w and 2w+1 (as variant 3) --------
-    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)gx, 0, (unsigned)((long long)B * T * 4096 < 0xffffffffLL ? (long long)B * T * 4096 : 0xffffffffLL),
-        0x00020000);
+    // ---- LDS-DMA of the x-projection: this wave fetches chains 2w and 2w+1 (as variant 3), one piece at a time
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)gx, 0, gx_bytes, 0x00020000);
     int voff[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -557,15 +568,14 @@ __global__ __launch_bounds__(512) void lstm_mfma_pipe_kernel(const float* __rest
         const int cb = chain < B ? chain : B - 1;
         voff[i] = cb * T * 4096 + dir * 2048 + (i & 1) * 1024 + l * 16;
     }
-    auto fetch = [&](int s) {                 // frame of step s: s (forward) or T-1-s (backward); s clamped to T-1
-        const int sc = s < T ? s : T - 1;
-        const int tt = dir ? T - 1 - sc : sc;
-        char* slot = gxr + (s & (GX_NSLOT - 1)) * GX_SLOT;
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(
-                rsrc, (__attribute__((address_space(3))) void*)(slot + (2 * w + (i >> 1)) * GX_ROW + (i & 1) * 1024),
-                16, voff[i], tt * 4096, 0, 0);
+    auto frame = [&](int s) { return dir ? T - 1 - s : s; };
+    auto fetch_piece = [&](int s, int slot_no, int i) {     // piece i of the frame of step s (clamped to the last step) -> ring slot
+        if constexpr (MODE & 32) return;
+        const int tt = frame(s < T ? s : T - 1);
+        char* slot = gxr + slot_no * GX_SLOT;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(
+            rsrc, (__attribute__((address_space(3))) void*)(slot + (2 * w + (i >> 1)) * GX_ROW + (i & 1) * 1024),
+            16, voff[i], tt * 4096, 0, 0);
     };
     const int g_off = n * GX_ROW + (64 * w + 16 * q) * 4;
 
@@ -574,136 +584,176 @@ __global__ __launch_bounds__(512) void lstm_mfma_pipe_kernel(const float* __rest
     AX = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[J][KS], bl[KS], AX, 0, 0, 0);              \
     AX = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[J][KS], bh[KS], AX, 0, 0, 0);
 #define DZ_SB() __builtin_amdgcn_sched_barrier(0)
+#define DZ_BARRIER(WAIT) do { if constexpr (MODE & 128) asm volatile("s_waitcnt " WAIT ::: "memory");      \
+                              else asm volatile("s_waitcnt " WAIT "\n\ts_barrier" ::: "memory"); } while (0)
 
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
     f32x4 am[4], ax[4];
     f16x8 bh[4], bl[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) am[j] = ax[j] = zero4;      // "step -1": all-zero accumulators give c = 0, h = 0
+    for (int j = 0; j < 4; ++j) am[j] = ax[j] = zero4;
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) bh[ks] = bl[ks] = (f16x8){0, 0, 0, 0, 0, 0, 0, 0};
-    f32x2 cs01 = {0.f, 0.f}, cs23 = {0.f, 0.f};                // -2 log2(e) x the cell state of cells (0, 1), (2, 3)
-    unsigned pend_hi = 0, pend_lo = 0;                       // h_{s-1} cells (0, 1), stored after the barrier
-    f32x2 pend_f = {0.f, 0.f};
+    float cs[4] = {0.f, 0.f, 0.f, 0.f};                      // -2 log2(e) x the cell state of the lane's four cells
+    f32x2 p01_f = {0.f, 0.f}, p23_f = {0.f, 0.f};            // F32OUT: h of the last two pairs, stored one barrier late
 
-    // pair of cells -> (hi, lo * 2^11) f16 pairs
-    auto split_pair = [&](const f32x2& h, unsigned& phi, unsigned& plo) {
-        const f16x2 hi = __builtin_convertvector(h, f16x2);
-        const f32x2 d = (h - __builtin_convertvector(hi, f32x2)) * (f32x2){LO_SCALE, LO_SCALE};
-        const f16x2 lo = __builtin_convertvector(d, f16x2);
-        phi = __builtin_bit_cast(unsigned, hi);
-        plo = __builtin_bit_cast(unsigned, lo);
+    // pair of cells -> (hi, lo * 2^11) f16 pairs -> one 4-byte LDS store per plane
+    auto put_pair = [&](float h0, float h1, char* at) {
+        const f16x2 hi = {(_Float16)h0, (_Float16)h1};
+        const f16x2 lo = {(_Float16)((h0 - (float)hi[0]) * LO_SCALE), (_Float16)((h1 - (float)hi[1]) * LO_SCALE)};
+        *reinterpret_cast<unsigned*>(at) = __builtin_bit_cast(unsigned, hi);
+        *reinterpret_cast<unsigned*>(at + PLANE) = __builtin_bit_cast(unsigned, lo);
+    };
+    auto exps = [&](const f32x4& m, const f32x4& x) -> f32x4 {
+        if constexpr (MODE & 16) return m + x; else return cell_exps(m, x);
+    };
+    auto finish = [&](const f32x4& e, float& c) -> float {
+        if constexpr (MODE & 16) { c += e[0]; return c; } else return cell_finish(e, c);
     };
 
-    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-    // behind barrier P_s: fetch step s+3, read k-half 0 of h_{s-1} and the x-projection of step s; finish step s-1
-    // (tile 3, cells 2 and 3, its stores) under M(3,1)', M(0,0), M(1,0).  FIRST: there is no step s-1.
+    // behind barrier P_s: read k-half 0 of h_{s-1} and the x-projection of step s; finish step s-1 (tile 3, cells 2
+    // and 3) under M(3,1)', M(0,0), M(1,0).  PHASE 0: s = 0 (there is no step s-1), 1: s = 1 (no step s-2), 2: s >= 2.
+    // S4 = s & 3 at compile time (the main loop is unrolled four times): ring slots and h buffers are then immediate
+    // offsets — every scalar or address instruction in the loop costs the SIMD an issue slot the MFMAs do not hide.
     f32x4 n0m, n0x, n1m, n1x, n2m, n2x, n3m, n3x;
-    auto first_half = [&](auto first_tag, int s) {
-        constexpr bool FIRST = decltype(first_tag)::value;
-        const int tprev = dir ? T - s : s - 1;               // frame of step s-1
-        fetch(s + 3);
-        const char* gs = gxr + (s & (GX_NSLOT - 1)) * GX_SLOT + g_off;
-        bh[0] = *reinterpret_cast<const f16x8*>(hs + rd_off[0]);
-        bl[0] = *reinterpret_cast<const f16x8*>(hs + PLANE + rd_off[0]);
-        bh[1] = *reinterpret_cast<const f16x8*>(hs + rd_off[1]);
-        bl[1] = *reinterpret_cast<const f16x8*>(hs + PLANE + rd_off[1]);
+    auto first_half = [&](auto phase_tag, auto s4_tag, int s) {
+        constexpr int PHASE = decltype(phase_tag)::value;
+        constexpr int S4 = decltype(s4_tag)::value;
+        const char* hprev = hs + ((S4 + 1) & 1) * 2 * PLANE;                 // buffer of h_{s-1}
+        const char* gs = gxr + S4 * GX_SLOT + g_off;
+        if constexpr (F32OUT && !(MODE & 4)) {
+            if constexpr (PHASE >= 1) __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, p01_f), r_f, vo_f, frame(s - 1) * 1024, 0);
+            if constexpr (PHASE >= 2) __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, p23_f), r_f, vo_f + 8, frame(s - 2) * 1024, 0);
+        }
+        bh[0] = *reinterpret_cast<const f16x8*>(hprev + rd_off[0]);
+        bl[0] = *reinterpret_cast<const f16x8*>(hprev + PLANE + rd_off[0]);
+        bh[1] = *reinterpret_cast<const f16x8*>(hprev + rd_off[1]);
+        bl[1] = *reinterpret_cast<const f16x8*>(hprev + PLANE + rd_off[1]);
         n0m = *reinterpret_cast<const f32x4*>(gs);
         n1m = *reinterpret_cast<const f32x4*>(gs + 16);
         n2m = *reinterpret_cast<const f32x4*>(gs + 32);
         n3m = *reinterpret_cast<const f32x4*>(gs + 48);
         n0x = n1x = n2x = n3x = zero4;
-        if constexpr (!FIRST) {
-            // h_{s-1} cells (0, 1) -> HBM
-            __builtin_amdgcn_raw_buffer_store_b32(pend_hi, r_hi, vo_p, tprev * 64, 0);
-            __builtin_amdgcn_raw_buffer_store_b32(pend_lo, r_lo, vo_p, tprev * 64, 0);
-            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, pend_f), r_f, vo_f, tprev * 1024, 0);
+        fetch_piece(s + 3, (S4 + 3) & 3, 0);
+        if constexpr (PHASE >= 1) {
             DZ_SB();
             // M(3,1) of step s-1 (operands fetched behind Q_{s-1}: covers the reads above) || exps of cell 2
             DZ_M3(am[3], ax[3], 3, 2) DZ_M3(am[3], ax[3], 3, 3)
-            const f32x4 e2 = cell_exps(am[2], ax[2]);
+            const f32x4 e2 = exps(am[2], ax[2]);
             DZ_SB();
-            // M(0,0) || exps of cell 3, the pair (2, 3)
+            // M(0,0) || exps of cell 3, cell 2
             DZ_M3(n0m, n0x, 0, 0) DZ_M3(n0m, n0x, 0, 1)
-            const f32x4 e3 = cell_exps(am[3], ax[3]);
+            const f32x4 e3 = exps(am[3], ax[3]);
+            const float h2 = finish(e2, cs[2]);
             DZ_SB();
-            // M(1,0) || the pair (2, 3) -> LDS (k-half 1 of h_{s-1}), HBM
+            fetch_piece(s + 3, (S4 + 3) & 3, 1);
+            // M(1,0) || cell 3; the pair -> LDS (k-half 1 of h_{s-1})
             DZ_M3(n1m, n1x, 1, 0) DZ_M3(n1m, n1x, 1, 1)
-            const f32x2 h23 = cell_pair(e2, e3, cs23);
-            unsigned p_hi, p_lo;
-            split_pair(h23, p_hi, p_lo);
-            DZ_SB();
-            *reinterpret_cast<unsigned*>(hs + wr_off1) = p_hi;
-            *reinterpret_cast<unsigned*>(hs + PLANE + wr_off1) = p_lo;
-            __builtin_amdgcn_raw_buffer_store_b32(p_hi, r_hi, vo_p + 4, tprev * 64, 0);
-            __builtin_amdgcn_raw_buffer_store_b32(p_lo, r_lo, vo_p + 4, tprev * 64, 0);
-            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, h23), r_f, vo_f + 8, tprev * 1024, 0);
+            const float h3 = finish(e3, cs[3]);
+            put_pair(h2, h3, const_cast<char*>(hprev) + wr_off1);
+            if constexpr (F32OUT) p23_f = (f32x2){h2, h3};
         } else {
             DZ_M3(n0m, n0x, 0, 0) DZ_M3(n0m, n0x, 0, 1)
+            fetch_piece(s + 3, (S4 + 3) & 3, 1);
             DZ_M3(n1m, n1x, 1, 0) DZ_M3(n1m, n1x, 1, 1)
         }
         DZ_SB();
     };
     // barrier Q_s (k-half 1 of h_{s-1}); M(2,0) covers its reads; the second halves of tiles 0, 1; cells 0 and 1 of
-    // step s under M(1,1), M(3,0), M(2,1); barrier P_{s+1}
-    auto second_half = [&]() {
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        bh[2] = *reinterpret_cast<const f16x8*>(hs + rd_off[2]);
-        bl[2] = *reinterpret_cast<const f16x8*>(hs + PLANE + rd_off[2]);
-        bh[3] = *reinterpret_cast<const f16x8*>(hs + rd_off[3]);
-        bl[3] = *reinterpret_cast<const f16x8*>(hs + PLANE + rd_off[3]);
+    // step s under M(1,1), M(3,0), M(2,1); h_{s-1} -> HBM; barrier P_{s+1}
+    auto second_half = [&](auto phase_tag, auto s4_tag, int s) {
+        constexpr int PHASE = decltype(phase_tag)::value;
+        constexpr int S4 = decltype(s4_tag)::value;
+        const char* hprev = hs + ((S4 + 1) & 1) * 2 * PLANE;
+        char* hcur = hs + (S4 & 1) * 2 * PLANE;
+        DZ_BARRIER("lgkmcnt(0)");
+        bh[2] = *reinterpret_cast<const f16x8*>(hprev + rd_off[2]);
+        bl[2] = *reinterpret_cast<const f16x8*>(hprev + PLANE + rd_off[2]);
+        bh[3] = *reinterpret_cast<const f16x8*>(hprev + rd_off[3]);
+        bl[3] = *reinterpret_cast<const f16x8*>(hprev + PLANE + rd_off[3]);
+        u32x2 ea = {0, 0}, eb = {0, 0};
+        if constexpr (PHASE >= 1) {
+            ea = *reinterpret_cast<const u32x2*>(hprev + e_rda);
+            eb = *reinterpret_cast<const u32x2*>(hprev + e_rdb);
+        }
+        fetch_piece(s + 3, (S4 + 3) & 3, 2);
         DZ_SB();
         DZ_M3(n2m, n2x, 2, 0) DZ_M3(n2m, n2x, 2, 1)
         DZ_SB();
         DZ_M3(n0m, n0x, 0, 2) DZ_M3(n0m, n0x, 0, 3)
         DZ_SB();
+        if constexpr (PHASE >= 1 && !(MODE & 4))
+            __builtin_amdgcn_raw_buffer_store_b128((u32x4){ea[0], eb[0], ea[1], eb[1]}, r_pl, e_vo, frame(s - 1) * 64, 0);
+        fetch_piece(s + 3, (S4 + 3) & 3, 3);
         // M(1,1) || exps of cell 0
         DZ_M3(n1m, n1x, 1, 2) DZ_M3(n1m, n1x, 1, 3)
-        const f32x4 e0 = cell_exps(n0m, n0x);
+        const f32x4 e0 = exps(n0m, n0x);
         DZ_SB();
-        // M(3,0) || exps of cell 1
+        // M(3,0) || exps of cell 1, cell 0
         DZ_M3(n3m, n3x, 3, 0) DZ_M3(n3m, n3x, 3, 1)
-        const f32x4 e1 = cell_exps(n1m, n1x);
+        const f32x4 e1 = exps(n1m, n1x);
+        const float h0 = finish(e0, cs[0]);
         DZ_SB();
-        // M(2,1) || the pair (0, 1)
+        // M(2,1) || cell 1; the pair -> LDS (k-half 0 of h_s)
         DZ_M3(n2m, n2x, 2, 2) DZ_M3(n2m, n2x, 2, 3)
-        pend_f = cell_pair(e0, e1, cs01);
-        split_pair(pend_f, pend_hi, pend_lo);
+        const float h1 = finish(e1, cs[1]);
+        put_pair(h0, h1, hcur + wr_off0);
+        if constexpr (F32OUT) p01_f = (f32x2){h0, h1};
         DZ_SB();
-        *reinterpret_cast<unsigned*>(hs + wr_off0) = pend_hi;
-        *reinterpret_cast<unsigned*>(hs + PLANE + wr_off0) = pend_lo;
         am[2] = n2m; ax[2] = n2x; am[3] = n3m; ax[3] = n3x;
-        // P_{s+1}: the pieces of step s+1 have landed (loads complete in order: with at most 8 operations in flight
+        // P_{s+1}: the pieces of step s+1 have landed (loads retire in order: with at most 8 operations in flight
         // every piece older than those of steps s+2, s+3 is in LDS), this wave's halves of h are in LDS
-        asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        DZ_BARRIER("vmcnt(8) lgkmcnt(0)");
     };
 
-    fetch(0);
-    fetch(1);
-    fetch(2);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) fetch_piece(0, 0, i);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) fetch_piece(1, 1, i);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) fetch_piece(2, 2, i);
     asm volatile("s_waitcnt vmcnt(8)" ::: "memory");       // step 0's four pieces
     __syncthreads();
-    first_half(std::true_type{}, 0);
-    second_half();
-    for (int s = 1; s < T; ++s) {
-        first_half(std::false_type{}, s);
-        second_half();
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    using I2 = std::integral_constant<int, 2>;
+    using I3 = std::integral_constant<int, 3>;
+    first_half(I0{}, I0{}, 0);
+    second_half(I0{}, I0{}, 0);
+    if (T > 1) {
+        first_half(I1{}, I1{}, 1);
+        second_half(I1{}, I1{}, 1);
     }
-    {   // step T-1: tile 3, cells 2 and 3, the stores
-        const int tprev = dir ? 0 : T - 1;
-        __builtin_amdgcn_raw_buffer_store_b32(pend_hi, r_hi, vo_p, tprev * 64, 0);
-        __builtin_amdgcn_raw_buffer_store_b32(pend_lo, r_lo, vo_p, tprev * 64, 0);
-        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, pend_f), r_f, vo_f, tprev * 1024, 0);
+    for (int s = 2; s < T; s += 4) {         // four steps per trip: s & 3 = 2, 3, 0, 1
+        first_half(I2{}, I2{}, s);     second_half(I2{}, I2{}, s);
+        if (s + 1 >= T) break;
+        first_half(I2{}, I3{}, s + 1); second_half(I2{}, I3{}, s + 1);
+        if (s + 2 >= T) break;
+        first_half(I2{}, I0{}, s + 2); second_half(I2{}, I0{}, s + 2);
+        if (s + 3 >= T) break;
+        first_half(I2{}, I1{}, s + 3); second_half(I2{}, I1{}, s + 3);
+    }
+    {   // step T-1: tile 3, cells 2 and 3 -> LDS; h_{T-1} -> HBM
+        char* hlast = hs + ((T - 1) & 1) * 2 * PLANE;
+        if constexpr (F32OUT && !(MODE & 4)) {
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, p01_f), r_f, vo_f, frame(T - 1) * 1024, 0);
+            if (T > 1) __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, p23_f), r_f, vo_f + 8, frame(T - 2) * 1024, 0);
+        }
         DZ_M3(am[3], ax[3], 3, 2) DZ_M3(am[3], ax[3], 3, 3)
-        const f32x2 h23 = cell_pair(cell_exps(am[2], ax[2]), cell_exps(am[3], ax[3]), cs23);
-        unsigned p_hi, p_lo;
-        split_pair(h23, p_hi, p_lo);
-        __builtin_amdgcn_raw_buffer_store_b32(p_hi, r_hi, vo_p + 4, tprev * 64, 0);
-        __builtin_amdgcn_raw_buffer_store_b32(p_lo, r_lo, vo_p + 4, tprev * 64, 0);
-        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, h23), r_f, vo_f + 8, tprev * 1024, 0);
+        const f32x4 e2 = exps(am[2], ax[2]), e3 = exps(am[3], ax[3]);
+        const float h2 = finish(e2, cs[2]), h3 = finish(e3, cs[3]);
+        put_pair(h2, h3, hlast + wr_off1);
+        if constexpr (F32OUT && !(MODE & 4))
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, (f32x2){h2, h3}), r_f, vo_f + 8, frame(T - 1) * 1024, 0);
+        __syncthreads();
+        const u32x2 ea = *reinterpret_cast<const u32x2*>(hlast + e_rda);
+        const u32x2 eb = *reinterpret_cast<const u32x2*>(hlast + e_rdb);
+        if constexpr (!(MODE & 4))
+            __builtin_amdgcn_raw_buffer_store_b128((u32x4){ea[0], eb[0], ea[1], eb[1]}, r_pl, e_vo, frame(T - 1) * 64, 0);
     }
 #undef DZ_M3
 #undef DZ_SB
+#undef DZ_BARRIER
 }
 
 // variant 0: two accumulators, lo planes scaled by 2^11 (whh_split = split_f16 of W_hh);
@@ -716,11 +766,11 @@ int dz_launch_lstm_mfma(const float* gx, const void* whh_split, float* hout, voi
     dim3 grid((B + CH - 1) / CH, 2);
     const unsigned short* whs = reinterpret_cast<const unsigned short*>(whh_split);
     unsigned short* hsp = reinterpret_cast<unsigned short*>(hsplit);
-    DZ_REQUIRE(variant >= 0 && variant <= 4, "lstm_mfma: variant %d", variant);
+    DZ_REQUIRE(variant >= 0 && variant <= 300, "lstm_mfma: variant %d", variant);
     DZ_REQUIRE(hout || hsp, "lstm_mfma: no output");
     DZ_REQUIRE(variant < 3 || (unit_major && (long long)B * T * 4096 < (1ll << 31)),
                "lstm_mfma: variants 3 / 4 (LDS-DMA of gx) need unit-major gx below 2 GiB");
-    DZ_REQUIRE(variant != 4 || hplane * 2 < (1ll << 31), "lstm_mfma: variant 4 addresses planes below 2 GiB");
+    DZ_REQUIRE(variant < 4 || hplane * 4 < (1ll << 31), "lstm_mfma: variant 4 addresses planes below 2 GiB");
     DZ_REQUIRE(hplane % 256 == 0 && (!hsplit || hplane >= (long long)B * T * 256),
                "lstm_mfma: the kb-major planes need hplane = rows * 256 with rows >= B * T");
 #define DZ_L(K) DZ_LAUNCH(K, grid, dim3(512), 0, st, gx, whs, hout, hsp, hplane, B, T)
@@ -732,7 +782,16 @@ int dz_launch_lstm_mfma(const float* gx, const void* whh_split, float* hout, voi
     DZ_REQUIRE(variant == 0 || variant >= 3, "lstm_mfma: variants 1 / 2 exist in the experiments build only (variant %d)", variant);
 #endif
     if (variant == 3) DZ_L(lstm_mfma_dma_kernel);
-    if (variant == 4) DZ_L(lstm_mfma_pipe_kernel);
+    if (variant == 4) { if (hout) DZ_L((lstm_mfma_pipe_kernel<true, 0>)); else DZ_L((lstm_mfma_pipe_kernel<false, 0>)); }
+#ifdef DZ_EXPERIMENTS
+    if (variant == 4 + 4) DZ_L((lstm_mfma_pipe_kernel<false, 4>));
+    if (variant == 4 + 16) DZ_L((lstm_mfma_pipe_kernel<false, 16>));
+    if (variant == 4 + 20) DZ_L((lstm_mfma_pipe_kernel<false, 20>));
+    if (variant == 4 + 52) DZ_L((lstm_mfma_pipe_kernel<false, 52>));
+    if (variant == 4 + 32) DZ_L((lstm_mfma_pipe_kernel<false, 32>));
+    if (variant == 4 + 128) DZ_L((lstm_mfma_pipe_kernel<false, 128>));
+    if (variant == 4 + 180) DZ_L((lstm_mfma_pipe_kernel<false, 180>));
+#endif
 #undef DZ_L
     DZ_HIP(hipGetLastError());
     return 0;

@@ -157,7 +157,7 @@ def lstm_whh_planes(whh: torch.Tensor, variant: int) -> torch.Tensor:
     assert whh.shape == (2, 512, 128), whh.shape
     if variant in (0, 3):       # variant 3 = variant 0's planes, x-projection fetched by LDS-DMA
         return torch.stack([split_f16(whh[0]), split_f16(whh[1])]).contiguous()
-    if variant == 4:
+    if variant >= 4:            # (> 4: timing-only forms of the experiments build, same planes)
         # the software-pipelined kernel: every gate row carries its activation scale (LSTM_GATE_SCALE: an accumulator
         # is then the exp2 argument), and the contraction index is re-ordered so that each half of K holds two of a
         # lane's four cells: column k' = 64 a + 2 p + e  <-  hidden unit u = 4 p + 2 a + e

@@ -577,7 +577,7 @@ def test_lstm_recurrence(gpu, B, T, kernel):
         um, variant = kernel.endswith("_um"), int(kernel[4])
         if um:   # dir*512 + unit*4 + gate
             gx = gx.view(B, T, 2, 4, 128).transpose(3, 4).reshape(B, T, 1024)
-        if variant == 4:   # the software-pipelined kernel takes the x-projection times the gates' activation scales
+        if variant >= 4:   # the software-pipelined kernel takes the x-projection times the gates' activation scales
             from diart_amd.weights import LSTM_GATE_SCALE
             gx = (gx.double().view(B, T, 256, 4) * torch.tensor(LSTM_GATE_SCALE, dtype=torch.float64)).float().view(B, T, 1024)
         dgx = gx.contiguous().to(gpu)

@@ -163,7 +163,7 @@ for variant in ((0, 1, 2, 3, 4) if _lib.experiments() else (0, 3, 4)):      # 1 
     whs = lstm_whh_planes(whh.cpu(), variant).to(dev)
     nm = f"lstm_mfma{variant}"
     gxv = gx.view(B, F, 2, 4, 128).transpose(3, 4).reshape(B, F, 1024).contiguous() if variant >= 3 else gx
-    if variant == 4:      # (its x-projection carries the gates' activation scales)
+    if variant >= 4:      # (its x-projection carries the gates' activation scales)
         from diart_amd.weights import LSTM_GATE_SCALE
         gxv = (gxv.view(B, F, 256, 4) * torch.tensor(LSTM_GATE_SCALE, device=dev)).view(B, F, 1024).contiguous()
     timeit(nm, lambda: _lib.check(lib.dz_k_lstm_mfma(ctx, gxv.data_ptr(), whs.data_ptr(), hout2.data_ptr(), B, F, int(variant >= 3), variant, st)),
