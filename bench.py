@@ -132,9 +132,9 @@ def device_kernel(tag, precision):
     DEVICE kernel, so the layers that share one instantiation are one entry."""
     split = precision == "f16x3"
     pre = split                                                       # wide layers on k_gemm_pre.hip
-    # the recurrence the ENGINE of this precision runs (StreamBatch.recurrence: the matrix-core form for >= 32 streams
-    # unless DZ_LSTM says otherwise), else weights.default_lstm_variant
-    lstm = RECURRENCE.get(precision) or os.environ.get("DZ_LSTM", "valu")
+    # the recurrence the ENGINE of this precision runs (StreamBatch.recurrence: the matrix-core form for >= 64 streams
+    # unless --recurrence says otherwise), else the model's own ("valu")
+    lstm = RECURRENCE.get(precision) or "valu"
     k = KERNELS[tag]
     fused_pool = split and pre and os.environ.get("DZ_POOL_FUSE", "1") != "0"
     if k["bound"] == "hbm":
@@ -217,7 +217,10 @@ def parse():
     ap.add_argument("--cpu-worker", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--cpu-threads", type=int, default=8, help=argparse.SUPPRESS)
     ap.add_argument("--kernel-table", type=str, default="", help="write the per-kernel table here")
-    ap.add_argument("--precision", type=str, default="", help="f16x3 | f32 (default: DZ_PRECISION or f16x3)")
+    ap.add_argument("--precision", type=str, default="", help="f16x3 | f32 (default: f16x3)")
+    ap.add_argument("--recurrence", type=str, default="", help="StreamBatch(recurrence=): valu | 0 | 3 | 4 (default: the engine's choice)")
+    ap.add_argument("--lanes", type=int, default=0, help="StreamBatch(lanes=) (default: the engine's choice)")
+    ap.add_argument("--inflight", type=int, default=0, help="StreamBatch(inflight=) (default: lanes + 1)")
     ap.add_argument("--no-host-pass", action="store_true",
                     help="skip the extra pass that uploads each step's new audio from pinned host memory")
     ap.add_argument("--pmc", choices=["on", "all", "off"], default=os.environ.get("DZ_BENCH_PMC", "on"),
@@ -382,7 +385,8 @@ def host_rehearsal(args, precision, usable, ranks=8):
     cores = allowed[:share]
     steps = max(args.steps, 100)
     cmd = [sys.executable, str(ROOT / "bench.py"), "--steps", str(steps), "--warmup", "5", "--no-cpu-baseline", "--no-exact-f32",
-           "--no-host-pass", "--pmc", "off", "--no-rehearsal", "--precision", precision, "--streams", str(args.streams)]
+           "--no-host-pass", "--pmc", "off", "--no-rehearsal", "--precision", precision, "--streams", str(args.streams),
+           *engine_args(args)]
     res = {}
     for tag, pin in (("unpinned", None), ("pinned", cores)):
         env = dict(os.environ)      # (a pinned child sees < 4 usable cores: StreamBatch stops its pool spinning itself)
@@ -415,7 +419,16 @@ def _match_pmc(files, groups, key):
     return got
 
 
-def pmc_live(precision):
+def engine_args(args):
+    """The engine parameters of this command, for its child runs."""
+    out = []
+    for flag, v in (("--recurrence", args.recurrence), ("--lanes", args.lanes), ("--inflight", args.inflight)):
+        if v:
+            out += [flag, str(v)]
+    return out
+
+
+def pmc_live(precision, args=None):
     """HBM traffic and matrix-core busy time of every kernel FROM THIS RUN'S BOX: rocprofv3 --pmc
     passes of this same command (short: 3 steps) as child processes, collected as
     MI355X_MICROARCH.md prescribes — separate passes (FETCH_SIZE / WRITE_SIZE / matrix-core busy),
@@ -431,7 +444,8 @@ def pmc_live(precision):
     t_start, budget = time.monotonic(), float(os.environ.get("DZ_PMC_BUDGET_S", "200"))
     work = Path(tempfile.mkdtemp(prefix="dz_pmc_"))
     cmd = [sys.executable, str(ROOT / "bench.py"), "--steps", "3", "--warmup", "1", "--no-cpu-baseline",
-           "--no-exact-f32", "--no-host-pass", "--pmc", "off", "--no-rehearsal", "--precision", precision]
+           "--no-exact-f32", "--no-host-pass", "--pmc", "off", "--no-rehearsal", "--precision", precision,
+           *(engine_args(args) if args is not None else [])]
     env = dict(os.environ, PYTHONDONTWRITEBYTECODE="1", TMPDIR="/tmp", DZ_SETTLE_STEPS="0")
     passes = {"FETCH_SIZE": ["FETCH_SIZE"], "WRITE_SIZE": ["WRITE_SIZE"],
               "MFMA": ["SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CYCLES", "GRBM_GUI_ACTIVE"]}
@@ -936,7 +950,8 @@ def main():
         p_ = StreamBatch(HipSegmentation(seg_state, max_batch=n, precision=prec),
                          HipEmbedding(emb_state, max_batch=n, precision=prec),
                          n, device=device, cluster_threads=host_threads,
-                         tail=not args.no_tail)
+                         tail=not args.no_tail, recurrence=args.recurrence or None, lanes=args.lanes or None,
+                         inflight=args.inflight or None)
         if p_.recurrence:
             RECURRENCE[prec] = p_.recurrence
         return p_
@@ -1143,8 +1158,8 @@ def main():
 
     if rank == 0:
         cps = D.whole_job_rate(n, args.steps, elapsed, world)
-        pmc = pmc_live(precision) if (world == 1 and args.pmc != "off") else None
-        pmc32 = pmc_live("f32") if (pmc is not None and exact is not None and args.pmc == "all") else None
+        pmc = pmc_live(precision, args) if (world == 1 and args.pmc != "off") else None
+        pmc32 = pmc_live("f32", args) if (pmc is not None and exact is not None and args.pmc == "all") else None
         roof, per_kernel = build_roofline(table, precision, n_sampled, pmc)
         roof["whole_path_tflops"] = round(cps / world * ALG_GFLOP_PER_CHUNK / 1e3, 2)
         roof["concurrency_note"] = ("per-kernel durations are measured while the kernels of %d HIP streams overlap on the "
@@ -1183,7 +1198,7 @@ def main():
                        "rccl_ranks": (torch.distributed.get_world_size() if world > 1 and torch.distributed.get_backend() == "nccl"
                                       else 0), "cpu_affinity": affinity,
                        "weights_abs_sum_per_rank": wsums, "host_threads_per_rank": host_threads,
-                       "steps_in_flight": pipe.max_inflight, "lanes": pipe.depth, "recurrence": pipe.recurrence or os.environ.get("DZ_LSTM", "valu"), "seg_sub_batches": pipe.seg_split,
+                       "steps_in_flight": pipe.max_inflight, "lanes": pipe.depth, "recurrence": pipe.recurrence or "valu", "seg_sub_batches": pipe.seg_split,
                        "hip_streams": pipe.num_hip_streams,
                        "exact_f32_value": exact["value"] if exact else None,
                        "host_fed_value": host_fed["value"] if host_fed else None},

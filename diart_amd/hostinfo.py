@@ -76,7 +76,8 @@ def bind_rank(local_rank: int, local_world: int, device_index=None) -> dict:
     that time-share a 16-core grant, a rank whose pool migrates across sockets pays remote-memory latency on
     every pinned-buffer touch.  Never raises; returns what it did (goes into the bench line)."""
     info = {"bound": False, "cpus": None}
-    if local_world <= 1 or os.environ.get("DZ_NO_AFFINITY") or not hasattr(os, "sched_setaffinity"):
+    from .config import setting
+    if local_world <= 1 or str(setting("affinity", None, "1")) == "0" or not hasattr(os, "sched_setaffinity"):
         return info
     try:
         allowed = os.sched_getaffinity(0)

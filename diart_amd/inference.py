@@ -231,12 +231,11 @@ class Benchmark:
             self.output_path = Path(output_path).expanduser()
             self.output_path.mkdir(parents=True, exist_ok=True)
         self.show_progress, self.show_report, self.batch_size = show_progress, show_report, batch_size
-        # files of this process that share one GPU batch (``FileBatch``); None = DZ_CONCURRENT_FILES or 16,
-        # 0 = the reference's one-file-at-a-time loop.  Only the HIP x-vector diarization pipeline has
-        # the batched path; anything else falls back to the loop.
-        import os
-        self.concurrent_files = int(os.environ.get("DZ_CONCURRENT_FILES", "16")) if concurrent_files is None \
-            else int(concurrent_files)
+        # files of this process that share one GPU batch (``FileBatch``); None = 16, 0 = the reference's
+        # one-file-at-a-time loop.  Only the HIP x-vector diarization pipeline has the batched path; anything else
+        # falls back to the loop.
+        from .config import setting
+        self.concurrent_files = int(setting("concurrent_files", concurrent_files, 16, int))
         self.last_path = None      # "file_batch" | "one_file_at_a_time": which path the last call took
 
     def get_file_paths(self) -> List[Path]:

@@ -34,17 +34,17 @@ from .weights import PackedEcapa, PackedEmbedding, PackedSegmentation
 StateSource = Union[str, Path, Dict[str, torch.Tensor]]
 
 
-def default_precision() -> str:
-    """Arithmetic of the GEMM-shaped layers when a model does not say: ``DZ_PRECISION`` or "f16x3"
+def default_precision(given: Optional[str] = None) -> str:
+    """Arithmetic of the GEMM-shaped layers: the ``precision=`` argument of a model, "f16x3" when it does not say
     (f32 operands split into two f16 numbers = 22 mantissa bits, three f16 MFMAs per product, f32
     accumulation: measured against the f32 CPU restatement of the networks it is indistinguishable
-    from "f32", the exact-f32 MFMA path, and 1.4x faster end to end; weights.PRECISIONS,
-    DESIGN.md 4.4)."""
-    import os
+    from "f32", the exact-f32 MFMA path, and 1.8x faster end to end; weights.PRECISIONS,
+    DESIGN.md 4.2); ``DZ_ENGINE=precision=...`` overrides both (config.py)."""
+    from .config import setting
     from .weights import PRECISIONS
-    p = os.environ.get("DZ_PRECISION", "f16x3")
+    p = setting("precision", given, "f16x3")
     if p not in PRECISIONS:
-        raise ValueError(f"DZ_PRECISION={p!r}: expected one of {PRECISIONS}")
+        raise ValueError(f"precision={p!r}: expected one of {PRECISIONS}")
     return p
 
 
@@ -145,32 +145,40 @@ class HipSegmentation(_HipModule):
     ``SegmentationModel.__call__`` (reference models.py:188-198)."""
 
     def __init__(self, state: Dict[str, torch.Tensor], max_batch: int = 64, powerset: bool = False,
-                 precision: Optional[str] = None):
+                 precision: Optional[str] = None, recurrence: Optional[str] = None):
+        """``recurrence``: the LSTM recurrence kernel of this model's own calls — "valu" (default: one chain per CU on
+        the f32 vector units, the shortest layer) or a matrix-core variant "0" | "3" | "4" (16 chains per workgroup,
+        default precision only).  A throughput engine (``StreamBatch``) chooses its own (``struct_throughput``)."""
         super().__init__(state, max_batch)
+        from .config import setting
         self.powerset = bool(powerset)
-        self.precision = default_precision() if precision is None else precision
+        self.precision = default_precision(precision)
+        self.recurrence = str(setting("recurrence", recurrence, "valu"))
         self.num_speakers: Optional[int] = None
 
     def _extra_state(self):
-        return {"powerset": self.powerset, "precision": self.precision}
+        return {"powerset": self.powerset, "precision": self.precision, "recurrence": self.recurrence}
 
     def _pack(self, device):
-        p = PackedSegmentation(self._state, device, powerset=self.powerset, precision=self.precision)
+        p = PackedSegmentation(self._state, device, powerset=self.powerset, precision=self.precision,
+                               recurrence=self.recurrence)
         self.num_speakers = p.num_speakers
         return p
 
-    def _create(self, num_samples, cap, throughput: bool = False):
+    def _create(self, num_samples, cap, throughput: bool = False, recurrence: Optional[str] = None):
         """``throughput``: the handle of an engine that keeps several steps in flight (``StreamBatch``): the matrix-core
-        recurrence (``PackedSegmentation.struct_throughput``) instead of the low-latency one."""
+        recurrence (``PackedSegmentation.struct_throughput``) instead of the low-latency one; ``recurrence``: that
+        kernel, whatever the model's own (``PackedSegmentation.struct_for``)."""
         h = _lib.vp()
         lib = _lib.load()
-        w = self._packed.struct_throughput if throughput else self._packed.struct
+        w = (self._packed.struct_for(recurrence) if recurrence is not None else
+             self._packed.struct_throughput if throughput else self._packed.struct)
         _lib.check(lib.dz_seg_create(_lib.context(self.device.index), C.byref(w),
                                      cap, num_samples, C.byref(h)), "dz_seg_create")
         return h
 
     def throughput_recurrence(self) -> str:
-        """What a throughput handle of this model runs its recurrence on: "valu" | "0" | "3" (bench.py names the kernel)."""
+        """What a throughput handle of this model runs its recurrence on: "valu" | "0" | "3" | "4" (bench.py names the kernel)."""
         p = self._packed
         return str(int(p.struct_throughput.lstm_variant)) if p.struct_throughput.whh_split[0] else "valu"
 
@@ -206,7 +214,7 @@ class HipEmbedding(_HipModule):
 
     def __init__(self, state: Dict[str, torch.Tensor], max_batch: int = 64, precision: Optional[str] = None):
         super().__init__(state, max_batch)
-        self.precision = default_precision() if precision is None else precision
+        self.precision = default_precision(precision)
 
     def _extra_state(self):
         return {"precision": self.precision}
@@ -278,7 +286,7 @@ class HipEcapaEmbedding(_HipModule):
 
     def __init__(self, state: Dict[str, torch.Tensor], max_batch: int = 192, precision: Optional[str] = None):
         super().__init__(state, max_batch)
-        self.precision = default_precision() if precision is None else precision
+        self.precision = default_precision(precision)
 
     def _extra_state(self):
         return {"precision": self.precision}

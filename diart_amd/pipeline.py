@@ -36,6 +36,9 @@ from .blocks.clustering import BatchedSpeakerClustering
 from .features import Annotation, Segment
 from .models import HipEmbedding, HipSegmentation, _as_rows
 
+# lanes of a throughput engine (>= 64 streams per step on the matrix-core recurrence): profiles/r06*_lanes_grid.json
+THROUGHPUT_LANES = 6
+
 
 class AudioRing:
     """Device-resident rolling window of N streams (``dz_ring_*``): per step only the ``hop`` new
@@ -161,7 +164,19 @@ class StreamBatch:
                  device: Optional[torch.device] = None, cluster_threads: int = 8,
                  seg_split: Optional[int] = None, emb_split: Optional[int] = None,
                  tail: bool = False, duration: float = 5.0, step: float = 0.5,
-                 latency: Optional[float] = None, depth: Optional[int] = None):
+                 latency: Optional[float] = None, depth: Optional[int] = None, *, lanes: Optional[int] = None,
+                 recurrence: Optional[str] = None, inflight: Optional[int] = None, wait: Optional[str] = None,
+                 warmup: Optional[int] = None):
+        """Engine parameters (``DZ_ENGINE`` overrides them, config.py):
+        ``lanes`` (= ``depth``): steps the GPU works on at once, each with its own HIP streams, handles and scratch
+        arenas (~0.85 GB per lane at 64 streams) — default 2, or ``THROUGHPUT_LANES`` for a throughput engine;
+        ``recurrence``: the LSTM recurrence kernel, "valu" | "0" | "3" | "4" — default: the matrix-core kernel of
+        ``weights.THROUGHPUT_LSTM_VARIANT`` for a throughput engine (>= 64 streams per step, default precision),
+        else the model's own;
+        ``inflight``: steps a throughput caller keeps between ``launch`` and ``finish`` (default lanes + 1);
+        ``wait``: how the host waits for a step, "spin" | "block" | "auto" (by the cores this rank has);
+        ``warmup``: warm steps on silence before the first real step of a window size (default 10, 0 = off)."""
+        from .config import setting
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else device
         self.seg, self.emb = segmentation.to(self.device), embedding.to(self.device)
         self.device = self.seg.device
@@ -199,16 +214,23 @@ class StreamBatch:
         # (profiles/r05u_recurrence_lanes_grid.json; in round 4, with the slower front end, the same pair measured
         # equal).  Fewer streams (FileBatch's 32 windows per step lost 11 % with it), the exact-f32 precision and an
         # explicit DZ_LSTM keep what they had; the synchronous blocks API always runs the low-latency recurrence.
-        self.throughput = (num_streams >= 64 and "DZ_LSTM" not in os.environ
-                           and getattr(self.seg, "precision", "f32") == "f16x3")
-        self.recurrence = self.seg.throughput_recurrence() if self.throughput else None    # None: the model's default
-        self.depth = max(1, int(os.environ.get("DZ_DEPTH", "6" if self.throughput else "2") if depth is None else depth))
+        rec = setting("recurrence", recurrence, None)
+        split = getattr(self.seg, "precision", "f32") == "f16x3"
+        self.throughput = num_streams >= 64 and rec is None and split and getattr(self.seg, "recurrence", "valu") == "valu"
+        # the kernel this engine's handles run: None = the model's own struct
+        self.recurrence = self.seg.throughput_recurrence() if self.throughput else (str(rec) if rec is not None and split else None)
+        if depth is not None and lanes is not None and int(depth) != int(lanes):
+            raise ValueError(f"StreamBatch: depth={depth} and lanes={lanes} name the same thing")
+        matrix_core = self.recurrence not in (None, "valu")
+        self.depth = max(1, int(setting("lanes", lanes if lanes is not None else depth,
+                                        THROUGHPUT_LANES if (self.throughput or (matrix_core and num_streams >= 64)) else 2, int)))
         # How many launched-but-unfinished steps a throughput caller (bench.py, FileBatch) keeps: `depth` lanes
         # run concurrently, the steps beyond that wait IN THE STREAMS of their lane, so that a lane's next
         # step starts the moment the previous one ends instead of after the host has come back from
         # finish() (clustering of an older step + launch overhead: ~0.5 ms per step, during which the
-        # lane's segmentation stream sat empty).  DZ_INFLIGHT overrides (>= depth).
-        self.max_inflight = max(self.depth, int(os.environ.get("DZ_INFLIGHT", str(self.depth + 1))))
+        # lane's segmentation stream sat empty).
+        self.max_inflight = max(self.depth, int(setting("inflight", inflight, self.depth + 1, int)))
+        self.warmup_steps = max(0, int(setting("warmup", warmup, 10, int)))
         # DZ_SHARED_EMB=1: ONE set of embedding streams serves every lane in step order and the
         # pooling of step t is enqueued `lag` = depth - 1 launches later, behind the frame features
         # of the following steps (only the last two kernels of the embedding network wait for the
@@ -230,10 +252,13 @@ class StreamBatch:
         except ValueError:
             ranks_here = 1
         self.cores_per_rank = usable_cores() / ranks_here
-        mode = os.environ.get("DZ_WAIT", "auto")
+        mode = str(setting("wait", wait, "auto"))
+        if mode not in ("auto", "spin", "block"):
+            raise ValueError(f"StreamBatch: wait={mode!r} (expected auto | spin | block)")
         self.blocking_wait = mode == "block" or (mode == "auto" and self.cores_per_rank < 4)
-        if self.cores_per_rank < 4:
-            _lib.load().dz_host_pool_set_spin(0)                   # idle pool workers sleep at once
+        # idle pool workers poll 40 us for the next job when this rank has cores to spare, else they sleep at once
+        # (process-wide setting: the newest engine's situation decides)
+        _lib.load().dz_host_pool_set_spin(0 if self.cores_per_rank < 4 else 40)
         self.shared_stats = _lib.exp_env("DZ_SHARED_STATS", "1") != "0"
         self.shared_emb = _lib.exp_env("DZ_SHARED_EMB", "0") != "0"
         self.lag = self.depth - 1 if self.shared_emb else 0
@@ -325,7 +350,8 @@ class StreamBatch:
         got = self._sub.get((S, lane))
         if got is None:
             sa, sb = self._ranges(self.n, self.seg_split), self._ranges(self.n, self.emb_split)
-            hs = [self.seg._create(S, max(1, -(-self.n // self.seg_split)), throughput=self.throughput) for _ in sa]
+            hs = [self.seg._create(S, max(1, -(-self.n // self.seg_split)), throughput=self.throughput,
+                                   recurrence=None if self.throughput else self.recurrence) for _ in sa]
             he = [self.emb._create(S, max(1, -(-self.n // self.emb_split))) for _ in sb]
             got = self._sub[(S, lane)] = (hs, he, sa, sb)
         return got
@@ -492,9 +518,9 @@ class StreamBatch:
         launches of each kernel on each queue — gone after warm steps, while warming the streams, the copy
         path and the events alone did not move them.  Complete steps (GPU + host half: the worker pool's
         threads start here too) while no stream has any state yet, GPU-only steps for a second window size
-        later on; ~0.1 s of construction time instead of latency spikes in a live stream.  DZ_WARMUP=<steps>
+        later on; ~0.1 s of construction time instead of latency spikes in a live stream.  ``warmup=<steps>``
         (0 = off)."""
-        steps = int(os.environ.get("DZ_WARMUP", "10"))
+        steps = self.warmup_steps
         if steps <= 0:
             return
         zeros = torch.zeros((self.n, S), dtype=torch.float32, device=self.device)

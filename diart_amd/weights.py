@@ -98,12 +98,12 @@ def split_f16(w: torch.Tensor, name: Optional[str] = None) -> torch.Tensor:
         rep = float(rep)
         SPLIT_REPORT.append((name or f"matrix{len(SPLIT_REPORT)}", tuple(w.shape), rep))
         if rep > SPLIT_LIMIT:
-            import os
+            from .config import setting
             msg = (f"split_f16({name or 'matrix'}): the f16x3 planes represent this layer to {rep:.2e} (relative, RMS) — "
                    f"an f32 copy rounds to ~3e-8; its weights lie below the range the split holds to 22 bits "
                    f"(|w| >= 2^-14).  Load the model with precision=\"f32\"")
-            if os.environ.get("DZ_SPLIT_STRICT", "1") != "0":
-                raise ValueError(msg + " (DZ_SPLIT_STRICT=0 turns this into a warning)")
+            if str(setting("split_strict", None, "1")) != "0":
+                raise ValueError(msg + " (DZ_ENGINE=split_strict=0 turns this into a warning)")
             import warnings
             warnings.warn(msg)
     return torch.stack([hi, lo]).view(torch.int16).contiguous()
@@ -196,17 +196,19 @@ def lstm_scale_gx(t: torch.Tensor, unit_major: bool = True) -> torch.Tensor:
     return (t.double() * sc[g].view(shape)).float()
 
 
-THROUGHPUT_LSTM_VARIANT = 4      # k_lstm_mfma.hip, the software-pipelined form: what a throughput engine runs unless DZ_LSTM says otherwise
+THROUGHPUT_LSTM_VARIANT = 4      # k_lstm_mfma.hip, the software-pipelined form: what a throughput engine runs unless told otherwise
+RECURRENCES = ("valu", "0", "1", "2", "3", "4")
 
 
-def default_lstm_variant() -> int:
-    """``DZ_LSTM``: ``valu`` (-1: one chain per CU on the f32 vector units even in the f16x3
-    precision) or the matrix-core variant 0 / 3 / 4 (1 / 2: experiments build; ``lstm_whh_planes``)."""
-    import os
-    v = os.environ.get("DZ_LSTM", "valu")
-    v = -1 if v == "valu" else int(v)
+def lstm_variant_of(recurrence) -> int:
+    """``recurrence`` ("valu" | "0" | "3" | "4"; "1" / "2": experiments build) -> -1 (one chain per CU on the f32
+    vector units, k_lstm.hip) or the matrix-core variant of k_lstm_mfma.hip (``lstm_whh_planes``)."""
+    r = "valu" if recurrence is None else str(recurrence)
+    if r not in RECURRENCES:
+        raise ValueError(f"recurrence={recurrence!r}: expected one of {RECURRENCES}")
+    v = -1 if r == "valu" else int(r)
     if v in (1, 2) and not _lib.EXPERIMENTS:
-        raise ValueError(f"DZ_LSTM={v}: matrix-core recurrence variants 1 / 2 exist in the experiments build only "
+        raise ValueError(f"recurrence={r}: matrix-core recurrence variants 1 / 2 exist in the experiments build only "
                          "(DZ_EXPERIMENTS=1); the shipped library has valu, 0, 3 and 4")
     return v
 
@@ -318,54 +320,38 @@ class PackedConv0Pair:
 
 
 class PackedSegmentation:
-    """``dz_seg_weights`` + the tensors behind it."""
+    """``dz_seg_weights`` + the tensors behind it.
+
+    ``struct`` is what the synchronous blocks API runs: the recurrence named by ``recurrence`` ("valu" by default: one
+    chain per CU, the shortest layer).  ``struct_for(r)`` is the same network with another recurrence kernel (built on
+    first use, cached): the W_hh planes of that matrix-core variant and, for variant 4, an x-projection whose rows carry
+    the gates' activation scales; everything else is shared, not copied.  ``struct_throughput`` = what a throughput
+    engine (``StreamBatch`` with >= 64 streams per step, several steps in flight) creates its handles from."""
 
     def __init__(self, sd: Dict[str, torch.Tensor], device: torch.device, powerset: bool = False,
-                 num_speakers: int | None = None, precision: str = "f32"):
+                 num_speakers: int | None = None, precision: str = "f32", recurrence: Optional[str] = None):
         assert precision in PRECISIONS, precision
         split = precision == "f16x3"
         pk = _Packed(device)
         g = lambda k: sd[k].detach().cpu().float()
         w = _lib.SegWeights()
         w.sinc = _pack_sincnet(sd, pk, split=split)
-        lstm_variant = default_lstm_variant()
-        whh_tp, proj_tp = [], []
+        self._split, self._lstm = split, []
         for layer in range(4):
             # rows of the stacked W_ih (and the bias) go unit-major, dir*512 + unit*4 + gate, so the
             # x-projection GEMM writes the four gates of a unit next to each other and the recurrence
             # reads them as one 16-byte word (PyTorch's order is dir*512 + gate*128 + unit)
             um = lambda t: t.reshape(2, 4, 128, *t.shape[1:]).transpose(1, 2).reshape(t.shape).contiguous()
             wih = um(torch.cat([g(f"lstm.weight_ih_l{layer}"), g(f"lstm.weight_ih_l{layer}_reverse")], 0))
-            kpad = 64 if layer == 0 else 256
             bias = um(torch.cat([g(f"lstm.bias_ih_l{layer}") + g(f"lstm.bias_hh_l{layer}"),
                                  g(f"lstm.bias_ih_l{layer}_reverse") + g(f"lstm.bias_hh_l{layer}_reverse")], 0))
-
-            def put_proj(wm, bv, tag):
-                """-> (f32 W_ih, its split planes or None, bias) on the device"""
-                # layer 0 runs on k_gemm_split.hip (row-major planes), layers 1..3 on k_gemm_pre.hip (kb-major)
-                sp = pk.put_split(_pad2(wm, 1024, kpad), f"lstm.weight_ih_l{layer}{tag}", kb=layer > 0) if split else None
-                return pk.put(_pad2(wm, 1024, kpad)), sp, pk.put(bv)
-
-            w.wih[layer], sp, w.bih[layer] = put_proj(wih, bias, "")
-            if split:
-                w.wih_split[layer] = sp
-            if split and lstm_variant == 4:     # the engine's own recurrence is variant 4: its x-projection carries the gate scales
-                w.wih[layer], w.wih_split[layer], w.bih[layer] = put_proj(lstm_scale_gx(wih), lstm_scale_gx(bias), " (scaled)")
-            elif split and lstm_variant < 0 and THROUGHPUT_LSTM_VARIANT == 4:
-                proj_tp.append(put_proj(lstm_scale_gx(wih), lstm_scale_gx(bias), " (scaled)"))
             whh = torch.stack([g(f"lstm.weight_hh_l{layer}"), g(f"lstm.weight_hh_l{layer}_reverse")], 0)
             assert whh.shape == (2, 512, 128)
+            self._lstm.append((wih, bias, whh))
+            w.wih[layer], sp, w.bih[layer] = self._put_proj(pk, layer, wih, bias, "")
+            if split:
+                w.wih_split[layer] = sp
             w.whh[layer] = pk.put(whh)
-            if split and lstm_variant >= 0:   # [dir][plane][512][128] f16 for the matrix-core recurrence
-                d = lstm_whh_planes(whh, lstm_variant).to(pk.device)
-                pk.tensors.append(d)
-                w.whh_split[layer] = d.data_ptr()
-                w.lstm_variant = lstm_variant
-            if split:                         # ... and always for the throughput engines (struct_throughput below)
-                tv = lstm_variant if lstm_variant >= 0 else THROUGHPUT_LSTM_VARIANT
-                d = lstm_whh_planes(whh, tv).to(pk.device)
-                pk.tensors.append(d)
-                whh_tp.append(d.data_ptr())
         w.lin0_w, w.lin0_b = pk.put(g("linear.0.weight")), pk.put(g("linear.0.bias"))
         w.lin1_w, w.lin1_b = pk.put(g("linear.1.weight")), pk.put(g("linear.1.bias"))
         if split:
@@ -382,20 +368,48 @@ class PackedSegmentation:
             w.num_speakers = s
         else:
             w.num_speakers = ncls
-        self.struct, self.pack = w, pk
+        self.pack = pk
         self.num_speakers = int(w.num_speakers)
-        # The same weights for a THROUGHPUT engine (StreamBatch with many streams per launch and several steps in
-        # flight): the recurrence on the matrix cores, 16 chains per workgroup — a seventh of the CU-time at twice the
-        # latency of the one-chain-per-CU kernel the synchronous blocks API keeps.
-        self.struct_throughput = w
-        if split and whh_tp and lstm_variant < 0:
-            tw = _lib.SegWeights.from_buffer_copy(w)
-            for layer in range(4):
-                tw.whh_split[layer] = whh_tp[layer]
-                if proj_tp:
-                    tw.wih[layer], tw.wih_split[layer], tw.bih[layer] = proj_tp[layer]
-            tw.lstm_variant = THROUGHPUT_LSTM_VARIANT
-            self.struct_throughput = tw
+        self._structs = {"valu": w}
+        self.recurrence = "valu" if recurrence is None else str(recurrence)
+        self.struct = self.struct_for(self.recurrence)
+
+    def _put_proj(self, pk, layer, wm, bv, tag):
+        """-> (f32 W_ih, its split planes or None, bias) of one layer on the device"""
+        kpad = 64 if layer == 0 else 256
+        # layer 0 runs on k_gemm_split.hip (row-major planes), layers 1..3 on k_gemm_pre.hip (kb-major)
+        sp = pk.put_split(_pad2(wm, 1024, kpad), f"lstm.weight_ih_l{layer}{tag}", kb=layer > 0) if self._split else None
+        return pk.put(_pad2(wm, 1024, kpad)), sp, pk.put(bv)
+
+    def struct_for(self, recurrence: Optional[str]):
+        """The weight struct whose recurrence runs on ``recurrence`` ("valu" | "0" | "3" | "4"); exact f32 has only
+        "valu" (the matrix-core kernels are split-f16 arithmetic)."""
+        r = "valu" if recurrence is None else str(recurrence)
+        v = lstm_variant_of(r)
+        if not self._split:
+            v, r = -1, "valu"
+        got = self._structs.get(r)
+        if got is None:
+            got = _lib.SegWeights.from_buffer_copy(self._structs["valu"])
+            for layer, (wih, bias, whh) in enumerate(self._lstm):
+                d = lstm_whh_planes(whh, v).to(self.pack.device)        # [dir][plane][512][128] f16
+                self.pack.tensors.append(d)
+                got.whh_split[layer] = d.data_ptr()
+                if v == 4:        # its x-projection carries the gates' activation scales
+                    got.wih[layer], got.wih_split[layer], got.bih[layer] = self._put_proj(
+                        self.pack, layer, lstm_scale_gx(wih), lstm_scale_gx(bias), " (scaled)")
+            got.lstm_variant = v
+            self._structs[r] = got
+        return got
+
+    @property
+    def struct_throughput(self):
+        """A THROUGHPUT engine's weights (StreamBatch with many streams per launch and several steps in flight): the
+        recurrence on the matrix cores, 16 chains per workgroup — a seventh of the CU-time of the one-chain-per-CU
+        kernel at twice its latency — unless the model was built with an explicit recurrence."""
+        if not self._split or self.recurrence != "valu":
+            return self.struct
+        return self.struct_for(str(THROUGHPUT_LSTM_VARIANT))
 
 
 class PackedEmbedding:

@@ -947,7 +947,7 @@ def test_f16x3_dynamic_range_map(gpu, monkeypatch):
     import json
     import warnings
     from pathlib import Path
-    monkeypatch.setenv("DZ_SPLIT_STRICT", "0")       # the map goes below what split_f16 accepts for a real layer
+    monkeypatch.setenv("DZ_ENGINE", "split_strict=0")  # the map goes below what split_f16 accepts for a real layer
     warnings.simplefilter("ignore")
     g = torch.Generator().manual_seed(11)
     M, K, N = 256, 512, 128

@@ -410,16 +410,15 @@ def test_back_half_refuses_a_batch_the_front_half_did_not_prepare(gpu):
 def test_warm_steps_leave_no_trace(gpu, monkeypatch):
     """StreamBatch runs warm steps on silence before the first real one (pipeline.py _warm_up: the output
     tail is built and the first-launch set-up absorbed while no stream is live).  They must leave nothing
-    behind: identical segmentation / embeddings / clustering / speech turns with DZ_WARMUP=0, stream clocks
+    behind: identical segmentation / embeddings / clustering / speech turns with warmup=0, stream clocks
     at zero, lanes starting at 0."""
     n, W, hop, steps = 4, 80000, 8000, 6
     audio = torch.from_numpy(synth_streams(n, (W + hop * steps) / 16000.0, seed0=77)).to(gpu)
     seg_sd, emb_sd = synth_segmentation_state(), synth_embedding_state()
 
     def run(warm):
-        monkeypatch.setenv("DZ_WARMUP", str(warm))
         sb = StreamBatch(M.HipSegmentation(seg_sd, max_batch=n), M.HipEmbedding(emb_sd, max_batch=n), n,
-                         device=gpu, tail=True, latency=1.0)
+                         device=gpu, tail=True, latency=1.0, warmup=warm)
         out = []
         for t in range(steps):
             ticket = sb.launch(audio[:, t * hop:t * hop + W])

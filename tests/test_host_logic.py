@@ -492,13 +492,14 @@ def test_windows_batch_span_detection_matches_torch_stack():
 
 
 def test_throughput_weights_carry_the_matrix_core_recurrence(monkeypatch):
-    """Round 5: a packed segmentation model holds TWO weight structs — `struct` (what the synchronous blocks API runs:
-    the one-chain-per-CU recurrence unless DZ_LSTM says otherwise) and `struct_throughput` (what a StreamBatch of >= 64
-    streams creates its handles from: the same pointers plus W_hh as f16 planes for the matrix-core recurrence, variant
-    3).  Exact f32 has no such form; an explicit DZ_LSTM applies to both."""
+    """A packed segmentation model holds one weight struct per recurrence kernel, built on first use: `struct` (what
+    the synchronous blocks API runs: the one-chain-per-CU recurrence unless `recurrence=` says otherwise) and
+    `struct_throughput` (what a StreamBatch of >= 64 streams creates its handles from: the same pointers plus W_hh as
+    f16 planes for the matrix-core recurrence, variant 4, whose x-projection carries the gates' activation scales).
+    Exact f32 has no such form; an explicit recurrence applies to both."""
     from diart_amd.synth import synth_segmentation_state
     from diart_amd.weights import PackedSegmentation, THROUGHPUT_LSTM_VARIANT
-    monkeypatch.delenv("DZ_LSTM", raising=False)
+    monkeypatch.delenv("DZ_ENGINE", raising=False)
     sd = synth_segmentation_state()
     p = PackedSegmentation(sd, torch.device("cpu"), precision="f16x3")
     assert not p.struct.whh_split[0] and all(p.struct_throughput.whh_split[i] for i in range(4))
@@ -508,8 +509,9 @@ def test_throughput_weights_carry_the_matrix_core_recurrence(monkeypatch):
         a, b = list(getattr(p.struct, name)), list(getattr(p.struct_throughput, name))
         assert all(a) and all(b) and not set(a) & set(b), name
     assert p.struct.lin0_split == p.struct_throughput.lin0_split and p.struct.sinc.filt_split == p.struct_throughput.sinc.filt_split
+    p3 = p.struct_for("3")                                               # another kernel of the same model, cached
+    assert p3 is p.struct_for("3") and p3.lstm_variant == 3 and list(p3.wih_split) == list(p.struct.wih_split)
     p32 = PackedSegmentation(sd, torch.device("cpu"), precision="f32")
     assert p32.struct_throughput is p32.struct and not p32.struct.whh_split[0]
-    monkeypatch.setenv("DZ_LSTM", "0")
-    p0 = PackedSegmentation(sd, torch.device("cpu"), precision="f16x3")
+    p0 = PackedSegmentation(sd, torch.device("cpu"), precision="f16x3", recurrence="0")
     assert p0.struct_throughput is p0.struct and p0.struct.whh_split[0] and p0.struct.lstm_variant == 0

@@ -59,8 +59,8 @@ ranks2|ranks8)   # the multi-rank path of bench.py as ONE command; on a one-GPU 
   N=${SEC#ranks}
   NG=$(python -c "import torch;print(torch.cuda.device_count())")
   # (rehearsal: N ranks on ONE GPU — each keeps the two-lane engine, N x 6 lanes of the 64-stream default would only queue)
-  if [ "$NG" -ge "$N" ]; then ENVX="X=1"; else ENVX="DZ_FORCE_DEVICE=0 DZ_DIST_BACKEND=gloo DZ_DEPTH=2 DZ_LSTM=valu"; fi
-  env $ENVX timeout -s KILL 600 python bench.py --gpus $N --steps 20 --warmup 5 --no-cpu-baseline --no-exact-f32 --no-host-pass --no-rehearsal --pmc off --details $OUT/bench_${N}_ranks_details.json > $OUT/bench_${N}_ranks.json 2> $OUT/bench_${N}_ranks.err
+  if [ "$NG" -ge "$N" ]; then ENVX="X=1"; EARGS=""; else ENVX="DZ_FORCE_DEVICE=0 DZ_DIST_BACKEND=gloo"; EARGS="--lanes 2 --recurrence valu"; fi
+  env $ENVX timeout -s KILL 600 python bench.py --gpus $N $EARGS --steps 20 --warmup 5 --no-cpu-baseline --no-exact-f32 --no-host-pass --no-rehearsal --pmc off --details $OUT/bench_${N}_ranks_details.json > $OUT/bench_${N}_ranks.json 2> $OUT/bench_${N}_ranks.err
   echo "exit $? lines $(grep -c '^{' $OUT/bench_${N}_ranks.json) chars $(wc -c < $OUT/bench_${N}_ranks.json)"; cut -c1-700 $OUT/bench_${N}_ranks.json
   grep -E "process group up|cpu affinity" $OUT/bench_${N}_ranks.err | cut -c1-200 | head -16 ;;
 yardstick)
@@ -74,14 +74,15 @@ files)       # config 4 shape on one GPU (16 files, AMI hyper-parameters), and t
 ktest)       # quick: the kernel tests of the files named in KTEST (default: conv0 tests), then the conv0 lines of kbench
   timeout -s KILL 600 python -m pytest ${KTEST:-tests/test_gpu_kernels.py -k conv0} -q -m gpu -p no:cacheprovider -x 2>&1 | grep -v amdgpu.ids | tail -15
   timeout -s KILL 300 python tools/kbench.py --only ${KONLY:-sinc_conv0_split,sinc_conv0_pair} 2>&1 | grep -v amdgpu.ids | grep " us " | cut -c1-100 ;;
-ab)          # same-visit A/B of bench.py (200 steps, headline pass only) over environment settings: AB_A / AB_B, e.g.
-             # AB_A="DZ_EXPERIMENTS=1 DZ_CONV0_PAIR=0" AB_B="DZ_EXPERIMENTS=1"; alternating, ${AB_N:-2} rounds
+ab)          # same-visit A/B of bench.py (200 steps, headline pass only) over environment settings AB_A / AB_B and / or
+             # bench arguments AB_ARGS_A / AB_ARGS_B, e.g. AB_ARGS_A="--recurrence 3 --lanes 6" AB_ARGS_B="--lanes 4";
+             # alternating, ${AB_N:-2} rounds
   for i in $(seq 1 ${AB_N:-2}); do
     for arm in A B; do
-      if [ $arm = A ]; then E="$AB_A"; else E="$AB_B"; fi
-      env $E timeout -s KILL 300 python bench.py --steps ${AB_STEPS:-200} --warmup 10 --pmc off --no-cpu-baseline --no-rehearsal --no-exact-f32 --no-host-pass \
+      if [ $arm = A ]; then E="${AB_A:-X=1}"; XA="$AB_ARGS_A"; else E="${AB_B:-X=1}"; XA="$AB_ARGS_B"; fi
+      env $E timeout -s KILL 300 python bench.py --steps ${AB_STEPS:-200} --warmup 10 --pmc off --no-cpu-baseline --no-rehearsal --no-exact-f32 --no-host-pass $XA \
         --details $OUT/ab_${arm}_${i}_details.json > $OUT/ab_${arm}_$i.json 2> $OUT/ab_${arm}_$i.err
-      echo "$arm$i [$E] $(python -c "import json,sys; d=json.load(open('$OUT/ab_${arm}_$i.json')); print(d['value'], d['ms_per_step'])" 2>&1 | tail -1)"
+      echo "$arm$i [$E $XA] $(python -c "import json,sys; d=json.load(open('$OUT/ab_${arm}_$i.json')); print(d['value'], d['ms_per_step'])" 2>&1 | tail -1)"
     done
   done ;;
 verify_dry)  # tools/verify_real.py end to end on a stand-in corpus (synthetic checkpoints + WAVs): twice, the second run

@@ -94,7 +94,7 @@ def main():
         if not args.skip_gates:
             gates = {}
             for precision in ("f16x3", "f32"):
-                env = dict(os.environ, DZ_CKPT_DIR=str(ckpt), DZ_PRECISION=precision)
+                env = dict(os.environ, DZ_CKPT_DIR=str(ckpt), DZ_ENGINE=f"precision={precision}")
                 r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-m", "gpu", "-p", "no:cacheprovider",
                                     str(ROOT / "tests" / "test_gpu_parity_r2.py"), "-k", "real_checkpoints"],
                                    env=env, capture_output=True, text=True, cwd=str(ROOT))
