@@ -143,7 +143,7 @@ def device_kernel(tag, precision):
                 "seg_classifier": "seg_head_kernel"}[tag], "hbm", PEAK_HBM_GBPS, "GB/s"
     if k["bound"] == "rec":
         if split and lstm != "valu":
-            sym = {"0": "lstm_mfma_kernel<true>", "3": "lstm_mfma_dma_kernel", "4": "lstm_mfma_pipe_kernel"}.get(
+            sym = {"0": "lstm_mfma_kernel<true>", "3": "lstm_mfma_dma_kernel", "4": "lstm_mfma_pipe_kernel<false, 0>"}.get(
                 lstm, "lstm_mfma1_kernel<true, %d>" % (0 if lstm == "1" else 8))
             return sym, "mfma", PEAK_F16_MATRIX_TFLOPS / SPLIT_PRODUCTS, "TFLOP/s"
         pk = "false" if xenv("DZ_LSTM_PK", "1") == "0" else "true"      # packed-FMA template argument
@@ -235,6 +235,11 @@ def parse():
     ap.add_argument("--details", type=str, default=os.environ.get("DZ_BENCH_DETAILS", "gpurun_out/bench_details.json"),
                     help="side file for the full record (per-kernel tables, exact-f32 tables, rehearsal, notes); "
                          "stdout carries ONE compact JSON line (diart_amd/benchline.py)")
+    ap.add_argument("--serial-steps", type=int, default=8,
+                    help="steps of the serialised roofline pass (one lane, one HIP stream, every launch bracketed: a kernel's "
+                         "duration there is its alone-time, what rocprofv3 --kernel-trace --stats of the same pass reports); 0 = off")
+    ap.add_argument("--serial-only", action="store_true",
+                    help="run ONLY the serialised roofline pass (the command profiles/*_rocprofv3_kernel_stats_serial_*.csv are traces of)")
     ap.add_argument("--no-exact-f32", action="store_true",
                     help="skip the second, untimed-for-`value` pass on the exact-f32 MFMA path")
     return ap.parse_args()
@@ -549,15 +554,15 @@ def build_roofline(table, precision, n_sampled, pmc):
         return e
 
     per_kernel = [entry(g, v) for g, v in sorted(groups.items(), key=lambda kv: -kv[1]["ms"])]
-    # The dominant kernel = the device kernel with the largest share of the chip's CU-TIME, whatever bounds it: its total
-    # time x the fraction of the 256 CUs its launches occupy (`cus_occupied`: the recurrence kernels hold 8 - 128 CUs for
-    # their whole duration; every other kernel is launched to fill the chip).  By plain time the matrix-core recurrence
-    # (four launches of ~0.5 ms on EIGHT CUs, under the other steps' kernels) would lead with 3 % of the machine.
+    # share of the chip's CU-time (total time x the fraction of the 256 CUs the launches occupy): reported next to
+    # the share of kernel time, never used to choose
     cu_time = {e["kernel"]: groups[e["kernel"]]["ms"] * min(1.0, e.get("cus_occupied", 256.0) / 256.0) for e in per_kernel}
     tot_cu = sum(cu_time.values()) or 1.0
     for e in per_kernel:
         e["share_of_cu_time"] = round(cu_time[e["kernel"]] / tot_cu, 4)
-    roof = dict(max(per_kernel, key=lambda e: cu_time[e["kernel"]]))
+    # The dominant kernel = the device kernel with the largest TOTAL duration, exactly the first row of
+    # `rocprofv3 --kernel-trace --stats` of the same pass (the recurrence: four launches per step on eight CUs).
+    roof = dict(per_kernel[0])
     roof["peak_note"] = {
         "mfma": ("f16 matrix peak 2500 TFLOP/s / 3: the split-f16 path spends three f16 MFMAs per algorithmic "
                  "product; `achieved` counts algorithmic FLOPs only" if roof["peak"] > 200 else "exact-f32 matrix peak"),
@@ -599,7 +604,7 @@ def step_level(per_kernel, ms_per_step, precision, source):
            "kernels_without_pmc_row_counted_at_algorithmic_bytes": missing,
            "peak_gbps": PEAK_HBM_GBPS, "frac_of_peak": round(byts / step_us / 1e3 / PEAK_HBM_GBPS, 4) if byts else None,
            "alg_bytes_per_step": int(alg), "source": source}
-    mk = next((dict(k) for k in per_kernel if k["bound"] == "mfma"), None)
+    mk = next((dict(k) for k in per_kernel if k["bound"] == "mfma" and not k["kernel"].startswith("lstm_")), None)
     return mfma, hbm, mk
 
 
@@ -946,7 +951,14 @@ def main():
     from diart_amd.hostinfo import usable_cores
     usable = usable_cores()
     host_threads = max(1, min(8, usable))
-    def make_pipe(prec):
+    def make_pipe(prec, serial_recurrence=False):
+        """The engine of this run, or (serial_recurrence is not False) the MEASUREMENT engine of the roofline pass:
+        one lane, one HIP stream, one step in flight, the recurrence kernel named."""
+        if serial_recurrence is not False:
+            return StreamBatch(HipSegmentation(seg_state, max_batch=n, precision=prec),
+                               HipEmbedding(emb_state, max_batch=n, precision=prec),
+                               n, device=device, cluster_threads=host_threads, tail=not args.no_tail,
+                               recurrence=serial_recurrence, lanes=1, inflight=1, serial=True, warmup=0)
         p_ = StreamBatch(HipSegmentation(seg_state, max_batch=n, precision=prec),
                          HipEmbedding(emb_state, max_batch=n, precision=prec),
                          n, device=device, cluster_threads=host_threads,
@@ -956,7 +968,12 @@ def main():
             RECURRENCE[prec] = p_.recurrence
         return p_
 
-    pipe = make_pipe(precision)
+    if args.serial_only:
+        from diart_amd.weights import THROUGHPUT_LSTM_VARIANT
+        RECURRENCE[precision] = args.recurrence or (str(THROUGHPUT_LSTM_VARIANT) if n >= 64 and precision == "f16x3" else "valu")
+        pipe = make_pipe(precision, RECURRENCE[precision] if precision == "f16x3" else None)
+    else:
+        pipe = make_pipe(precision)
 
     def window(t):
         return audio[:, t * hop: t * hop + S]
@@ -1091,7 +1108,49 @@ def main():
                              gaps_ms=host["step_gaps_ms"], profiled_every=PROF_EVERY if prof else None)
         return el, tab, sampled[0]
 
+    def serial_pass(prec, engine=None):
+        """The roofline pass: `--serial-steps` steps on the MEASUREMENT engine (one lane, ONE HIP stream, one step in
+        flight: no two kernels overlap), every launch bracketed with its dispatch's own start / stop timestamps ->
+        (kernel table, sampled steps, ms per serialised step).  A kernel's duration here is its alone-time at this
+        job's shapes: what `rocprofv3 --kernel-trace --stats` of `bench.py --serial-only` reports per kernel
+        (profiles/*_rocprofv3_kernel_stats_serial_*.csv; tests/test_roofline_repro.py holds the line to it)."""
+        sp = engine or make_pipe(prec, RECURRENCE.get(prec) if prec == "f16x3" else None)
+        run(0, min(total_steps, 4), sp)
+        torch.cuda.synchronize()
+        lib.dz_prof_enable(1)
+        sampled[0] = 0
+        k = max(1, min(args.serial_steps, total_steps))
+        t0 = time.perf_counter()
+        run(0, k, sp, profiled=True, every=1)
+        torch.cuda.synchronize()
+        ms = 1e3 * (time.perf_counter() - t0) / k
+        lib.dz_prof_collect()
+        tab = kernel_table(lib, prec)
+        lib.dz_prof_enable(0)
+        log(f"serialised roofline pass ({prec}): {k} steps, {ms:.3f} ms per step, {len(tab)} kernel tags")
+        return tab, k, ms
+
+    if args.serial_only:
+        tab, k, ms = serial_pass(precision, pipe)
+        roof, per_kernel = build_roofline(tab, precision, k, None)
+        cps = n * 1e3 / ms
+        out = {"metric": "real-time-factor xRT streams/GPU @500ms step", "value": round(cps / 2, 2),
+               "unit": "xRT 16 kHz streams (chunks/s / 2)", "n_gpus": 1, "steps": k, "warmup": 4, "ms_per_step": round(ms, 3),
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32" if precision == "f32" else "f16x3",
+               "data": "synthetic",
+               "config": {"workload": "configs[1] on the MEASUREMENT engine: one lane, one HIP stream, one step in flight (the "
+                                      "serialised roofline pass of bench.py alone; NOT the metric)", "streams_per_gpu": n,
+                          "chunks_per_step": n, "lanes": 1, "steps_in_flight": 1, "recurrence": RECURRENCE.get(precision, "valu")},
+               "roofline": dict(roof, serialised=True, serialised_ms_per_step=round(ms, 3)),
+               "roofline_kernels": per_kernel, "cpu_baseline": None}
+        if args.kernel_table:
+            Path(args.kernel_table).parent.mkdir(parents=True, exist_ok=True)
+            Path(args.kernel_table).write_text(json.dumps(tab, indent=1))
+        emit(out, args.details)
+        return
+
     elapsed, table, n_sampled = timed_pass(pipe, f"timed region ({precision})")
+    serial = serial_pass(precision) if args.serial_steps > 0 else None
     host_line = {"cpu_ms_per_step": round(host["cpu_ms_per_step"], 3), "launch_ms_per_step": round(host["launch_ms_per_step"], 3),
                  "step_period_ms_in_timed_region": host["step_period_ms"],
                  "clustering_tail_wall_ms_per_step": round(host["work_ms_per_step"], 3), "threads": host_threads,
@@ -1112,7 +1171,8 @@ def main():
                  "note": "same job with precision='f32' (v_mfma_f32_16x16x4_f32 everywhere): the reference's own "
                          "arithmetic; per-kernel brackets and roofline collected exactly like the headline pass",
                  "host_step_period_ms": period.get("exact-f32 pass"),
-                 "_table": table32, "_sampled": n_sampled32}
+                 "_table": table32, "_sampled": n_sampled32,
+                 "_serial": serial_pass("f32") if args.serial_steps > 0 else None}
 
     # ---- the same job fed from HOST buffers: every step uploads the 500 ms of new audio of each
     # stream (pinned memory -> device ring, dz_ring_push) instead of finding it in HBM ------------
@@ -1160,16 +1220,34 @@ def main():
         cps = D.whole_job_rate(n, args.steps, elapsed, world)
         pmc = pmc_live(precision, args) if (world == 1 and args.pmc != "off") else None
         pmc32 = pmc_live("f32", args) if (pmc is not None and exact is not None and args.pmc == "all") else None
-        roof, per_kernel = build_roofline(table, precision, n_sampled, pmc)
+        # per-kernel roofline from the SERIALISED pass (alone-times, reproducible from rocprofv3's kernel stats of
+        # `--serial-only`); the brackets of the timed region — taken while `lanes` steps share the chip — go to the details
+        # file as `roofline_kernels_overlapped` and are never quoted as kernel efficiency
+        _, per_kernel_ovl = build_roofline(table, precision, n_sampled, pmc)
+        if serial is not None:
+            roof, per_kernel = build_roofline(serial[0], precision, serial[1], pmc)
+            roof["serialised"], roof["serialised_ms_per_step"] = True, round(serial[2], 3)
+        else:
+            roof, per_kernel = build_roofline(table, precision, n_sampled, pmc)
+            roof["serialised"] = False
+        peak_path = PEAK_F32_MATRIX_TFLOPS if precision == "f32" else PEAK_F16_MATRIX_TFLOPS / SPLIT_PRODUCTS
         roof["whole_path_tflops"] = round(cps / world * ALG_GFLOP_PER_CHUNK / 1e3, 2)
-        roof["concurrency_note"] = ("per-kernel durations are measured while the kernels of %d HIP streams overlap on the "
-                                    "chip: their sum per step exceeds ms_per_step" % pipe.num_hip_streams)
+        whole_path_frac = round(roof["whole_path_tflops"] / peak_path, 4)
         roof["exact_f32_value"] = exact["value"] if exact else None
         roof["host_fed_value"] = host_fed["value"] if host_fed else None
+        whole_path_frac_f32 = None
         if exact is not None:
-            r32, pk32 = build_roofline(exact.pop("_table"), "f32", exact.pop("_sampled"), pmc32)
+            ser32 = exact.pop("_serial")
+            t32, s32 = exact.pop("_table"), exact.pop("_sampled")
+            _, exact["roofline_kernels_overlapped"] = build_roofline(t32, "f32", s32, pmc32)
+            r32, pk32 = build_roofline(ser32[0], "f32", ser32[1], pmc32) if ser32 else build_roofline(t32, "f32", s32, pmc32)
+            r32["serialised"] = ser32 is not None
+            if ser32:
+                r32["serialised_ms_per_step"] = round(ser32[2], 3)
             r32["whole_path_tflops"] = round(2 * exact["value"] / world * ALG_GFLOP_PER_CHUNK / 1e3, 2)
+            whole_path_frac_f32 = round(r32["whole_path_tflops"] / PEAK_F32_MATRIX_TFLOPS, 4)
             exact["roofline"], exact["roofline_kernels"] = r32, pk32
+        # step-level utilisation: launches per step and PMC per-launch figures x the timed region's step time
         mfma_step, hbm_step, roof_mfma = step_level(per_kernel, 1e3 * elapsed / args.steps, precision, roof.get("traffic_source"))
         if exact is not None:
             exact["mfma_util_step"], exact["hbm_gbps_step"], exact["roofline_mfma"] = step_level(
@@ -1199,13 +1277,18 @@ def main():
                                       else 0), "cpu_affinity": affinity,
                        "weights_abs_sum_per_rank": wsums, "host_threads_per_rank": host_threads,
                        "steps_in_flight": pipe.max_inflight, "lanes": pipe.depth, "recurrence": pipe.recurrence or "valu", "seg_sub_batches": pipe.seg_split,
+                       "settle_steps": settle, "engine": "StreamBatch(%s)" % ", ".join(
+                           f"{k}={v}" for k, v in (("recurrence", args.recurrence), ("lanes", args.lanes), ("inflight", args.inflight)) if v) ,
                        "hip_streams": pipe.num_hip_streams,
                        "exact_f32_value": exact["value"] if exact else None,
                        "host_fed_value": host_fed["value"] if host_fed else None},
             "roofline": roof, "roofline_mfma": roof_mfma, "mfma_util_step": mfma_step, "hbm_gbps_step": hbm_step,
-            "roofline_kernels": per_kernel,
-            "roofline_sampling": f"{n_sampled} of the {args.steps} timed steps (every {PROF_EVERY}th) carried the "
-                                 "per-kernel event pairs; instrumenting every launch costs ~15 % of throughput",
+            "whole_path_frac": whole_path_frac, "whole_path_frac_exact_f32": whole_path_frac_f32,
+            "roofline_kernels": per_kernel, "roofline_kernels_overlapped": per_kernel_ovl,
+            "roofline_sampling": (f"`roofline*`: the serialised pass ({serial[1]} steps on one lane / one HIP stream, every launch "
+                                  f"bracketed, {serial[2]:.3f} ms per step); " if serial else "") +
+                                 f"`roofline_kernels_overlapped`: {n_sampled} of the {args.steps} timed steps (every {PROF_EVERY}th) "
+                                 "carried the per-kernel event pairs while the lanes overlap",
             "exact_f32": exact,
             "host_fed": host_fed,
             "host": host_line,

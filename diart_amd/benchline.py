@@ -16,8 +16,9 @@ from pathlib import Path
 
 MAX_LINE = 4000          # characters; the verdict's bound is 4 KB, the driver's capture 16 018
 
-_ROOF_KEYS = ("kernel", "bound", "achieved", "peak", "unit", "frac", "avg_launch_us", "launches_per_step",
-              "alg_gflop_per_launch", "alg_bytes_per_launch", "traffic", "traffic_over_alg_bytes", "share_of_cu_time")
+_ROOF_KEYS = ("kernel", "bound", "achieved", "peak", "unit", "frac", "frac_of_occupied_cus", "cus_occupied", "avg_launch_us",
+              "launches_per_step", "alg_gflop_per_launch", "alg_bytes_per_launch", "traffic", "traffic_over_alg_bytes",
+              "share_of_kernel_time")
 # dropped in this order when the line is too long (it never is with the fields below; belt and braces)
 _OPTIONAL = ("roofline_exact_f32", "host_rehearsal", "host", "roofline_mfma", "step_period_ms")
 
@@ -57,6 +58,7 @@ def compact(full, details_file=None):
         "weights_abs_sum_per_rank": _minmax(cfg.get("weights_abs_sum_per_rank")),
         "host_threads_per_rank": cfg.get("host_threads_per_rank"),
         "steps_in_flight": cfg.get("steps_in_flight"), "lanes": cfg.get("lanes"), "recurrence": cfg.get("recurrence"),
+        "settle_steps": cfg.get("settle_steps"), "engine": cfg.get("engine"),
         "cpu_affinity": cfg.get("cpu_affinity"),
     }
     for k in ("latency_ms", "chunk_ms", "file_seconds", "wall_s"):           # configs 1 / 5
@@ -67,11 +69,17 @@ def compact(full, details_file=None):
     out["value_host_fed"] = host_fed.get("value")
     r = _roof(roof)
     if r is not None:
-        r["share_of_kernel_time"] = roof.get("share_of_kernel_time")
         r["whole_path_tflops"] = roof.get("whole_path_tflops")
-        if cfg.get("lanes"):      # (how to read avg_launch_us: `lanes` steps run concurrently, a launch shares the chip with theirs)
+        # serialised: durations from the one-lane / one-stream pass (alone-times, = rocprofv3 --kernel-trace --stats of
+        # `bench.py --serial-only`); False: brackets taken while `steps_overlapping` steps shared the chip
+        r["serialised"] = bool(roof.get("serialised"))
+        if roof.get("serialised"):
+            r["serialised_ms_per_step"] = roof.get("serialised_ms_per_step")
+        elif cfg.get("lanes"):
             r["steps_overlapping"] = cfg.get("lanes")
     out["roofline"] = r
+    out["whole_path_frac"] = full.get("whole_path_frac")
+    out["whole_path_frac_exact_f32"] = full.get("whole_path_frac_exact_f32")
     out["roofline_mfma"] = _roof(full.get("roofline_mfma"), roof.get("traffic_source"))
     out["roofline_exact_f32"] = _roof(exact.get("roofline"))
     out["mfma_busy_frac_step"] = mfma.get("busy_frac_pmc")

@@ -166,7 +166,7 @@ class StreamBatch:
                  tail: bool = False, duration: float = 5.0, step: float = 0.5,
                  latency: Optional[float] = None, depth: Optional[int] = None, *, lanes: Optional[int] = None,
                  recurrence: Optional[str] = None, inflight: Optional[int] = None, wait: Optional[str] = None,
-                 warmup: Optional[int] = None):
+                 warmup: Optional[int] = None, serial: bool = False):
         """Engine parameters (``DZ_ENGINE`` overrides them, config.py):
         ``lanes`` (= ``depth``): steps the GPU works on at once, each with its own HIP streams, handles and scratch
         arenas (~0.85 GB per lane at 64 streams) — default 2, or ``THROUGHPUT_LANES`` for a throughput engine;
@@ -175,7 +175,10 @@ class StreamBatch:
         else the model's own;
         ``inflight``: steps a throughput caller keeps between ``launch`` and ``finish`` (default lanes + 1);
         ``wait``: how the host waits for a step, "spin" | "block" | "auto" (by the cores this rank has);
-        ``warmup``: warm steps on silence before the first real step of a window size (default 10, 0 = off)."""
+        ``warmup``: warm steps on silence before the first real step of a window size (default 10, 0 = off);
+        ``serial``: MEASUREMENT engine — one lane whose segmentation and embedding chains share ONE HIP stream, so
+        that no two kernels ever overlap and a kernel's bracketed duration is its alone-time (what
+        ``rocprofv3 --kernel-trace --stats`` of the same run reports): ``bench.py``'s roofline pass."""
         from .config import setting
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else device
         self.seg, self.emb = segmentation.to(self.device), embedding.to(self.device)
@@ -274,6 +277,11 @@ class StreamBatch:
         self.lanes = [dict(a=mk(pa, self.seg_split), b=shared_b or mk(pb, self.emb_split),
                            f=mk(pf, self.seg_split) if self.seg_front else None)
                       for _ in range(self.depth)]
+        self.serial = bool(serial)
+        if self.serial:
+            if self.depth != 1 or self.seg_split != 1 or self.emb_split != 1 or self.seg_front:
+                raise ValueError("StreamBatch(serial=True) is one lane with one stream: lanes=1, no sub-batches")
+            self.lanes[0]["b"] = self.lanes[0]["a"]
         self.streams_a, self.streams_b = self.lanes[0]["a"], self.lanes[0]["b"]
         self.stream_a, self.stream_b = self.streams_a[0], self.streams_b[0]
         self.num_hip_streams = self.depth * self.seg_split + self.emb_split * (1 if self.shared_emb else self.depth)

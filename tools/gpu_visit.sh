@@ -3,7 +3,7 @@
 #   tools/gpu_visit.sh <tag> <section> [<section> ...]
 # Outputs go to gpurun_out/<tag>/ (merged back by gpurun); `tools/gpu_visit.sh <tag> collect` afterwards, run
 # LOCALLY, copies the judged summaries into profiles/<tag>_*.
-# sections: tests smoke driver driver2 long rocprof config3 config5 config1 ranks8 ranks2 yardstick kbench files exp_tests
+# sections: tests smoke driver driver2 long rocprof rocprof_serial config3 config5 config1 ranks8 ranks2 yardstick kbench files exp_tests
 TAG=${1:?tag}; shift
 OUT=gpurun_out/$TAG
 mkdir -p $OUT profiles
@@ -44,6 +44,21 @@ rocprof)     # rocprofv3 --kernel-trace --stats of the bench command, both preci
   for P in f16x3 f32; do
     python tools/prof_summary.py $OUT/prof_$P $OUT/kernel_stats_$P.md "rocprofv3 --kernel-trace --stats, bench.py --steps 10 --precision $P ($TAG)" > /dev/null
     cp $(find $OUT/prof_$P -name '*kernel_stats.csv' | head -1) $OUT/rocprofv3_kernel_stats_$P.csv
+  done
+  find $OUT -name '*kernel_trace*' -size +3M -delete ;;
+rocprof_serial)   # rocprofv3 --kernel-trace --stats of the SERIALISED roofline pass alone (one lane, one HIP stream): the per-kernel
+             # durations bench.py's `roofline` is computed from (tests/test_roofline_repro.py holds the line to this csv)
+  cd /tmp
+  for P in f16x3 f32; do
+    timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d $REPO/$OUT/prof_serial_$P -o prof -- \
+      python $REPO/bench.py --serial-only --serial-steps 10 --precision $P --pmc off --details $REPO/$OUT/bench_serial_${P}_details.json \
+      > $REPO/$OUT/bench_serial_$P.json 2> $REPO/$OUT/prof_serial_$P.log
+    echo "rocprof serial $P exit $?"
+  done
+  cd $REPO
+  for P in f16x3 f32; do
+    python tools/prof_summary.py $OUT/prof_serial_$P $OUT/kernel_stats_serial_$P.md "rocprofv3 --kernel-trace --stats, bench.py --serial-only --serial-steps 10 --precision $P ($TAG)" > /dev/null
+    cp $(find $OUT/prof_serial_$P -name '*kernel_stats.csv' | head -1) $OUT/rocprofv3_kernel_stats_serial_$P.csv
   done
   find $OUT -name '*kernel_trace*' -size +3M -delete ;;
 config3)
@@ -95,6 +110,8 @@ verify_dry)  # tools/verify_real.py end to end on a stand-in corpus (synthetic c
 collect)     # LOCAL: judged copies
   for f in bench_driver.json bench_driver_details.json bench_200.json kernels_events_bench_run.json kernel_stats_f16x3.md kernel_stats_f32.md \
            rocprofv3_kernel_stats_f16x3.csv rocprofv3_kernel_stats_f32.csv kernels_events_rocprof_run_f16x3.json kernels_events_rocprof_run_f32.json \
+           rocprofv3_kernel_stats_serial_f16x3.csv rocprofv3_kernel_stats_serial_f32.csv kernel_stats_serial_f16x3.md kernel_stats_serial_f32.md \
+           bench_serial_f16x3.json bench_serial_f32.json \
            bench_config3.json bench_config5.json bench_config1.json bench_8_ranks.json bench_2_ranks.json gemm_yardstick.json kbench_isolated.json \
            long_horizon.txt file_benchmark_config4.json pytest_gpu_experiments.txt bench_driver_short_1.json bench_driver_short_2.json verify_real_dry_run.json; do
     [ -f $OUT/$f ] && cp $OUT/$f profiles/${TAG}_$f
