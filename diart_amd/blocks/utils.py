@@ -60,6 +60,8 @@ def _common_span(datas):
     hop_b = addrs[1] - addrs[0]
     if hop_b < 0 or hop_b % 16 or any(b - a != hop_b for a, b in zip(addrs, addrs[1:])):
         return None
+    if hop_b >= 4 * n:          # windows that do not overlap (far apart in one large or mmap'd buffer): the span would
+        return None             # move MORE than the stacked batch does
     lo, hi = root.__array_interface__["data"][0], root.__array_interface__["data"][0] + root.nbytes
     if not root.flags["C_CONTIGUOUS"] or addrs[0] < lo or addrs[-1] + 4 * n > hi:
         return None

@@ -62,6 +62,8 @@ extern "C" int dz_ctx_create(int hip_device, dz_ctx** out) {
     c->oflag_host = c->oflag_dev = nullptr;
     c->conv0_frag = c->convp_frag = nullptr;
     c->conv0_src = c->convp_src = nullptr;
+    c->conv0_user = c->convp_user = nullptr;
+    c->conv0_used = c->convp_used = false;
     c->convp_cin = c->convp_kpad = 0;
     DZ_HIP(hipSetDevice(hip_device));
     DZ_HIP(hipHostMalloc((void**)&c->oflag_host, sizeof(int), hipHostMallocMapped));
@@ -249,13 +251,13 @@ static int option_index(const char* name) {
 }
 extern "C" int dz_set_option(const char* name, int value) {
     const int i = option_index(name);
-    DZ_REQUIRE(i >= 0, "dz_set_option: unknown option '%s' (f32_gemm, pool_fuse)", name ? name : "(null)");
+    DZ_REQUIRE(i >= 0, "dz_set_option: unknown option '%s' (f32_gemm, pool_fuse, pack_cache)", name ? name : "(null)");
     __atomic_store_n(&g_options[i], value, __ATOMIC_RELAXED);
     return 0;
 }
 extern "C" int dz_get_option(const char* name, int* value) {
     const int i = option_index(name);
-    DZ_REQUIRE(i >= 0 && value, "dz_get_option: unknown option '%s' (f32_gemm, pool_fuse)", name ? name : "(null)");
+    DZ_REQUIRE(i >= 0 && value, "dz_get_option: unknown option '%s' (f32_gemm, pool_fuse, pack_cache)", name ? name : "(null)");
     *value = dz_option(i);
     return 0;
 }
@@ -473,6 +475,7 @@ extern "C" int dz_seg_create(dz_ctx* ctx, const dz_seg_weights* w, int max_batch
     hipError_t e = hipMalloc((void**)&s->arena, measure.used);
     if (e != hipSuccess) {
         dz_set_error("dz_seg_create: hipMalloc(%zu) failed: %s", measure.used, hipGetErrorString(e));
+        (void)hipEventDestroy(s->ev_gx0_free);
         delete s;
         return 1;
     }
@@ -480,7 +483,12 @@ extern "C" int dz_seg_create(dz_ctx* ctx, const dz_seg_weights* w, int max_batch
     Arena real;
     real.base = s->arena; real.size = measure.used;
     seg_carve(s, real);
-    if (int rc = sinc_repack(w->sinc, s->ss)) { (void)hipFree(s->arena); delete s; return rc; }
+    if (int rc = sinc_repack(w->sinc, s->ss)) {
+        (void)hipFree(s->arena);
+        (void)hipEventDestroy(s->ev_gx0_free);       // (the event leaked on this path)
+        delete s;
+        return rc;
+    }
     *out = s;
     return 0;
 }
@@ -1078,7 +1086,10 @@ extern "C" int dz_k_conv_pool(dz_ctx* ctx, const dz_convgemm_desc* d, void* stre
     DzRangeScope range_scope(ctx->oflag_dev);
     // kernel-level entry: the weights go into fragment order on every call (the handles do it once, at create)
     DZ_REQUIRE(d->Wsplit && (d->Cin == 80 || d->Cin == 64), "dz_k_conv_pool: Wsplit is NULL or Cin is not 80 / 64");
+    std::lock_guard<std::mutex> frag_lock(ctx->frag_mu);
     if (!ctx->convp_frag) DZ_HIP(hipMalloc(&ctx->convp_frag, (size_t)dz_conv_pool_wfrag_bytes(80)));
+    if (ctx->convp_used && ctx->convp_user != (hipStream_t)stream) DZ_HIP(hipStreamSynchronize(ctx->convp_user));
+    ctx->convp_user = (hipStream_t)stream; ctx->convp_used = true;
     int rc;
     if (!(dz_option(DZ_OPT_PACK_CACHE) && ctx->convp_src == d->Wsplit && ctx->convp_cin == d->Cin && ctx->convp_kpad == d->Kpad)) {
         if ((rc = dz_launch_conv_pool_wfrag(d->Cin, d->Wsplit, d->Kpad, ctx->convp_frag, (hipStream_t)stream))) return rc;
@@ -1135,7 +1146,10 @@ extern "C" int dz_k_sinc_conv0_split(dz_ctx* ctx, const float* d_wave, long long
     // kernel-level entry: the bank goes into fragment order on every call (the handles do it once, at create)
     // (option "pack_cache", off by default: skip the repack when the bank pointer is the one of the previous call —
     // for the timing tools, whose weights do not change; a framework's allocator may hand the same address out again)
+    std::lock_guard<std::mutex> frag_lock(ctx->frag_mu);
     if (!ctx->conv0_frag) DZ_HIP(hipMalloc(&ctx->conv0_frag, (size_t)dz_sinc_bank_frag_bytes()));
+    if (ctx->conv0_used && ctx->conv0_user != (hipStream_t)stream) DZ_HIP(hipStreamSynchronize(ctx->conv0_user));
+    ctx->conv0_user = (hipStream_t)stream; ctx->conv0_used = true;
     if (!(dz_option(DZ_OPT_PACK_CACHE) && ctx->conv0_src == d_filt_split)) {
         if ((rc = dz_launch_sinc_bank_frag(d_filt_split, ctx->conv0_frag, (hipStream_t)stream))) return rc;
         ctx->conv0_src = d_filt_split;

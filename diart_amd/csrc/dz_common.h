@@ -476,4 +476,9 @@ struct dz_ctx {
     const void* conv0_src;                 // option "pack_cache": what the two scratch buffers were packed from
     const void* convp_src;
     int convp_cin, convp_kpad;
+    // the two scratch buffers are shared by every caller of the context: one lock around "repack + launch", and a
+    // repack first waits for the stream whose kernel may still be reading the scratch
+    std::mutex frag_mu;
+    hipStream_t conv0_user, convp_user;
+    bool conv0_used, convp_used;
 };

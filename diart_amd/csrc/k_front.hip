@@ -964,7 +964,11 @@ int dz_launch_sinc_conv0_split(const float* wave, long long stride, int B, int S
                                int stats_are_moments, float gamma, float beta, const void* fsp,
                                float* y0, int P0, float* partials, int ntile, hipStream_t st, const void* ffrag) {
     const int total = ntile * B;
-    const int grid = total < 512 ? total : 512;    // two resident workgroups per CU
+    // two resident workgroups per CU — and never a tile range that touches three chunks: a workgroup keeps the
+    // (mean, rstd) of its first two chunks only (stat_s), so its range holds at most ntile + 1 tiles (beyond
+    // ~520 chunks of 5 s the 512-workgroup grid gave ranges of ntile + 2 tiles and the third chunk read past stat_s)
+    const int need = (total + ntile) / (ntile + 1);
+    const int grid = total < 512 ? total : (need > 512 ? need : 512);
     static const int cus = [] {
         int dev = 0, n = 256;
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
@@ -1239,7 +1243,8 @@ int dz_launch_sinc_conv0_pair(const float* wave, long long stride, int B, int S,
         if (hipGetDevice(&dev) == hipSuccess) hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
         return n > 0 ? n : 256;
     }();
-    const int grid = total < cus ? total : cus;        // one workgroup (one wave per SIMD) per CU
+    const int need = (total + ntile) / (ntile + 1);    // (a range touches at most two chunks: see dz_launch_sinc_conv0_split)
+    const int grid = total < cus ? total : (need > cus ? need : cus);        // one workgroup (one wave per SIMD) per CU
     DZ_LAUNCH(sinc_conv0_pair_kernel, dim3(grid), dim3(256), 0, st, wave, stride, S, moments,
               reinterpret_cast<const unsigned short*>(fsp), bsum, gamma_seg, gamma_emb, y0_seg, y0_emb, P0, part_seg,
               part_emb, ntile, total, dz_cur_oflag);

@@ -352,6 +352,45 @@ def test_convgemm_pool3(gpu, Cin, Tin, split):
     assert torch.allclose(ps[..., 1], (ref ** 2).sum(2), rtol=1e-5, atol=1e-4)
 
 
+def test_sinc_conv0_split_more_chunks_than_a_workgroup_range_holds(gpu):
+    """a workgroup of sinc_conv0_v2 keeps the statistics of the first TWO chunks of its tile range; the
+    512-workgroup grid gave ranges of ntile + 2 tiles beyond ~520 chunks (reachable through the reference-shaped
+    (batch x speakers) rows call with a large max_batch) and the third chunk was normalised with whatever lay behind
+    the two slots.  700 short chunks (3 tiles each: 2 100 tiles, ranges of 5 on 512 workgroups), every chunk at its
+    own loudness so that a borrowed (mean, rstd) shows."""
+    from diart_amd.synth import synth_segmentation_state, synth_stream
+    from diart_amd.weights import sinc_filters, split_f16, _pad2
+    sd = synth_segmentation_state()
+    p = "sincnet.conv1d.0.filterbank."
+    filt = sinc_filters(sd[p + "low_hz_"], sd[p + "band_hz_"], sd[p + "window_"], sd[p + "n_"])
+    B, S = 700, 2661
+    wave = synth_stream(9, (B * 40 + S) / 16000.0 + 1.0)
+    x = torch.stack([torch.from_numpy(wave[i * 40: i * 40 + S].copy()) for i in range(B)])
+    x = x * (1.0 + (torch.arange(B) % 13).float()[:, None]) + 0.01 * (torch.arange(B) % 7).float()[:, None]
+    gamma, beta = 1.1, 0.03
+    xn = F.instance_norm(x[:, None, :]) * gamma + beta
+    ref = F.max_pool1d(F.conv1d(xn, filt[:, None, :], stride=10).abs(), 3, 3)
+    P0 = ref.shape[2]
+    lib = _lib.load()
+    d = torch.zeros(B, (S + 3) // 4 * 4 + 64)
+    d[:, :S] = x
+    d = d.to(gpu)
+    st = torch.empty(B, 2, device=gpu)
+    _lib.check(lib.dz_k_wave_stats(_ctx(gpu), d.data_ptr(), d.stride(0), B, S, st.data_ptr(), None))
+    fs = split_f16(_pad2(filt, 96, 256)).to(gpu)
+    nt = lib.dz_k_conv0_split_ntile(S)
+    assert nt == 3 and -(-nt * B // 512) >= nt + 2          # the old grid's ranges spanned three chunks
+    y0 = torch.full((B, P0, 80), float("nan"), device=gpu)
+    part = torch.full((B, nt, 80, 2), float("nan"), device=gpu)
+    _lib.check(lib.dz_k_sinc_conv0_split(_ctx(gpu), d.data_ptr(), d.stride(0), B, S, st.data_ptr(), gamma, beta,
+                                         fs.data_ptr(), y0.data_ptr(), part.data_ptr(), None))
+    _sync()
+    got = y0.cpu().permute(0, 2, 1)
+    assert not torch.isnan(got).any()
+    per_chunk = ((got - ref).flatten(1).norm(dim=1) / ref.flatten(1).norm(dim=1))
+    assert per_chunk.max().item() < 2e-5, (int(per_chunk.argmax()), per_chunk.max().item())
+
+
 @pytest.mark.parametrize("mode", [None, "DZ_CONV0_ROT=1", "DZ_CONV0_ROT=2", "DZ_CONV0_ROT=3", "DZ_CONV0_V2=0"],
                          ids=["shipped", "no-complementary-roles", "inverted-roles", "roles-by-wave-index", "three-wave-kernel"])
 def test_sinc_conv0_split_many_tiles_per_workgroup(gpu, monkeypatch, mode):
