@@ -1157,23 +1157,6 @@ def main():
                  "usable_cores": usable,
                  "note": "CPU time of all threads of the rank per step (launching thread + worker pool) in the timed region"}
 
-    # ---- the same job on the exact-f32 MFMA path: the number at the reference's own arithmetic,
-    # measured the same way (own per-kernel brackets, own roofline), not `value` ----------------------
-    exact = None
-    if precision != "f32" and not args.no_exact_f32:
-        p32 = make_pipe("f32")
-        prof_warm(p32)
-        run(0, args.warmup, p32)
-        torch.cuda.synchronize()
-        e32, table32, n_sampled32 = timed_pass(p32, "exact-f32 pass")
-        exact = {"value": round(D.whole_job_rate(n, args.steps, e32, world) / 2, 2),
-                 "ms_per_step": round(1e3 * e32 / args.steps, 3), "dtype": "f32",
-                 "note": "same job with precision='f32' (v_mfma_f32_16x16x4_f32 everywhere): the reference's own "
-                         "arithmetic; per-kernel brackets and roofline collected exactly like the headline pass",
-                 "host_step_period_ms": period.get("exact-f32 pass"),
-                 "_table": table32, "_sampled": n_sampled32,
-                 "_serial": serial_pass("f32") if args.serial_steps > 0 else None}
-
     # ---- the same job fed from HOST buffers: every step uploads the 500 ms of new audio of each
     # stream (pinned memory -> device ring, dz_ring_push) instead of finding it in HBM ------------
     host_fed = None
@@ -1185,18 +1168,32 @@ def main():
         for i in range(S // hop - 1):
             ring.push(pinned[i])
 
-        feed = torch.cuda.Stream(device)     # uploads + the launch's input event: off the default stream
+        hmode = int(os.environ.get("DZ_HOSTFED", "7"))        # A/B switches of this pass: 1 = feed stream at high priority,
+        #                                                        2 = the block of step t+1 is pushed right behind launch(t), 4 = settling steps
+        feed = torch.cuda.Stream(device, priority=-1 if hmode & 1 else 0)     # uploads + the launch's input event: off the default stream
 
         hf = {"push": 0.0, "launch": 0.0, "finish": 0.0}
+        nblk = len(pinned)
 
         def run_ring(first, count):
+            """`count` steps: the new 500 ms of every stream go pinned host -> ring (one scatter kernel that reads the
+            pinned block in place), the step is launched on the ring's current window.  With bit 2 the upload of step
+            t+1 is enqueued right behind launch(t) — before the host waits for the oldest step — so that it never sits
+            at the head of a step's dependent chain (a file / batch feeder has the next block; a live source would push
+            on arrival, 500 ms earlier still)."""
             inflight = []
+            pushed_ahead = False
             for t in range(first, first + count):
                 h0 = time.perf_counter()
                 with torch.cuda.stream(feed):
-                    ring.push(pinned[S // hop - 1 + t])
+                    if not pushed_ahead:
+                        ring.push(pinned[(S // hop - 1 + t) % nblk])
                     h1 = time.perf_counter()
                     inflight.append(pipe.launch(ring))
+                    pushed_ahead = False
+                    if hmode & 2 and t + 1 < first + count:
+                        ring.push(pinned[(S // hop - 1 + t + 1) % nblk])
+                        pushed_ahead = True
                 h2 = time.perf_counter()
                 if len(inflight) >= pipe.max_inflight:
                     pipe.finish(inflight.pop(0), want_scores=True)
@@ -1206,15 +1203,53 @@ def main():
             while inflight:
                 pipe.finish(inflight.pop(0), want_scores=True)
 
+        if hmode & 4 and settle > 0:        # the same settling the headline pass gets (its own pattern, untimed)
+            done_ = 0
+            while done_ < settle:
+                k = min(total_steps, settle - done_)
+                run_ring(0, k)
+                done_ += k
+            torch.cuda.synchronize()
+            ring.reset()
+            pipe.reset()
+            for i in range(S // hop - 1):
+                ring.push(pinned[i])
         run_ring(0, args.warmup)
         eh = D.timed_max_over_ranks(lambda: run_ring(args.warmup, args.steps), device)
         host_fed = {"value": round(D.whole_job_rate(n, args.steps, eh, world) / 2, 2), "ms_per_step": round(1e3 * eh / args.steps, 3),
-                    "h2d_bytes_per_step": n * hop * 4,
+                    "h2d_bytes_per_step": n * hop * 4, "mode": hmode, "settle_steps": settle if hmode & 4 else 0,
                     "note": "PCIe-inclusive: per step the 8000 new samples of every stream go pinned host -> "
                             "device ring (dz_ring_push), the window is read in place; not `value`"}
         log(f"host-fed pass: {eh:.3f}s; host time per step: push {1e3 * hf['push'] / (args.steps + args.warmup):.3f} ms, "
             f"launch {1e3 * hf['launch'] / (args.steps + args.warmup):.3f} ms, finish "
             f"{1e3 * hf['finish'] / (args.steps + args.warmup):.3f} ms")
+
+    # ---- the same job on the exact-f32 MFMA path: the number at the reference's own arithmetic,
+    # measured the same way (own per-kernel brackets, own roofline), not `value` ----------------------
+    exact = None
+    if precision != "f32" and not args.no_exact_f32:
+        p32 = make_pipe("f32")
+        prof_warm(p32)
+        # the same settling as the headline pass, a third as many steps (they take twice as long): a timed region that
+        # starts right behind the creation of an engine (arenas allocated, weights packed) reads 7 - 8 % low
+        # (profiles/r06d_pass_order.json: 13 070 behind the serialised pass's engine, 14 100 - 14 250 settled)
+        if settle > 0:
+            done_ = 0
+            while done_ < settle // 3:
+                k = min(total_steps, settle // 3 - done_)
+                run(0, k, p32)
+                done_ += k
+            torch.cuda.synchronize()
+        run(0, args.warmup, p32)
+        torch.cuda.synchronize()
+        e32, table32, n_sampled32 = timed_pass(p32, "exact-f32 pass")
+        exact = {"value": round(D.whole_job_rate(n, args.steps, e32, world) / 2, 2),
+                 "ms_per_step": round(1e3 * e32 / args.steps, 3), "dtype": "f32",
+                 "note": "same job with precision='f32' (v_mfma_f32_16x16x4_f32 everywhere): the reference's own "
+                         "arithmetic; per-kernel brackets and roofline collected exactly like the headline pass",
+                 "host_step_period_ms": period.get("exact-f32 pass"),
+                 "_table": table32, "_sampled": n_sampled32,
+                 "_serial": serial_pass("f32") if args.serial_steps > 0 else None}
 
     if rank == 0:
         cps = D.whole_job_rate(n, args.steps, elapsed, world)
