@@ -63,8 +63,8 @@ __device__ __forceinline__ float leaky(float v) { return v > 0.f ? v : v * DZ_LE
 // then the epilogue parameters, the tile rows' pooling weights and the reduction scratch
 constexpr int YT_PITCH = 132;                                   // floats; = 4 mod 32: conflict-free 16-byte row writes
 constexpr int POOL_PAR = BM * YT_PITCH * 4;                     // bias | e0 | e1
-constexpr int POOL_WT = POOL_PAR + 3 * BN * 4;                  // [4][128] weights of the tile's rows
-constexpr int POOL_RED = POOL_WT + 4 * BM * 4;                  // [2 parts][2 halves][4][128]
+constexpr int POOL_WT = POOL_PAR + 3 * BN * 4;                  // [128 rows][4 speakers] weights of the tile's rows
+constexpr int POOL_RED = POOL_WT + 4 * BM * 4;                  // [4 waves][4 speakers][128] partial sums of one pass
 constexpr int POOL_S0 = POOL_RED + 2 * 2 * 4 * BN * 4;          // [8 (part, k)][8 sub-ranges][2], then [8][2]
 constexpr size_t POOL_LDS = POOL_S0 + 8 * 8 * 2 * 4 + 8 * 2 * 4;
 
@@ -355,7 +355,7 @@ __device__ __forceinline__ void gemm_pre_tile(const DzConvGemm& p, const int t0,
                     v[e] = x;
                 }
                 if (POOL) {
-                    *reinterpret_cast<f32x4*>(yt + (t - t0) * YT_PITCH + nc) = v;
+                    if (!(flags & 16)) *reinterpret_cast<f32x4*>(yt + (t - t0) * YT_PITCH + nc) = v;
                     continue;
                 }
                 const long long idx = (long long)t * p.ldy + n;
@@ -387,18 +387,28 @@ __device__ __forceinline__ void gemm_pre_tile(const DzConvGemm& p, const int t0,
     }
     dz_flag_range(p.oflag, amax);
     if constexpr (POOL) {
+        if (flags & 24) return;
         // ---- weighted statistics pooling of the tile (DzPoolFuse) ---------------------------------------
-        float* wt = reinterpret_cast<float*>(smem + POOL_WT);
-        float* red = reinterpret_cast<float*>(smem + POOL_RED);
+        // Round 6: the same two passes (sum w x -> mean, then sum w (x - mean)^2: no cancellation whatever the
+        // weights select), laid out for throughput.  The form of round 3 — one column and 64 rows per thread, four
+        // dependent LDS reads per row, twice — cost as much as the GEMM of the tile: 80 of the layer's 162 us
+        // (timing-only builds, DZ_GP_DBG=8 / 16).  Now wave v sweeps rows 32 v .. 32 v + 31, a lane owns two columns
+        // (one 8-byte read per row; the row's <= 4 weights are one broadcast 16-byte read, four rows in flight), the
+        // four waves' partial sums meet in LDS, every lane derives the means of its two columns from them and sweeps
+        // again.  A tile touches at most two chunks ("parts"), handled one after the other.  (A single pass on
+        // shifted moments was tried first: 19 us instead of 30, but OverlappedSpeechPenalty weights select frames
+        // whose features sit thousands of their own deviations from any cheap shift — 1e-2 in the embeddings.)
+        float* wt = reinterpret_cast<float*>(smem + POOL_WT);          // [128 rows][4 speakers]
+        float* red = reinterpret_cast<float*>(smem + POOL_RED);        // [4 waves][4 speakers][128]
         float* s0t = reinterpret_cast<float*>(smem + POOL_S0);
         float* s0f = s0t + 8 * 8 * 2;
         const int K = q->K, P = q->P, T = q->T;
         // pooling weights of the tile's rows (the interpolation of stats_pool_reg_kernel, k_pool.hip)
-        for (int i = tid; i < K * BM; i += 256) {
-            const int k = i >> 7, rl = i & 127, r = t0 + rl;
+        for (int i = tid; i < 4 * BM; i += 256) {
+            const int rl = i >> 2, k = i & 3, r = t0 + rl;
             const int b = r / P, t = r - b * P;
             float wv = 0.f;
-            if (t < T && r < p.Tout) {
+            if (k < K && t < T && r < p.Tout) {
                 wv = 1.f;
                 if (q->w) {
                     const float* wr = q->w + (long long)(b * K + k) * q->Fw;
@@ -420,7 +430,6 @@ __device__ __forceinline__ void gemm_pre_tile(const DzConvGemm& p, const int t0,
         const int b0 = t0 / P;
         int rb = (b0 + 1) * P - t0;                        // first local row of the next chunk
         if (rb > BM) rb = BM;
-        const int c = tid & 127, h = tid >> 7;
         // (sum w, sum w^2) of each (part, speaker): 8 sub-ranges of 16 rows, then summed in fixed order
         if (tid < 64) {
             const int pk = tid >> 3, sub = tid & 7, part = pk >> 2, k = pk & 3;
@@ -428,29 +437,13 @@ __device__ __forceinline__ void gemm_pre_tile(const DzConvGemm& p, const int t0,
             if (k < K) {
                 const int lo = max(part ? rb : 0, 16 * sub), hi = min(part ? BM : rb, 16 * sub + 16);
                 for (int r = lo; r < hi; ++r) {
-                    const float wv = wt[k * BM + r];
+                    const float wv = wt[4 * r + k];
                     a += wv;
                     a2 += wv * wv;
                 }
             }
             s0t[(pk * 8 + sub) * 2] = a;
             s0t[(pk * 8 + sub) * 2 + 1] = a2;
-        }
-        // pass 1: sum w x over this thread's half of the rows, per part and speaker
-        float s1[2][4];
-#pragma unroll
-        for (int part = 0; part < 2; ++part) {
-#pragma unroll
-            for (int k = 0; k < 4; ++k) s1[part][k] = 0.f;
-            const int lo = max(part ? rb : 0, 64 * h), hi = min(part ? BM : rb, 64 * h + 64);
-            for (int r = lo; r < hi; ++r) {
-                const float x = yt[r * YT_PITCH + c];
-#pragma unroll
-                for (int k = 0; k < 4; ++k)
-                    if (k < K) s1[part][k] += wt[k * BM + r] * x;
-            }
-#pragma unroll
-            for (int k = 0; k < 4; ++k) red[((part * 2 + h) * 4 + k) * BN + c] = s1[part][k];
         }
         __syncthreads();
         if (tid < 8) {
@@ -462,54 +455,81 @@ __device__ __forceinline__ void gemm_pre_tile(const DzConvGemm& p, const int t0,
             s0f[tid * 2] = a;
             s0f[tid * 2 + 1] = a2;
         }
-        float mean[2][4];
+        const int wv_ = tid >> 6, c2 = 2 * (tid & 63);
+        const int nx = p.Tout / P;                         // chunks in this launch
+        auto pool_part = [&](auto kk_tag, const int part) {
+            constexpr int KK = decltype(kk_tag)::value;
+            const int lo = max(part ? rb : 0, 32 * wv_), hi = min(part ? BM : rb, 32 * wv_ + 32);   // wave-uniform
+            float S[KK][2];
 #pragma unroll
-        for (int part = 0; part < 2; ++part)
-#pragma unroll
-            for (int k = 0; k < 4; ++k)
-                mean[part][k] = red[((part * 2 + 0) * 4 + k) * BN + c] + red[((part * 2 + 1) * 4 + k) * BN + c];
-        __syncthreads();                                   // s0f is complete; every thread has read pass 1's sums
-#pragma unroll
-        for (int part = 0; part < 2; ++part) {
-            float m2[4];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const float v1 = s0f[(part * 4 + k) * 2];
-                mean[part][k] = v1 > 0.f ? mean[part][k] / v1 : 0.f;
-                m2[k] = 0.f;
-            }
-            const int lo = max(part ? rb : 0, 64 * h), hi = min(part ? BM : rb, 64 * h + 64);
+            for (int k = 0; k < KK; ++k) S[k][0] = S[k][1] = 0.f;
+#pragma unroll 4
             for (int r = lo; r < hi; ++r) {
-                const float x = yt[r * YT_PITCH + c];
+                const f32x2 x = *reinterpret_cast<const f32x2*>(yt + r * YT_PITCH + c2);
+                const f32x4 w4 = *reinterpret_cast<const f32x4*>(wt + 4 * r);
 #pragma unroll
-                for (int k = 0; k < 4; ++k)
-                    if (k < K) {
-                        const float d = x - mean[part][k];
-                        m2[k] += (d * d) * wt[k * BM + r];
-                    }
+                for (int k = 0; k < KK; ++k) {
+                    S[k][0] = __builtin_fmaf(w4[k], x[0], S[k][0]);
+                    S[k][1] = __builtin_fmaf(w4[k], x[1], S[k][1]);
+                }
             }
 #pragma unroll
-            for (int k = 0; k < 4; ++k) red[((part * 2 + h) * 4 + k) * BN + c] = m2[k];
-        }
-        __syncthreads();
-        if (h == 0) {
-            const int nx = p.Tout / P;                       // chunks in this launch
+            for (int k = 0; k < KK; ++k)
+                *reinterpret_cast<f32x2*>(red + (wv_ * 4 + k) * BN + c2) = (f32x2){S[k][0], S[k][1]};
+            __syncthreads();                               // pass-1 sums of the four waves (and s0f) are in LDS
+            float mean[KK][2];
 #pragma unroll
-            for (int part = 0; part < 2; ++part) {
-                const int b = b0 + part;
-                if (b >= nx || (part && rb >= BM)) continue;
+            for (int k = 0; k < KK; ++k) {
+                f32x2 a = {0.f, 0.f};
+#pragma unroll
+                for (int v = 0; v < 4; ++v) a += *reinterpret_cast<const f32x2*>(red + (v * 4 + k) * BN + c2);   // fixed order
+                const float v1 = s0f[(part * 4 + k) * 2];
+                mean[k][0] = v1 > 0.f ? a[0] / v1 : 0.f;
+                mean[k][1] = v1 > 0.f ? a[1] / v1 : 0.f;
+            }
+            __syncthreads();                               // every lane has read the sums: the scratch takes pass 2's
+#pragma unroll
+            for (int k = 0; k < KK; ++k) S[k][0] = S[k][1] = 0.f;
+#pragma unroll 4
+            for (int r = lo; r < hi; ++r) {
+                const f32x2 x = *reinterpret_cast<const f32x2*>(yt + r * YT_PITCH + c2);
+                const f32x4 w4 = *reinterpret_cast<const f32x4*>(wt + 4 * r);
+#pragma unroll
+                for (int k = 0; k < KK; ++k) {
+                    const float d0 = x[0] - mean[k][0], d1 = x[1] - mean[k][1];
+                    S[k][0] = __builtin_fmaf(w4[k] * d0, d0, S[k][0]);
+                    S[k][1] = __builtin_fmaf(w4[k] * d1, d1, S[k][1]);
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < KK; ++k)
+                *reinterpret_cast<f32x2*>(red + (wv_ * 4 + k) * BN + c2) = (f32x2){S[k][0], S[k][1]};
+            __syncthreads();
+            const int b = b0 + part;
+            if (wv_ == 0 && b < nx) {
                 const int piece = t0 / BM - (b * P) / BM;    // 0 .. np - 1
-                for (int k = 0; k < K; ++k) {
-                    const float M2 = red[((part * 2 + 0) * 4 + k) * BN + c] + red[((part * 2 + 1) * 4 + k) * BN + c];
-                    float* o = q->part + ((((long long)b * q->np + piece) * K + k) * p.Npad + n0 + c) * 2;
-                    o[0] = mean[part][k];
-                    o[1] = M2;
-                    if (n0 == 0 && c == 0) {
+#pragma unroll
+                for (int k = 0; k < KK; ++k) {
+                    f32x2 m2 = {0.f, 0.f};
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) m2 += *reinterpret_cast<const f32x2*>(red + (v * 4 + k) * BN + c2);
+                    float* o = q->part + ((((long long)b * q->np + piece) * K + k) * p.Npad + n0 + c2) * 2;
+                    *reinterpret_cast<f32x4*>(o) = (f32x4){mean[k][0], m2[0], mean[k][1], m2[1]};
+                    if (n0 == 0 && c2 == 0) {
                         float* so = q->s0 + (((long long)b * q->np + piece) * K + k) * 2;
                         so[0] = s0f[(part * 4 + k) * 2];
                         so[1] = s0f[(part * 4 + k) * 2 + 1];
                     }
                 }
+            }
+        };
+        for (int part = 0; part < (rb < BM ? 2 : 1); ++part) {
+            if (part) __syncthreads();                     // the output lanes of part 0 are done with the scratch
+            switch (K) {
+                case 1: pool_part(std::integral_constant<int, 1>{}, part); break;
+                case 2: pool_part(std::integral_constant<int, 2>{}, part); break;
+                case 3: pool_part(std::integral_constant<int, 3>{}, part); break;
+                default: pool_part(std::integral_constant<int, 4>{}, part); break;
             }
         }
     }
@@ -540,12 +560,15 @@ __global__ __launch_bounds__(256, 2) void gemm_pre_kernel(DzConvGemm p, int mbig
 
 // tdnn5 with the statistics pooling in its epilogue: 128 x 128 tiles only (the launcher falls back to the
 // unfused path when a launch would use small tiles)
-__global__ __launch_bounds__(256, 2) void gemm_pre_pool_kernel(DzConvGemm p, DzPoolFuse q, int gx) {
+__global__ __launch_bounds__(256, 2) void gemm_pre_pool_kernel(DzConvGemm p, DzPoolFuse q, int gx, int flags) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int gy = p.Npad / BN;
     int bx, by, bz;
     dz_tile_map_lin(blockIdx.x, gx, gy, 1, p.agroup, bx, by, bz);
-    gemm_pre_tile<DZ_EPI_TDNN, 2, 2, 2, true, true>(p, bx * BM, by * BN, smem, 0, &q);
+#ifndef DZ_EXPERIMENTS
+    flags = 0;                   // (timing-only variants: experiments build, DZ_GP_DBG 8 = no pooling of the tile, 16 = no tile either)
+#endif
+    gemm_pre_tile<DZ_EPI_TDNN, 2, 2, 2, true, true>(p, bx * BM, by * BN, smem, flags, &q);
 }
 
 // 384 x 128 tiles, 12 waves (3 per SIMD), one workgroup per CU: a third fewer operand bytes per MFMA
@@ -689,7 +712,7 @@ int dz_launch_gemm_pre_pool(const DzConvGemm& p_in, const DzPoolFuse& q, hipStre
     static DzAttrOnce attr_once;
     DZ_HIP(attr_once.raise((const void*)gemm_pre_pool_kernel, (int)POOL_LDS));
     const int gx = (p.Tout + BM - 1) / BM, gy = p.Npad / BN;
-    DZ_LAUNCH(gemm_pre_pool_kernel, dim3(gx * gy), dim3(256), POOL_LDS, st, p, q, gx);
+    DZ_LAUNCH(gemm_pre_pool_kernel, dim3(gx * gy), dim3(256), POOL_LDS, st, p, q, gx, dbg_flags());
     DZ_HIP(hipGetLastError());
     return 0;
 }
