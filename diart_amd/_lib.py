@@ -40,7 +40,7 @@ class SegWeights(C.Structure):
 class EmbWeights(C.Structure):
     _fields_ = [("sinc", SincNetWeights), ("tw", vp * 5), ("tb", vp * 5), ("ts", vp * 5),
                 ("th", vp * 5), ("emb_w", vp), ("emb_b", vp), ("dimension", C.c_int),
-                ("tw_split", vp * 5)]
+                ("tw_split", vp * 5), ("pool_nearest", C.c_int)]
 
 
 class Layer(C.Structure):

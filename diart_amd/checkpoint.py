@@ -251,6 +251,22 @@ def _is_safetensors(path: Path) -> bool:
         return False
 
 
+def pyannote_version(path: Union[str, Path]):
+    """``(major, minor)`` of the ``pyannote.audio`` that wrote a PyTorch-Lightning checkpoint (its top-level
+    ``"pyannote.audio"["versions"]["pyannote.audio"]`` entry), or None (safetensors, plain state dicts, no such entry).
+    Decides how ``StatsPool`` resamples its pooling weights: ``mode="nearest"`` from 3.1 on, ``"linear"`` before."""
+    path = Path(path)
+    if not path.is_file() or _is_safetensors(path):
+        return None
+    try:
+        obj, _ = load_object(path)
+        ver = obj["pyannote.audio"]["versions"]["pyannote.audio"]
+        nums = [int("".join(ch for ch in part if ch.isdigit()) or 0) for part in str(ver).split(".")[:2]]
+        return (nums[0], nums[1] if len(nums) > 1 else 0)
+    except Exception:      # noqa: BLE001 — any shape of "no version recorded"
+        return None
+
+
 def read_state(path: Union[str, Path]) -> Dict[str, torch.Tensor]:
     """``{parameter name: CPU tensor}`` of a checkpoint file (see the module docstring)."""
     path = Path(path)

@@ -807,6 +807,7 @@ static int emb_frames(dz_emb* e, const float* d_wave, long long stride, int B, h
 static int emb_head(dz_emb* e, const float* d_weights, int Fw, int rows, int rows_per_x,
                     int normalize, float* d_out, hipStream_t st) {
     int rc;
+    if (e->w.pool_nearest && d_weights) Fw = -Fw;      // the internal launchers carry the resampling mode in the sign (dz_pool_weight)
     const int nx = rows / rows_per_x;
     if (e->pending_B > 0) {
         DZ_REQUIRE(nx == e->pending_B, "dz_emb_pool: %d chunks, but the frame features of %d are pending", nx,
@@ -1218,6 +1219,7 @@ extern "C" int dz_k_stats_pool(dz_ctx* ctx, const float* d_x, int frames, int ch
     DZ_REQUIRE(ctx && d_x && d_out, "dz_k_stats_pool: NULL argument");
     DZ_REQUIRE(rows >= 1 && rows_per_x >= 1 && frames >= 2, "dz_k_stats_pool: empty input");
     DZ_HIP(hipSetDevice(ctx->device));
+    DZ_REQUIRE(!d_weights || weight_frames >= 2 || weight_frames <= -2, "dz_k_stats_pool: weight_frames %d", weight_frames);
     return dz_launch_stats_pool(d_x, (long long)frames * ldx, frames, channels, ldx, d_weights,
                                 d_weights ? weight_frames : frames, rows, rows_per_x, d_out, ldo,
                                 (hipStream_t)stream);

@@ -323,9 +323,30 @@ int dz_g3_error(int reset);
 // statistics of the tile's rows; dz_launch_pool_combine merges the tile pieces of a chunk
 // (Chan et al.).  Rows are the flattened frames of the batch: row r = chunk r / P, frame r % P, frames
 // >= T of a chunk carry no weight.
+// Pooling weight of output frame t of T from a row of |Fw| weights — pyannote's StatsPool resamples the (N, Fw) weights
+// to the T frames of the features: Fw > 0: F.interpolate(mode="linear", align_corners=False), the form
+// of pyannote.audio 2.x .. 3.0; Fw < 0 (the sign is how the internal launchers carry the mode): mode="nearest",
+// pyannote.audio >= 3.1 — source index floor(t * (|Fw| / T)) computed in f32 like PyTorch's nearest kernel.
+__device__ __forceinline__ float dz_pool_weight(const float* wr, int Fw, int T, int t) {
+    const int F = Fw < 0 ? -Fw : Fw;
+    if (F == T) return wr[t];
+    const float scale = (float)F / (float)T;
+    if (Fw < 0) {
+        int i = (int)floorf((float)t * scale);
+        if (i > F - 1) i = F - 1;
+        return wr[i];
+    }
+    float src = scale * ((float)t + 0.5f) - 0.5f;
+    if (src < 0.f) src = 0.f;
+    const int i0 = (int)src;
+    const int i1 = i0 + (i0 < F - 1 ? 1 : 0);
+    const float l1 = src - (float)i0;
+    return (1.f - l1) * wr[i0] + l1 * wr[i1];
+}
+
 struct DzPoolFuse {
     const float* w;     // [nx * K][Fw] pooling weights (speaker-major per chunk) or NULL (all ones)
-    int Fw, K;          // weight frames per row (interpolated to T when Fw != T); speakers per chunk, <= 4
+    int Fw, K;          // weight frames per row (resampled to T when |Fw| != T; negative: nearest, see dz_pool_weight); speakers per chunk, <= 4
     int P, T;           // row pitch per chunk / valid frames per chunk
     int np;             // piece slots per chunk = dz_pool_pieces(P): 128-row tiles a chunk can touch
     float* part;        // [nx][np][K][Npad][2] = (mean, M2) of the piece

@@ -410,19 +410,7 @@ __device__ __forceinline__ void gemm_pre_tile(const DzConvGemm& p, const int t0,
             float wv = 0.f;
             if (k < K && t < T && r < p.Tout) {
                 wv = 1.f;
-                if (q->w) {
-                    const float* wr = q->w + (long long)(b * K + k) * q->Fw;
-                    if (q->Fw == T) {
-                        wv = wr[t];
-                    } else {
-                        float src = ((float)q->Fw / (float)T) * ((float)t + 0.5f) - 0.5f;
-                        if (src < 0.f) src = 0.f;
-                        const int i0 = (int)src;
-                        const int i1 = i0 + (i0 < q->Fw - 1 ? 1 : 0);
-                        const float l1 = src - (float)i0;
-                        wv = (1.f - l1) * wr[i0] + l1 * wr[i1];
-                    }
-                }
+                if (q->w) wv = dz_pool_weight(q->w + (long long)(b * K + k) * (q->Fw < 0 ? -q->Fw : q->Fw), q->Fw, T, t);
             }
             wt[i] = wv;
         }
@@ -694,7 +682,7 @@ int dz_launch_gemm_pre_pool(const DzConvGemm& p_in, const DzPoolFuse& q, hipStre
                    p.Npad % BN == 0 && p.Tout == p.Tin,
                "gemm_pre_pool: built for the flattened 1 x 1 TDNN layer");
     DZ_REQUIRE(q.np == dz_pool_pieces(q.P), "gemm_pre_pool: np must be dz_pool_pieces(P)");
-    DZ_REQUIRE(q.K >= 1 && q.K <= 4 && q.P >= BM && q.T >= 2 && q.T <= q.P && p.Tout % q.P == 0 && q.Fw >= 2,
+    DZ_REQUIRE(q.K >= 1 && q.K <= 4 && q.P >= BM && q.T >= 2 && q.T <= q.P && p.Tout % q.P == 0 && (q.Fw >= 2 || q.Fw <= -2),
                "gemm_pre_pool: 1..4 speakers, chunk pitch >= 128 rows (got K %d, P %d, T %d)", q.K, q.P, q.T);
     DZ_REQUIRE(p.ldx > 0 && p.ldx % KT == 0 && p.xplane % p.ldx == 0 && p.xplane / p.ldx >= p.Tin,
                "gemm_pre_pool: kb-major input planes need ldx %% 32 == 0 and xplane = rows * ldx with rows >= Tin");

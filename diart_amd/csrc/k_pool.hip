@@ -42,23 +42,11 @@ __global__ __launch_bounds__(256) void stats_pool_reg_kernel(
             xr[i] = (live && t < T) ? Xb[(long long)t * ldx] : 0.f;
         }
     }
-    const float scale = (float)Fw / (float)T;
+    const int Fabs = Fw < 0 ? -Fw : Fw;
     for (int idx = tid; idx < K * T; idx += 256) {
         const int k = idx / T, t = idx - k * T;
         float wv = 1.f;
-        if (weights) {
-            const float* wr = weights + (long long)(xi * ktot + kofs + k) * Fw;
-            if (Fw == T) {
-                wv = wr[t];
-            } else {
-                float src = scale * ((float)t + 0.5f) - 0.5f;
-                if (src < 0.f) src = 0.f;
-                const int i0 = (int)src;
-                const int i1 = i0 + (i0 < Fw - 1 ? 1 : 0);
-                const float l1 = src - (float)i0;
-                wv = (1.f - l1) * wr[i0] + l1 * wr[i1];
-            }
-        }
+        if (weights) wv = dz_pool_weight(weights + (long long)(xi * ktot + kofs + k) * Fabs, Fw, T, t);
         wk[idx] = wv;
     }
     __syncthreads();

@@ -212,15 +212,20 @@ class HipEmbedding(_HipModule):
 
     dimension = 512
 
-    def __init__(self, state: Dict[str, torch.Tensor], max_batch: int = 64, precision: Optional[str] = None):
+    def __init__(self, state: Dict[str, torch.Tensor], max_batch: int = 64, precision: Optional[str] = None,
+                 weight_interp: Optional[str] = None):
+        """``weight_interp``: StatsPool's resampling of the pooling weights to the feature frames — "linear"
+        (pyannote.audio 2.x .. 3.0: ``F.interpolate(mode="linear")``; the default, setup.cfg pins ``>=2.1.1``) or
+        "nearest" (pyannote.audio >= 3.1).  ``EmbeddingLoader`` sets it from the version a checkpoint records."""
         super().__init__(state, max_batch)
         self.precision = default_precision(precision)
+        self.weight_interp = weight_interp or "linear"
 
     def _extra_state(self):
-        return {"precision": self.precision}
+        return {"precision": self.precision, "weight_interp": self.weight_interp}
 
     def _pack(self, device):
-        return PackedEmbedding(self._state, device, precision=self.precision)
+        return PackedEmbedding(self._state, device, precision=self.precision, weight_interp=self.weight_interp)
 
     def _create(self, num_samples, cap):
         h = _lib.vp()
@@ -355,15 +360,23 @@ class EmbeddingLoader:
     None = decide from the checkpoint keys."""
 
     def __init__(self, state: StateSource, max_batch: int = 64, arch: Optional[str] = None,
-                 precision: Optional[str] = None):
+                 precision: Optional[str] = None, weight_interp: Optional[str] = None):
+        """``weight_interp`` (x-vector only): "linear" | "nearest" | None = from the ``pyannote.audio`` version the
+        checkpoint file records (>= 3.1: "nearest"; older, absent, or a plain state dict: "linear")."""
         self.state, self.max_batch, self.arch, self.precision = state, max_batch, arch, precision
+        self.weight_interp = weight_interp
 
     def __call__(self):
         sd = _read_state(self.state)
         arch = self.arch or ("ecapa" if any(k.startswith("asp.") for k in sd) else "xvector")
         if arch == "ecapa":
             return HipEcapaEmbedding(sd, self.max_batch, self.precision)
-        return HipEmbedding(sd, self.max_batch, self.precision)
+        interp = self.weight_interp
+        if interp is None and not isinstance(self.state, dict):
+            from .checkpoint import pyannote_version
+            v = pyannote_version(self.state)
+            interp = "nearest" if v is not None and v >= (3, 1) else "linear"
+        return HipEmbedding(sd, self.max_batch, self.precision, interp)
 
 
 # --------------------------------------------------------------------------- #
@@ -445,8 +458,8 @@ class EmbeddingModel(LazyModel):
 
     @staticmethod
     def from_state(state: StateSource, max_batch: int = 64, arch: Optional[str] = None,
-                   precision: Optional[str] = None) -> "EmbeddingModel":
-        return EmbeddingModel(EmbeddingLoader(state, max_batch, arch, precision))
+                   precision: Optional[str] = None, weight_interp: Optional[str] = None) -> "EmbeddingModel":
+        return EmbeddingModel(EmbeddingLoader(state, max_batch, arch, precision, weight_interp))
 
     @staticmethod
     def from_pyannote(model, use_hf_token=True) -> "EmbeddingModel":

@@ -417,12 +417,18 @@ class PackedEmbedding:
 
     TDNN = [(64, 512, 512), (512, 512, 512), (512, 512, 512), (512, 512, 512), (512, 1500, 1536)]
 
-    def __init__(self, sd: Dict[str, torch.Tensor], device: torch.device, precision: str = "f32"):
+    def __init__(self, sd: Dict[str, torch.Tensor], device: torch.device, precision: str = "f32",
+                 weight_interp: str = "linear"):
+        """``weight_interp``: how StatsPool resamples the pooling weights to the feature frames — "linear"
+        (``F.interpolate(mode="linear")``, pyannote.audio 2.x .. 3.0) or "nearest" (pyannote.audio >= 3.1)."""
         assert precision in PRECISIONS, precision
+        if weight_interp not in ("linear", "nearest"):
+            raise ValueError(f"weight_interp={weight_interp!r}: expected 'linear' or 'nearest'")
         split = precision == "f16x3"
         pk = _Packed(device)
         g = lambda k: sd[k].detach().cpu().float()
         w = _lib.EmbWeights()
+        w.pool_nearest = int(weight_interp == "nearest")
         w.sinc = _pack_sincnet(sd, pk, split=split)
         for i, (cin_pad, cout, npad) in enumerate(self.TDNN):
             cw = g(f"tdnns.{3 * i}.weight")

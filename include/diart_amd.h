@@ -128,6 +128,9 @@ typedef struct {
     int dimension;               /* D = 512 */
     const void* tw_split[5];     /* split-f16 planes of tw[i] (optional, NULL = exact f32): tw_split[0] row-major
                                     [2][Npad][Kpad], tw_split[1..4] kb-major (see dz_seg_weights)  */
+    int pool_nearest;            /* how StatsPool resamples the (N, Fw) pooling weights to the T feature frames: 0 =
+                                    F.interpolate(mode="linear", align_corners=False) (pyannote.audio 2.x .. 3.0),
+                                    1 = mode="nearest" (pyannote.audio >= 3.1)                                     */
 } dz_emb_weights;
 
 /* ---- segmentation: replaces the callable behind SegmentationModel.__call__ --
@@ -377,6 +380,7 @@ int dz_k_lstm_mfma(dz_ctx* ctx, const float* d_gx, const void* d_whh_split, floa
  * further; gx in PyTorch column order (variants 3 / 4: unit-major, as dz_k_lstm_mfma)             */
 int dz_k_lstm_planes(dz_ctx* ctx, const float* d_gx, const float* d_whh, const void* d_whh_split,
                      int variant, void* d_hsplit, long long hplane, int batch, int frames, void* stream);
+/* weight_frames < 0: |weight_frames| weights per row, resampled with mode="nearest" (see dz_emb_weights.pool_nearest) */
 int dz_k_stats_pool(dz_ctx* ctx, const float* d_x, int frames, int channels, int ldx,
                     const float* d_weights, int weight_frames, int rows, int rows_per_x,
                     float* d_out, int ldo, void* stream);

@@ -203,10 +203,10 @@ class XVectorSincNetRef(nn.Module):
             x = m(x)
         return x  # (N,1500,279)
 
-    def forward(self, waveforms: torch.Tensor, weights: Optional[torch.Tensor] = None):
-        return self.embedding(stats_pool_ref(self.frames(waveforms), weights))
+    def forward(self, waveforms: torch.Tensor, weights: Optional[torch.Tensor] = None, interp_mode: str = "linear"):
+        return self.embedding(stats_pool_ref(self.frames(waveforms), weights, interp_mode=interp_mode))
 
-    def forward_multi(self, waveforms: torch.Tensor, weights: torch.Tensor) -> torch.Tensor:
+    def forward_multi(self, waveforms: torch.Tensor, weights: torch.Tensor, interp_mode: str = "linear") -> torch.Tensor:
         """De-duplicated equivalent of the reference's (B*K)-row call.
 
         waveforms (B,1,S); weights (B,F,K) -> (B,K,D).  Mathematically identical
@@ -217,7 +217,7 @@ class XVectorSincNetRef(nn.Module):
         B, Fw, K = weights.shape
         fr = fr.unsqueeze(1).expand(B, K, *fr.shape[1:]).reshape(B * K, *fr.shape[1:])
         w = weights.permute(0, 2, 1).reshape(B * K, Fw)
-        return self.embedding(stats_pool_ref(fr, w)).view(B, K, -1)
+        return self.embedding(stats_pool_ref(fr, w, interp_mode=interp_mode)).view(B, K, -1)
 
 
 def count_params(m: nn.Module) -> int:

@@ -632,8 +632,13 @@ def test_lstm_recurrence(gpu, B, T, kernel):
 # --------------------------------------------------------------------------- #
 @pytest.mark.parametrize("K,Fw,T", [(1, 293, 279), (3, 293, 279), (4, 293, 279), (5, 293, 279), (3, 279, 279),
                                     (1, 0, 279), (3, 293, 321), (3, 589, 571), (2, 40, 37)])
-def test_stats_pool(gpu, K, Fw, T):
+@pytest.mark.parametrize("interp", ["linear", "nearest"])
+def test_stats_pool(gpu, K, Fw, T, interp):
+    """interp: how the (N, Fw) weights are resampled to the T feature frames — F.interpolate(mode="linear") of
+    pyannote.audio 2.x .. 3.0, or mode="nearest" of >= 3.1 (a negative weight_frames at the kernel-level entry)."""
     from oracle.models_ref import stats_pool_ref
+    if interp == "nearest" and Fw in (0, T):
+        pytest.skip("nothing to resample")
     g = torch.Generator().manual_seed(K * 7 + Fw)
     nx, Cc, ld = 3, 1500, 1536
     x = torch.randn(nx, T, ld, generator=g) + 0.5
@@ -645,11 +650,12 @@ def test_stats_pool(gpu, K, Fw, T):
     dw = w.to(gpu) if w is not None else None
     out = torch.full((rows, 3008), float("nan"), device=gpu)
     _lib.check(_lib.load().dz_k_stats_pool(_ctx(gpu), dx.data_ptr(), T, Cc, ld,
-                                           dw.data_ptr() if dw is not None else None, Fw, rows, K,
+                                           dw.data_ptr() if dw is not None else None,
+                                           -Fw if interp == "nearest" else Fw, rows, K,
                                            out.data_ptr(), 3008, None))
     _sync()
     seq = x[:, :, :Cc].permute(0, 2, 1).repeat_interleave(K, dim=0)  # (rows,C,T)
-    ref = stats_pool_ref(seq, w)
+    ref = stats_pool_ref(seq, w, interp_mode=interp)
     got = out.cpu()[:, :3000]
     assert not torch.isnan(got).any()
     assert (got - ref).abs().max().item() < 2e-5 * max(1.0, ref.abs().max().item())

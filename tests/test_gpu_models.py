@@ -167,6 +167,35 @@ def test_precisions_agree_with_each_other(gpu, chunks):
     assert ds < 5e-5 and de < 5e-6
 
 
+@pytest.mark.parametrize("B", [2, 12])
+def test_nearest_weight_interpolation_of_pyannote_3_1(gpu, oracle_models, B):
+    """pyannote.audio >= 3.1 resamples StatsPool's weights with mode="nearest" (2.x .. 3.0: "linear"; the reference pins
+    >= 2.1.1, /root/reference/setup.cfg:35).  `weight_interp="nearest"` against the oracle's `interp_mode="nearest"`,
+    through the stand-alone pooling kernel (2 chunks: the latency regime) and the pooled tdnn5 epilogue (12 chunks), the
+    de-duplicated and the reference-shaped call; and it is NOT the linear answer."""
+    from diart_amd.synth import synth_streams
+    x = torch.from_numpy(synth_streams(B, 5.0, seed0=60))[:, None, :80000].contiguous()
+    g = torch.Generator().manual_seed(5)
+    w = torch.rand(B, 3, 293, generator=g) ** 4 + 1e-8              # speaker-major (B, K, F): peaky, so the mode matters
+    ref_model = oracle_models[1]
+    outs = {}
+    for interp in ("nearest", "linear"):
+        emb = M.EmbeddingModel.from_state(synth_embedding_state(), max_batch=3 * B, weight_interp=interp)
+        emb.to(gpu)
+        assert emb.model.weight_interp == interp
+        multi = emb.model.forward_multi(x.to(gpu), w.to(gpu)).cpu()
+        rows = emb(x.repeat(1, 3, 1).reshape(3 * B, 1, -1).to(gpu), w.reshape(3 * B, 293).to(gpu)).cpu().view(B, 3, 512)
+        outs[interp] = (multi, rows)
+    with torch.no_grad():
+        refs = {m: ref_model.forward_multi(x, w.permute(0, 2, 1), interp_mode=m) for m in ("nearest", "linear")}
+    for interp in ("nearest", "linear"):
+        for got in outs[interp]:
+            rel = ((got - refs[interp]).norm(dim=-1) / refs[interp].norm(dim=-1)).max().item()
+            assert rel < 1e-4, (interp, rel)
+    assert ((refs["nearest"] - refs["linear"]).norm(dim=-1) / refs["linear"].norm(dim=-1)).max().item() > 1e-3
+    assert ((outs["nearest"][0] - refs["linear"]).norm(dim=-1) / refs["linear"].norm(dim=-1)).max().item() > 1e-3
+
+
 def test_pooling_fused_into_tdnn5_equals_the_two_launch_path(gpu, oracle_models, monkeypatch):
     """Round 3: tdnn5 keeps its 128 x 128 output tile in LDS and reduces it to weighted moments there
     (k_gemm_pre.hip pooled epilogue + pool_combine) instead of writing 110 MB of frame features for
