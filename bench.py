@@ -47,6 +47,8 @@ F_SEG, F_E1, F_E2, F_E3 = 293, 289, 285, 279
 # (the layer's input + output read / written once, f32) and weight bytes per LAUNCH.
 KERNELS = {
     "wave_stats": dict(mac=0, io=320_000, w=0, bound="hbm"),
+    # y2 [293][64] f32 -> InstanceNorm + LeakyReLU -> two f16 planes (k_gemm_split.hip norm_split_kernel), once per network
+    "norm_split": dict(mac=0, io=F_SEG * 64 * (4 + 2 * 2), w=0, bound="hbm"),
     # tile partials -> InstanceNorm scale / shift (exact-f32 path and DZ_FUSED_NORM=0 only: launch-bound)
     "finalize_norm": dict(mac=0, io=(10 * 64 * 2 + 2 * 64) * 4, w=0, bound="hbm"),
     "sinc_conv0": dict(mac=160_138_000, io=320_000 + 2658 * 80 * 4, w=128 * 96 * 4, bound="mfma_f32"),
@@ -83,6 +85,8 @@ def kernels_for(precision):
     k = {n: dict(v) for n, v in KERNELS.items()}
     if not EXPERIMENTS:
         k.pop("sinc_conv0_pair", None)               # (the pair launch exists in the experiments build only)
+    if precision != "f16x3":
+        k.pop("norm_split", None)                    # (exact f32: the consumers normalise on load)
     if precision == "f16x3" and os.environ.get("DZ_POOL_FUSE", "1") != "0":
         moments = POOL_PIECES * 3 * 1536 * 2 * 4
         k["tdnn5"]["io"] = F_SEG * 512 * 4 + moments + 3 * F_SEG * 4
@@ -138,7 +142,7 @@ def device_kernel(tag, precision):
     k = KERNELS[tag]
     fused_pool = split and pre and os.environ.get("DZ_POOL_FUSE", "1") != "0"
     if k["bound"] == "hbm":
-        return {"wave_stats": "wave_stats_kernel", "finalize_norm": "finalize_norm_kernel",
+        return {"wave_stats": "wave_stats_kernel", "finalize_norm": "finalize_norm_kernel", "norm_split": "norm_split_kernel",
                 "stats_pool": "pool_combine_kernel" if fused_pool else "stats_pool_reg_kernel<3, 72>",
                 "seg_classifier": "seg_head_kernel"}[tag], "hbm", PEAK_HBM_GBPS, "GB/s"
     if k["bound"] == "rec":
@@ -165,7 +169,9 @@ def device_kernel(tag, precision):
         return sym.get(tag, "convgemm_kernel<128, false, 3>"), "mfma", PEAK_F32_MATRIX_TFLOPS, "TFLOP/s"
     if pre and tag == "seg_mlp" and xenv("DZ_MLP_HEAD", "1") != "0":
         return "mlp_head_kernel", "mfma", PEAK_F16_MATRIX_TFLOPS / SPLIT_PRODUCTS, "TFLOP/s"
-    nsplit = pre and xenv("DZ_NORM_SPLIT", "0") == "1" and xenv("DZ_CONV_POOL", "1") != "0"
+    # the first layer behind each SincNet reads planes a one-off norm + split pass wrote (round 6) unless the experiments
+    # build's switches take the fused norms away
+    nsplit = pre and xenv("DZ_CONV_POOL", "1") != "0" and xenv("DZ_FUSED_NORM", "1") != "0"
     if pre and (tag in ("tdnn2", "tdnn3", "tdnn4", "tdnn5", "lstm_proj", "seg_mlp") or (nsplit and tag in ("lstm_proj0", "tdnn1"))):
         ilv = "true" if xenv("DZ_GP_LOOP", "1") != "0" else "false"
         kern = lambda epi: f"gemm_pre_kernel<{epi}, {ilv}>"

@@ -34,13 +34,13 @@ class SegWeights(C.Structure):
                 ("lin0_w", vp), ("lin0_b", vp), ("lin1_w", vp), ("lin1_b", vp),
                 ("cls_w", vp), ("cls_b", vp),
                 ("num_classes", C.c_int), ("powerset", C.c_int), ("num_speakers", C.c_int),
-                ("wih_split", vp * 4), ("lin0_split", vp), ("lin1_split", vp), ("whh_split", vp * 4), ("lstm_variant", C.c_int)]
+                ("wih_split", vp * 4), ("lin0_split", vp), ("lin1_split", vp), ("whh_split", vp * 4), ("lstm_variant", C.c_int), ("wih0_split_kb", vp)]
 
 
 class EmbWeights(C.Structure):
     _fields_ = [("sinc", SincNetWeights), ("tw", vp * 5), ("tb", vp * 5), ("ts", vp * 5),
                 ("th", vp * 5), ("emb_w", vp), ("emb_b", vp), ("dimension", C.c_int),
-                ("tw_split", vp * 5), ("pool_nearest", C.c_int)]
+                ("tw_split", vp * 5), ("tw0_split_kb", vp), ("pool_nearest", C.c_int)]
 
 
 class Layer(C.Structure):

@@ -113,9 +113,9 @@ static const char* kProfNames[PROF_TAGS] = {
     "stats_pool", "emb_linear", "l2norm", "osp", "powerset", "cdist", "lstm_proj0",
     // config 3 (ecapa_api.hip; DZ_T_ECAPA_* in dz_common.h)
     "ecapa_fbank", "ecapa_block0", "ecapa_wide1x1", "ecapa_res2net", "ecapa_se", "ecapa_asp", "ecapa_fc",
-    "sinc_conv0_pair", "", "", ""};
+    "sinc_conv0_pair", "norm_split", "", ""};
 enum { T_WAVE = 0, T_CONV0, T_FIN, T_CONV1, T_CONV2, T_PROJ, T_REC, T_MLP, T_CLS, T_TDNN1, T_TDNN2,
-       T_TDNN3, T_TDNN4, T_TDNN5, T_POOL, T_EMBLIN, T_L2, T_OSP, T_PSET, T_CDIST, T_PROJ0, T_CONV0_PAIR = 28 };
+       T_TDNN3, T_TDNN4, T_TDNN5, T_POOL, T_EMBLIN, T_L2, T_OSP, T_PSET, T_CDIST, T_PROJ0, T_CONV0_PAIR = 28, T_NSPLIT = 29 };
 thread_local DzLaunchProf* dz_launch_prof = nullptr;
 thread_local int* dz_cur_oflag = nullptr;
 struct Prof {
@@ -296,6 +296,7 @@ static int run_gemm(DzConvGemm& p, const void* split, hipStream_t st, const void
 
 struct SincScratch {
     float *stats, *y0, *part0, *sc0, *sh0, *y1, *part1, *sc1, *sh1, *y2, *part2, *sc2, *sh2;
+    float* y2s;      // y2 normalised + split: the f16 planes [2][Bm * P2 rows][64] (kb-major) the first layer of each network reads
     void *bank_frag, *w1_frag, *w2_frag;     // the sinc bank / conv1 / conv2 weights in their kernels' fragment order (filled once, at create)
     void carve(Arena& a, const SincGeom& g, int Bm) {
         bank_frag = a.take((size_t)dz_sinc_bank_frag_bytes() / 4);
@@ -314,6 +315,7 @@ struct SincScratch {
         part2 = a.take((size_t)Bm * g.nt2 * 64 * 2);
         sc2 = a.take((size_t)Bm * 64);
         sh2 = a.take((size_t)Bm * 64);
+        y2s = a.take((size_t)Bm * g.P2 * 64);
     }
 };
 
@@ -343,6 +345,17 @@ static void sinc_out_norm(DzConvGemm& p, const dz_sincnet_weights& w, const Sinc
     } else {
         p.nscale = s.sc2; p.nshift = s.sh2;
     }
+}
+
+// Round 6: y2 is normalised and split ONCE (norm_split_kernel) and its two consumers — the first LSTM projection, tdnn1
+// — run on the pre-split GEMM: whenever the weights came with kb-major planes for that layer and the SincNet's norms
+// are the fused ones (tile partials).  -> planes in s.y2s, plane = B * P2 * 64 elements.
+static bool sinc_pre_split_ok(const dz_sincnet_weights& w, const void* first_layer_kb) {
+    return first_layer_kb != nullptr && sinc_fused_norm(w);
+}
+static int sinc_norm_split(const dz_sincnet_weights& w, const SincGeom& g, const SincScratch& s, int B, hipStream_t st) {
+    ProfScope ps(T_NSPLIT, B);
+    return dz_launch_norm_split(s.y2, s.part2, g.nt2, g.P2, w.in2_g, w.in2_b, s.y2s, (long long)B * g.P2 * 64, B, st);
 }
 
 // wave -> y2 [B][P2][64] (pre-norm) + part2 (or sc2/sh2): the consumer applies InstanceNorm +
@@ -582,9 +595,18 @@ static int seg_forward(dz_seg* s, const float* d_wave, long long wave_stride, in
             p.B = 1; p.Tin = p.Tout = p.Tstore = B * F; p.Cin = 256; p.K = 256; p.Kpad = 256;
             p.ldx = 256;
         }
+        const bool pre0 = layer == 0 && s->pre && sinc_pre_split_ok(s->w.sinc, s->w.wih0_split_kb);
+        if (do_proj && pre0) {       // y2 -> normalised planes, then the projection as one flattened pre-split GEMM
+            if ((rc = sinc_norm_split(s->w.sinc, s->g, s->ss, B, st))) return rc;
+            p.X = nullptr; p.norm_on_load = 0; p.npart = nullptr; p.nscale = p.nshift = nullptr;
+            p.B = 1; p.Tin = p.Tout = p.Tstore = B * F; p.xbs = p.ybs = 0;
+        }
         if (do_proj)
         { ProfScope ps(layer == 0 ? T_PROJ0 : T_PROJ, B);
-          if (layer > 0 && s->pre) {
+          if (pre0) {
+              p.Xsplit = s->ss.y2s; p.xplane = rows * 64; p.Wsplit = s->w.wih0_split_kb;
+              rc = dz_launch_gemm_pre(p, st);
+          } else if (layer > 0 && s->pre) {
               p.X = nullptr; p.Xsplit = lin; p.xplane = rows * 256; p.Wsplit = s->w.wih_split[layer];
               rc = dz_launch_gemm_pre(p, st);
           } else {
@@ -774,7 +796,11 @@ static int emb_frames(dz_emb* e, const float* d_wave, long long stride, int B, h
         p.dil = kTdnnDil[i]; p.K = cin[i] * kTdnnTaps[i]; p.Kpad = (p.K + 31) / 32 * 32;
         p.Npad = npad[i]; p.Nstore = npad[i]; p.ldx = cin[i]; p.ldy = npad[i];
         p.epi = DZ_EPI_TDNN;
-        if (i == 0) {
+        const bool pre0 = i == 0 && e->pre && sinc_pre_split_ok(e->w.sinc, e->w.tw0_split_kb);
+        if (pre0) {                   // y2 -> normalised planes; tdnn1 flattened over B * P rows like the layers behind it
+            if ((rc = sinc_norm_split(e->w.sinc, e->g, e->ss, B, st))) return rc;
+            p.B = 1; p.Tin = B * P; p.Tout = p.Tstore = B * P - span;
+        } else if (i == 0) {
             p.B = B; p.Tin = P; p.Tout = p.Tstore = e->T[0];
             p.xbs = (long long)P * cin[i]; p.ybs = (long long)P * npad[i];
             sinc_out_norm(p, e->w.sinc, e->g, e->ss, e->w.tw_split[0] != nullptr);
@@ -791,7 +817,11 @@ static int emb_frames(dz_emb* e, const float* d_wave, long long stride, int B, h
             return 0;
         }
         { ProfScope ps(T_TDNN1 + i, B);
-          if (i > 0 && e->pre) {
+          if (pre0) {
+              p.X = nullptr; p.Xsplit = e->ss.y2s; p.xplane = (long long)B * P * 64; p.Wsplit = e->w.tw0_split_kb;
+              p.Y = nullptr; p.Ysplit = outp; p.yplane = plane;
+              rc = dz_launch_gemm_pre(p, st);
+          } else if (i > 0 && e->pre) {
               p.X = nullptr; p.Xsplit = in; p.xplane = plane; p.Wsplit = e->w.tw_split[i];
               if (i < 4) { p.Y = nullptr; p.Ysplit = outp; p.yplane = plane; }
               rc = dz_launch_gemm_pre(p, st);

@@ -317,6 +317,47 @@ int launch(const DzConvGemm& p, hipStream_t st) {
     return 0;
 }
 
+// ---------------------------------------------------------------------------------------------
+// InstanceNorm + LeakyReLU + split of the last SincNet stage's output, ONCE (round 6): y2 [B][P][64] f32 (raw pooled
+// values) + the producer's tile partials -> the two f16 planes (hi, lo * 2^11) of [B * P rows][64] in the kb-major
+// order k_gemm_pre.hip reads.  The two layers that consume y2 — the first LSTM projection and tdnn1 — ran on
+// gemm_split_kernel with this arithmetic in their operand-staging prologue (norm-on-load): per 32-wide k-tile every
+// workgroup normalised and split its rows again (tdnn1: each row five times, once per tap; proj0: once per 128-column
+// tile, eight times), on the vector units that the MFMAs of the same SIMD then wait for — 52 / 36 us
+// for 5.7 / 2.3 GFLOP.  After this 4.8 MB pass both run on the pre-split GEMM like every other wide layer.
+// grid (ceil(P / 32), B), 256 threads: 32 rows x 64 channels per workgroup, 8 channels per thread.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void norm_split_kernel(const float* __restrict__ y, const float* __restrict__ part,
+                                                         int ntile, int P, const float* __restrict__ gamma,
+                                                         const float* __restrict__ beta, unsigned short* __restrict__ planes,
+                                                         long long plane, int* oflag) {
+    __shared__ __attribute__((aligned(16))) float nrm_s[128];          // scale[64] | shift[64]
+    __shared__ double scratch[2 * 4 * 64];                              // dz_norm_from_partials: 2 G C doubles, G = 256 / 64
+    const int tid = threadIdx.x, b = blockIdx.y;
+    dz_norm_from_partials(part, b, ntile, 64, P, gamma, beta, nrm_s, tid, 256, scratch);
+    __syncthreads();
+    const int row = blockIdx.x * 32 + (tid >> 3), c = (tid & 7) * 8;
+    if (row >= P) return;
+    const long long R = plane >> 6, r = (long long)b * P + row;         // rows of a plane, this row
+    const float* x = y + r * 64 + c;
+    const f32x4 v0 = *reinterpret_cast<const f32x4*>(x), v1 = *reinterpret_cast<const f32x4*>(x + 4);
+    const f32x4 s0 = *reinterpret_cast<const f32x4*>(nrm_s + c), s1 = *reinterpret_cast<const f32x4*>(nrm_s + c + 4);
+    const f32x4 h0 = *reinterpret_cast<const f32x4*>(nrm_s + 64 + c), h1 = *reinterpret_cast<const f32x4*>(nrm_s + 64 + c + 4);
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        v[e] = leaky(v0[e] * s0[e] + h0[e]);
+        v[4 + e] = leaky(v1[e] * s1[e] + h1[e]);
+    }
+    float amax = 0.f;
+    u32x4 hi, lo;
+    split8(v, hi, lo, amax);
+    const long long idx = dz_kb(r, c, R);                               // eight columns of one k-block row: 16 bytes per plane
+    *reinterpret_cast<u32x4*>(planes + idx) = hi;
+    *reinterpret_cast<u32x4*>(planes + plane + idx) = lo;
+    dz_flag_range(oflag, amax);
+}
+
 }  // namespace
 
 int dz_launch_gemm_split(const DzConvGemm& p_in, hipStream_t st) {
@@ -384,4 +425,16 @@ int dz_launch_gemm_split(const DzConvGemm& p_in, hipStream_t st) {
 #undef DZ_SP
     dz_set_error("gemm_split: epilogue %d is not built on the split-f16 path", p.epi);
     return 2;
+}
+
+// y2 [B][P][64] (raw) + part [B][ntile][64][2] + InstanceNorm affine -> planes [2][B * P rows][64] kb-major (see norm_split_kernel)
+int dz_launch_norm_split(const float* y, const float* part, int ntile, int P, const float* gamma, const float* beta,
+                         void* planes, long long plane, int B, hipStream_t st) {
+    DZ_REQUIRE(y && part && gamma && beta && planes, "norm_split: NULL argument");
+    DZ_REQUIRE(B >= 1 && P >= 1 && ntile >= 1 && plane >= (long long)B * P * 64 && plane % 64 == 0,
+               "norm_split: bad geometry (B %d, P %d, plane %lld)", B, P, plane);
+    DZ_LAUNCH(norm_split_kernel, dim3((P + 31) / 32, B), dim3(256), 0, st, y, part, ntile, P, gamma, beta,
+              reinterpret_cast<unsigned short*>(planes), plane, dz_cur_oflag);
+    DZ_HIP(hipGetLastError());
+    return 0;
 }

@@ -336,7 +336,7 @@ class PackedSegmentation:
         g = lambda k: sd[k].detach().cpu().float()
         w = _lib.SegWeights()
         w.sinc = _pack_sincnet(sd, pk, split=split)
-        self._split, self._lstm = split, []
+        self._split, self._lstm, self._wih0_kb = split, [], {}
         for layer in range(4):
             # rows of the stacked W_ih (and the bias) go unit-major, dir*512 + unit*4 + gate, so the
             # x-projection GEMM writes the four gates of a unit next to each other and the recurrence
@@ -368,6 +368,8 @@ class PackedSegmentation:
             w.num_speakers = s
         else:
             w.num_speakers = ncls
+        if split:
+            w.wih0_split_kb = self._wih0_kb[""]
         self.pack = pk
         self.num_speakers = int(w.num_speakers)
         self._structs = {"valu": w}
@@ -379,6 +381,8 @@ class PackedSegmentation:
         kpad = 64 if layer == 0 else 256
         # layer 0 runs on k_gemm_split.hip (row-major planes), layers 1..3 on k_gemm_pre.hip (kb-major)
         sp = pk.put_split(_pad2(wm, 1024, kpad), f"lstm.weight_ih_l{layer}{tag}", kb=layer > 0) if self._split else None
+        if layer == 0 and self._split:      # ... and kb-major too: the first projection behind the norm + split pass (round 6)
+            self._wih0_kb[tag] = pk.put_split(_pad2(wm, 1024, kpad), f"lstm.weight_ih_l0{tag} (kb)", kb=True)
         return pk.put(_pad2(wm, 1024, kpad)), sp, pk.put(bv)
 
     def struct_for(self, recurrence: Optional[str]):
@@ -398,6 +402,8 @@ class PackedSegmentation:
                 if v == 4:        # its x-projection carries the gates' activation scales
                     got.wih[layer], got.wih_split[layer], got.bih[layer] = self._put_proj(
                         self.pack, layer, lstm_scale_gx(wih), lstm_scale_gx(bias), " (scaled)")
+                    if layer == 0:
+                        got.wih0_split_kb = self._wih0_kb[" (scaled)"]
             got.lstm_variant = v
             self._structs[r] = got
         return got
@@ -438,6 +444,8 @@ class PackedEmbedding:
             if split:
                 # tdnn1 runs on k_gemm_split.hip (row-major planes), tdnn2..5 on k_gemm_pre.hip (kb-major)
                 w.tw_split[i] = pk.put_split(_conv_pack(cw, cin_pad, npad, (k + 31) // 32 * 32), f"tdnn{i + 1}", kb=i > 0)
+                if i == 0:      # ... and kb-major too: tdnn1 behind the norm + split pass (round 6)
+                    w.tw0_split_kb = pk.put_split(_conv_pack(cw, cin_pad, npad, (k + 31) // 32 * 32), "tdnn1 (kb)", kb=True)
             w.tb[i] = pk.put(_pad1(g(f"tdnns.{3 * i}.bias"), npad))
             bn = f"tdnns.{3 * i + 2}."
             scale = g(bn + "weight") / torch.sqrt(g(bn + "running_var") + BN_EPS)

@@ -115,6 +115,9 @@ typedef struct {
                                     in, H scaled by 2^0 / 2^8; 4 = the software-pipelined kernel: gate rows times
                                     -log2(e) (i, f, o) / -2 log2(e) (g), columns in the kernel's k' order, AND
                                     wih / wih_split / bih carry the same row scales (gx arrives pre-scaled)      */
+    const void* wih0_split_kb;   /* W_ih of layer 0 once more as kb-major planes [2][64 / 32][1024][32] (optional): the first
+                                    projection then reads the SincNet output as planes a one-off norm_split_kernel wrote
+                                    and runs on k_gemm_pre.hip like layers 1..3 (see dz_emb_weights.tw0_split_kb)        */
 } dz_seg_weights;
 
 typedef struct {
@@ -128,6 +131,9 @@ typedef struct {
     int dimension;               /* D = 512 */
     const void* tw_split[5];     /* split-f16 planes of tw[i] (optional, NULL = exact f32): tw_split[0] row-major
                                     [2][Npad][Kpad], tw_split[1..4] kb-major (see dz_seg_weights)  */
+    const void* tw0_split_kb;    /* tdnn1's planes once more in the kb-major order (optional): with them — and the SincNet's fused
+                                    norms — the last SincNet stage's output is normalised and split ONCE (norm_split_kernel)
+                                    and tdnn1 runs on the pre-split GEMM (k_gemm_pre.hip) like tdnn2..5                     */
     int pool_nearest;            /* how StatsPool resamples the (N, Fw) pooling weights to the T feature frames: 0 =
                                     F.interpolate(mode="linear", align_corners=False) (pyannote.audio 2.x .. 3.0),
                                     1 = mode="nearest" (pyannote.audio >= 3.1)                                     */
