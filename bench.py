@@ -1160,6 +1160,9 @@ def main():
     host_line = {"cpu_ms_per_step": round(host["cpu_ms_per_step"], 3), "launch_ms_per_step": round(host["launch_ms_per_step"], 3),
                  "step_period_ms_in_timed_region": host["step_period_ms"],
                  "clustering_tail_wall_ms_per_step": round(host["work_ms_per_step"], 3), "threads": host_threads,
+                 # (details file only) the launch-to-launch gaps of the headline pass: with `steps_in_flight` launched ahead the
+                 # host launches in bursts and then waits for the oldest step — max ~ steps_in_flight x the step
+                 "step_gaps_ms_in_timed_region": list(host["step_gaps_ms"]),
                  "usable_cores": usable,
                  "note": "CPU time of all threads of the rank per step (launching thread + worker pool) in the timed region"}
 

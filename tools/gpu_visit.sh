@@ -108,6 +108,9 @@ verify_dry)  # tools/verify_real.py end to end on a stand-in corpus (synthetic c
   timeout -s KILL 600 python tools/verify_real.py --ckpt $OUT/dry/ckpt --ami $OUT/dry/ami --out $OUT/dry/run2 --skip-gates --expected $OUT/dry/expected.rttm 2>&1 | grep "der_vs_reference_hypothesis\|files_compared" | cut -c1-200
   cp $OUT/dry/run2/verify_real.json $OUT/verify_real_dry_run.json; rm -rf $OUT/dry ;;
 collect)     # LOCAL: judged copies
+  for f in bench_8_ranks.json bench_2_ranks.json; do      # (gloo prints its own lines on stdout in the rehearsal: keep the bench line)
+    [ -f $OUT/$f ] && last_json $OUT/$f > $OUT/$f.tmp && mv $OUT/$f.tmp $OUT/$f
+  done
   for f in bench_driver.json bench_driver_details.json bench_200.json kernels_events_bench_run.json kernel_stats_f16x3.md kernel_stats_f32.md \
            rocprofv3_kernel_stats_f16x3.csv rocprofv3_kernel_stats_f32.csv kernels_events_rocprof_run_f16x3.json kernels_events_rocprof_run_f32.json \
            rocprofv3_kernel_stats_serial_f16x3.csv rocprofv3_kernel_stats_serial_f32.csv kernel_stats_serial_f16x3.md kernel_stats_serial_f32.md \
