@@ -217,10 +217,11 @@ __device__ __forceinline__ void gemm_pre_tile(const DzConvGemm& p, const int t0,
         };
         int soff_next = 0, stage_next = 0;
         const bool no_dma = flags & 2, no_rd = flags & 4;           // TIMING EXPERIMENTS (DZ_GP_DBG, wrong results)
+        const bool skip_a = (flags & 32) && !isB;                   // ... 32: the activation pieces of taps > 0 are not fetched (what re-using one fetch per channel block would save)
         auto piece = [&](int j) {                                   // j = 0..7: pieces r2 + 2j of "8 hi, then 8 lo"
             const int lo = j >= 4, i = r2 + 2 * (j & 3);            // i-th 16-row block of the plane (r2 folded into bases)
             (void)i;
-            if (no_dma) return;
+            if (no_dma || (skip_a && tap != 0 && cblk > 0)) return;       // (the first channel block fills both stages with finite data)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(lo ? rs_lo : rs_hi,
                 (__attribute__((address_space(3))) void*)(dbase + stage_next * STAGE + lo * dplane + (j & 3) * 2048), 16,
                 vofs + (j & 3) * 2 * vstep, soff_next, 0, 0);
