@@ -244,6 +244,10 @@ def parse():
     ap.add_argument("--serial-steps", type=int, default=8,
                     help="steps of the serialised roofline pass (one lane, one HIP stream, every launch bracketed: a kernel's "
                          "duration there is its alone-time, what rocprofv3 --kernel-trace --stats of the same pass reports); 0 = off")
+    ap.add_argument("--overlap-brackets", action="store_true",
+                    help="also bracket every 10th step of the TIMED passes (per-kernel durations while the lanes overlap -> "
+                         "`roofline_kernels_overlapped` in the details file, --kernel-table); off by default: the roofline comes "
+                         "from the serialised pass, and event pairs on a timed step cost it ~15 %")
     ap.add_argument("--serial-only", action="store_true",
                     help="run ONLY the serialised roofline pass (the command profiles/*_rocprofv3_kernel_stats_serial_*.csv are traces of)")
     ap.add_argument("--no-exact-f32", action="store_true",
@@ -560,6 +564,8 @@ def build_roofline(table, precision, n_sampled, pmc):
         return e
 
     per_kernel = [entry(g, v) for g, v in sorted(groups.items(), key=lambda kv: -kv[1]["ms"])]
+    if not per_kernel:            # (no brackets were taken on this pass)
+        return None, []
     # share of the chip's CU-time (total time x the fraction of the 256 CUs the launches occupy): reported next to
     # the share of kernel time, never used to choose
     cu_time = {e["kernel"]: groups[e["kernel"]]["ms"] * min(1.0, e.get("cus_occupied", 256.0) / 256.0) for e in per_kernel}
@@ -988,6 +994,8 @@ def main():
 
     # every 10th step of the timed region carries the per-kernel event pairs (DZ_PROF_EVERY=1: all)
     PROF_EVERY = max(1, int(os.environ.get("DZ_PROF_EVERY", "10")))
+    # brackets on the TIMED passes: only on request (or when the serialised pass is off and something has to feed the roofline)
+    BRACKETS = (args.overlap_brackets or args.serial_steps <= 0 or bool(args.kernel_table)) and not os.environ.get("DZ_NO_PROF")
     sampled = [0]
     stamps = []                    # host clock at every launch (the timed passes report the spread of the step period)
 
@@ -1054,7 +1062,7 @@ def main():
     # stream that carry such events are a start-up cost of the runtime (seen once as a ~11 ms launch call inside a
     # 25 ms timed region: 17 718 xRT on a box whose untouched passes of the same run gave 24 400 - 27 200): pay it here
     def prof_warm(p):
-        if not os.environ.get("DZ_NO_PROF"):
+        if BRACKETS:
             lib.dz_prof_enable(1)
             run(0, min(total_steps, 2 * p.max_inflight), p, profiled=True, every=1)      # every lane's streams
             lib.dz_prof_collect()
@@ -1069,7 +1077,7 @@ def main():
     # the timed region below is exactly K full steps on windows of its own.
     settle = int(os.environ.get("DZ_SETTLE_STEPS", "150"))
     if settle > 0:
-        prof_on = not os.environ.get("DZ_NO_PROF")
+        prof_on = BRACKETS
         lib.dz_prof_enable(1 if prof_on else 0)
         done_ = 0
         while done_ < settle:
@@ -1088,7 +1096,7 @@ def main():
     def timed_pass(p, label):
         """K timed steps of pipeline `p` (barrier + synchronize on both sides, max over ranks) with the
         per-kernel event pairs on every PROF_EVERY-th step -> (elapsed s, kernel table, sampled steps)."""
-        prof = not os.environ.get("DZ_NO_PROF")
+        prof = BRACKETS
         lib.dz_prof_enable(1 if prof else 0)
         sampled[0] = 0
         host["launch"] = host["finish"] = 0.0
@@ -1331,8 +1339,9 @@ def main():
             "roofline_kernels": per_kernel, "roofline_kernels_overlapped": per_kernel_ovl,
             "roofline_sampling": (f"`roofline*`: the serialised pass ({serial[1]} steps on one lane / one HIP stream, every launch "
                                   f"bracketed, {serial[2]:.3f} ms per step); " if serial else "") +
-                                 f"`roofline_kernels_overlapped`: {n_sampled} of the {args.steps} timed steps (every {PROF_EVERY}th) "
-                                 "carried the per-kernel event pairs while the lanes overlap",
+                                 (f"`roofline_kernels_overlapped`: {n_sampled} of the {args.steps} timed steps (every {PROF_EVERY}th) "
+                                  "carried the per-kernel event pairs while the lanes overlap" if n_sampled else
+                                  "the timed passes carry no event pairs (--overlap-brackets takes them on every 10th step)"),
             "exact_f32": exact,
             "host_fed": host_fed,
             "host": host_line,
