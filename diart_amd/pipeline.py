@@ -173,7 +173,8 @@ class StreamBatch:
         ``recurrence``: the LSTM recurrence kernel, "valu" | "0" | "3" | "4" — default: the matrix-core kernel of
         ``weights.THROUGHPUT_LSTM_VARIANT`` for a throughput engine (>= 64 streams per step, default precision),
         else the model's own;
-        ``inflight``: steps a throughput caller keeps between ``launch`` and ``finish`` (default lanes + 1);
+        ``inflight``: steps a throughput caller keeps between ``launch`` and ``finish`` (default lanes + 1; lanes + 2 for a
+        throughput engine);
         ``wait``: how the host waits for a step, "spin" | "block" | "auto" (by the cores this rank has);
         ``warmup``: warm steps on silence before the first real step of a window size (default 10, 0 = off);
         ``serial``: MEASUREMENT engine — one lane whose segmentation and embedding chains share ONE HIP stream, so
@@ -232,7 +233,10 @@ class StreamBatch:
         # step starts the moment the previous one ends instead of after the host has come back from
         # finish() (clustering of an older step + launch overhead: ~0.5 ms per step, during which the
         # lane's segmentation stream sat empty).
-        self.max_inflight = max(self.depth, int(setting("inflight", inflight, self.depth + 1, int)))
+        # Round 6: a throughput engine keeps lanes + 2 (the second spare ticket covers the host's own launch + tail time of
+        # a step: +3 % in the 20-step form, profiles/r06l_inflight_grid.json); the two-lane engines keep lanes + 1.
+        spare = 2 if (self.throughput or (matrix_core and num_streams >= 64)) else 1
+        self.max_inflight = max(self.depth, int(setting("inflight", inflight, self.depth + spare, int)))
         self.warmup_steps = max(0, int(setting("warmup", warmup, 10, int)))
         # DZ_SHARED_EMB=1: ONE set of embedding streams serves every lane in step order and the
         # pooling of step t is enqueued `lag` = depth - 1 launches later, behind the frame features
