@@ -30,7 +30,7 @@ driver2)     # twice more, short form (no PMC children, no CPU leg): run-to-run 
     cut -c1-200 $OUT/bench_driver_short_$i.json
   done ;;
 long)        # 200 timed steps
-  timeout -s KILL 600 python bench.py --steps 200 --warmup 10 --pmc off --no-cpu-baseline --no-rehearsal --kernel-table $OUT/kernels_events_bench_run.json --details $OUT/bench_200_details.json > $OUT/bench_200.json 2> $OUT/bench_200.err
+  timeout -s KILL 600 python bench.py --steps 200 --warmup 10 --pmc off --no-cpu-baseline --no-rehearsal --details $OUT/bench_200_details.json > $OUT/bench_200.json 2> $OUT/bench_200.err
   echo "exit $?"; cut -c1-260 $OUT/bench_200.json ;;
 rocprof)     # rocprofv3 --kernel-trace --stats of the bench command, both precisions
   cd /tmp
