@@ -56,7 +56,8 @@ constexpr size_t lds_bytes(int MW) { return 2 * (size_t)stage_bytes(MW) + 3 * BN
 constexpr int MW_BIG = 6;                  // 384 x 128 tiles, 12 waves, one workgroup per CU
 constexpr float LO_UNSCALE = 1.f / 2048.f;
 
-__device__ __forceinline__ float leaky(float v) { return v > 0.f ? v : v * DZ_LEAKY_SLOPE; }
+// (slope < 1: max(v, slope v) is v for v > 0 and slope v otherwise — the same values as the select, one instruction less)
+__device__ __forceinline__ float leaky(float v) { return fmaxf(v, v * DZ_LEAKY_SLOPE); }
 
 // One output tile of (32 MT MW) x (64 NT): MW x 2 waves, MT x NT fragments of 32 x 32 per wave.
 // LDS of the pooled epilogue (after the k-loop): the f32 output tile [128][YT_PITCH] over the two stages,
@@ -326,6 +327,78 @@ __device__ __forceinline__ void gemm_pre_tile(const DzConvGemm& p, const int t0,
     float amax = 0.f;
     float* yt = reinterpret_cast<float*>(smem);
     if (POOL) __syncthreads();        // every wave is done with the last k-tile: the tile buffer reuses the stages
+    // Round 6: the common cases — the whole tile inside the stored columns, ONE kind of output — without a single
+    // per-element test.  The general loop below carries eight compare / select pairs, four exec-masked regions and
+    // two 64-bit address computations per group of four columns (2 000 instructions for the 64 values of a lane,
+    // run beside the other workgroup's MFMAs on the same issue ports: plane output cost 10 % of a tdnn layer over
+    // f32 output).  Here the stores are buffer stores: the k-block of a column group is a scalar offset, the four
+    // groups of a 32-column block immediates, a row beyond Tout an out-of-range offset the hardware drops.
+    if constexpr (!POOL) {
+        const bool whole = n0 + 64 * NT <= p.Nstore;
+        const long long ybytes = Yhi ? 2 * (long long)yrows * p.ldy : 4 * (long long)p.Tout * p.ldy;
+        if (whole && (Yhi != nullptr) != (p.Y != nullptr) && ybytes < (1ll << 31) && !(flags & 64)) {
+            const unsigned nrec = __builtin_amdgcn_readfirstlane((unsigned)ybytes);
+            const __amdgpu_buffer_rsrc_t r0 = __builtin_amdgcn_make_buffer_rsrc(Yhi ? (void*)Yhi : (void*)p.Y, 0, nrec, 0x00020000);
+            const __amdgpu_buffer_rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc(Yhi ? (void*)(Yhi + p.yplane) : (void*)p.Y, 0, nrec, 0x00020000);
+            typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+            typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+            const float* parl = par + wn * 32 * NT + 4 * g;
+            auto sweep = [&](auto planes_c) {
+                constexpr bool PL = decltype(planes_c)::value;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const int t = t0 + wm * 32 * MT + mt * 32 + li;
+                const bool ok = t < p.Tout;
+                float am = 0.f;
+                // planes: ((k-block) * rows + t) * 64 bytes + (column & 31) * 2; f32: (t * ldy + column) * 4
+                const int vo = !ok ? (int)0x80000000 : PL ? t * 64 + 8 * g : (t * p.ldy + 4 * g) * 4;
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    const int cb = n0 + wn * 32 * NT + nt * 32;                  // first column of the 32-column block
+                    const int so = __builtin_amdgcn_readfirstlane(PL ? (cb >> 5) * (int)yrows * 64 : cb * 4);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        asm volatile("" ::: "memory");
+                        const float* pg = parl + nt * 32 + 8 * k;        // one base register, immediate offsets
+                        const f32x4 bv = *reinterpret_cast<const f32x4*>(pg);
+                        f32x4 e0 = {1.f, 1.f, 1.f, 1.f}, e1 = {0.f, 0.f, 0.f, 0.f};
+                        if (EPI == DZ_EPI_TDNN || EPI == DZ_EPI_RELU_BN) {
+                            e0 = *reinterpret_cast<const f32x4*>(pg + BN);
+                            e1 = *reinterpret_cast<const f32x4*>(pg + 2 * BN);
+                        }
+                        f32x4 v;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            float x = (accm[mt][nt][4 * k + e] + accx[mt][nt][4 * k + e] * LO_UNSCALE) + bv[e];
+                            if (EPI == DZ_EPI_BIAS_LEAKY) x = leaky(x);
+                            if (EPI == DZ_EPI_TDNN) x = leaky(x) * e0[e] + e1[e];
+                            if (EPI == DZ_EPI_RELU_BN) x = fmaxf(x, 0.f) * e0[e] + e1[e];
+                            v[e] = x;
+                        }
+                        if constexpr (!PL) {
+                            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r0, vo + 32 * k, so, 0);
+                        } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            am = fmaxf(am, fabsf(v[e]));
+                            v[e] = __builtin_amdgcn_fmed3f(v[e], -65504.f, 65504.f);
+                        }
+                        asm volatile("" : "+v"(am));        // (or the maxima sink into `if (ok)` below and every group's values stay live)
+                        const f16x4 hi = __builtin_convertvector(v, f16x4);
+                        const f16x4 lo = __builtin_convertvector((v - __builtin_convertvector(hi, f32x4)) * 2048.f, f16x4);
+                        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, hi), r0, vo + 16 * k, so, 0);
+                        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, lo), r1, vo + 16 * k, so, 0);
+                        }
+                    }
+                }
+                if (ok) amax = fmaxf(amax, am);
+            }
+            };
+            if (Yhi) sweep(std::true_type{}); else sweep(std::false_type{});
+            dz_flag_range(p.oflag, amax);
+            return;
+        }
+    }
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
         const int t = t0 + wm * 32 * MT + mt * 32 + li;
