@@ -343,15 +343,20 @@ __device__ __forceinline__ void gemm_pre_tile(const DzConvGemm& p, const int t0,
             typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
             typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
             const float* parl = par + wn * 32 * NT + 4 * g;
-            auto sweep = [&](auto planes_c) {
-                constexpr bool PL = decltype(planes_c)::value;
+            // KIND 0: f32 output; 1: planes, one 8-byte store per group and plane; 2 (default): planes, the lanes of a
+            // row (g = 0, 1) exchange every second group through v_permlane32_swap so that each holds EIGHT consecutive
+            // columns: one 16-byte store per pair of groups and plane, 32 contiguous bytes per row and instruction
+            auto sweep = [&](auto kind_c) {
+                constexpr int KIND = decltype(kind_c)::value;
+                constexpr bool PL = KIND != 0;
+                u32x2 ph = {0u, 0u}, pw = {0u, 0u};
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
                 const int t = t0 + wm * 32 * MT + mt * 32 + li;
                 const bool ok = t < p.Tout;
                 float am = 0.f;
                 // planes: ((k-block) * rows + t) * 64 bytes + (column & 31) * 2; f32: (t * ldy + column) * 4
-                const int vo = !ok ? (int)0x80000000 : PL ? t * 64 + 8 * g : (t * p.ldy + 4 * g) * 4;
+                const int vo = !ok ? (int)0x80000000 : KIND == 2 ? t * 64 + 16 * g : KIND == 1 ? t * 64 + 8 * g : (t * p.ldy + 4 * g) * 4;
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) {
                     const int cb = n0 + wn * 32 * NT + nt * 32;                  // first column of the 32-column block
@@ -386,15 +391,35 @@ __device__ __forceinline__ void gemm_pre_tile(const DzConvGemm& p, const int t0,
                         asm volatile("" : "+v"(am));        // (or the maxima sink into `if (ok)` below and every group's values stay live)
                         const f16x4 hi = __builtin_convertvector(v, f16x4);
                         const f16x4 lo = __builtin_convertvector((v - __builtin_convertvector(hi, f32x4)) * 2048.f, f16x4);
-                        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, hi), r0, vo + 16 * k, so, 0);
-                        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, lo), r1, vo + 16 * k, so, 0);
+                        if constexpr (KIND == 1) {
+                            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, hi), r0, vo + 16 * k, so, 0);
+                            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, lo), r1, vo + 16 * k, so, 0);
+                        } else if ((k & 1) == 0) {
+                            ph = __builtin_bit_cast(u32x2, hi);
+                            pw = __builtin_bit_cast(u32x2, lo);
+                        } else {
+                            // even group in ph / pw, odd group here: the upper half-wave's even group <-> the lower's odd
+                            const u32x2 ch = __builtin_bit_cast(u32x2, hi), cw = __builtin_bit_cast(u32x2, lo);
+                            u32x4 oh, ow;
+#pragma unroll
+                            for (int d = 0; d < 2; ++d) {
+                                const auto sh = __builtin_amdgcn_permlane32_swap(ph[d], ch[d], false, false);
+                                const auto sw2 = __builtin_amdgcn_permlane32_swap(pw[d], cw[d], false, false);
+                                oh[d] = sh[0]; oh[2 + d] = sh[1];
+                                ow[d] = sw2[0]; ow[2 + d] = sw2[1];
+                            }
+                            __builtin_amdgcn_raw_buffer_store_b128(oh, r0, vo + 32 * (k >> 1), so, 0);
+                            __builtin_amdgcn_raw_buffer_store_b128(ow, r1, vo + 32 * (k >> 1), so, 0);
+                        }
                         }
                     }
                 }
                 if (ok) amax = fmaxf(amax, am);
             }
             };
-            if (Yhi) sweep(std::true_type{}); else sweep(std::false_type{});
+            if (!Yhi) sweep(std::integral_constant<int, 0>{});
+            else if (flags & 128) sweep(std::integral_constant<int, 1>{});
+            else sweep(std::integral_constant<int, 2>{});
             dz_flag_range(p.oflag, amax);
             return;
         }
