@@ -881,6 +881,18 @@ def config1(args):
 
 def main():
     args = parse()
+    if os.environ.get("DZ_BENCH_SCHED"):               # experiment: fifo:<prio> | nice:<n> for every thread created from here on
+        kind, _, val = os.environ["DZ_BENCH_SCHED"].partition(":")
+        try:
+            if kind == "fifo":
+                os.sched_setscheduler(0, os.SCHED_FIFO, os.sched_param(int(val or 1)))
+            elif kind == "rr":
+                os.sched_setscheduler(0, os.SCHED_RR, os.sched_param(int(val or 1)))
+            elif kind == "nice":
+                os.nice(int(val or -10))
+            print(f"[bench] scheduling: {kind} {val} applied", file=sys.stderr, flush=True)
+        except Exception as exc:      # noqa: BLE001
+            print(f"[bench] scheduling: {kind} {val} refused: {exc!r}", file=sys.stderr, flush=True)
     if args.cpu_worker:
         return cpu_baseline_worker(args.cpu_chunks, args.cpu_threads, 20.0)
     if args.config == 3:
@@ -978,6 +990,10 @@ def main():
                          inflight=args.inflight or None)
         if p_.recurrence:
             RECURRENCE[prec] = p_.recurrence
+        if os.environ.get("DZ_LAUNCH_TRACE"):
+            p_.slow_launches = []
+        if os.environ.get("DZ_BENCH_D2H") == "memcpy":       # A/B arm: results by hipMemcpyAsync as before round 6
+            p_.d2h_by_kernel = False
         return p_
 
     if args.serial_only:
@@ -1015,12 +1031,15 @@ def main():
             h1 = time.perf_counter()
             if len(inflight) >= pipe.max_inflight:
                 pipe.finish(inflight.pop(0), want_scores=True)
+            h2 = time.perf_counter()
             host["launch"] += h1 - h0
-            host["finish"] += time.perf_counter() - h1
+            host["finish"] += h2 - h1
+            parts.append((h1 - h0, h2 - h1, pipe.host_seconds["wait"], pipe.host_seconds["work"]))
         while inflight:
             pipe.finish(inflight.pop(0), want_scores=True)
 
     main_pipe = [pipe]
+    parts = []                     # per launched step: (launch s, finish s, cumulative wait s, cumulative work s)
 
     def barrier():
         if world > 1:
@@ -1037,6 +1056,8 @@ def main():
     import gc
     gc.collect()
     gc.freeze()
+    if os.environ.get("DZ_BENCH_GC") == "0":          # experiment: no cyclic collections at all from here on
+        gc.disable()
     # ---- size the host threads from what the second batch of settling steps measures -----------
     n_settle = min(total_steps, 10)
     host["launch"] = host["finish"] = 0.0
@@ -1103,12 +1124,19 @@ def main():
         p.host_seconds["wait"] = p.host_seconds["work"] = 0.0
         cpu0 = time.process_time()                     # CPU time of every thread of this process
         del stamps[:]
+        del parts[:]
         el = D.timed_max_over_ranks(lambda: run(args.warmup, args.steps, p, profiled=prof), device)
         gaps = np.diff(np.asarray(stamps)) * 1e3 if len(stamps) > 2 else np.zeros(1)
         # launch-to-launch period of the host loop inside the timed region: a one-off stall (runtime, OS) shows up as
         # max >> p50 — `value` is still total / K, as the contract says
         host["step_period_ms"] = {"p50": round(float(np.median(gaps)), 3), "max": round(float(gaps.max()), 3)}
         host["step_gaps_ms"] = [round(float(g), 3) for g in gaps]        # details file only (where a stall sits)
+        # ... and what the host was doing in the slow periods: (step, period, launch, waiting for the GPU, clustering / tail) ms
+        pw = np.diff(np.asarray([0.0] + [q[2] for q in parts])) if parts else np.zeros(0)
+        pk = np.diff(np.asarray([0.0] + [q[3] for q in parts])) if parts else np.zeros(0)
+        host["slow_periods_ms"] = [[int(i), round(float(gaps[i]), 2), round(1e3 * parts[i][0], 2), round(1e3 * float(pw[i]), 2),
+                                    round(1e3 * float(pk[i]), 2)] for i in range(min(len(gaps), len(parts)))
+                                   if gaps[i] > 3.0 * max(0.1, float(np.median(gaps)))][:40]
         host["cpu_ms_per_step"] = 1e3 * (time.process_time() - cpu0) / args.steps
         host["launch_ms_per_step"], host["work_ms_per_step"] = 1e3 * host["launch"] / args.steps, 1e3 * p.host_seconds["work"] / args.steps
         hs = p.host_seconds
@@ -1171,6 +1199,8 @@ def main():
                  # (details file only) the launch-to-launch gaps of the headline pass: with `steps_in_flight` launched ahead the
                  # host launches in bursts and then waits for the oldest step — max ~ steps_in_flight x the step
                  "step_gaps_ms_in_timed_region": list(host["step_gaps_ms"]),
+                 "slow_periods_ms_step_period_launch_wait_work": list(host.get("slow_periods_ms", [])),
+                 "slow_launches_ms_by_call": (getattr(pipe, "slow_launches", None) or [])[-20:],
                  "usable_cores": usable,
                  "note": "CPU time of all threads of the rank per step (launching thread + worker pool) in the timed region"}
 

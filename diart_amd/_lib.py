@@ -101,6 +101,7 @@ SIGNATURES = {
     "dz_osp": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_int,
                          C.c_int, vp, vp]),
     "dz_l2_normalize": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_float, vp]),
+    "dz_results_to_host": (C.c_int, [vp, vp, vp, C.c_longlong, vp, vp, C.c_longlong, vp]),
     "dz_cdist_cosine": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]),
     "dz_clu_create": (C.c_int, [C.c_double, C.c_double, C.c_double, C.c_int, C.POINTER(vp)]),
     "dz_clu_reset": (C.c_int, [vp]),

@@ -126,6 +126,46 @@ __global__ __launch_bounds__(256) void ring_gather_kernel(const float* __restric
     *reinterpret_cast<f32x4*>(out + (long long)jrow * ostride + 4 * j) = *reinterpret_cast<const f32x4*>(src);
 }
 
+// ---------------------------------------------------------------------------
+// A step's results -> pinned host memory with ONE kernel (stores over the host link; pinned memory is mapped at
+// its own address).  Why not hipMemcpyAsync: on this runtime a device-to-host copy call now and then blocks its
+// caller until everything queued on that stream has run — measured in `StreamBatch`: about once per 150 steps
+// the D2H copy at the end of a step's launch sat 6 - 13 ms in the call (a whole step's latency under load; the
+// segmentation copy or the embedding copy, never the kernel launches or the event calls around them), the
+// host fed nothing meanwhile and the eight steps in flight drained: -3 to -7 % on a 200-step run, 8 ms of a 19 ms
+// driver-form region (profiles/r06z_launch_stalls.json).  A kernel launch does not take that path.
+// Replaces the two `.cpu()` of /root/reference/src/diart/blocks/segmentation.py:47 and blocks/embedding.py:68.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void results_to_host_kernel(const float* __restrict__ a, float* __restrict__ ha,
+                                                              long long na, const float* __restrict__ b,
+                                                              float* __restrict__ hb, long long nb) {
+    long long i = (long long)blockIdx.x * 256 + threadIdx.x;          // 16-byte piece of (a | b)
+    const long long pa = (na + 3) / 4;
+    const float* src = a;
+    float* dst = ha;
+    long long n = na;
+    if (i >= pa) { i -= pa; src = b; dst = hb; n = nb; }
+    if (4 * i + 3 < n) {
+        reinterpret_cast<f32x4*>(dst)[i] = reinterpret_cast<const f32x4*>(src)[i];
+    } else {
+        for (long long j = 4 * i; j < n; ++j) dst[j] = src[j];
+    }
+}
+
+extern "C" int dz_results_to_host(dz_ctx* ctx, const float* d_a, float* h_a, long long n_a, const float* d_b,
+                                  float* h_b, long long n_b, void* stream) {
+    DZ_REQUIRE(ctx && d_a && h_a && n_a >= 1, "dz_results_to_host: NULL / empty first buffer");
+    DZ_REQUIRE(n_b >= 0 && (n_b == 0 || (d_b && h_b)), "dz_results_to_host: NULL second buffer");
+    DZ_REQUIRE((((uintptr_t)d_a | (uintptr_t)h_a | (uintptr_t)d_b | (uintptr_t)h_b) & 15) == 0,
+               "dz_results_to_host: buffers must be 16-byte aligned");
+    DZ_HIP(hipSetDevice(ctx->device));
+    const long long pieces = (n_a + 3) / 4 + (n_b + 3) / 4;
+    DZ_LAUNCH(results_to_host_kernel, dim3((unsigned)((pieces + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+              d_a, h_a, n_a, d_b, h_b, n_b);
+    DZ_HIP(hipGetLastError());
+    return 0;
+}
+
 extern "C" int dz_ring_destroy(dz_ring* r) {
     if (r) {
         if (r->buf) (void)hipFree(r->buf);

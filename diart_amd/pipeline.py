@@ -25,6 +25,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import time as _time
 from typing import List, Optional, Sequence, Tuple
 
 import numpy as np
@@ -301,6 +302,9 @@ class StreamBatch:
         self._pending: List[dict] = []                     # launched, pooling not enqueued yet
         # where finish() spends its time: waiting for the GPU vs clustering + output tail on the host
         self.host_seconds = {"wait": 0.0, "work": 0.0}
+        # measurement (bench.py sets it to a list): launches that took the host more than 2 ms, by the call they sat in
+        self.slow_launches: Optional[list] = None
+        self.d2h_by_kernel = True          # (False: the hipMemcpyAsync pair, kept for the A/B of profiles/r06z_launch_stalls.json)
         self._sub: dict = {}
         self._warmed: set = set()
         self._warming, self._real_steps = False, 0       # (see _warm_up)
@@ -438,6 +442,7 @@ class StreamBatch:
             self._real_launches += 1
         lane = self.lanes[self._t % self.depth]
         hsegs, hembs, _, _ = self._handles(S, self._t % self.depth)
+        marks = [("start", _time.perf_counter())] if self.slow_launches is not None else None
         # sub-batch ranges of THIS step's rows (each at most the capacity its handle was built for)
         sa, sb = self._ranges(N, self.seg_split), self._ranges(N, self.emb_split)
         K = self.seg.num_speakers
@@ -465,6 +470,8 @@ class StreamBatch:
             _lib.check(lib.dz_wave_stats(self._ctx, base, stride, N, S, stats.data_ptr(), a0.cuda_stream),
                        "dz_wave_stats")
             slot["ev_in"].record(a0)
+            if marks is not None:
+                marks.append(("wave_stats", _time.perf_counter()))
         pair = self.conv0_pair and stats is not None
         if pair:
             if self._pair is None:
@@ -503,6 +510,8 @@ class StreamBatch:
                                               int(self.norm_w), slot["w"][i0:i1].data_ptr(), a.cuda_stream),
                        "dz_seg_forward_osp")
             ev.record(a)
+            if marks is not None:
+                marks.append(("seg_forward_osp", _time.perf_counter()))
         for (i0, i1), h, b, ev in zip(sb, hembs, lane["b"], slot["ev_frames"]):
             b.wait_event(slot["ev_conv0"] if pair else slot["ev_in"])
             if i1 > i0 and self._ablate != "noemb":
@@ -511,6 +520,8 @@ class StreamBatch:
                 _lib.check(lib.dz_emb_frames(h, base + i0 * stride * esz, stride, i1 - i0, b.cuda_stream),
                            "dz_emb_frames")
             ev.record(b)
+            if marks is not None:
+                marks.append(("emb_frames", _time.perf_counter()))
         slot["rows"], slot["slots"] = N, None
         slot["keep"] = keep                              # keep the view alive until the GPU is done
         slot["pool"] = (lane, hembs, sa, sb, N, K, F)     # what _enqueue_pool needs
@@ -519,6 +530,10 @@ class StreamBatch:
         self._pending.append(slot)
         while len(self._pending) > self.lag:
             self._enqueue_pool(self._pending.pop(0))
+        if marks is not None:
+            marks.append(("pool", _time.perf_counter()))
+            if marks[-1][1] - marks[0][1] > 2e-3:           # a launch that took more than 2 ms: where
+                self.slow_launches.append([self._t] + [(b[0], round(1e3 * (b[1] - a[1]), 2)) for a, b in zip(marks, marks[1:])])
         self._t += 1
         return slot
 
@@ -596,14 +611,28 @@ class StreamBatch:
                 continue
             _lib.check(lib.dz_emb_pool(h, slot["w"][i0:i1].data_ptr(), i1 - i0, K, F, 1,
                                        slot["emb"][i0:i1].data_ptr(), b.cuda_stream), "dz_emb_pool")
+        tr = self.slow_launches is not None
+        m0 = _time.perf_counter() if tr else 0.0
         b0 = lane["b"][0]
         for b, ev in zip(lane["b"][1:], slot["ev_emb"]):
             ev.record(b)
             b0.wait_event(ev)
-        with torch.cuda.stream(b0):
-            slot["seg_h"][:N].copy_(slot["seg"][:N], non_blocking=True)
-            slot["emb_h"][:N].copy_(slot["emb"][:N], non_blocking=True)
+        # Results -> pinned memory by a kernel of our own.  The two hipMemcpyAsync (tensor.copy_) that stood here
+        # blocked the launching thread for a whole step's latency about once per 150 steps (csrc/ring.hip).
+        D = slot["emb"].shape[2]
+        if self.d2h_by_kernel:
+            _lib.check(lib.dz_results_to_host(self._ctx, slot["seg"].data_ptr(), slot["seg_h"].data_ptr(), N * F * K,
+                                              slot["emb"].data_ptr(), slot["emb_h"].data_ptr(), N * K * D,
+                                              b0.cuda_stream), "dz_results_to_host")
+        else:
+            with torch.cuda.stream(b0):
+                slot["seg_h"][:N].copy_(slot["seg"][:N], non_blocking=True)
+                slot["emb_h"][:N].copy_(slot["emb"][:N], non_blocking=True)
+        m2 = _time.perf_counter() if tr else 0.0
         slot["done"].record(b0)
+        if tr and _time.perf_counter() - m0 > 2e-3:
+            self.slow_launches.append(["pool tail", ("results to host", round(1e3 * (m2 - m0), 2)),
+                                       ("record done", round(1e3 * (_time.perf_counter() - m2), 2))])
         slot["pool"] = None
 
     # ------------------------------------------------------------------ host half

@@ -260,6 +260,14 @@ int dz_osp(dz_ctx* ctx, const float* d_seg, int batch, int frames, int speakers,
            float gamma, float beta, int normalize, int speaker_major,
            float* d_out, void* stream);
 
+/* ---- the `.cpu()` of blocks/segmentation.py:47 and blocks/embedding.py:68 for a whole step: two device
+ * buffers (n_a, n_b floats; n_b may be 0) -> two PINNED host buffers in one kernel launch on `stream`
+ * (device stores over the host link; all four pointers 16-byte aligned).  Not hipMemcpyAsync: that call
+ * now and then blocks its caller for a whole step's latency (csrc/ring.hip).  Complete when an event
+ * recorded on `stream` behind it has fired.                                                       */
+int dz_results_to_host(dz_ctx* ctx, const float* d_a, float* h_a, long long n_a,
+                       const float* d_b, float* h_b, long long n_b, void* stream);
+
 /* ---- EmbeddingNormalization(norm): functional.py:16-27; rows (R,D) in place  */
 int dz_l2_normalize(dz_ctx* ctx, float* d_emb, int rows, int dim, float norm, void* stream);
 

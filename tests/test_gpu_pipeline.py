@@ -178,6 +178,48 @@ def test_audio_ring_is_the_rolling_window(gpu):
     assert ring.filled == 0
 
 
+@pytest.mark.parametrize("na,nb", [(64 * 293 * 3, 64 * 3 * 512), (879, 1536), (5, 0), (4, 3), (1, 1), (1027, 2)])
+def test_results_to_host_is_an_exact_copy(gpu, na, nb):
+    """dz_results_to_host (the `.cpu()` of blocks/segmentation.py:47 and blocks/embedding.py:68 for a whole step):
+    two device buffers -> two pinned host buffers in one launch, bit-exact, any length (16-byte pieces + a scalar
+    tail), nothing written behind the end; misaligned buffers are refused.  StreamBatch uses it instead of
+    hipMemcpyAsync (csrc/ring.hip: that call blocks now and then)."""
+    from diart_amd import _lib
+    lib, ctx = _lib.load(), _lib.context(gpu.index or 0)
+    g = torch.Generator().manual_seed(na + 7 * nb)
+    a = torch.randn(na + 8, generator=g).to(gpu)
+    b = torch.randn(max(nb, 1) + 8, generator=g).to(gpu)
+    ha = torch.full((na + 8,), -7.0).pin_memory()
+    hb = torch.full((max(nb, 1) + 8,), -7.0).pin_memory()
+    st = torch.cuda.current_stream(gpu)
+    _lib.check(lib.dz_results_to_host(ctx, a.data_ptr(), ha.data_ptr(), na, b.data_ptr() if nb else None,
+                                      hb.data_ptr() if nb else None, nb, st.cuda_stream))
+    ev = torch.cuda.Event()
+    ev.record(st)
+    ev.synchronize()
+    assert torch.equal(ha[:na], a[:na].cpu()) and bool((ha[na:] == -7.0).all())
+    assert torch.equal(hb[:nb], b[:nb].cpu()) and bool((hb[nb:] == -7.0).all())
+    assert lib.dz_results_to_host(ctx, a.data_ptr() + 4, ha.data_ptr(), 4, None, None, 0, st.cuda_stream) != 0
+
+
+def test_stream_batch_results_by_kernel_equal_the_memcpy_pair(gpu):
+    """The two ways of bringing a step's results to the host give the same arrays."""
+    n, S, hop, steps = 8, 80000, 8000, 4
+    audio = torch.from_numpy(synth_streams(n, (S + hop * steps) / 16000.0, seed0=91)).to(gpu)
+    outs = []
+    for by_kernel in (True, False):
+        pipe = StreamBatch(M.HipSegmentation(synth_segmentation_state(), max_batch=n), M.HipEmbedding(synth_embedding_state(), max_batch=n),
+                           n, device=gpu, tail=False)
+        pipe.d2h_by_kernel = by_kernel
+        got = []
+        for t in range(steps):
+            seg, emb, _, assign = pipe.finish(pipe.launch(audio[:, t * hop: t * hop + S]))
+            got.append((seg.copy(), emb.copy(), assign.copy()))
+        outs.append(got)
+    for (s0, e0, a0), (s1, e1, a1) in zip(*outs):
+        assert np.array_equal(s0, s1) and np.array_equal(e0, e1, equal_nan=True) and np.array_equal(a0, a1)
+
+
 def test_stream_batch_on_ring_with_splits_and_tail(gpu):
     """StreamBatch reading the device ring, with the networks split into sub-batches on separate
     HIP streams, and the C++ output tail: identical segmentation / embeddings / clustering to the
