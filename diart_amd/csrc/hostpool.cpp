@@ -6,6 +6,7 @@
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
+#include <memory>
 #include <mutex>
 #include <thread>
 #include <vector>
@@ -20,15 +21,23 @@ constexpr int MAX_WORKERS = 63;
 std::atomic<int> g_spin_us{40};
 int spin_us() { return g_spin_us.load(std::memory_order_relaxed); }
 
+// One parallel-for.  Lives on the heap and is shared with the workers that picked it up, so that a worker which
+// wakes up AFTER the job is complete (a sleeping thread can take a scheduler tick — 4 ms — to get a core on a busy
+// node) finds every index handed out and walks away: the caller waits for the ITEMS, never for the workers.
+// Until round 6 every spawned worker had to acknowledge every job; the launching thread then sat 4 - 8 ms in a
+// 0.3 ms clustering / tail call about once per 200 steps while eight GPU steps drained (profiles/r06z_launch_stalls.json).
+struct Job {
+    const std::function<void(int, int)>* fn = nullptr;     // valid until done == n (the caller does not return before)
+    int n = 0, helpers = 0;                                // helpers: workers 1..helpers may take indices
+    std::atomic<int> next{0}, done{0};                     // next index to hand out; items completed
+};
+
 struct Pool {
     std::mutex callers;                       // one parallel-for at a time
-    std::mutex mu;                            // guards gen / the sleeping workers
+    std::mutex mu;                            // guards cur / the sleeping workers
     std::condition_variable wake;
     std::atomic<unsigned long long> gen{0};   // bumped once per job
-    // the job
-    const std::function<void(int, int)>* fn = nullptr;
-    int n = 0, helpers = 0;                   // helpers: workers 1..helpers may join this job
-    std::atomic<int> next{0}, left{0};        // next index to hand out; workers that have not acknowledged
+    std::shared_ptr<Job> cur;                 // the job in flight (null between jobs)
     int spawned = 0;
     pid_t owner = 0;
 };
@@ -36,19 +45,17 @@ struct Pool {
 Pool* g_pool = nullptr;                       // leaked on purpose: workers outlive static destruction
 std::mutex g_pool_mu;
 
-void drain(Pool* p, int worker) {
+void drain(Job* j, int worker) {
     for (;;) {
-        const int i = p->next.fetch_add(1, std::memory_order_relaxed);
-        if (i >= p->n) return;
-        (*p->fn)(worker, i);
+        const int i = j->next.fetch_add(1, std::memory_order_relaxed);
+        if (i >= j->n) return;
+        (*j->fn)(worker, i);
+        j->done.fetch_add(1, std::memory_order_release);
     }
 }
 
-// `seen` starts at the generation current when the worker was spawned (read under `callers`, where
-// gen cannot move): a worker never looks at — or acknowledges — a job published before it existed.
-// Starting every worker at 0 let one spawned into a pool with gen > 0 acknowledge the job that was
-// about to be published, and then that job again (`left` ended one short, the caller
-// returned while a worker was still inside fn()).
+// `seen` starts at the generation current when the worker was spawned (read under `callers`, where gen cannot
+// move): a worker never looks at a job published before it existed.
 void worker_main(Pool* p, int id, unsigned long long seen) {
     for (;;) {
         // wait for a job newer than the last one this worker looked at: spin briefly, then sleep
@@ -61,9 +68,13 @@ void worker_main(Pool* p, int id, unsigned long long seen) {
             }
             __builtin_ia32_pause();
         }
-        seen = p->gen.load(std::memory_order_acquire);
-        if (id <= p->helpers) drain(p, id);
-        p->left.fetch_sub(1, std::memory_order_acq_rel);   // every worker acknowledges every job
+        std::shared_ptr<Job> j;
+        {
+            std::lock_guard<std::mutex> lk(p->mu);
+            seen = p->gen.load(std::memory_order_acquire);
+            j = p->cur;                        // null: that job is already complete
+        }
+        if (j && id <= j->helpers) drain(j.get(), id);
     }
 }
 
@@ -93,28 +104,29 @@ void dz_host_parallel(int n, int threads, const std::function<void(int, int)>& f
         const int id = ++p->spawned;
         std::thread(worker_main, p, id, p->gen.load(std::memory_order_acquire)).detach();
     }
-    // every spawned worker looks at and acknowledges every job (so the job fields are never rewritten
-    // while a worker may still read them); only the first `helpers` of them take indices
-    p->fn = &fn;
-    p->n = n;
-    p->helpers = threads - 1;
-    p->next.store(0, std::memory_order_relaxed);
-    p->left.store(p->spawned, std::memory_order_relaxed);
+    auto job = std::make_shared<Job>();
+    job->fn = &fn;
+    job->n = n;
+    job->helpers = threads - 1;
     {
         std::lock_guard<std::mutex> lk(p->mu);
+        p->cur = job;
         p->gen.fetch_add(1, std::memory_order_release);
     }
     p->wake.notify_all();
-    drain(p, 0);
-    // wait for the acknowledgements: a short spin, then give the core away — on an oversubscribed rank the worker
-    // that has not acknowledged yet may be waiting for exactly this core
-    for (int spins = 0; p->left.load(std::memory_order_acquire) > 0; ++spins) {
+    drain(job.get(), 0);
+    // wait for the items other threads are still inside: a short spin, then give the core away — on an
+    // oversubscribed rank the worker that holds the last item may be waiting for exactly this core
+    for (int spins = 0; job->done.load(std::memory_order_acquire) < n; ++spins) {
         if (spins < 2000)
             __builtin_ia32_pause();
         else
             std::this_thread::yield();
     }
-    p->fn = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(p->mu);
+        p->cur.reset();
+    }
 }
 
 extern "C" int dz_host_pool_set_spin(int microseconds) {
