@@ -85,3 +85,65 @@ def test_soak_memory_flat_and_no_drift(gpu):
     assert np.array_equal(seg0, seg_last)
     both_nan = np.isnan(emb0) & np.isnan(emb_last)
     assert np.array_equal(np.where(both_nan, 0, emb0), np.where(both_nan, 0, emb_last))
+
+
+def _run_alone(gpu, audio, steps):
+    pipe = _engine(gpu, audio.shape[0])
+    out = []
+    for t in range(steps):
+        seg, emb, scores, assign = pipe(audio[:, t * 8000: t * 8000 + 80000])
+        out.append((seg.copy(), emb.copy(), scores.copy(), assign.copy()))
+    return out
+
+
+def _same(a, b):
+    for x, y in zip(a, b):
+        both = np.isnan(x) & np.isnan(y) if x.dtype.kind == "f" else np.zeros(x.shape, bool)
+        if not np.array_equal(np.where(both, 0, x), np.where(both, 0, y)):
+            return False
+    return True
+
+
+def test_two_engines_interleaved_and_on_two_threads(gpu):
+    """Two engines in one process (two stream groups of a service, /root/reference/src/diart/sources.py:204-271 has one
+    source per connection): (1) their steps interleaved on one thread with both kept in flight, (2) each driven by its
+    own thread at the same time (ctypes releases the GIL: the library's error slot, range flag, context scratch and
+    host pool see real concurrency).  Every step's segmentation, embeddings, scores and assignments equal what each
+    engine computes alone."""
+    import threading
+    from diart_amd.synth import synth_streams
+    steps = 12
+    audio = [torch.from_numpy(synth_streams(8, 5.0 + 0.5 * steps, seed0=900 + 50 * k)).to(gpu) for k in range(2)]
+    alone = [_run_alone(gpu, a, steps) for a in audio]
+
+    pipes = [_engine(gpu, 8) for _ in range(2)]
+    tickets, got = [[], []], [[], []]
+    for t in range(steps):
+        for k in range(2):
+            tickets[k].append(pipes[k].launch(audio[k][:, t * 8000: t * 8000 + 80000]))
+        for k in range(2):
+            if len(tickets[k]) >= 2:
+                got[k].append(tuple(np.copy(v) for v in pipes[k].finish(tickets[k].pop(0))))
+    for k in range(2):
+        while tickets[k]:
+            got[k].append(tuple(np.copy(v) for v in pipes[k].finish(tickets[k].pop(0))))
+        assert len(got[k]) == steps and all(_same(g, a) for g, a in zip(got[k], alone[k])), f"interleaved, engine {k}"
+    del pipes
+
+    res, errs = [None, None], []
+
+    def drive(k):
+        try:
+            res[k] = _run_alone(gpu, audio[k], steps)
+        except Exception as exc:      # noqa: BLE001
+            errs.append((k, repr(exc)))
+
+    for rep in range(3):
+        th = [threading.Thread(target=drive, args=(k,)) for k in range(2)]
+        for x in th:
+            x.start()
+        for x in th:
+            x.join()
+        assert not errs, errs
+        for k in range(2):
+            assert all(_same(g, a) for g, a in zip(res[k], alone[k])), f"threads, repetition {rep}, engine {k}"
