@@ -147,3 +147,42 @@ def test_two_engines_interleaved_and_on_two_threads(gpu):
         assert not errs, errs
         for k in range(2):
             assert all(_same(g, a) for g, a in zip(res[k], alone[k])), f"threads, repetition {rep}, engine {k}"
+
+
+@pytest.mark.parametrize("precision", ["f16x3", "f32"])
+def test_very_large_batches_are_right_or_loud(gpu, precision):
+    """`max_batch` has no upper bound in the C ABI and a reference-shaped caller may ask for anything
+    (`Benchmark(batch_size=...)`, /root/reference/src/diart/inference.py:275; the embedding model sees batch x speakers
+    rows, blocks/embedding.py:57-59).  Kernels address their operands with 32-bit offsets, so a large batch must either
+    compute what the same chunks give in batches of 64 (segmentation bit for bit, embeddings to 1e-6: the library's
+    own batch-independence property) or fail with an error — never return garbage.  1 024 and 4 000 chunks (the LSTM's
+    x-projection of 4 000 chunks is 4.8 GB, past every 32-bit byte offset; measured beyond that: 8 000 chunks are refused
+    by the split-f16 embedding and computed by the exact-f32 path through its round-1 kernels, 2.8e-6 from the batches
+    of 64)."""
+    from diart_amd import models as M
+    from diart_amd._lib import DiartAmdError
+    from diart_amd.synth import synth_embedding_state, synth_segmentation_state, synth_stream
+    stream = torch.from_numpy(synth_stream(33, 5.0 + 0.05 * 4000 + 1.0)).to(gpu)
+    seg = M.HipSegmentation(synth_segmentation_state(), max_batch=64, precision=precision).to(gpu)
+    emb = M.HipEmbedding(synth_embedding_state(), max_batch=64, precision=precision).to(gpu)
+    for B in (1024, 4000):
+        x = stream.unfold(0, 80000, 800)[:B][:, None, :]          # B overlapping windows, read in place
+        assert x.shape[0] == B
+        w = (torch.rand(B, 3, 293, generator=torch.Generator().manual_seed(B)) ** 2 + 1e-8).to(gpu)
+        ref_s = torch.cat([seg(x[i:i + 64]) for i in range(0, B, 64)]).cpu()
+        ref_e = torch.cat([emb.forward_multi(x[i:i + 64], w[i:i + 64]) for i in range(0, B, 64)]).cpu()
+        try:
+            got_s = seg(x).cpu()
+        except DiartAmdError as exc:
+            print(f"segmentation, {B} chunks: refused ({str(exc)[:120]})")
+        else:
+            assert torch.equal(got_s, ref_s), f"segmentation at batch {B} differs from batches of 64"
+        try:
+            got_e = emb.forward_multi(x, w).cpu()
+        except DiartAmdError as exc:
+            print(f"embedding, {B} chunks: refused ({str(exc)[:120]})")
+        else:
+            rel = ((got_e - ref_e).norm(dim=-1) / ref_e.norm(dim=-1)).max().item()
+            assert rel < 1e-6, f"embedding at batch {B}: relative difference {rel} to batches of 64"
+        # the models go back to small batches afterwards
+        assert torch.equal(seg(x[:3]).cpu(), ref_s[:3])
