@@ -233,3 +233,50 @@ def test_pooling_fused_into_tdnn5_equals_the_two_launch_path(gpu, oracle_models,
         cos = torch.nn.functional.cosine_similarity(got.double(), ref.double(), dim=-1)
         assert cos.min().item() >= EMB_COS and ((got - ref).norm(dim=-1) / ref.norm(dim=-1)).max().item() < 1e-4
     assert ((outs["1"][2] - ref0).norm(dim=-1) / ref0.norm(dim=-1)).max().item() < 1e-4
+
+
+def _degenerate_windows():
+    """Windows a live service and the reference's file reader really produce: digital silence, a constant (DC) level,
+    a file's last chunk padded with zeros (/root/reference/src/diart/sources.py:117-120), a nearly silent recording,
+    full-scale clipping, one click, a window whose loud part is short."""
+    g = torch.Generator().manual_seed(123)
+    S = 80000
+    speech = torch.from_numpy(synth_stream(17, 5.0))[:S]
+    rows = {
+        "silence": torch.zeros(S),
+        "dc": torch.full((S,), 0.25),
+        "zero_padded_tail": torch.cat([speech[:30000], torch.zeros(S - 30000)]),
+        "nearly_silent": 1e-6 * torch.randn(S, generator=g),
+        "clipped_square": torch.sign(torch.sin(torch.arange(S) * 2 * np.pi * 220 / 16000)),
+        "click": torch.zeros(S).index_fill_(0, torch.tensor([40000]), 1.0),
+        "loud_burst_in_silence": torch.cat([torch.zeros(60000), 0.9 * torch.randn(2000, generator=g).clamp(-1, 1), torch.zeros(18000)]),
+        "speech": speech,
+    }
+    return list(rows), torch.stack(list(rows.values()))[:, None, :].float()
+
+
+@pytest.mark.parametrize("precision", ["f32", "f16x3"])
+def test_degenerate_windows_match_the_oracle(gpu, oracle_models, precision):
+    """Same gates as ordinary audio, both arithmetic modes; no NaN / Inf and no range flag (a window of silence
+    normalises to zeros, a constant to zeros too: InstanceNorm's eps keeps both finite)."""
+    names, x = _degenerate_windows()
+    seg = M.HipSegmentation(synth_segmentation_state(), max_batch=len(names), precision=precision).to(gpu)
+    emb = M.HipEmbedding(synth_embedding_state(), max_batch=len(names), precision=precision).to(gpu)
+    w = torch.rand(len(names), 293, 3, generator=torch.Generator().manual_seed(5)) ** 2 + 1e-8
+    with torch.no_grad():
+        rs = oracle_models[0](x)
+        re = oracle_models[1].forward_multi(x, w)
+        re0 = oracle_models[1](x)
+    gs = seg(x.to(gpu)).cpu()
+    ge = emb.forward_multi(x.to(gpu), w.permute(0, 2, 1).contiguous().to(gpu)).cpu()
+    ge0 = emb(x.to(gpu)).cpu()
+    _lib.range_check(gpu.index)
+    assert torch.isfinite(gs).all() and torch.isfinite(ge).all() and torch.isfinite(ge0).all()
+    for i, nm in enumerate(names):
+        d = (gs[i] - rs[i]).abs()
+        rel = ((ge[i] - re[i]).norm(dim=-1) / re[i].norm(dim=-1)).max().item()
+        rel0 = ((ge0[i] - re0[i]).norm() / re0[i].norm()).item()
+        cos = torch.nn.functional.cosine_similarity(ge[i].double(), re[i].double(), dim=-1).min().item()
+        print(f"{precision} {nm}: seg max|d| {d.max().item():.2e}, emb rel {rel:.2e} / unweighted {rel0:.2e}, cos {cos:.7f}")
+        assert d.max().item() < SEG_MAX and d.mean().item() < SEG_MEAN, nm
+        assert cos >= EMB_COS and rel < 1e-4 and rel0 < 1e-4, nm
