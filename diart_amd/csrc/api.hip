@@ -436,6 +436,7 @@ struct dz_seg {
     int Bm;
     bool pre;    // wide layers on k_gemm_pre.hip (activations travel as f16 hi/lo planes)
     const float* ext_stats;   // dz_seg_use_wave_stats: consumed (and cleared) by the next forward
+    const float* cur_stats;   // the slice moments the front half of the current forward normalised with (NaN rows, dz_ws_bad)
     int ext_conv0_B;          // dz_sinc_conv0_pair wrote y0 / part0 of this many chunks: consumed by the next forward
     char* arena;
     SincScratch ss;
@@ -477,7 +478,7 @@ extern "C" int dz_seg_create(dz_ctx* ctx, const dz_seg_weights* w, int max_batch
     DZ_HIP(hipSetDevice(ctx->device));
     dz_seg* s = new (std::nothrow) dz_seg;
     DZ_REQUIRE(s != nullptr, "dz_seg_create: out of memory");
-    s->ctx = ctx; s->w = *w; s->g = g; s->Bm = max_batch; s->arena = nullptr; s->ext_stats = nullptr;
+    s->ctx = ctx; s->w = *w; s->g = g; s->Bm = max_batch; s->arena = nullptr; s->ext_stats = nullptr; s->cur_stats = nullptr;
     s->ext_conv0_B = 0;
     s->front_B = 0; s->ev_gx0_free = nullptr;
     DZ_HIP(hipEventCreateWithFlags(&s->ev_gx0_free, hipEventDisableTiming));
@@ -570,6 +571,7 @@ static int seg_forward(dz_seg* s, const float* d_wave, long long wave_stride, in
         DZ_REQUIRE(pair_B == 0 || pair_B == B, "dz_seg_forward: dz_sinc_conv0_pair ran for %d chunks, this call has %d",
                    pair_B, B);
         if ((rc = run_sincnet(s->w.sinc, s->g, s->ss, d_wave, wave_stride, B, st, ext, pair_B > 0))) return rc;
+        s->cur_stats = ext ? ext : s->ss.stats;
     }
 
     // 4 x { x-projection of both directions as one GEMM (N = 1024); persistent recurrence }.
@@ -650,6 +652,7 @@ static int seg_forward(dz_seg* s, const float* d_wave, long long wave_stride, in
         m.b0 = s->w.lin0_b; m.b1 = s->w.lin1_b; m.cw = s->w.cls_w; m.cb = s->w.cls_b;
         m.rows = B * F; m.F = F; m.classes = s->w.num_classes; m.K = s->w.num_speakers; m.powerset = s->w.powerset;
         m.gamma = gamma; m.beta = beta; m.seg = d_out; m.wout = d_osp;
+        m.wave_mom = s->cur_stats;        // (split-f16 path: its clamps turn NaN into finite values)
         ProfScope ps(T_MLP, B);
         return dz_launch_mlp_head(m, st);
     }
@@ -672,7 +675,7 @@ static int seg_forward(dz_seg* s, const float* d_wave, long long wave_stride, in
     // classifier + sigmoid / powerset decision (+ OverlappedSpeechPenalty weights): one launch
     ProfScope ps(T_CLS, B);
     return dz_launch_seg_head(s->m1, s->w.cls_w, s->w.cls_b, B, F, s->w.num_classes, s->w.num_speakers,
-                              s->w.powerset, d_out, gamma, beta, normalize, d_osp, st);
+                              s->w.powerset, d_out, gamma, beta, normalize, d_osp, st, s->pre ? s->cur_stats : nullptr);
 }
 
 // ---------------------------------------------------------------------------
@@ -685,6 +688,7 @@ struct dz_emb {
     int Bm, T[5];
     bool pre;    // tdnn2..5 on k_gemm_pre.hip (tdnn1 writes f16 hi/lo planes)
     const float* ext_stats;   // dz_emb_use_wave_stats: consumed (and cleared) by the next forward
+    const float* cur_stats;   // the slice moments dz_emb_frames normalised with (NaN rows of dz_emb_pool, dz_ws_bad)
     int ext_conv0_B;          // dz_sinc_conv0_pair: see dz_seg
     char* arena;
     SincScratch ss;
@@ -728,7 +732,7 @@ extern "C" int dz_emb_create(dz_ctx* ctx, const dz_emb_weights* w, int max_batch
     DZ_HIP(hipSetDevice(ctx->device));
     dz_emb* e = new (std::nothrow) dz_emb;
     DZ_REQUIRE(e != nullptr, "dz_emb_create: out of memory");
-    e->ctx = ctx; e->w = *w; e->g = g; e->Bm = max_batch; e->arena = nullptr; e->ext_stats = nullptr;
+    e->ctx = ctx; e->w = *w; e->g = g; e->Bm = max_batch; e->arena = nullptr; e->ext_stats = nullptr; e->cur_stats = nullptr;
     e->ext_conv0_B = 0;
     e->pending_B = 0; e->pending_in = nullptr;
     e->pre = w->tw_split[0] && w->tw_split[1] && w->tw_split[2] &&
@@ -772,6 +776,7 @@ static int emb_frames(dz_emb* e, const float* d_wave, long long stride, int B, h
     e->ext_conv0_B = 0;
     DZ_REQUIRE(pair_B == 0 || pair_B == B, "dz_emb_frames: dz_sinc_conv0_pair ran for %d chunks, this call has %d", pair_B, B);
     if ((rc = run_sincnet(e->w.sinc, e->g, e->ss, d_wave, stride, B, st, ext, pair_B > 0))) return rc;
+    e->cur_stats = ext ? ext : e->ss.stats;
     const int cin[5] = {64, 512, 512, 512, 512};
     const int npad[5] = {512, 512, 512, 512, 1536};
     // Row pitch P = P2 for every activation.  tdnn1 normalises on load with per-chunk statistics, so
@@ -884,7 +889,8 @@ static int emb_head(dz_emb* e, const float* d_weights, int Fw, int rows, int row
     p.epi = DZ_EPI_BIAS; p.ksplit = kEmbSplit; p.ysplit = (long long)rows * 512;
     { ProfScope ps(T_EMBLIN, rows / rows_per_x); if ((rc = dz_launch_convgemm(p, st))) return rc; }
     ProfScope ps(T_L2, rows / rows_per_x);
-    return dz_launch_splitk_finish(e->parts, kEmbSplit, p.ysplit, rows, 512, normalize, d_out, st);
+    return dz_launch_splitk_finish(e->parts, kEmbSplit, p.ysplit, rows, 512, normalize, d_out, st, e->pre ? e->cur_stats : nullptr,
+                                   rows_per_x);
 }
 
 extern "C" int dz_emb_forward(dz_emb* e, const float* d_wave, long long wave_stride,

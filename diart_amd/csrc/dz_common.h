@@ -255,6 +255,18 @@ void dz_set_error(const char* fmt, ...);
 // wave statistics in two steps: slice moments, then (mean, rstd) merged by the consumer
 #define DZ_WS_G 8   /* slices per chunk in wave_stats */
 // slice moments of the raw waveform -> mom[B][DZ_WS_G][2] (mean_i, M2_i)
+// A window with a NaN / Inf sample (or slice sums beyond f32) has a non-finite slice mean.  PyTorch's InstanceNorm1d then
+// makes the whole window NaN and every output of that row is NaN (the reference drops such a chunk's speakers,
+// /root/reference/src/diart/blocks/clustering.py:137-145).  The exact-f32 kernels propagate NaN by themselves; the
+// split-f16 kernels clamp their operands to +-65504 (`v_med3_f32` turns NaN into a finite value: that is what keeps one
+// row's garbage out of its neighbours' tiles), so their LAST kernels ask this and write NaN rows themselves.
+__device__ __forceinline__ bool dz_ws_bad(const float* __restrict__ mom, int b) {
+    const unsigned* m = reinterpret_cast<const unsigned*>(mom) + (long long)b * 2 * DZ_WS_G;
+    bool bad = false;
+#pragma unroll
+    for (int i = 0; i < DZ_WS_G; ++i) bad |= (m[2 * i] & 0x7f800000u) == 0x7f800000u;      // mean_i is Inf or NaN
+    return bad;
+}
 #ifdef DZ_EXPERIMENTS
 extern long long* dz_conv_pool_dbg;
 #endif
@@ -447,7 +459,7 @@ __device__ __forceinline__ void dz_osp_frame(const float* s, int K, float gamma,
 
 int dz_launch_seg_head(const float* m1, const float* cw, const float* cb, int B, int F, int classes, int K,
                        int powerset, float* seg, float gamma, float beta, int normalize, float* wout,
-                       hipStream_t st);
+                       hipStream_t st, const float* wave_mom = nullptr);
 // lin0 (256 -> 128, LeakyReLU) -> lin1 (128 -> 128, LeakyReLU) -> classifier -> activation (-> OSP
 // weights, not normalised) in one launch: k_mlp_head.hip
 struct DzMlpHead {
@@ -460,11 +472,14 @@ struct DzMlpHead {
     float* seg;                // [rows][K]
     float* wout;               // [rows / F][K][F] or NULL
     int* oflag;
+    const float* wave_mom;     // wave_stats moments of the rows' chunks, or NULL: chunks with non-finite ones get NaN rows (dz_ws_bad)
 };
 int dz_launch_mlp_head(const DzMlpHead& p, hipStream_t st);
 int dz_launch_l2norm(float* x, int rows, int dim, float norm, hipStream_t st);
+// wave_mom (or NULL): wave_stats moments of the rows' chunks (row r belongs to chunk r / rows_per_x): NaN rows for dz_ws_bad chunks
 int dz_launch_splitk_finish(const float* parts, int nsplit, long long stride, int rows, int dim,
-                            int normalize, float* out, hipStream_t st);
+                            int normalize, float* out, hipStream_t st, const float* wave_mom = nullptr,
+                            int rows_per_x = 1);
 int dz_launch_powerset(const float* logp, int rows, int classes, int speakers, float* out,
                        hipStream_t st);
 int dz_launch_cdist(const float* emb, const double* centers, int n, int k, int g, int dim,

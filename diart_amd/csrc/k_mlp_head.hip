@@ -210,11 +210,13 @@ __global__ __launch_bounds__(256) void mlp_head_kernel(DzMlpHead p) {
         }
         float s[8];
         dz_seg_decide(lg, p.classes, p.K, p.powerset, s);
+        const int b = t / p.F, f = t - b * p.F;
+        if (p.wave_mom && dz_ws_bad(p.wave_mom, b))          // a window with NaN / Inf samples: NaN rows, like the reference
+            for (int k = 0; k < p.K; ++k) s[k] = __builtin_nanf("");
         for (int k = 0; k < p.K; ++k) p.seg[(long long)t * p.K + k] = s[k];
         if (p.wout) {
             float wv[8];
             dz_osp_frame(s, p.K, p.gamma, p.beta, wv);
-            const int b = t / p.F, f = t - b * p.F;
             for (int k = 0; k < p.K; ++k) p.wout[((long long)b * p.K + k) * p.F + f] = wv[k];
         }
     }

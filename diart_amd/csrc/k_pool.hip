@@ -215,7 +215,8 @@ constexpr int SH_PITCH = 129;
 __global__ __launch_bounds__(256) void seg_head_kernel(const float* __restrict__ m1, const float* __restrict__ cw,
                                                        const float* __restrict__ cb, int F, int classes, int K,
                                                        int powerset, float* __restrict__ seg, float gamma,
-                                                       float beta, int normalize, float* __restrict__ wout) {
+                                                       float beta, int normalize, float* __restrict__ wout,
+                                                       const float* __restrict__ wave_mom) {
     extern __shared__ float hbuf[];   // [SH_ROWS][SH_PITCH] slice | [F][K] weights | [2][K] min / max
     float* xs = hbuf;
     float* wbuf = hbuf + SH_ROWS * SH_PITCH;
@@ -244,6 +245,8 @@ __global__ __launch_bounds__(256) void seg_head_kernel(const float* __restrict__
             }
             float s[8];
             dz_seg_decide(lg, classes, K, powerset, s);
+            if (wave_mom && dz_ws_bad(wave_mom, b))            // a window with NaN / Inf samples: NaN rows, like the reference
+                for (int k = 0; k < K; ++k) s[k] = __builtin_nanf("");
             const int f = f0 + tid;
             for (int k = 0; k < K; ++k) sb[f * K + k] = s[k];
             if (wout) {
@@ -312,7 +315,8 @@ __global__ __launch_bounds__(256) void l2norm_kernel(float* __restrict__ x, int 
 __global__ __launch_bounds__(512) void splitk_finish_kernel(const float* __restrict__ parts,
                                                             int nsplit, long long stride, int rows,
                                                             int dim, int normalize,
-                                                            float* __restrict__ out) {
+                                                            float* __restrict__ out,
+                                                            const float* __restrict__ wave_mom, int rows_per_x) {
     __shared__ float sq[8][64];
     __shared__ float nrm;
     const int row = blockIdx.x, i = threadIdx.x, l = i & 63, w = i >> 6;
@@ -344,6 +348,7 @@ __global__ __launch_bounds__(512) void splitk_finish_kernel(const float* __restr
         __syncthreads();
         a = a / nrm;
     }
+    if (wave_mom && dz_ws_bad(wave_mom, row / rows_per_x)) a = __builtin_nanf("");      // (block-uniform)
     if (i < dim) out[(long long)row * dim + i] = a;
 }
 
@@ -498,13 +503,13 @@ int dz_launch_osp(const float* seg, int B, int F, int K, float gamma, float beta
 // [B][K][F] OSP weights
 int dz_launch_seg_head(const float* m1, const float* cw, const float* cb, int B, int F, int classes, int K,
                        int powerset, float* seg, float gamma, float beta, int normalize, float* wout,
-                       hipStream_t st) {
+                       hipStream_t st, const float* wave_mom) {
     DZ_REQUIRE(classes >= 1 && classes <= 8 && K >= 1 && K <= 8 && (powerset || K == classes),
                "seg_head: classes %d / speakers %d", classes, K);
     const size_t lds = sizeof(float) * ((size_t)SH_ROWS * SH_PITCH + (size_t)F * K + 2 * K);
     DZ_REQUIRE(lds <= 64 * 1024, "seg_head: %d frames x %d speakers do not fit in LDS", F, K);
     DZ_LAUNCH(seg_head_kernel, dim3(B), dim3(256), lds, st, m1, cw, cb, F, classes, K, powerset, seg, gamma,
-              beta, normalize, wout);
+              beta, normalize, wout, wave_mom);
     DZ_HIP(hipGetLastError());
     return 0;
 }
@@ -516,10 +521,11 @@ int dz_launch_l2norm(float* x, int rows, int dim, float norm, hipStream_t st) {
 }
 
 int dz_launch_splitk_finish(const float* parts, int nsplit, long long stride, int rows, int dim,
-                            int normalize, float* out, hipStream_t st) {
+                            int normalize, float* out, hipStream_t st, const float* wave_mom, int rows_per_x) {
     DZ_REQUIRE(dim <= 512, "splitk_finish: dim %d > 512", dim);
+    DZ_REQUIRE(rows_per_x >= 1, "splitk_finish: rows_per_x %d", rows_per_x);
     DZ_LAUNCH(splitk_finish_kernel, dim3(rows), dim3(512), 0, st, parts, nsplit,
-                       stride, rows, dim, normalize, out);
+                       stride, rows, dim, normalize, out, wave_mom, rows_per_x);
     DZ_HIP(hipGetLastError());
     return 0;
 }

@@ -280,3 +280,42 @@ def test_degenerate_windows_match_the_oracle(gpu, oracle_models, precision):
         print(f"{precision} {nm}: seg max|d| {d.max().item():.2e}, emb rel {rel:.2e} / unweighted {rel0:.2e}, cos {cos:.7f}")
         assert d.max().item() < SEG_MAX and d.mean().item() < SEG_MEAN, nm
         assert cos >= EMB_COS and rel < 1e-4 and rel0 < 1e-4, nm
+
+
+@pytest.mark.parametrize("precision", ["f32", "f16x3"])
+def test_nan_or_inf_samples_make_nan_rows_like_torch(gpu, chunks, oracle_models, precision):
+    """One NaN (or Inf) sample in a window: PyTorch's InstanceNorm1d makes the whole window NaN, so the reference's
+    segmentation and embeddings of that row are NaN and its clustering drops the chunk's speakers
+    (/root/reference/src/diart/blocks/clustering.py:137-145).  The exact-f32 kernels propagate NaN by themselves; the
+    split-f16 kernels clamp operands (NaN becomes a finite value there), so their last kernels write the NaN rows from
+    the waveform statistics.  Every other row of the batch is bit-identical to the clean batch, through the model calls
+    and through a StreamBatch step (whose stream with the bad window gets no speaker for it)."""
+    from diart_amd.pipeline import StreamBatch
+    x = chunks[:5].clone()
+    clean = x.clone()
+    x[1, 0, 40000] = float("nan")
+    x[3, 0, 7] = float("inf")
+    with torch.no_grad():
+        rs, re = oracle_models[0](x), oracle_models[1](x)
+    assert torch.isnan(rs[[1, 3]]).all() and torch.isnan(re[[1, 3]]).all() and torch.isfinite(rs[[0, 2, 4]]).all()
+    seg = M.HipSegmentation(synth_segmentation_state(), max_batch=8, precision=precision).to(gpu)
+    emb = M.HipEmbedding(synth_embedding_state(), max_batch=8, precision=precision).to(gpu)
+    w = (torch.rand(5, 3, 293, generator=torch.Generator().manual_seed(2)) ** 2 + 1e-8).to(gpu)
+    gs, gs0 = seg(x.to(gpu)).cpu(), seg(clean.to(gpu)).cpu()
+    ge, ge0 = emb(x.to(gpu)).cpu(), emb(clean.to(gpu)).cpu()
+    gm, gm0 = emb.forward_multi(x.to(gpu), w).cpu(), emb.forward_multi(clean.to(gpu), w).cpu()
+    rows = x.repeat(1, 3, 1).reshape(15, 1, -1).to(gpu)                 # the reference's (batch spk) rows
+    gr = emb(rows, w.reshape(15, 293)).cpu().view(5, 3, 512)
+    for bad in (1, 3):
+        assert torch.isnan(gs[bad]).all() and torch.isnan(ge[bad]).all() and torch.isnan(gm[bad]).all() and torch.isnan(gr[bad]).all()
+    good = [0, 2, 4]
+    assert torch.equal(gs[good], gs0[good]) and torch.equal(ge[good], ge0[good]) and torch.equal(gm[good], gm0[good])
+    assert torch.isfinite(gr[good]).all()
+    _lib.range_check(gpu.index)                                         # not an out-of-range event
+    # one StreamBatch step: 5 streams, the same windows
+    pipe = StreamBatch(M.HipSegmentation(synth_segmentation_state(), max_batch=5, precision=precision),
+                       M.HipEmbedding(synth_embedding_state(), max_batch=5, precision=precision), 5, device=gpu)
+    s1, e1, scores, assign = pipe(x[:, 0, :].to(gpu))
+    assert np.isnan(s1[[1, 3]]).all() and np.isnan(e1[[1, 3]]).all() and np.isfinite(s1[good]).all()
+    assert (assign[[1, 3]] < 0).all(), assign                            # no speaker of the bad windows is assigned
+    assert np.isfinite(scores[good]).all()
