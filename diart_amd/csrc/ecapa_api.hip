@@ -190,6 +190,12 @@ extern "C" int dz_ecapa_forward(dz_ecapa* e, const float* d_wave, long long wave
     int* h_short = h_nmask + e->Nm;
     DZ_HIP(hipMemcpyAsync(h_lens, e->lens, sizeof(int) * N, hipMemcpyDeviceToHost, st));
     DZ_HIP(hipStreamSynchronize(st));   // the batch geometry (frames) depends on the longest row
+    // a row whose kept samples hold a NaN / Inf comes back as -(len + 1): it keeps its place in the batch geometry
+    // (speechbrain pads and normalises by the longest row whatever its values) and its embedding is NaN — what the
+    // reference computes for it, and what the split-f16 layers' clamps would otherwise turn into a finite vector
+    std::vector<char> bad((size_t)N, 0);
+    for (int i = 0; i < N; ++i)
+        if (h_lens[i] < 0) { h_lens[i] = -h_lens[i] - 1; bad[i] = 1; }
     int lmax = 0;
     for (int i = 0; i < N; ++i) lmax = h_lens[i] > lmax ? h_lens[i] : lmax;
     e->lastN = N;
@@ -202,9 +208,10 @@ extern "C" int dz_ecapa_forward(dz_ecapa* e, const float* d_wave, long long wave
     const int T = 1 + lmax / HOP;
     e->lastT = T;
     for (int i = 0; i < N; ++i) {
-        h_short[i] = h_lens[i] < MIN_NUM_SAMPLES;
+        const bool too_short = h_lens[i] < MIN_NUM_SAMPLES;
+        h_short[i] = too_short || bad[i];       // (only dz_launch_nan_rows reads it)
         // float32 arithmetic of torch: wav_lens / max_len, then * T
-        const float rel = h_short[i] ? 1.0f : (float)h_lens[i] / (float)lmax;
+        const float rel = too_short ? 1.0f : (float)h_lens[i] / (float)lmax;
         const float v = rel * (float)T;
         int nv = (int)nearbyintf(v);            // torch.round: half to even
         nv = nv < 1 ? 1 : (nv > T ? T : nv);

@@ -25,12 +25,23 @@ __global__ __launch_bounds__(1024) void mask_compact_kernel(const float* __restr
                                                            long long sig_stride,
                                                            int* __restrict__ lens) {
     __shared__ int cnt[256];
+    __shared__ int bad_s;                     // a kept sample is NaN / Inf: the row's length is reported as -(len + 1)
     const int row = blockIdx.x, tid = threadIdx.x;
     const float* w = wave + (long long)row * stride;
     float* o = sig + (long long)row * sig_stride + 200;
+    if (tid == 0) bad_s = 0;
+    __syncthreads();
+    bool bad = false;
+    auto finite = [](float v) { return (__float_as_uint(v) & 0x7f800000u) != 0x7f800000u; };
     if (masks == nullptr) {
-        for (int s = tid; s < S; s += blockDim.x) o[s] = w[s];
-        if (tid == 0) lens[row] = S;
+        for (int s = tid; s < S; s += blockDim.x) {
+            const float v = w[s];
+            bad |= !finite(v);
+            o[s] = finite(v) ? v : 0.f;       // (the row's embedding is NaN whatever is computed from this)
+        }
+        if (bad) bad_s = 1;
+        __syncthreads();
+        if (tid == 0) lens[row] = bad_s ? -(S + 1) : S;
         return;
     }
     const float* m = masks + (long long)row * Fw;
@@ -52,14 +63,21 @@ __global__ __launch_bounds__(1024) void mask_compact_kernel(const float* __restr
     __syncthreads();
     int pos = 0;
     for (int i = 0; i < w4; ++i) pos += cnt[i];
-    if (tid == (int)blockDim.x - 1) lens[row] = pos + c;
+    const int total = pos + c;
     const unsigned long long below = (1ull << lane) - 1ull;
     for (int s = s0; s < s1; s += 64) {
         const bool k = kept(s + lane);
         const unsigned long long b = __ballot(k);
-        if (k) o[pos + __popcll(b & below)] = w[s + lane];
+        if (k) {
+            const float v = w[s + lane];
+            bad |= !finite(v);
+            o[pos + __popcll(b & below)] = finite(v) ? v : 0.f;
+        }
         pos += __popcll(b);
     }
+    if (bad) bad_s = 1;
+    __syncthreads();
+    if (tid == (int)blockDim.x - 1) lens[row] = bad_s ? -(total + 1) : total;
 }
 
 // spec [rows][lds] = (re[0..200] | im[0..200]) -> pw [rows][204] (cols 201..203 = 0)

@@ -142,7 +142,10 @@ typedef struct {
 /* ---- segmentation: replaces the callable behind SegmentationModel.__call__ --
  * /root/reference/src/diart/models.py:188-198 (-> pyannote PyanNet.forward, :133)
  * waveform (B,1,S) -> (B,F,K).  d_wave rows are `wave_stride` floats apart so a
- * rolling window can be addressed in place (operators.py:44-100).             */
+ * rolling window can be addressed in place (operators.py:44-100).
+ * A window holding a NaN / Inf sample gives a NaN row (what PyTorch's InstanceNorm1d makes of
+ * it; blocks/clustering.py:137-145 then ignores the chunk) in BOTH arithmetic modes, and never
+ * touches the other rows of the batch; the same holds for the embedding entry points below.  */
 int dz_seg_create(dz_ctx* ctx, const dz_seg_weights* w, int max_batch, int num_samples, dz_seg** out);
 int dz_seg_forward(dz_seg* seg, const float* d_wave, long long wave_stride, int batch,
                    float* d_out, void* stream);
@@ -249,7 +252,8 @@ int dz_ecapa_forward(dz_ecapa* e, const float* d_wave, long long wave_stride, co
                      int n_rows, int mask_frames, float* d_out, void* stream);
 /* device pointer + element count of an intermediate of the LAST forward (parity tests):
  * 0 features (N,T,80)  1 block0 (N,T,1024)  2 cat (N,T,3072)  3 mfa (N,T,3072)
- * 4 pooled (N,6144)    5 kept-sample counts (N) as int32;  *frames receives T            */
+ * 4 pooled (N,6144)    5 kept-sample counts (N) as int32, -(count + 1) for a row whose kept
+ * samples hold a NaN / Inf (its embedding is NaN);  *frames receives T                   */
 int dz_ecapa_peek(dz_ecapa* e, int which, const void** d_ptr, long long* count, int* frames);
 int dz_ecapa_destroy(dz_ecapa* e);
 

@@ -113,3 +113,30 @@ def test_operator_api_with_ecapa(gpu, oracle):
     ok = ~torch.isnan(ref[..., 0])
     cos = (got[ok].double() * ref[ok].double()).sum(-1)
     assert cos.min().item() > 0.99999
+
+
+def test_nan_samples_only_count_where_the_mask_keeps_them(gpu, oracle, hip):
+    """A NaN / Inf sample the mask KEEPS makes that row's embedding NaN (the reference's fbank of it is NaN); one the
+    mask drops never reaches the network.  The row keeps its place in the batch geometry (padding to the longest row),
+    so the other rows are bit-identical to the clean batch."""
+    S, Fw = 80000, 293
+    x = torch.from_numpy(synth_streams(4, 5.0, seed0=70))[:, None, :S].contiguous()
+    masks = torch.zeros(4, Fw)
+    masks[0, 20:200] = 1.0
+    masks[1, :] = 1.0                                # the longest row — and the one with the kept NaN
+    masks[2, 100:250] = 1.0
+    masks[3, 50:150] = 1.0
+    clean = hip(x.to(gpu), masks.to(gpu)).cpu().numpy()
+    bad = x.clone()
+    bad[1, 0, 33333] = float("nan")                  # kept (row 1 keeps everything)
+    bad[2, 0, 100] = float("inf")                    # frame 0 of row 2: dropped by its mask
+    bad[3, 0, int(100 * S / Fw)] = float("inf")      # frame 100 of row 3: kept
+    ref = oracle(bad, masks)
+    got = hip(bad.to(gpu), masks.to(gpu)).cpu().numpy()
+    assert np.isnan(ref[1]).all() and np.isnan(ref[3]).all() and np.isfinite(ref[[0, 2]]).all()
+    assert np.array_equal(np.isnan(got), np.isnan(ref))
+    assert np.array_equal(got[[0, 2]], clean[[0, 2]])
+    from diart_amd import _lib
+    _lib.range_check(gpu.index)                       # a NaN row, not an out-of-range error for the whole call
+    lens = hip.peek(S, 5)[0].cpu().numpy()
+    assert (lens[[1, 3]] < 0).all() and (lens[[0, 2]] > 0).all()         # -(len + 1) marks a row with non-finite samples
