@@ -81,6 +81,11 @@ def split_f16(w: torch.Tensor, name: Optional[str] = None) -> torch.Tensor:
     plane 1 ``lo = f16((w - hi) * 2^11)`` — the two-term split ``k_gemm_split.hip`` multiplies with
     (``w = hi + lo * 2^-11`` to 22 mantissa bits; the scale keeps ``lo`` a normal f16)."""
     w = w.detach().float().cpu().contiguous()
+    if w.numel() and not bool(torch.isfinite(w).all()):
+        # (max() of a tensor with NaN is NaN and every comparison below would pass: the kernels' clamps would then turn
+        # the NaN planes into finite garbage where an f32 model gives NaN outputs)
+        raise ValueError(f"split_f16({name or 'matrix'}): {int((~torch.isfinite(w)).sum())} non-finite weights — a damaged "
+                         "checkpoint; the \"f16x3\" arithmetic refuses it (precision=\"f32\" computes NaN outputs like the reference)")
     big = float(w.abs().max()) if w.numel() else 0.0
     if big > 65504.0:
         raise ValueError(f"split_f16: |value| up to {big:g} does not fit the f16 range (+-65504) of the "

@@ -339,6 +339,13 @@ def test_split_f16_measures_how_well_a_layer_is_represented():
     assert W.SPLIT_REPORT[-1][0] == "tiny layer" and W.SPLIT_REPORT[-1][2] > W.SPLIT_LIMIT
     split_f16(torch.randn(64, 256) * 2.0 ** -12, "small but fine")      # 2^-12: still 22-bit grade
     assert W.SPLIT_REPORT[-1][2] < 2.0 ** -21
+    # a damaged checkpoint (NaN / Inf weights) is refused too: every comparison above passes for NaN, and the kernels'
+    # clamps would turn NaN planes into finite garbage
+    for bad in (float("nan"), float("inf")):
+        w = torch.randn(8, 32)
+        w[3, 5] = bad
+        with pytest.raises(ValueError, match="non-finite"):
+            split_f16(w, "damaged layer")
 
 
 def test_kb_major_is_the_index_map_the_kernels_use():
