@@ -571,7 +571,9 @@ static int seg_forward(dz_seg* s, const float* d_wave, long long wave_stride, in
         DZ_REQUIRE(pair_B == 0 || pair_B == B, "dz_seg_forward: dz_sinc_conv0_pair ran for %d chunks, this call has %d",
                    pair_B, B);
         if ((rc = run_sincnet(s->w.sinc, s->g, s->ss, d_wave, wave_stride, B, st, ext, pair_B > 0))) return rc;
-        s->cur_stats = ext ? ext : s->ss.stats;
+        // (front half alone with the handle's OWN moments: the next dz_seg_front may overwrite them before this step's
+        // back half reads them — the NaN rows then come from caller-owned moments only, dz_seg_use_wave_stats)
+        s->cur_stats = ext ? ext : (phase == 0 ? s->ss.stats : nullptr);
     }
 
     // 4 x { x-projection of both directions as one GEMM (N = 1024); persistent recurrence }.
