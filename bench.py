@@ -666,14 +666,22 @@ def config3(args):
     for i in range(args.warmup):
         pipe(chunks[i * B:(i + 1) * B])
     torch.cuda.synchronize()
+    # the ECAPA rows of a step are padded to the frames of the LONGEST kept row of its batch (the reference pads the
+    # same way: PretrainedSpeakerEmbedding's pad_sequence), so the algorithmic work of a step follows the batch
+    # geometry of that step, not a full 5 s mask: read back (one ctypes call, no synchronisation) after every step
+    ecapa = cfg.embedding.model
+    frames_of = lambda: ecapa.last_frames(S)           # noqa: E731
     t0 = time.perf_counter()
-    turns = 0
+    turns, frames_timed = 0, []
     for i in range(args.warmup, total):
         turns += sum(len(a) for a, _ in pipe(chunks[i * B:(i + 1) * B]))
+        frames_timed.append(frames_of())
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     cps = B * args.steps / elapsed
-    gflop_chunk = 2.0 * (656_230_928 + 3 * ECAPA_MAC_PER_ROW) / 1e9
+    T_FULL = 498                                         # frames of a full 5 s mask (ECAPA_MAC_PER_ROW is written for it)
+    t_timed = sum(frames_timed) / max(1, len(frames_timed))
+    gflop_chunk = 2.0 * (656_230_928 + 3 * ECAPA_MAC_PER_ROW * t_timed / T_FULL) / 1e9
     # ---- where a step's wall time goes (a few extra untimed steps; every phase of the synchronous blocks API ends
     # in a `.cpu()`, so host clocks around the three calls of SpeakerDiarization.__call__ are honest) -------------
     phases = {"stack": 0.0, "segmentation": 0.0, "embedding": 0.0, "finalise": 0.0}
@@ -696,12 +704,14 @@ def config3(args):
     # ---- per-kernel brackets (the dispatches' own timestamps), on a few extra steps after the timed region ------
     nprof = min(4, args.steps)
     lib.dz_prof_enable(1)
+    frames_prof = []
     for i in range(nprof):
         pipe(chunks[(args.warmup + i) * B:(args.warmup + i + 1) * B])
+        frames_prof.append(frames_of())
     lib.dz_prof_collect()
     name, ms, n_, ch = C.c_char_p(), C.c_double(), C.c_longlong(), C.c_longlong()
     split = precision != "f32"
-    T_ROW = 498                                          # frames of a full 5 s mask
+    T_ROW = sum(frames_prof) / max(1, len(frames_prof))  # frames every row of the bracketed steps was padded to (mean)
     mac_row = {                                          # algorithmic MACs per ECAPA row, by bracket
         "ecapa_fbank": T_ROW * (400 * 402 + 201 * 80), "ecapa_block0": T_ROW * 80 * 5 * 1024,
         "ecapa_wide1x1": T_ROW * (6 * 1024 * 1024 + 3072 * 3072), "ecapa_res2net": 3 * T_ROW * 7 * 128 * 128 * 3,
@@ -740,12 +750,17 @@ def config3(args):
         "config": {"workload": "configs[2]: single MI355X, pyannote/segmentation-3.0 (powerset) + speechbrain ECAPA-TDNN "
                                "architectures (random-init weights), 5 s window / 500 ms step, one synthetic stream through "
                                "the blocks pipeline in batches of 32 consecutive windows (96 embedding rows per step)",
-                   "chunks_per_step": B, "speech_turns_emitted": turns, "host_phases_ms": phases},
+                   "chunks_per_step": B, "speech_turns_emitted": turns, "host_phases_ms": phases,
+                   "ecapa_frames_per_row": {"timed_mean": round(t_timed, 1), "timed_min": min(frames_timed, default=0),
+                                            "timed_max": max(frames_timed, default=0), "bracketed_mean": round(T_ROW, 1),
+                                            "full_mask": T_FULL}},
         "roofline": dict(dom, traffic=None, whole_path_tflops=round(cps * gflop_chunk / 1e3, 2),
                          alg_gflop_per_chunk=round(gflop_chunk, 2), kernel_time_ms_per_step=round(tot, 3),
                          peak_note="f16 matrix peak / 3 for the layers on the split-f16 kernels (three MFMAs per "
                                    "algorithmic product), exact-f32 matrix peak for the others; brackets = the "
-                                   "dispatches' own timestamps over %d steps after the timed region" % nprof),
+                                   "dispatches' own timestamps over %d steps after the timed region; algorithmic work "
+                                   "= 96 rows x the frames the step's batch was padded to (config.ecapa_frames_per_row), "
+                                   "not a full 5 s mask" % nprof),
         "roofline_kernels": groups,
         "cpu_baseline": None,
     }

@@ -327,6 +327,14 @@ class HipEcapaEmbedding(_HipModule):
                    "dz_ecapa_forward")
         return out
 
+    def last_frames(self, num_samples: int) -> int:
+        """Frames of the batch geometry of the last forward (= those of its longest kept row, what every row is
+        padded to: ``dz_ecapa_peek``); no copy, no synchronisation.  ``bench.py --config 3`` prices its kernels with it."""
+        ptr, cnt, frames = _lib.vp(), C.c_longlong(), C.c_int()
+        _lib.check(_lib.load().dz_ecapa_peek(self._handles[num_samples][0], 5, C.byref(ptr),
+                                             C.byref(cnt), C.byref(frames)), "dz_ecapa_peek")
+        return frames.value
+
     def peek(self, num_samples: int, which: int) -> torch.Tensor:
         """Intermediate of the last forward (parity tests): see ``dz_ecapa_peek``."""
         ptr, cnt, frames = _lib.vp(), C.c_longlong(), C.c_int()
