@@ -155,6 +155,52 @@ def test_full_size_properties_64_streams(gpu):
     assert (e_all[0] - e_all[1]).abs().max().item() > 1e-3
 
 
+@pytest.mark.parametrize("precision", ["f16x3", "f32"])
+@pytest.mark.parametrize("recurrence", ["valu", "4"])
+def test_full_size_invariances_of_the_graphs(gpu, precision, recurrence):
+    """More oracle-free properties at BASELINE.json config 2 size (64 chunks per launch), this time of the GRAPHS
+    (third-party PyanNet / XVectorSincNet reached from /root/reference/src/diart/models.py:133, :262), in both
+    arithmetic modes and with the latency- and the throughput-form recurrence:
+
+    * both networks start with InstanceNorm1d(1) on the waveform: a DC offset changes nothing but roundings;
+    * the statistics pooling is a ratio of weighted sums (paper Eq. 1): scaling the pooling weights of a speaker by
+      a power of two scales every sum exactly — the embedding does not move by a bit;
+    * the K speakers of a chunk are pooled independently from shared frame features: permuting the weight rows
+      permutes the embeddings, bit for bit;
+    * an all-zero weight row is a speaker that is never active: the pooling has nothing to average, the row is NaN (torch's
+      0 / 0) and the other speakers of the chunk are untouched."""
+    if recurrence != "valu" and precision == "f32":
+        pytest.skip("the matrix-core recurrences are split-f16 kernels")
+    n = 64
+    seg = M.HipSegmentation(synth_segmentation_state(), max_batch=n, precision=precision, recurrence=recurrence).to(gpu)
+    emb = M.HipEmbedding(synth_embedding_state(), max_batch=n, precision=precision).to(gpu)
+    x = torch.from_numpy(synth_streams(n, 5.0, seed0=900)).to(gpu)[:, None, :80000]
+    s0 = seg(x)
+    s_dc = seg(x + 0.25)
+    assert (s_dc - s0).abs().max().item() < 5e-5, (s_dc - s0).abs().max().item()
+    from diart_amd.functional import overlapped_speech_penalty
+    w = overlapped_speech_penalty(s0, 3, 10, speaker_major=True).contiguous()          # (64, 3, 293)
+    e0 = emb.forward_multi(x, w, normalize=True)
+    e_dc = emb.forward_multi(x + 0.25, w, normalize=True)
+    assert (e_dc * e0).sum(-1).min().item() > EMB_COS
+    # weight scale (per speaker, powers of two)
+    scale = torch.tensor([4.0, 0.5, 1024.0], device=gpu)[None, :, None]
+    e_sc = emb.forward_multi(x, (w * scale).contiguous(), normalize=True)
+    assert torch.equal(e_sc, e0)
+    # speaker permutation
+    perm = [2, 0, 1]
+    e_pm = emb.forward_multi(x, w[:, perm].contiguous(), normalize=True)
+    assert torch.equal(e_pm, e0[:, perm])
+    # a speaker without weight
+    wz = w.clone()
+    wz[5, 1] = 0.0
+    e_z = emb.forward_multi(x, wz, normalize=True)
+    assert torch.isnan(e_z[5, 1]).all()
+    keep = torch.ones(n, 3, dtype=torch.bool, device=gpu)
+    keep[5, 1] = False
+    assert torch.equal(e_z[keep], e0[keep])
+
+
 def test_audio_ring_is_the_rolling_window(gpu):
     """dz_ring_*: pushing 500 ms blocks reproduces the windows rearrange_audio_stream emits
     (operators.py:44-100: the last `duration` seconds after every block, from the first complete
