@@ -19,6 +19,9 @@ ap.add_argument("--batch", type=int, default=64)
 ap.add_argument("--only", type=str, default="")
 ap.add_argument("--reps", type=int, default=20)
 ap.add_argument("--agroup", type=int, default=0)
+ap.add_argument("--power", type=float, default=0.0,
+                help="seconds each kernel is looped for while a side thread samples the card's hwmon files (shader clock, "
+                     "package power): adds clock / watts / joules per launch to every row")
 args = ap.parse_args()
 only = set(filter(None, args.only.split(",")))
 dev = torch.device("cuda", 0)
@@ -28,6 +31,56 @@ ctx = _lib.context(0)
 B = args.batch
 st = torch.cuda.current_stream(dev).cuda_stream
 results = {}
+
+
+class PowerSampler:
+    """Shader clock (freq1_input) and package power (power1_average) of every card the box shows, every 20 ms; the
+    card under test is the one whose power moves (a one-GPU box still lists the node's eight cards in sysfs)."""
+
+    def __init__(self):
+        import glob
+        import threading
+        self.f = sorted(glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*/freq1_input"))
+        import os
+        self.p = []
+        for x in self.f:                                  # the package power file's name differs between driver versions
+            cand = [x.replace("freq1_input", n) for n in ("power1_average", "power1_input")]
+            self.p.append(next((c for c in cand if os.path.exists(c)), cand[0]))
+        self.rows, self.stop = [], False
+        self.th = threading.Thread(target=self.run, daemon=True)
+        self.th.start()
+
+    @staticmethod
+    def rd(path):
+        try:
+            return float(open(path).read())
+        except Exception:      # noqa: BLE001
+            return float("nan")
+
+    def run(self):
+        import time
+        while not self.stop:
+            self.rows.append((time.time(), [self.rd(x) / 1e6 for x in self.f], [self.rd(x) / 1e6 for x in self.p]))
+            time.sleep(0.02)
+
+    def window(self, t0, t1, card):
+        import statistics
+        w = [r for r in self.rows if t0 <= r[0] <= t1]
+        if not w:
+            return None, None
+        return statistics.median(r[1][card] for r in w), statistics.median(r[2][card] for r in w)
+
+    def card(self):
+        import math
+        span = []
+        for c in range(len(self.f)):
+            v = [r[2][c] for r in self.rows if not math.isnan(r[2][c])]
+            span.append(max(v) - min(v) if v else 0.0)
+        return max(range(len(span)), key=span.__getitem__) if span else 0
+
+
+sampler = PowerSampler() if args.power > 0 else None
+power_windows = []        # (name, t0, t1, launches)
 
 
 def timeit(name, fn, flop=None, bytes_=None):
@@ -50,6 +103,16 @@ def timeit(name, fn, flop=None, bytes_=None):
         row["gbps"] = round(bytes_ / us / 1e3, 1)
     results[name] = row
     print(f"{name:14s} {us:9.1f} us  {row.get('tflops', '')} TF  {row.get('gbps', '')} GB/s", flush=True)
+    if sampler is not None:
+        import time
+        n = max(args.reps, int(args.power * 1e6 / max(us, 1.0)))
+        torch.cuda.synchronize()
+        t0 = time.time()
+        for _ in range(n):
+            fn()
+        torch.cuda.synchronize()
+        t1 = time.time()
+        power_windows.append((name, t0 + 0.15 * (t1 - t0), t1 - 0.02, n, (t1 - t0) / n))
 
 
 def convgemm(name, Bn, Tin, Cin, N, taps, dil, epi, Npad=None, pro=False, pool=False, ksplit=0):
@@ -247,6 +310,23 @@ if not only or "mlp_head" in only:
                                                             segb.data_ptr(), 3.0, 10.0, 0, wb.data_ptr(), st)),
            bytes_=rows * 134 * 4.0)
     only.update(only_saved)
+if sampler is not None:
+    import time
+    time.sleep(1.5)
+    t_idle = time.time()
+    time.sleep(0.5)
+    sampler.stop = True
+    sampler.th.join()
+    card = sampler.card()
+    _, idle_w = sampler.window(t_idle, t_idle + 0.5, card)
+    print(f"power: card {card}, idle {idle_w:.0f} W")
+    for name, t0, t1, n, sec in power_windows:
+        mhz, watts = sampler.window(t0, t1, card)
+        if watts is None:
+            continue
+        results[name].update({"loop_us": round(sec * 1e6, 1), "sclk_mhz": round(mhz), "package_w": round(watts),
+                              "joules_per_launch": round(watts * sec, 4), "joules_above_idle": round((watts - idle_w) * sec, 4)})
+        print(f"{name:22s} looped {sec * 1e6:8.1f} us  {mhz:5.0f} MHz  {watts:5.0f} W  {watts * sec * 1e3:7.2f} mJ / launch")
 out = Path("gpurun_out")
 out.mkdir(exist_ok=True)
 (out / "kbench.json").write_text(json.dumps(results, indent=1))
