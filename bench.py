@@ -217,6 +217,9 @@ def parse():
     ap.add_argument("--streams", type=int, default=64, help="concurrent streams per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-rehearsal", action="store_true", help="skip the 8-rank host-contention rehearsal (N = 1 only)")
+    ap.add_argument("--power-seconds", type=float, default=float(os.environ.get("DZ_BENCH_POWER_S", "1.5")),
+                    help="N = 1: length of the untimed pass behind the timed region during which the card's hwmon files "
+                         "(package power, shader clock) are sampled -> `power` (0: off)")
     ap.add_argument("--no-tail", action="store_true",
                     help="stop after clustering (skip the C++ aggregation + binarisation tail)")
     ap.add_argument("--cpu-chunks", type=int, default=32, help="windows per batch of the bounded CPU sample (Benchmark's batch_size, inference.py:275)")
@@ -400,7 +403,7 @@ def host_rehearsal(args, precision, usable, ranks=8):
     cores = allowed[:share]
     steps = max(args.steps, 100)
     cmd = [sys.executable, str(ROOT / "bench.py"), "--steps", str(steps), "--warmup", "5", "--no-cpu-baseline", "--no-exact-f32",
-           "--no-host-pass", "--pmc", "off", "--no-rehearsal", "--precision", precision, "--streams", str(args.streams),
+           "--no-host-pass", "--pmc", "off", "--no-rehearsal", "--power-seconds", "0", "--precision", precision, "--streams", str(args.streams),
            *engine_args(args)]
     res = {}
     for tag, pin in (("unpinned", None), ("pinned", cores)):
@@ -459,7 +462,7 @@ def pmc_live(precision, args=None):
     t_start, budget = time.monotonic(), float(os.environ.get("DZ_PMC_BUDGET_S", "200"))
     work = Path(tempfile.mkdtemp(prefix="dz_pmc_"))
     cmd = [sys.executable, str(ROOT / "bench.py"), "--steps", "3", "--warmup", "1", "--no-cpu-baseline",
-           "--no-exact-f32", "--no-host-pass", "--pmc", "off", "--no-rehearsal", "--precision", precision,
+           "--no-exact-f32", "--no-host-pass", "--pmc", "off", "--no-rehearsal", "--power-seconds", "0", "--precision", precision,
            *(engine_args(args) if args is not None else [])]
     env = dict(os.environ, PYTHONDONTWRITEBYTECODE="1", TMPDIR="/tmp", DZ_SETTLE_STEPS="0")
     passes = {"FETCH_SIZE": ["FETCH_SIZE"], "WRITE_SIZE": ["WRITE_SIZE"],
@@ -1207,6 +1210,50 @@ def main():
         return
 
     elapsed, table, n_sampled = timed_pass(pipe, f"timed region ({precision})")
+
+    def power_pass(p):
+        """What the GPU draws while this pipeline runs: an UNTIMED pass of `--power-seconds` on the same engine, right behind
+        the timed region, with the card's own hwmon files (package power, shader clock) sampled every 40 ms by a side thread;
+        the median of the last 60 % of the pass (the power reading is itself an average that takes ~0.3 s to settle).
+        profiles/r06zl_clock_power.json: the default-precision pipeline sits at the package's power budget."""
+        from diart_amd.hwmon import PowerSampler
+        sm = PowerSampler(period=0.04, device_index=device.index)
+        if not sm.available:
+            sm.stop()
+            return None
+        try:
+            torch.cuda.synchronize()
+            time.sleep(1.0)                                  # idle reference (the reading is a ~0.3 s average)
+            t_idle = time.time()
+            t0 = time.time()
+            steps_done, flying = 0, []
+            while time.time() - t0 < args.power_seconds:         # one continuous pass: no drain between its steps
+                flying.append(p.launch(window(steps_done % total_steps)))
+                steps_done += 1
+                if len(flying) >= p.max_inflight:
+                    p.finish(flying.pop(0), want_scores=True)
+            while flying:
+                p.finish(flying.pop(0), want_scores=True)
+            torch.cuda.synchronize()
+            t1 = time.time()
+        finally:
+            sm.stop()
+        card = sm.card()
+        _, idle_w, _ = sm.window(t_idle - 0.25, t_idle, card)
+        mhz, watts, ns = sm.window(t0 + 0.4 * (t1 - t0), t1 - 0.02, card)
+        if watts is None:
+            return None
+        ms = 1e3 * (t1 - t0) / max(1, steps_done)
+        return {"package_w": round(watts), "sclk_mhz": round(mhz), "idle_w": round(idle_w) if idle_w is not None else None,
+                "ms_per_step": round(ms, 3), "joules_per_step": round(watts * ms / 1e3, 3), "seconds": round(t1 - t0, 2),
+                "steps": steps_done, "samples": ns, "card_matched_by_pci_address": sm.own is not None,
+                "source": "amdgpu hwmon (power1_average | power1_input, freq1_input) of the card whose power moved, sampled every "
+                          "40 ms by a side thread during an untimed pass behind the timed region; median of its last 60 %"}
+
+    power = power_pass(pipe) if (world == 1 and rank == 0 and args.power_seconds > 0) else None
+    if power:
+        log(f"power pass: {power['package_w']} W at {power['sclk_mhz']} MHz over {power['steps']} steps "
+            f"({power['ms_per_step']} ms / step, {power['joules_per_step']} J / step; idle {power['idle_w']} W)")
     serial = serial_pass(precision) if args.serial_steps > 0 else None
     host_line = {"cpu_ms_per_step": round(host["cpu_ms_per_step"], 3), "launch_ms_per_step": round(host["launch_ms_per_step"], 3),
                  "step_period_ms_in_timed_region": host["step_period_ms"],
@@ -1380,7 +1427,7 @@ def main():
                        "exact_f32_value": exact["value"] if exact else None,
                        "host_fed_value": host_fed["value"] if host_fed else None},
             "roofline": roof, "roofline_mfma": roof_mfma, "mfma_util_step": mfma_step, "hbm_gbps_step": hbm_step,
-            "whole_path_frac": whole_path_frac, "whole_path_frac_exact_f32": whole_path_frac_f32,
+            "whole_path_frac": whole_path_frac, "whole_path_frac_exact_f32": whole_path_frac_f32, "power": power,
             "roofline_kernels": per_kernel, "roofline_kernels_overlapped": per_kernel_ovl,
             "roofline_sampling": (f"`roofline*`: the serialised pass ({serial[1]} steps on one lane / one HIP stream, every launch "
                                   f"bracketed, {serial[2]:.3f} ms per step); " if serial else "") +

@@ -20,7 +20,7 @@ _ROOF_KEYS = ("kernel", "bound", "achieved", "peak", "unit", "frac", "frac_of_oc
               "launches_per_step", "alg_gflop_per_launch", "alg_bytes_per_launch", "traffic", "traffic_over_alg_bytes",
               "share_of_kernel_time")
 # dropped in this order when the line is too long (it never is with the fields below; belt and braces)
-_OPTIONAL = ("roofline_exact_f32", "host_rehearsal", "host", "roofline_mfma", "step_period_ms")
+_OPTIONAL = ("roofline_exact_f32", "host_rehearsal", "host", "roofline_mfma", "step_period_ms", "power")
 
 
 def _roof(entry, source=None):
@@ -86,6 +86,9 @@ def compact(full, details_file=None):
     out["mfma_issued_frac_of_peak_step"] = mfma.get("frac_of_peak")
     out["hbm_gbps_step"] = hbm.get("gbps")
     out["hbm_frac_step"] = hbm.get("frac_of_peak")
+    pw = full.get("power")
+    if isinstance(pw, dict):        # what the card drew while the pipeline ran (hwmon): the default precision sits at the power budget
+        out["power"] = {k: pw.get(k) for k in ("package_w", "sclk_mhz", "idle_w", "joules_per_step")}
     cb = full.get("cpu_baseline")
     if isinstance(cb, dict):
         out["cpu_baseline"] = {"value": cb.get("value"), "unit": cb.get("unit"), "cores": cb.get("cores"),

@@ -50,6 +50,17 @@ def test_eight_rank_record_and_pathological_strings_still_fit():
     assert len(json.dumps(d)) < 4096
 
 
+def test_power_entry_reaches_the_line():
+    """bench.py's hwmon reading of the pass behind the timed region (package watts, shader clock): four numbers in the line,
+    the prose stays in the details file."""
+    full = copy.deepcopy(FULL)
+    full["power"] = {"package_w": 1365, "sclk_mhz": 2032, "idle_w": 242, "ms_per_step": 0.846, "joules_per_step": 1.155,
+                     "seconds": 1.5, "steps": 1750, "samples": 44, "source": "x" * 500}
+    d = json.loads(benchline.line(full, None))
+    assert d["power"] == {"package_w": 1365, "sclk_mhz": 2032, "idle_w": 242, "joules_per_step": 1.155}
+    assert len(json.dumps(d)) < 4096
+
+
 def test_missing_parts_do_not_break_the_line():
     d = json.loads(benchline.line({"metric": "m", "value": 1.0}, None))
     assert d["roofline"] is None and d["cpu_baseline"] is None and d["value"] == 1.0

@@ -33,53 +33,9 @@ st = torch.cuda.current_stream(dev).cuda_stream
 results = {}
 
 
-class PowerSampler:
-    """Shader clock (freq1_input) and package power (power1_average) of every card the box shows, every 20 ms; the
-    card under test is the one whose power moves (a one-GPU box still lists the node's eight cards in sysfs)."""
+from diart_amd.hwmon import PowerSampler  # noqa: E402
 
-    def __init__(self):
-        import glob
-        import threading
-        self.f = sorted(glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*/freq1_input"))
-        import os
-        self.p = []
-        for x in self.f:                                  # the package power file's name differs between driver versions
-            cand = [x.replace("freq1_input", n) for n in ("power1_average", "power1_input")]
-            self.p.append(next((c for c in cand if os.path.exists(c)), cand[0]))
-        self.rows, self.stop = [], False
-        self.th = threading.Thread(target=self.run, daemon=True)
-        self.th.start()
-
-    @staticmethod
-    def rd(path):
-        try:
-            return float(open(path).read())
-        except Exception:      # noqa: BLE001
-            return float("nan")
-
-    def run(self):
-        import time
-        while not self.stop:
-            self.rows.append((time.time(), [self.rd(x) / 1e6 for x in self.f], [self.rd(x) / 1e6 for x in self.p]))
-            time.sleep(0.02)
-
-    def window(self, t0, t1, card):
-        import statistics
-        w = [r for r in self.rows if t0 <= r[0] <= t1]
-        if not w:
-            return None, None
-        return statistics.median(r[1][card] for r in w), statistics.median(r[2][card] for r in w)
-
-    def card(self):
-        import math
-        span = []
-        for c in range(len(self.f)):
-            v = [r[2][c] for r in self.rows if not math.isnan(r[2][c])]
-            span.append(max(v) - min(v) if v else 0.0)
-        return max(range(len(span)), key=span.__getitem__) if span else 0
-
-
-sampler = PowerSampler() if args.power > 0 else None
+sampler = PowerSampler(device_index=0) if args.power > 0 else None
 power_windows = []        # (name, t0, t1, launches)
 
 
@@ -315,13 +271,12 @@ if sampler is not None:
     time.sleep(1.5)
     t_idle = time.time()
     time.sleep(0.5)
-    sampler.stop = True
-    sampler.th.join()
+    sampler.stop()
     card = sampler.card()
-    _, idle_w = sampler.window(t_idle, t_idle + 0.5, card)
-    print(f"power: card {card}, idle {idle_w:.0f} W")
+    _, idle_w, _ = sampler.window(t_idle, t_idle + 0.5, card)
+    print(f"power: card {card} ({'by PCI address' if sampler.own is not None else 'by power span'}), idle {idle_w:.0f} W")
     for name, t0, t1, n, sec in power_windows:
-        mhz, watts = sampler.window(t0, t1, card)
+        mhz, watts, _ = sampler.window(t0, t1, card)
         if watts is None:
             continue
         results[name].update({"loop_us": round(sec * 1e6, 1), "sclk_mhz": round(mhz), "package_w": round(watts),
