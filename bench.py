@@ -1250,7 +1250,12 @@ def main():
                 "source": "amdgpu hwmon (power1_average | power1_input, freq1_input) of the card whose power moved, sampled every "
                           "40 ms by a side thread during an untimed pass behind the timed region; median of its last 60 %"}
 
-    power = power_pass(pipe) if (world == 1 and rank == 0 and args.power_seconds > 0) else None
+    power = None
+    if world == 1 and rank == 0 and args.power_seconds > 0:
+        try:
+            power = power_pass(pipe)
+        except Exception as exc:      # noqa: BLE001 — an unreadable hwmon tree must not cost the run its line
+            log(f"power pass skipped: {exc!r}")
     if power:
         log(f"power pass: {power['package_w']} W at {power['sclk_mhz']} MHz over {power['steps']} steps "
             f"({power['ms_per_step']} ms / step, {power['joules_per_step']} J / step; idle {power['idle_w']} W)")
