@@ -7,6 +7,8 @@ speechbrain / checkpoints here), but their signal-processing front ends are stan
 * its triangular mel filterbank against the textbook construction (triangles between mel-spaced
   edges evaluated with numpy.interp — a different formulation of the same definition);
 * the DFT-as-GEMM matrices the HIP path multiplies with (diart_amd.weights) against numpy.fft;
+* SincNet's parametric filter bank (oracle AND diart_amd.weights.sinc_filters) against its definition — the windowed
+  quadrature band-pass of each (low, high) pair — evaluated by numerical quadrature, and its frequency response;
 * the LSTM restatement is pinned against torch.nn.LSTM elsewhere (test_oracle_golden.py)."""
 import numpy as np
 import torch
@@ -70,3 +72,60 @@ def test_dft_matrices_of_the_hip_path_match_numpy_fft():
     out = m @ frame
     assert np.allclose(out[:201], ref.real, atol=1e-10) and np.allclose(out[201:], -ref.imag, atol=1e-10)
     assert np.allclose(out[:201] ** 2 + out[201:] ** 2, np.abs(ref) ** 2, rtol=1e-10, atol=1e-10)
+
+
+def test_sinc_filter_bank_is_the_windowed_quadrature_band_pass_of_its_parameters():
+    """SincNet's first layer (asteroid ``ParamSincFB`` behind pyannote's ``SincNet``, third party; reached from
+    /root/reference/src/diart/models.py:133, :262) is defined by 40 (low, high) pairs: filter i is the band-pass whose
+    frequency response is 1 on [low_i, high_i] — an even ("cos") and an odd ("sin") impulse response, i.e.
+    ``h_c[n] = int 2 cos(2 pi f n) df`` and ``h_s[n] = int 2 sin(2 pi f n) df`` over the band (Ravanelli & Bengio 2018,
+    eq. 4 - 6) — truncated to 251 taps under a Hamming window and scaled by 1 / (2 band).  Here that definition is
+    evaluated by numerical quadrature in float64, with no closed form, and both restatements of the library's closed
+    form — the oracle's (``ParamSincFBRef.filters``) and the product's (``weights.sinc_filters``, what the HIP bank is
+    packed from) — must reproduce it, at the mel-spaced initial parameters and at random ones; the DFT of a filter must
+    be a band-pass where its parameters say."""
+    import torch
+    from diart_amd.weights import sinc_filters
+    from oracle.models_ref import ParamSincFBRef
+
+    sr, ks, half = 16000.0, 251, 125
+    n = np.arange(-half, half + 1, dtype=np.float64)
+    win = np.hamming(ks)
+    win[half] = 1.0                                               # the centre tap is the band itself, unwindowed
+    rng = np.random.default_rng(3)
+    for trial in range(3):
+        fb = ParamSincFBRef()
+        if trial:
+            with torch.no_grad():
+                fb.low_hz_.copy_(torch.from_numpy(rng.uniform(-200.0, 6000.0, (40, 1)).astype("float32")))
+                fb.band_hz_.copy_(torch.from_numpy(rng.uniform(-100.0, 1500.0, (40, 1)).astype("float32")))
+        low = 50.0 + np.abs(fb.low_hz_.detach().numpy().astype(np.float64)[:, 0])
+        high = np.clip(low + 50.0 + np.abs(fb.band_hz_.detach().numpy().astype(np.float64)[:, 0]), 50.0, sr / 2)
+        want = np.zeros((80, ks))
+        q = (np.arange(4000) + 0.5) / 4000.0                       # midpoint rule over the band
+        for i in range(40):
+            f = (low[i] + (high[i] - low[i]) * q)[:, None] / sr     # cycles per sample
+            band = high[i] - low[i]
+            hc = (2.0 * np.cos(2 * np.pi * f * n[None, :])).mean(0) * band          # = the integral over Hz
+            hs = (2.0 * np.sin(2 * np.pi * f * n[None, :])).mean(0) * band
+            want[i] = hc * win / (2.0 * band)
+            want[40 + i] = hs * win / (2.0 * band)
+        got_oracle = fb.filters().detach().numpy()[:, 0, :].astype(np.float64)
+        got_product = sinc_filters(fb.low_hz_.detach(), fb.band_hz_.detach(), fb.window_, fb.n_).numpy().reshape(80, ks).astype(np.float64)
+        scale = np.abs(want).max(axis=1, keepdims=True)
+        assert (np.abs(got_oracle - want) / scale).max() < 2e-4, (np.abs(got_oracle - want) / scale).max()
+        assert (np.abs(got_product - want) / scale).max() < 2e-4
+        assert np.array_equal(got_oracle[:, ::-1][:40], got_oracle[:40])            # even
+        assert np.array_equal(-got_oracle[:, ::-1][40:], got_oracle[40:])           # odd
+        # frequency response: largest inside the band, >= 20 dB down two main-lobe widths outside it
+        H = np.abs(np.fft.rfft(got_oracle, 8192, axis=1))
+        fr = np.fft.rfftfreq(8192, 1 / sr)
+        lobe = 2.0 * sr / ks
+        for i in range(80):
+            lo_, hi_ = low[i % 40], high[i % 40]
+            inside = (fr >= lo_) & (fr <= hi_)
+            outside = (fr < lo_ - 2 * lobe) | (fr > hi_ + 2 * lobe)
+            if hi_ - lo_ < 30.0 or not inside.any() or not outside.any():
+                continue
+            assert fr[np.argmax(H[i])] >= lo_ - lobe and fr[np.argmax(H[i])] <= hi_ + lobe
+            assert H[i][outside].max() < 0.1 * H[i][inside].max()
