@@ -31,5 +31,7 @@ def test_host_half_is_clean_under_sanitizers(tmp_path, flags, env):
     assert build.returncode == 0, build.stderr[-2000:]
     import os
     run = subprocess.run([str(exe), "40"], capture_output=True, text=True, timeout=300, env=dict(os.environ, **env))
+    if "unexpected memory mapping" in run.stderr or "ReExec" in run.stderr:
+        pytest.skip("the sanitizer runtime cannot map its shadow memory on this kernel (ASLR setting): " + run.stderr.strip().splitlines()[0])
     assert run.returncode == 0 and "host_sanitize ok" in run.stdout, (run.stdout[-500:] + run.stderr[-3000:])
     assert "ERROR: " not in run.stderr and "WARNING: ThreadSanitizer" not in run.stderr, run.stderr[-3000:]
