@@ -86,7 +86,10 @@ def kernels_for(precision):
     if not EXPERIMENTS:
         k.pop("sinc_conv0_pair", None)               # (the pair launch exists in the experiments build only)
     if precision != "f16x3":
-        k.pop("norm_split", None)                    # (exact f32: the consumers normalise on load)
+        if os.environ.get("DZ_F32_GEMM", "1") == "0":
+            k.pop("norm_split", None)                # (round-1 exact-f32 kernels everywhere: the consumers normalise on load)
+        else:                                        # exact f32 (round 6): the same pass with f32 rows out (norm_f32_kernel)
+            k["norm_split"]["io"] = F_SEG * 64 * (4 + 4)
     if precision == "f16x3" and os.environ.get("DZ_POOL_FUSE", "1") != "0":
         moments = POOL_PIECES * 3 * 1536 * 2 * 4
         k["tdnn5"]["io"] = F_SEG * 512 * 4 + moments + 3 * F_SEG * 4
@@ -142,7 +145,8 @@ def device_kernel(tag, precision):
     k = KERNELS[tag]
     fused_pool = split and pre and os.environ.get("DZ_POOL_FUSE", "1") != "0"
     if k["bound"] == "hbm":
-        return {"wave_stats": "wave_stats_kernel", "finalize_norm": "finalize_norm_kernel", "norm_split": "norm_split_kernel",
+        return {"wave_stats": "wave_stats_kernel", "finalize_norm": "finalize_norm_kernel",
+                "norm_split": "norm_split_kernel" if split else "norm_f32_kernel",
                 "stats_pool": "pool_combine_kernel" if fused_pool else "stats_pool_reg_kernel<3, 72>",
                 "seg_classifier": "seg_head_kernel"}[tag], "hbm", PEAK_HBM_GBPS, "GB/s"
     if k["bound"] == "rec":
@@ -164,7 +168,9 @@ def device_kernel(tag, precision):
                "tdnn1": "convgemm_kernel<128, true, 3>",
                "emb_linear": "convgemm_kernel<128, false, 0> (split-K)", "seg_head": "seg_head_kernel"}
         if os.environ.get("DZ_F32_GEMM", "1") != "0":                  # wide layers without a prologue: k_gemm_f32.hip
-            sym.update({"lstm_proj": "gemm_f32_kernel<0>", "seg_mlp": "gemm_f32_kernel<1>", "tdnn2": "gemm_f32_kernel<3>",
+            # (round 6: y2 is normalised once, norm_f32_kernel, and the first projection / tdnn1 are such layers too)
+            sym.update({"lstm_proj0": "gemm_f32_kernel<0>", "tdnn1": "gemm_f32_kernel<3>",
+                        "lstm_proj": "gemm_f32_kernel<0>", "seg_mlp": "gemm_f32_kernel<1>", "tdnn2": "gemm_f32_kernel<3>",
                         "tdnn3": "gemm_f32_kernel<3>", "tdnn4": "gemm_f32_kernel<3>", "tdnn5": "gemm_f32_kernel<3>"})
         return sym.get(tag, "convgemm_kernel<128, false, 3>"), "mfma", PEAK_F32_MATRIX_TFLOPS, "TFLOP/s"
     if pre and tag == "seg_mlp" and xenv("DZ_MLP_HEAD", "1") != "0":

@@ -358,6 +358,14 @@ static int sinc_norm_split(const dz_sincnet_weights& w, const SincGeom& g, const
     return dz_launch_norm_split(s.y2, s.part2, g.nt2, g.P2, w.in2_g, w.in2_b, s.y2s, (long long)B * g.P2 * 64, B, st);
 }
 
+// Exact-f32 weights (no split planes anywhere in the SincNet) with the f32 MFMA GEMM on: y2 is normalised ONCE into
+// s.y2s as f32 rows (norm_f32_kernel reads the tile partials itself: no third finalize_norm launch) and its two
+// consumers — the first LSTM projection, tdnn1 — run flattened on k_gemm_f32.hip.  The experiments build's
+// non-fused f16 configurations (DZ_FUSED_NORM=0 / DZ_CONV_POOL=0) keep finalize_norm + norm-on-load.
+static bool sinc_f32_norm_pass(const dz_sincnet_weights& w) {
+    return !w.filt_split && !w.w1_split && !w.w2_split && dz_option(DZ_OPT_F32_GEMM) != 0;
+}
+
 // wave -> y2 [B][P2][64] (pre-norm) + part2 (or sc2/sh2): the consumer applies InstanceNorm +
 // LeakyReLU on load.  4 launches (7 with the finalize_norm launches of the exact-f32 path).
 // ext_stats: slice moments of these B windows somebody already computed (dz_wave_stats: the
@@ -412,6 +420,10 @@ static int run_sincnet(const dz_sincnet_weights& w, const SincGeom& g, const Sin
     p.Tstore = g.P2; p.xbs = (long long)g.P1 * 64; p.ybs = (long long)g.P2 * 64;
     { ProfScope ps(T_CONV2, B); if ((rc = run_gemm(p, w.w2_split, st, s.w2_frag))) return rc; }
     if (fused) return 0;
+    if (sinc_f32_norm_pass(w)) {
+        ProfScope ps(T_NSPLIT, B);
+        return dz_launch_norm_f32(s.y2, s.part2, g.nt2, g.P2, w.in2_g, w.in2_b, s.y2s, B, st);
+    }
     ProfScope ps(T_FIN, B);
     return dz_launch_finalize_norm(s.part2, B, g.nt2, 64, g.P2, w.in2_g, w.in2_b, s.sc2, s.sh2, st);
 }
@@ -600,6 +612,11 @@ static int seg_forward(dz_seg* s, const float* d_wave, long long wave_stride, in
             p.ldx = 256;
         }
         const bool pre0 = layer == 0 && s->pre && sinc_pre_split_ok(s->w.sinc, s->w.wih0_split_kb);
+        if (layer == 0 && !pre0 && !s->w.wih_split[0] && sinc_f32_norm_pass(s->w.sinc)) {
+            // exact f32: y2 was normalised into y2s by run_sincnet; one flattened GEMM without a prologue (k_gemm_f32.hip)
+            p.X = s->ss.y2s; p.norm_on_load = 0; p.npart = nullptr; p.nscale = p.nshift = nullptr;
+            p.B = 1; p.Tin = p.Tout = p.Tstore = B * F; p.xbs = p.ybs = 0;
+        }
         if (do_proj && pre0) {       // y2 -> normalised planes, then the projection as one flattened pre-split GEMM
             if ((rc = sinc_norm_split(s->w.sinc, s->g, s->ss, B, st))) return rc;
             p.X = nullptr; p.norm_on_load = 0; p.npart = nullptr; p.nscale = p.nshift = nullptr;
@@ -807,6 +824,9 @@ static int emb_frames(dz_emb* e, const float* d_wave, long long stride, int B, h
         if (pre0) {                   // y2 -> normalised planes; tdnn1 flattened over B * P rows like the layers behind it
             if ((rc = sinc_norm_split(e->w.sinc, e->g, e->ss, B, st))) return rc;
             p.B = 1; p.Tin = B * P; p.Tout = p.Tstore = B * P - span;
+        } else if (i == 0 && !e->pre && !e->w.tw_split[0] && sinc_f32_norm_pass(e->w.sinc)) {
+            // exact f32: the normalised y2 (run_sincnet -> y2s), tdnn1 flattened over B * P rows like the layers behind it
+            p.X = e->ss.y2s; p.B = 1; p.Tin = B * P; p.Tout = p.Tstore = B * P - span;
         } else if (i == 0) {
             p.B = B; p.Tin = P; p.Tout = p.Tstore = e->T[0];
             p.xbs = (long long)P * cin[i]; p.ybs = (long long)P * npad[i];

@@ -308,6 +308,8 @@ int dz_launch_gemm_f32(const DzConvGemm& p, hipStream_t st);
 // k_gemm_split.hip: the same contraction on the f16 matrix cores with both operands split into
 // (hi, lo) f16 pairs — 3 MFMAs per product, f32 accumulation
 int dz_launch_gemm_split(const DzConvGemm& p, hipStream_t st);
+int dz_launch_norm_f32(const float* y, const float* part, int ntile, int P, const float* gamma, const float* beta,
+                       float* out, int B, hipStream_t st);
 int dz_launch_norm_split(const float* y, const float* part, int ntile, int P, const float* gamma, const float* beta,
                          void* planes, long long plane, int B, hipStream_t st);
 // k_conv_pool.hip: SincNet stages 1 / 2 (k = 5 conv + MaxPool1d(3) + partials) with the input tile

@@ -358,6 +358,34 @@ __global__ __launch_bounds__(256) void norm_split_kernel(const float* __restrict
     dz_flag_range(oflag, amax);
 }
 
+// The same pass with f32 output (round 6, exact-f32 path): y2 normalised once, [B * P rows][64] f32, so that the first
+// LSTM projection and tdnn1 run as flattened GEMMs without a prologue on k_gemm_f32.hip (they ran per chunk on the
+// round-1 kernel with the norm on load: 61 + 96 us a step) and the third finalize_norm launch of each SincNet goes.
+__global__ __launch_bounds__(256) void norm_f32_kernel(const float* __restrict__ y, const float* __restrict__ part,
+                                                       int ntile, int P, const float* __restrict__ gamma,
+                                                       const float* __restrict__ beta, float* __restrict__ out) {
+    __shared__ __attribute__((aligned(16))) float nrm_s[128];          // scale[64] | shift[64]
+    __shared__ double scratch[2 * 4 * 64];
+    const int tid = threadIdx.x, b = blockIdx.y;
+    dz_norm_from_partials(part, b, ntile, 64, P, gamma, beta, nrm_s, tid, 256, scratch);
+    __syncthreads();
+    const int row = blockIdx.x * 32 + (tid >> 3), c = (tid & 7) * 8;
+    if (row >= P) return;
+    const long long r = (long long)b * P + row;
+    const float* x = y + r * 64 + c;
+    const f32x4 v0 = *reinterpret_cast<const f32x4*>(x), v1 = *reinterpret_cast<const f32x4*>(x + 4);
+    const f32x4 s0 = *reinterpret_cast<const f32x4*>(nrm_s + c), s1 = *reinterpret_cast<const f32x4*>(nrm_s + c + 4);
+    const f32x4 h0 = *reinterpret_cast<const f32x4*>(nrm_s + 64 + c), h1 = *reinterpret_cast<const f32x4*>(nrm_s + 64 + c + 4);
+    f32x4 o0, o1;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        o0[e] = leaky(v0[e] * s0[e] + h0[e]);
+        o1[e] = leaky(v1[e] * s1[e] + h1[e]);
+    }
+    *reinterpret_cast<f32x4*>(out + r * 64 + c) = o0;
+    *reinterpret_cast<f32x4*>(out + r * 64 + c + 4) = o1;
+}
+
 }  // namespace
 
 int dz_launch_gemm_split(const DzConvGemm& p_in, hipStream_t st) {
@@ -435,6 +463,15 @@ int dz_launch_norm_split(const float* y, const float* part, int ntile, int P, co
                "norm_split: bad geometry (B %d, P %d, plane %lld)", B, P, plane);
     DZ_LAUNCH(norm_split_kernel, dim3((P + 31) / 32, B), dim3(256), 0, st, y, part, ntile, P, gamma, beta,
               reinterpret_cast<unsigned short*>(planes), plane, dz_cur_oflag);
+    DZ_HIP(hipGetLastError());
+    return 0;
+}
+
+int dz_launch_norm_f32(const float* y, const float* part, int ntile, int P, const float* gamma, const float* beta,
+                       float* out, int B, hipStream_t st) {
+    DZ_REQUIRE(y && part && gamma && beta && out, "norm_f32: NULL argument");
+    DZ_REQUIRE(B >= 1 && P >= 1 && ntile >= 1, "norm_f32: bad geometry (B %d, P %d)", B, P);
+    DZ_LAUNCH(norm_f32_kernel, dim3((P + 31) / 32, B), dim3(256), 0, st, y, part, ntile, P, gamma, beta, out);
     DZ_HIP(hipGetLastError());
     return 0;
 }
