@@ -1224,7 +1224,9 @@ def main():
         profiles/r06zl_clock_power.json: the default-precision pipeline sits at the package's power budget."""
         from diart_amd.hwmon import PowerSampler
         sm = PowerSampler(period=0.04, device_index=device.index)
-        if not sm.available:
+        if not sm.available or (sm.own is None and len(sm.freq) > 1):
+            # no hwmon tree, or several cards and none matched by PCI address: another tenant's card could be the one whose
+            # power moves most — no reading is better than somebody else's
             sm.stop()
             return None
         try:
